@@ -1,0 +1,131 @@
+/*
+ * mcdseg.h -- C ABI of libmcdseg.so, the MI355X (gfx950) kernels behind the MCD hot path.
+ *
+ * The reference (LittleWat/multichannel-semseg-with-uda) has no FFI layer: its hot path is a chain
+ * of stock ATen operators launched from Python.  Each entry point below replaces one such operator
+ * call site (cited as file:line of the reference); the Python host side in
+ * multichannel-semseg-with-uda_amd/mcdseg/ binds them with ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller;
+ *   - tensors are fp32, NCHW, contiguous; labels are int64;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never allocates,
+ *     never synchronises; scratch space is passed in by the caller (sizes from the *_bytes /
+ *     *_count helpers);
+ *   - return value 0 = launched; <0 = rejected (bad argument, unsupported shape, launch error) and
+ *     mcdseg_last_error() holds the reason (thread-local string).
+ */
+#ifndef MCDSEG_H
+#define MCDSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCDSEG_VERSION 100
+
+int mcdseg_version(void);
+const char* mcdseg_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution  (nn.Conv2d call sites: models/drn.py:21-23,127,177,199; models/dilated_fcn.py:227)
+ * groups = 1, square kernel, symmetric stride / padding / dilation.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mcdseg_conv_desc {
+  int32_t N, Cin, H, W;      /* input  [N,Cin,H,W]                      */
+  int32_t Cout, KH, KW;      /* weight [Cout,Cin,KH,KW]                 */
+  int32_t stride, pad, dil;
+  int32_t Ho, Wo;            /* output [N,Cout,Ho,Wo]                   */
+} mcdseg_conv_desc;
+
+/* Padded GEMM dims of the packed weight images: fprop image is [KH*KW][Kp_f][Mp_f] with M = Cout,
+ * K = Cin; dgrad image is [KH*KW][Kp_d][Mp_d] with M = Cin, K = Cout. */
+int mcdseg_conv_packed_dims(const mcdseg_conv_desc* d, int32_t* Mp_f, int32_t* Kp_f, int32_t* Mp_d, int32_t* Kp_d);
+/* w [Cout,Cin,KH,KW] -> fprop image and/or dgrad image (either destination may be NULL). */
+int mcdseg_conv_pack_weights(const mcdseg_conv_desc* d, const float* w, float* wp_fprop, float* wp_dgrad, void* stream);
+
+/* Number of per-channel partial-statistics rows conv_fprop writes (each row is 3*Mp_f floats:
+ * count, mean, M2 of one wave's slice of pixels). */
+int64_t mcdseg_conv_stat_rows(const mcdseg_conv_desc* d);
+/* y = conv(x, w) (+ bias).  If stat_partials != NULL also emits the train-mode BatchNorm partials of y
+ * (fused epilogue; nn.BatchNorm2d call sites models/drn.py:34,38,129,179,202). */
+int mcdseg_conv_fprop(const mcdseg_conv_desc* d, const float* x, const float* wp_fprop, const float* bias,
+                      float* y, float* stat_partials, void* stream);
+/* dx = conv_transpose(dy, w)   (autograd of the same call sites) */
+int mcdseg_conv_dgrad(const mcdseg_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* stream);
+/* dw = x (*) dy ; split over pixels into slabs in `workspace`, then reduced in a fixed order. */
+size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d);
+int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm2d (train: batch statistics, eps 1e-5, momentum 0.1; eval: running statistics)
+ * fused with ReLU and the residual add of BasicBlock/Bottleneck (models/drn.py:43-59, 80-100)
+ * ---------------------------------------------------------------------------------------------- */
+/* Merge the conv epilogue partials -> mean[C], rstd[C]; update running_mean/var (unbiased var) and
+ * ++num_batches_tracked when those pointers are non-NULL. */
+int mcdseg_bn_stats_finalize(const float* stat_partials, int64_t rows, int32_t C, int32_t Mp,
+                             float* mean, float* rstd, float* running_mean, float* running_var,
+                             int64_t* num_batches_tracked, float momentum, float eps, void* stream);
+/* eval mode: mean = running_mean, rstd = 1/sqrt(running_var+eps) */
+int mcdseg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps,
+                         float* mean, float* rstd, void* stream);
+/* y = act(gamma*(z-mean)*rstd + beta (+ residual)), act = ReLU if relu != 0 */
+int mcdseg_bn_apply(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    const float* residual, float* y, int32_t N, int32_t C, int32_t HW, int32_t relu, void* stream);
+/* Backward.  dy is the gradient w.r.t. y; y (the saved forward output) supplies the ReLU mask when
+ * relu != 0.  reduce: dgamma[c] = sum dy_m*xhat, dbeta[c] = sum dy_m.  With z == NULL only dbeta is
+ * produced (used for the conv bias gradient, models/dilated_fcn.py:227). */
+size_t mcdseg_bn_bwd_workspace_bytes(int32_t N, int32_t C, int32_t HW);
+int mcdseg_bn_bwd_reduce(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
+                         float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, int32_t relu,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* dz = gamma*rstd*(dy_m - dbeta/n - xhat*dgamma/n) (train) or gamma*rstd*dy_m (eval);
+ * dres (optional) = dy_m, the gradient of the residual branch. */
+int mcdseg_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
+                        const float* gamma, const float* dgamma, const float* dbeta, float* dz, float* dres,
+                        int32_t N, int32_t C, int32_t HW, int32_t relu, int32_t train, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * x8 learned up-sampler: depthwise ConvTranspose2d(C,C,16,stride 8,pad 4,groups=C,bias=False)
+ * (models/dilated_fcn.py:357-366, 479-491).  x [N,C,Hi,Wi] -> y [N,C,8Hi,8Wi], w [C,1,16,16].
+ * With x2/w2 != NULL computes y = up(x,w) + up(x2,w2) (ScoreFusion + AddFusion, models/fusion.py:24-29).
+ * ---------------------------------------------------------------------------------------------- */
+int mcdseg_up8_fwd(const float* x, const float* w, const float* x2, const float* w2, float* y,
+                   int32_t N, int32_t C, int32_t Hi, int32_t Wi, void* stream);
+int mcdseg_up8_bwd_input(const float* dy, const float* w, float* dx, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
+                         void* stream);
+size_t mcdseg_up8_bwd_weight_workspace_bytes(int32_t N, int32_t C, int32_t Hi, int32_t Wi);
+int mcdseg_up8_bwd_weight(const float* dy, const float* x, float* dw, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused per-pixel softmax -> weighted CE (both heads) -> L1 discrepancy, forward + gradient
+ * (loss.py:7-13 CrossEntropyLoss2d, loss.py:93-100 Diff2d; three-step use adapt_trainer.py:163-212)
+ *
+ *   losses[0] = CE(z1,labels)  losses[1] = CE(z2,labels)  losses[2] = mean|softmax(z1)-softmax(z2)|
+ *   losses[3] = sum_i w[y_i]
+ *   g1 = ce_coef * dCE1/dz1 + diff_coef * dDiff/dz1,   g2 likewise for z2.
+ * Any of z2 / labels / g1 / g2 may be NULL (single-head CE, discrepancy only, loss values only).
+ * ---------------------------------------------------------------------------------------------- */
+size_t mcdseg_loss_workspace_bytes(int32_t N, int32_t HW);
+int mcdseg_softmax_ce_l1(const float* z1, const float* z2, const int64_t* labels, const float* class_weight,
+                         int64_t ignore_index, float ce_coef, float diff_coef, float* g1, float* g2, float* losses,
+                         int32_t N, int32_t C, int32_t HW, void* workspace, size_t workspace_bytes, void* stream);
+/* buf[i] *= *scale (device scalar) -- applies autograd's upstream scalar without a host sync */
+int mcdseg_scale_by_device_scalar(float* buf, const float* scale, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SGD with momentum + weight decay on flat buffers (torch.optim.SGD via models/model_util.py:289-292)
+ *   d = g*grad_scale + wd*p ; v = mu*v + d ; p -= lr*v        (v starts at 0, so the first v = d)
+ * ---------------------------------------------------------------------------------------------- */
+int mcdseg_sgd_momentum_flat(float* p, const float* g, float* v, int64_t n, float lr, float momentum,
+                             float weight_decay, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCDSEG_H */

@@ -1,0 +1,366 @@
+// BatchNorm2d pieces around the conv kernels (all HBM-bound streaming / reduction kernels).
+//
+//   stats_finalize : merge the conv epilogue's (count, mean, M2) rows in fp64 -> mean, rstd, running stats
+//   apply          : y = relu(gamma*(z-mean)*rstd + beta + residual)             float4 streaming
+//   bwd_reduce     : dgamma = sum dy_m*xhat, dbeta = sum dy_m  (dy_m = dy masked by y>0)
+//   bwd_apply      : dz = gamma*rstd*(dy_m - dbeta/n - xhat*dgamma/n), dres = dy_m  float4 streaming
+//
+// Reference semantics: nn.BatchNorm2d(eps=1e-5, momentum=0.1) in train mode normalises with the biased
+// batch variance and moves running_var with the unbiased one (models/drn.py:34,38,129,179,202);
+// ReLU is in place after the residual add (models/drn.py:48,55-57).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// finalize: block = 32 channels x 32 row-groups.  Two passes over the partial rows (both cached):
+// pass 1 total count and mean, pass 2 M2 about that mean -- no divisions in the inner loops.
+__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __restrict__ part, int64_t rows, int C, int Mp,
+                                                                  float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                  float* __restrict__ running_mean,
+                                                                  float* __restrict__ running_var, int64_t* nbt,
+                                                                  float momentum, float eps) {
+  __shared__ double sh_a[32][33];
+  __shared__ double sh_b[32][33];
+  const int cx = threadIdx.x & 31;
+  const int g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  const bool cv = c < C;
+  double cnt = 0.0, wsum = 0.0;
+  if (cv) {
+    for (int64_t r = g; r < rows; r += 32) {
+      const float* row = part + (size_t)r * 3 * Mp;
+      const double n = (double)row[c];
+      cnt += n;
+      wsum += n * (double)row[Mp + c];
+    }
+  }
+  sh_a[g][cx] = cnt;
+  sh_b[g][cx] = wsum;
+  __syncthreads();
+  double tot_n = 0.0, tot_s = 0.0;
+  for (int k = 0; k < 32; ++k) {
+    tot_n += sh_a[k][cx];
+    tot_s += sh_b[k][cx];
+  }
+  const double mean = tot_n > 0.0 ? tot_s / tot_n : 0.0;
+  __syncthreads();
+  double m2 = 0.0;
+  if (cv) {
+    for (int64_t r = g; r < rows; r += 32) {
+      const float* row = part + (size_t)r * 3 * Mp;
+      const double n = (double)row[c];
+      const double d = (double)row[Mp + c] - mean;
+      m2 += (double)row[2 * (size_t)Mp + c] + n * d * d;
+    }
+  }
+  sh_a[g][cx] = m2;
+  __syncthreads();
+  if (g == 0 && cv) {
+    double tot_m2 = 0.0;
+    for (int k = 0; k < 32; ++k) tot_m2 += sh_a[k][cx];
+    const double var = tot_n > 0.0 ? tot_m2 / tot_n : 0.0;
+    mean_out[c] = (float)mean;
+    rstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean != nullptr) {
+      const double unbiased = tot_n > 1.0 ? tot_m2 / (tot_n - 1.0) : var;
+      running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+      running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    }
+  }
+  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int C, float eps,
+                                     float* __restrict__ mean, float* __restrict__ rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    mean[c] = rm[c];
+    rstd[c] = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// apply: grid.x = plane (n*C + c), grid.y = chunk of the plane; float4 when HW % 4 == 0.
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ res,
+                                                       float* __restrict__ y, int C, int HW, int relu) {
+  const int plane = blockIdx.x;
+  const int c = plane % C;
+  const float a = gamma[c] * rstd[c];
+  const float b = beta[c] - mean[c] * a;
+  const size_t base = (size_t)plane * HW;
+  if (VEC) {
+    const int n4 = HW >> 2;
+    const float4* z4 = reinterpret_cast<const float4*>(z + base);
+    const float4* r4 = res ? reinterpret_cast<const float4*>(res + base) : nullptr;
+    float4* y4 = reinterpret_cast<float4*>(y + base);
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n4; i += gridDim.y * blockDim.x) {
+      float4 v = z4[i];
+      v.x = fmaf(v.x, a, b); v.y = fmaf(v.y, a, b); v.z = fmaf(v.z, a, b); v.w = fmaf(v.w, a, b);
+      if (r4) {
+        const float4 q = r4[i];
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      if (relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      y4[i] = v;
+    }
+  } else {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < HW; i += gridDim.y * blockDim.x) {
+      float v = fmaf(z[base + i], a, b);
+      if (res) v += res[base + i];
+      if (relu) v = fmaxf(v, 0.f);
+      y[base + i] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward reduce: grid = (C, S).  Split s covers work items (n, chunk) with item = s, s+S, ...
+struct BwdPlan {
+  int cpp;    // chunks per plane
+  int chunk;  // elements per chunk (multiple of 4 when HW % 4 == 0)
+  int S;      // splits per channel
+};
+
+BwdPlan bwd_plan(int N, int C, int HW) {
+  BwdPlan pl;
+  int64_t want = ceil_div64(2048, C);  // splits per channel to fill the chip
+  int cpp = (int)ceil_div64(want, N);
+  const int max_cpp = HW / 2048 > 0 ? HW / 2048 : 1;
+  if (cpp > max_cpp) cpp = max_cpp;
+  if (cpp < 1) cpp = 1;
+  int chunk = ceil_div(HW, cpp);
+  chunk = round_up(chunk, 4);
+  pl.cpp = ceil_div(HW, chunk);
+  pl.chunk = chunk;
+  int64_t items = (int64_t)N * pl.cpp;
+  pl.S = (int)(items < want ? items : want);
+  if (pl.S < 1) pl.S = 1;
+  return pl;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                            const float* __restrict__ z, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ part, int N,
+                                                            int C, int HW, int relu, int cpp, int chunk) {
+  const int c = blockIdx.x;
+  const int S = gridDim.y;
+  const float mu = z ? mean[c] : 0.f;
+  const float rs = z ? rstd[c] : 0.f;
+  float s_dy = 0.f, s_dyx = 0.f;
+  const int items = N * cpp;
+  for (int item = blockIdx.y; item < items; item += S) {
+    const int n = item / cpp;
+    const int ch = item - n * cpp;
+    const int e0 = ch * chunk;
+    int e1 = e0 + chunk;
+    if (e1 > HW) e1 = HW;
+    const size_t base = ((size_t)n * C + c) * HW;
+    if (VEC) {
+      const float4* dy4 = reinterpret_cast<const float4*>(dy + base);
+      const float4* y4 = reinterpret_cast<const float4*>(y ? y + base : nullptr);
+      const float4* z4 = reinterpret_cast<const float4*>(z ? z + base : nullptr);
+      for (int i = (e0 >> 2) + threadIdx.x; i < (e1 >> 2); i += 256) {
+        float4 g = dy4[i];
+        if (relu) {
+          const float4 o = y4[i];
+          g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
+          g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+        }
+        s_dy += (g.x + g.y) + (g.z + g.w);
+        if (z) {
+          const float4 v = z4[i];
+          s_dyx += (g.x * ((v.x - mu) * rs) + g.y * ((v.y - mu) * rs)) + (g.z * ((v.z - mu) * rs) + g.w * ((v.w - mu) * rs));
+        }
+      }
+    } else {
+      for (int i = e0 + threadIdx.x; i < e1; i += 256) {
+        float g = dy[base + i];
+        if (relu && !(y[base + i] > 0.f)) g = 0.f;
+        s_dy += g;
+        if (z) s_dyx += g * ((z[base + i] - mu) * rs);
+      }
+    }
+  }
+  __shared__ float sh[2][4];
+  s_dy = wave_sum(s_dy);
+  s_dyx = wave_sum(s_dyx);
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = s_dy;
+    sh[1][threadIdx.x >> 6] = s_dyx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[((size_t)blockIdx.y * 2 + 0) * C + c] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    part[((size_t)blockIdx.y * 2 + 1) * C + c] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int S, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < S; ++s) {
+    a += (double)part[((size_t)s * 2 + 0) * C + c];
+    b += (double)part[((size_t)s * 2 + 1) * C + c];
+  }
+  if (dbeta) dbeta[c] = (float)a;
+  if (dgamma) dgamma[c] = (float)b;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           const float* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                           float* __restrict__ dz, float* __restrict__ dres, int N, int C,
+                                                           int HW, int relu, int train) {
+  const int plane = blockIdx.x;
+  const int c = plane % C;
+  const float mu = mean[c], rs = rstd[c];
+  const float a = gamma[c] * rs;
+  const float inv_n = 1.f / ((float)N * (float)HW);
+  const float k1 = train ? dbeta[c] * inv_n : 0.f;
+  const float k2 = train ? dgamma[c] * inv_n : 0.f;
+  const size_t base = (size_t)plane * HW;
+  if (VEC) {
+    const int n4 = HW >> 2;
+    const float4* dy4 = reinterpret_cast<const float4*>(dy + base);
+    const float4* y4 = reinterpret_cast<const float4*>(y ? y + base : nullptr);
+    const float4* z4 = reinterpret_cast<const float4*>(z + base);
+    float4* dz4 = reinterpret_cast<float4*>(dz + base);
+    float4* dr4 = dres ? reinterpret_cast<float4*>(dres + base) : nullptr;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n4; i += gridDim.y * blockDim.x) {
+      float4 g = dy4[i];
+      if (relu) {
+        const float4 o = y4[i];
+        g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
+        g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+      }
+      if (dr4) dr4[i] = g;
+      const float4 v = z4[i];
+      float4 o;
+      o.x = a * (g.x - k1 - ((v.x - mu) * rs) * k2);
+      o.y = a * (g.y - k1 - ((v.y - mu) * rs) * k2);
+      o.z = a * (g.z - k1 - ((v.z - mu) * rs) * k2);
+      o.w = a * (g.w - k1 - ((v.w - mu) * rs) * k2);
+      dz4[i] = o;
+    }
+  } else {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < HW; i += gridDim.y * blockDim.x) {
+      float g = dy[base + i];
+      if (relu && !(y[base + i] > 0.f)) g = 0.f;
+      if (dres) dres[base + i] = g;
+      dz[base + i] = a * (g - k1 - ((z[base + i] - mu) * rs) * k2);
+    }
+  }
+}
+
+int plane_chunks(int HW, bool vec) {
+  const int work = vec ? HW / 4 : HW;
+  int chunks = ceil_div(work, 256 * 4);  // ~4 elements (float4s) per thread
+  if (chunks < 1) chunks = 1;
+  if (chunks > 1024) chunks = 1024;
+  return chunks;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int mcdseg_bn_stats_finalize(const float* stat_partials, int64_t rows, int32_t C, int32_t Mp, float* mean, float* rstd,
+                                        float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                        float eps, void* stream) {
+  MCD_REQUIRE(stat_partials && mean && rstd, "bn_stats_finalize: null pointer");
+  MCD_REQUIRE(rows > 0 && C > 0 && Mp >= C, "bn_stats_finalize: bad dims rows=%lld C=%d Mp=%d", (long long)rows, C, Mp);
+  MCD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize: running stats must come in pairs");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, (hipStream_t)stream, stat_partials, rows, C,
+                     Mp, mean, rstd, running_mean, running_var, num_batches_tracked, momentum, eps);
+  MCD_LAUNCH_CHECK("bn_stats_finalize");
+  return 0;
+}
+
+extern "C" int mcdseg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps, float* mean,
+                                    float* rstd, void* stream) {
+  MCD_REQUIRE(running_mean && running_var && mean && rstd && C > 0, "bn_eval_stats: bad arguments");
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean, running_var,
+                     C, eps, mean, rstd);
+  MCD_LAUNCH_CHECK("bn_eval_stats");
+  return 0;
+}
+
+extern "C" int mcdseg_bn_apply(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                               const float* residual, float* y, int32_t N, int32_t C, int32_t HW, int32_t relu, void* stream) {
+  MCD_REQUIRE(z && mean && rstd && gamma && beta && y, "bn_apply: null pointer");
+  MCD_REQUIRE(N > 0 && C > 0 && HW > 0, "bn_apply: bad dims");
+  const bool vec = (HW % 4 == 0) && aligned16(z) && aligned16(y) && (!residual || aligned16(residual));
+  dim3 grid(N * C, plane_chunks(HW, vec));
+  if (vec)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual, y, C,
+                       HW, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual, y, C,
+                       HW, relu);
+  MCD_LAUNCH_CHECK("bn_apply");
+  return 0;
+}
+
+extern "C" size_t mcdseg_bn_bwd_workspace_bytes(int32_t N, int32_t C, int32_t HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  const BwdPlan pl = bwd_plan(N, C, HW);
+  return (size_t)pl.S * 2 * C * sizeof(float);
+}
+
+extern "C" int mcdseg_bn_bwd_reduce(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
+                                    float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, int32_t relu, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  MCD_REQUIRE(dy && workspace && (dgamma || dbeta), "bn_bwd_reduce: null pointer");
+  MCD_REQUIRE(!relu || y, "bn_bwd_reduce: relu mask needs y");
+  MCD_REQUIRE(!z || (mean && rstd), "bn_bwd_reduce: z needs mean/rstd");
+  MCD_REQUIRE(N > 0 && C > 0 && HW > 0, "bn_bwd_reduce: bad dims");
+  const BwdPlan pl = bwd_plan(N, C, HW);
+  MCD_REQUIRE(workspace_bytes >= (size_t)pl.S * 2 * C * sizeof(float), "bn_bwd_reduce: workspace too small");
+  MCD_REQUIRE(pl.S <= 65535, "bn_bwd_reduce: too many splits");
+  const bool vec = (HW % 4 == 0) && aligned16(dy) && (!y || aligned16(y)) && (!z || aligned16(z));
+  dim3 grid(C, pl.S);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, (float*)workspace, N, C, HW, relu,
+                       pl.cpp, pl.chunk);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, (float*)workspace, N, C, HW,
+                       relu, pl.cpp, pl.chunk);
+  MCD_LAUNCH_CHECK("bn_bwd_reduce");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float*)workspace, pl.S, C,
+                     z ? dgamma : nullptr, dbeta);
+  MCD_LAUNCH_CHECK("bn_bwd_finalize");
+  return 0;
+}
+
+extern "C" int mcdseg_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
+                                   const float* gamma, const float* dgamma, const float* dbeta, float* dz, float* dres, int32_t N,
+                                   int32_t C, int32_t HW, int32_t relu, int32_t train, void* stream) {
+  MCD_REQUIRE(dy && z && mean && rstd && gamma && dz, "bn_bwd_apply: null pointer");
+  MCD_REQUIRE(!relu || y, "bn_bwd_apply: relu mask needs y");
+  MCD_REQUIRE(!train || (dgamma && dbeta), "bn_bwd_apply: train mode needs dgamma/dbeta");
+  MCD_REQUIRE(N > 0 && C > 0 && HW > 0, "bn_bwd_apply: bad dims");
+  const bool vec = (HW % 4 == 0) && aligned16(dy) && aligned16(z) && aligned16(dz) && (!y || aligned16(y)) &&
+                   (!dres || aligned16(dres));
+  dim3 grid(N * C, plane_chunks(HW, vec));
+  hipStream_t st = (hipStream_t)stream;
+  if (vec)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres, N,
+                       C, HW, relu, train);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres, N,
+                       C, HW, relu, train);
+  MCD_LAUNCH_CHECK("bn_bwd_apply");
+  return 0;
+}

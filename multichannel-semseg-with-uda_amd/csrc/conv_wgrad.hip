@@ -1,0 +1,244 @@
+// Weight-gradient convolution on the f32-input MFMA of gfx950.
+//
+//   dW[co][ci][tap] = sum_{n,oy,ox} dY[n][co][oy][ox] * X[n][ci][oy*s + ky*d - pad][ox*s + kx*d - pad]
+//
+// GEMM view per tap: D[co][ci] = A[co][pix] * B[pix][ci], contraction over pixels.  Both operands are
+// pixel-contiguous in NCHW, so each wave instruction of the staging loop reads two 128-B pixel runs;
+// the LDS image is [row][32 pixels + 1 pad] which makes the transposed MFMA fragment reads
+// (32 consecutive rows, one pixel) conflict-free.  The pixel axis is split over workgroups
+// (image x chunk); every workgroup writes its partial D tile to a slab and a second kernel sums the
+// slabs in a fixed order (fp64 accumulate) -- deterministic, no float atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int BKP = 32;        // pixels per K-step
+constexpr int LDP = BKP + 1;   // padded LDS row
+
+struct WgradParams {
+  const float* x;
+  const float* dy;
+  float* slab;
+  int N, Cin, H, W, Cout, Ho, Wo;
+  int KH, KW, stride, pad, dil;
+  int co_p, ci_p;
+  int chunk, chunks_per_img;
+};
+
+struct WgradPlan {
+  int cfg;  // 0: 128x128, 1: 64x64, 2: 32x32 (one wave)
+  int bm, bn;
+  int co_p, ci_p;
+  int chunk, chunks_per_img, splits;
+  int64_t slab_floats;
+};
+
+WgradPlan make_plan(const mcdseg_conv_desc* d) {
+  WgradPlan pl;
+  const int lo = d->Cout < d->Cin ? d->Cout : d->Cin;
+  if (lo > 64) {
+    pl.cfg = 0; pl.bm = 128; pl.bn = 128;
+  } else if (lo > 32) {
+    pl.cfg = 1; pl.bm = 64; pl.bn = 64;
+  } else {
+    pl.cfg = 2; pl.bm = 32; pl.bn = 32;
+  }
+  pl.co_p = round_up(d->Cout, pl.bm);
+  pl.ci_p = round_up(d->Cin, pl.bn);
+  const int T = d->KH * d->KW;
+  const int64_t tiles = (int64_t)(pl.co_p / pl.bm) * (pl.ci_p / pl.bn) * T;
+  const int64_t want_wgs = pl.cfg == 2 ? 4096 : 1024;
+  const int64_t want_splits = ceil_div64(want_wgs, tiles);
+  const int hw = d->Ho * d->Wo;
+  int cpi = (int)ceil_div64(want_splits, d->N);
+  if (cpi < 1) cpi = 1;
+  int chunk = round_up(ceil_div(hw, cpi), BKP);
+  if (chunk < 8 * BKP) chunk = 8 * BKP;  // at least 8 K-steps of work per workgroup
+  if (chunk > round_up(hw, BKP)) chunk = round_up(hw, BKP);
+  pl.chunk = chunk;
+  pl.chunks_per_img = ceil_div(hw, chunk);
+  pl.splits = d->N * pl.chunks_per_img;
+  pl.slab_floats = (int64_t)pl.splits * T * pl.co_p * pl.ci_p;
+  return pl;
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_wgrad_kernel(WgradParams p) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int BM = 32 * WM * WAVES_M;
+  constexpr int BN = 32 * WN * WAVES_N;
+  constexpr int RP = NT / 32;  // rows staged per pass
+  constexpr int A_ITERS = BM / RP;
+  constexpr int B_ITERS = BN / RP;
+
+  __shared__ float smem[2 * (BM + BN) * LDP];
+  float* As = smem;                  // [2][BM][LDP]
+  float* Bs = smem + 2 * BM * LDP;   // [2][BN][LDP]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int tile_co = blockIdx.x;
+  const int ci_tiles = p.ci_p / BN;
+  const int tap = blockIdx.y / ci_tiles;
+  const int tile_ci = blockIdx.y - tap * ci_tiles;
+  const int split = blockIdx.z;
+  const int n = split / p.chunks_per_img;
+  const int chunk_id = split - n * p.chunks_per_img;
+  const int ky = tap / p.KW;
+  const int kx = tap - ky * p.KW;
+  const int HoWo = p.Ho * p.Wo;
+  const int HW = p.H * p.W;
+  const int r_begin = chunk_id * p.chunk;
+  int r_end = r_begin + p.chunk;
+  if (r_end > HoWo) r_end = HoWo;
+
+  const int sk = t & 31;
+  const int srg = t >> 5;
+  const float* dy_n = p.dy + (size_t)n * p.Cout * HoWo;
+  const float* x_n = p.x + (size_t)n * p.Cin * HW;
+  const int co0 = tile_co * BM + srg;
+  const int ci0 = tile_ci * BN + srg;
+
+  float areg[A_ITERS], breg[B_ITERS];
+  auto load_regs = [&](int r0) {
+    const int r = r0 + sk;
+    const bool rv = r < r_end;
+    int xoff = 0;
+    bool xv = false;
+    if (rv) {
+      const int oy = r / p.Wo;
+      const int ox = r - oy * p.Wo;
+      const int iy = oy * p.stride + ky * p.dil - p.pad;
+      const int ix = ox * p.stride + kx * p.dil - p.pad;
+      xv = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      xoff = iy * p.W + ix;
+    }
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int co = co0 + i * RP;
+      areg[i] = (rv && co < p.Cout) ? dy_n[(size_t)co * HoWo + r] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      const int ci = ci0 + i * RP;
+      breg[i] = (xv && ci < p.Cin) ? x_n[(size_t)ci * HW + xoff] : 0.f;
+    }
+  };
+  auto store_lds = [&](int buf) {
+    float* a = As + buf * BM * LDP;
+    float* b = Bs + buf * BN * LDP;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) a[(srg + i * RP) * LDP + sk] = areg[i];
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) b[(srg + i * RP) * LDP + sk] = breg[i];
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nsteps = (r_end - r_begin + BKP - 1) / BKP;
+  if (nsteps > 0) {
+    load_regs(r_begin);
+    store_lds(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int cur = s & 1;
+    const bool more = (s + 1) < nsteps;
+    if (more) load_regs(r_begin + (s + 1) * BKP);
+    const float* a_base = As + cur * BM * LDP + (wm * 32 * WM + l31) * LDP + lh;
+    const float* b_base = Bs + cur * BN * LDP + (wn * 32 * WN + l31) * LDP + lh;
+#pragma unroll
+    for (int kk = 0; kk < BKP; kk += 2) {
+      float a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = a_base[i * 32 * LDP + kk];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = b_base[j * 32 * LDP + kk];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  const int T = p.KH * p.KW;
+  float* out = p.slab + ((size_t)split * T + tap) * p.co_p * p.ci_p;
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tile_co * BM + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int col = tile_ci * BN + wn * 32 * WN + j * 32 + l31;
+        out[(size_t)row * p.ci_p + col] = acc[i][j][r];
+      }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int T, int co_p,
+                                    int ci_p, int splits) {
+  const int64_t total = (int64_t)T * Cout * Cin;
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ci = (int)(i % Cin);
+  const int64_t r = i / Cin;
+  const int co = (int)(r % Cout);
+  const int tap = (int)(r / Cout);
+  const size_t stride = (size_t)T * co_p * ci_p;
+  const float* src = slab + ((size_t)tap * co_p + co) * ci_p + ci;
+  double s = 0.0;
+  for (int k = 0; k < splits; ++k) s += (double)src[(size_t)k * stride];
+  dw[((size_t)co * Cin + ci) * T + tap] = (float)s;
+}
+
+}  // namespace
+
+extern "C" size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d) {
+  if (d == nullptr) return 0;
+  return (size_t)make_plan(d).slab_floats * sizeof(float);
+}
+
+extern "C" int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  MCD_REQUIRE(d && x && dy && dw && workspace, "conv_wgrad: null pointer");
+  MCD_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0, "conv_wgrad: bad dims");
+  const WgradPlan pl = make_plan(d);
+  MCD_REQUIRE(workspace_bytes >= (size_t)pl.slab_floats * sizeof(float), "conv_wgrad: workspace too small (%zu < %zu)",
+              workspace_bytes, (size_t)pl.slab_floats * sizeof(float));
+  MCD_REQUIRE(pl.splits <= 65535, "conv_wgrad: too many splits (%d)", pl.splits);
+  const int T = d->KH * d->KW;
+  WgradParams p;
+  p.x = x; p.dy = dy; p.slab = (float*)workspace;
+  p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+  p.co_p = pl.co_p; p.ci_p = pl.ci_p; p.chunk = pl.chunk; p.chunks_per_img = pl.chunks_per_img;
+  dim3 grid(pl.co_p / pl.bm, (pl.ci_p / pl.bn) * T, pl.splits);
+  MCD_REQUIRE(grid.y <= 65535, "conv_wgrad: grid.y too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (pl.cfg == 0)
+    hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+  else if (pl.cfg == 1)
+    hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 2>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 1>), grid, dim3(64), 0, st, p);
+  MCD_LAUNCH_CHECK("conv_wgrad");
+  const int64_t total = (int64_t)T * d->Cout * d->Cin;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
+                     d->Cout, d->Cin, T, pl.co_p, pl.ci_p, pl.splits);
+  MCD_LAUNCH_CHECK("conv_wgrad_reduce");
+  return 0;
+}

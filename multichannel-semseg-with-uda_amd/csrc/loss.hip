@@ -1,0 +1,257 @@
+// Fused per-pixel softmax -> weighted cross-entropy (one or two heads) -> L1 discrepancy, with the
+// gradients w.r.t. both logit tensors written in the same pass.
+//
+// Reference ops this replaces (each a separate full-tensor ATen pass over [N,C,H,W]):
+//   CrossEntropyLoss2d = log_softmax(dim 1) + weighted-mean NLL   (loss.py:7-13)
+//   Diff2d             = mean |softmax(o1) - softmax(o2)|          (loss.py:93-100)
+// Maths, per pixel i, p = softmax(z), W = sum_i w[y_i], M = N*C*H*W:
+//   dCE/dz_c   = w[y_i] (p_c - [c == y_i]) / W
+//   dDiff/dz1_c =  p1_c (s_c - sum_k s_k p1_k),  dDiff/dz2_c = -p2_c (s_c - sum_k s_k p2_k),  s = sign(p1-p2)/M
+//
+// One lane owns one pixel and keeps all C logits of both heads in registers; the class stride of NCHW is
+// H*W so every per-class load/store of a wave is one contiguous 256-B run.  Algorithmic traffic:
+// (2C reads + 2C writes) * 4 B + 8 B label per pixel; everything else stays in registers.
+#include "common.h"
+
+namespace {
+
+constexpr int LOSS_BLOCK = 256;
+
+__global__ __launch_bounds__(256) void label_wsum_kernel(const int64_t* __restrict__ labels, const float* __restrict__ cw,
+                                                         int64_t ignore_index, int C, int64_t P, float* __restrict__ part) {
+  float s = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t y = labels[i];
+    if (y != ignore_index && y >= 0 && y < C) s += cw ? cw[y] : 1.f;
+  }
+  __shared__ float sh[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void wsum_finalize_kernel(const float* __restrict__ part, int n, float* __restrict__ losses) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)part[i];
+  __shared__ double sh[4];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) losses[3] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+
+template <int NCMAX, bool TWO>
+__global__ __launch_bounds__(256) void softmax_ce_l1_kernel(const float* __restrict__ z1, const float* __restrict__ z2,
+                                                            const int64_t* __restrict__ labels, const float* __restrict__ cw,
+                                                            int64_t ignore_index, float ce_coef, float diff_coef,
+                                                            const float* __restrict__ losses_w, float* __restrict__ g1,
+                                                            float* __restrict__ g2, float* __restrict__ part, int C, int HW,
+                                                            int64_t P, float inv_m) {
+  const int64_t pix = blockIdx.x * (int64_t)LOSS_BLOCK + threadIdx.x;
+  const bool valid = pix < P;
+  float ce1 = 0.f, ce2 = 0.f, dsum = 0.f;
+  if (valid) {
+    const int64_t n = pix / HW;
+    const int hw = (int)(pix - n * HW);
+    const size_t base = (size_t)n * C * HW + hw;
+    float a[NCMAX], b[NCMAX];
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c) {
+      a[c] = (c < C) ? z1[base + (size_t)c * HW] : -INFINITY;
+      if (TWO) b[c] = (c < C) ? z2[base + (size_t)c * HW] : -INFINITY;
+    }
+    int y = -1;
+    float wy = 0.f;
+    if (labels != nullptr) {
+      const int64_t yl = labels[pix];
+      if (yl != ignore_index && yl >= 0 && yl < C) {
+        y = (int)yl;
+        wy = cw ? cw[y] : 1.f;
+      }
+    }
+    float m1 = a[0], m2 = TWO ? b[0] : 0.f;
+#pragma unroll
+    for (int c = 1; c < NCMAX; ++c) {
+      m1 = fmaxf(m1, a[c]);
+      if (TWO) m2 = fmaxf(m2, b[c]);
+    }
+    float s1 = 0.f, s2 = 0.f, zy1 = 0.f, zy2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c) {
+      if (c == y) {
+        zy1 = a[c];
+        if (TWO) zy2 = b[c];
+      }
+      a[c] = (c < C) ? expf(a[c] - m1) : 0.f;
+      s1 += a[c];
+      if (TWO) {
+        b[c] = (c < C) ? expf(b[c] - m2) : 0.f;
+        s2 += b[c];
+      }
+    }
+    if (y >= 0) {
+      ce1 = wy * ((m1 + logf(s1)) - zy1);
+      if (TWO) ce2 = wy * ((m2 + logf(s2)) - zy2);
+    }
+    const float r1 = 1.f / s1, r2 = TWO ? 1.f / s2 : 0.f;
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c) {
+      a[c] *= r1;
+      if (TWO) {
+        b[c] *= r2;
+        const float d = a[c] - b[c];
+        const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+        dsum += fabsf(d);
+        t1 = fmaf(sg, a[c], t1);
+        t2 = fmaf(sg, b[c], t2);
+      }
+    }
+    if (g1 != nullptr || g2 != nullptr) {
+      const float kce = (ce_coef != 0.f && y >= 0) ? ce_coef * wy / losses_w[3] : 0.f;
+      const float kd = diff_coef * inv_m;
+#pragma unroll
+      for (int c = 0; c < NCMAX; ++c) {
+        if (c < C) {
+          const float oh = (c == y) ? 1.f : 0.f;
+          float sg = 0.f;
+          if (TWO) {
+            const float d = a[c] - b[c];
+            sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+          }
+          if (g1 != nullptr) g1[base + (size_t)c * HW] = kce * (a[c] - oh) + (TWO ? kd * a[c] * (sg - t1) : 0.f);
+          if (TWO && g2 != nullptr) g2[base + (size_t)c * HW] = kce * (b[c] - oh) - kd * b[c] * (sg - t2);
+        }
+      }
+    }
+  }
+  __shared__ float sh[3][4];
+  ce1 = wave_sum(ce1);
+  ce2 = wave_sum(ce2);
+  dsum = wave_sum(dsum);
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = ce1;
+    sh[1][threadIdx.x >> 6] = ce2;
+    sh[2][threadIdx.x >> 6] = dsum;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int q = threadIdx.x;
+    part[(size_t)blockIdx.x * 3 + q] = (sh[q][0] + sh[q][1]) + (sh[q][2] + sh[q][3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ part, int64_t nblk, float* __restrict__ losses,
+                                                            double inv_m) {
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int64_t i = threadIdx.x; i < nblk; i += 256) {
+    s[0] += (double)part[i * 3 + 0];
+    s[1] += (double)part[i * 3 + 1];
+    s[2] += (double)part[i * 3 + 2];
+  }
+  __shared__ double sh[3][4];
+  for (int q = 0; q < 3; ++q) {
+    const double v = wave_sum_d(s[q]);
+    if ((threadIdx.x & 63) == 0) sh[q][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double W = (double)losses[3];
+    const double c1 = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    const double c2 = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    const double d = (sh[2][0] + sh[2][1]) + (sh[2][2] + sh[2][3]);
+    losses[0] = (W == 0.0 && c1 == 0.0) ? 0.f : (float)(c1 / W);
+    losses[1] = (W == 0.0 && c2 == 0.0) ? 0.f : (float)(c2 / W);
+    losses[2] = (float)(d * inv_m);
+  }
+}
+
+__global__ void scale_by_device_scalar_kernel(float* __restrict__ buf, const float* __restrict__ scale, int64_t n4, int64_t n) {
+  const float s = *scale;
+  float4* b4 = reinterpret_cast<float4*>(buf);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 v = b4[i];
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    b4[i] = v;
+  }
+  for (int64_t i = n4 * 4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) buf[i] *= s;
+}
+
+int wsum_blocks(int64_t P) {
+  const int64_t b = ceil_div64(P, 256 * 8);
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+template <int NCMAX>
+void launch_loss(bool two, dim3 grid, hipStream_t st, const float* z1, const float* z2, const int64_t* labels, const float* cw,
+                 int64_t ignore_index, float ce_coef, float diff_coef, const float* losses, float* g1, float* g2, float* part,
+                 int C, int HW, int64_t P, float inv_m) {
+  if (two)
+    hipLaunchKernelGGL((softmax_ce_l1_kernel<NCMAX, true>), grid, dim3(LOSS_BLOCK), 0, st, z1, z2, labels, cw, ignore_index, ce_coef,
+                       diff_coef, losses, g1, g2, part, C, HW, P, inv_m);
+  else
+    hipLaunchKernelGGL((softmax_ce_l1_kernel<NCMAX, false>), grid, dim3(LOSS_BLOCK), 0, st, z1, z2, labels, cw, ignore_index,
+                       ce_coef, diff_coef, losses, g1, g2, part, C, HW, P, inv_m);
+}
+
+}  // namespace
+
+extern "C" size_t mcdseg_loss_workspace_bytes(int32_t N, int32_t HW) {
+  if (N <= 0 || HW <= 0) return 0;
+  const int64_t P = (int64_t)N * HW;
+  return (size_t)(ceil_div64(P, LOSS_BLOCK) * 3 + wsum_blocks(P)) * sizeof(float);
+}
+
+extern "C" int mcdseg_softmax_ce_l1(const float* z1, const float* z2, const int64_t* labels, const float* class_weight,
+                                    int64_t ignore_index, float ce_coef, float diff_coef, float* g1, float* g2, float* losses,
+                                    int32_t N, int32_t C, int32_t HW, void* workspace, size_t workspace_bytes, void* stream) {
+  MCD_REQUIRE(z1 && losses && workspace, "softmax_ce_l1: null pointer");
+  MCD_REQUIRE(N > 0 && C > 0 && HW > 0, "softmax_ce_l1: bad dims");
+  MCD_REQUIRE(C <= 48, "softmax_ce_l1: at most 48 classes are kept in registers (got %d)", C);
+  MCD_REQUIRE(z2 != nullptr || (g2 == nullptr && diff_coef == 0.f), "softmax_ce_l1: discrepancy needs z2");
+  MCD_REQUIRE(labels != nullptr || ce_coef == 0.f, "softmax_ce_l1: cross-entropy needs labels");
+  MCD_REQUIRE(workspace_bytes >= mcdseg_loss_workspace_bytes(N, HW), "softmax_ce_l1: workspace too small");
+  const int64_t P = (int64_t)N * HW;
+  const int64_t nblk = ceil_div64(P, LOSS_BLOCK);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  float* wpart = part + nblk * 3;
+  const int wb = wsum_blocks(P);
+  if (labels != nullptr) {
+    hipLaunchKernelGGL(label_wsum_kernel, dim3(wb), dim3(256), 0, st, labels, class_weight, ignore_index, C, P, wpart);
+    MCD_LAUNCH_CHECK("label_wsum");
+    hipLaunchKernelGGL(wsum_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)wpart, wb, losses);
+    MCD_LAUNCH_CHECK("wsum_finalize");
+  } else {
+    (void)hipMemsetAsync(losses + 3, 0, sizeof(float), st);
+  }
+  const double inv_m = 1.0 / ((double)P * (double)C);
+  dim3 grid((unsigned)nblk);
+  const bool two = z2 != nullptr;
+  if (C <= 16)
+    launch_loss<16>(two, grid, st, z1, z2, labels, class_weight, ignore_index, ce_coef, diff_coef, losses, g1, g2, part, C, HW, P,
+                    (float)inv_m);
+  else if (C <= 24)
+    launch_loss<24>(two, grid, st, z1, z2, labels, class_weight, ignore_index, ce_coef, diff_coef, losses, g1, g2, part, C, HW, P,
+                    (float)inv_m);
+  else
+    launch_loss<48>(two, grid, st, z1, z2, labels, class_weight, ignore_index, ce_coef, diff_coef, losses, g1, g2, part, C, HW, P,
+                    (float)inv_m);
+  MCD_LAUNCH_CHECK("softmax_ce_l1");
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nblk, losses, inv_m);
+  MCD_LAUNCH_CHECK("loss_finalize");
+  return 0;
+}
+
+extern "C" int mcdseg_scale_by_device_scalar(float* buf, const float* scale, int64_t n, void* stream) {
+  MCD_REQUIRE(buf && scale && n >= 0, "scale_by_device_scalar: bad arguments");
+  if (n == 0) return 0;
+  MCD_REQUIRE((reinterpret_cast<uintptr_t>(buf) & 15) == 0, "scale_by_device_scalar: buffer must be 16-byte aligned");
+  const int64_t n4 = n / 4;
+  int64_t blocks = ceil_div64(n4 > 0 ? n4 : n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scale_by_device_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, buf, scale, n4, n);
+  MCD_LAUNCH_CHECK("scale_by_device_scalar");
+  return 0;
+}

@@ -1,0 +1,102 @@
+"""ctypes loader / builder for libmcdseg.so (C ABI: include/mcdseg.h)."""
+import ctypes
+import glob
+import os
+import subprocess
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+REPO = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INCLUDE = os.path.join(REPO, "include")
+LIB_PATH = os.path.join(HERE, "libmcdseg.so")
+
+c_void_p, c_int, c_i32, c_i64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64,
+                                                    ctypes.c_float, ctypes.c_size_t)
+
+
+class ConvDesc(ctypes.Structure):
+    """mirror of ``mcdseg_conv_desc``"""
+    _fields_ = [(n, c_i32) for n in ("N", "Cin", "H", "W", "Cout", "KH", "KW", "stride", "pad", "dil", "Ho", "Wo")]
+
+
+_P = ctypes.POINTER
+_SIGNATURES = {
+    # name: (restype, argtypes)   -- one entry per symbol declared in include/mcdseg.h
+    "mcdseg_version": (c_int, []),
+    "mcdseg_last_error": (ctypes.c_char_p, []),
+    "mcdseg_conv_packed_dims": (c_int, [_P(ConvDesc), _P(c_i32), _P(c_i32), _P(c_i32), _P(c_i32)]),
+    "mcdseg_conv_pack_weights": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mcdseg_conv_stat_rows": (c_i64, [_P(ConvDesc)]),
+    "mcdseg_conv_fprop": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mcdseg_conv_dgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mcdseg_conv_wgrad_workspace_bytes": (c_size_t, [_P(ConvDesc)]),
+    "mcdseg_conv_wgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mcdseg_bn_stats_finalize": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_float, c_float, c_void_p]),
+    "mcdseg_bn_eval_stats": (c_int, [c_void_p, c_void_p, c_i32, c_float, c_void_p, c_void_p, c_void_p]),
+    "mcdseg_bn_apply": (c_int, [c_void_p] * 7 + [c_i32] * 4 + [c_void_p]),
+    "mcdseg_bn_bwd_workspace_bytes": (c_size_t, [c_i32, c_i32, c_i32]),
+    "mcdseg_bn_bwd_reduce": (c_int, [c_void_p] * 7 + [c_i32] * 4 + [c_void_p, c_size_t, c_void_p]),
+    "mcdseg_bn_bwd_apply": (c_int, [c_void_p] * 10 + [c_i32] * 5 + [c_void_p]),
+    "mcdseg_up8_fwd": (c_int, [c_void_p] * 5 + [c_i32] * 4 + [c_void_p]),
+    "mcdseg_up8_bwd_input": (c_int, [c_void_p] * 3 + [c_i32] * 4 + [c_void_p]),
+    "mcdseg_up8_bwd_weight_workspace_bytes": (c_size_t, [c_i32] * 4),
+    "mcdseg_up8_bwd_weight": (c_int, [c_void_p] * 3 + [c_i32] * 4 + [c_void_p, c_size_t, c_void_p]),
+    "mcdseg_loss_workspace_bytes": (c_size_t, [c_i32, c_i32]),
+    "mcdseg_softmax_ce_l1": (c_int, [c_void_p] * 4 + [c_i64, c_float, c_float] + [c_void_p] * 3 + [c_i32] * 3 +
+                             [c_void_p, c_size_t, c_void_p]),
+    "mcdseg_scale_by_device_scalar": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
+    "mcdseg_sgd_momentum_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_float, c_void_p]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+_lock = threading.Lock()
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into mcdseg/libmcdseg.so (in-tree, so it travels with the repo)."""
+    srcs = sources()
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC,
+           "-o", LIB_PATH + ".tmp"] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError("libmcdseg.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                       "-- the HIP kernels are the only implementation, there is no fallback" % LIB_PATH)
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in _SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                if handle.mcdseg_version() != 100:
+                    raise RuntimeError("libmcdseg.so version mismatch: %d" % handle.mcdseg_version())
+                _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().mcdseg_last_error()
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

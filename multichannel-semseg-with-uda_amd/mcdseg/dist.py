@@ -1,0 +1,61 @@
+"""Data-parallel plumbing: one process per GPU, gradients summed by RCCL over xGMI.
+
+The reference's only multi-GPU mechanism is single-process ``nn.DataParallel``
+(models/model_util.py:36-37, 283-284).  Here every rank owns one MI355X and a full replica; after a
+backward pass the optimizer all-reduces its *flat* gradient buffer with one collective
+(``torch.distributed`` backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests) and the 1/world
+scale is folded into the SGD kernel.  BatchNorm uses per-rank batch statistics, as DataParallel's
+replicas do.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def init_from_env(backend=None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract).
+    Returns (rank, world, local_rank); a no-op for single-process runs."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world <= 1:
+        return 0, 1, local
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend)
+    return dist.get_rank(), dist.get_world_size(), local
+
+
+def all_reduce_sum_(flat):
+    """In-place sum of a flat buffer over all ranks (no-op when not distributed)."""
+    if is_distributed():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def broadcast_(tensors, src=0):
+    if is_distributed():
+        for t in tensors:
+            dist.broadcast(t, src=src)
+
+
+def barrier():
+    if is_distributed():
+        dist.barrier()

@@ -1,0 +1,379 @@
+"""torch.autograd wrappers around the libmcdseg kernels.
+
+PyTorch supplies device memory, the current HIP stream and the autograd tape; every arithmetic
+pass over activations, gradients and parameters below is a hand-written HIP kernel.  The functions
+mirror the ATen call sites of the reference's hot path:
+
+  conv_bn_act      nn.Conv2d + nn.BatchNorm2d + ReLU (+ residual)   models/drn.py:43-59, 80-100, 195-205
+  conv2d_bias      nn.Conv2d with bias (the 1x1 ``seg`` head)       models/dilated_fcn.py:226-232
+  up8 / up8_dual   depthwise ConvTranspose2d k16 s8 p4              models/dilated_fcn.py:357-366, 479-491
+  cross_entropy2d  log_softmax + weighted NLL                       loss.py:7-13
+  diff2d           mean |softmax - softmax|                         loss.py:93-100
+  mcd_losses       both of the above in one fused kernel            adapt_trainer.py:163-212
+"""
+import ctypes
+
+import torch
+
+from ._lib import ConvDesc, check, lib
+
+# bumped by the optimizer after every in-place parameter update (the kernels write through raw
+# pointers, so torch's own version counters do not move)
+WEIGHT_EPOCH = 0
+
+
+def bump_weight_epoch():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, name, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("mcdseg: %s must live on the GPU -- the HIP kernels are the only implementation "
+                           "(no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise TypeError("mcdseg: %s must be %s, got %s" % (name, dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 4) // 4 + 1, dtype=torch.float32, device=device)
+
+
+def conv_desc(x_shape, w_shape, stride, pad, dil):
+    n, cin, h, w = x_shape
+    cout, cin_w, kh, kw = w_shape
+    if cin_w != cin:
+        raise ValueError("mcdseg: conv expects %d input channels, got %d" % (cin_w, cin))
+    ho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    wo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    return ConvDesc(n, cin, h, w, cout, kh, kw, stride, pad, dil, ho, wo)
+
+
+class PackedWeights:
+    """GEMM images of one conv kernel, refreshed when the parameter changes."""
+
+    def __init__(self):
+        self.key = None
+        self.wf = None
+        self.wd = None
+
+    def get(self, weight, desc, need_dgrad=True):
+        key = (weight.data_ptr(), weight._version, WEIGHT_EPOCH, weight.device)
+        if key != self.key or (need_dgrad and self.wd is None):
+            L = lib()
+            mpf, kpf, mpd, kpd = (ctypes.c_int32() for _ in range(4))
+            check(L.mcdseg_conv_packed_dims(ctypes.byref(desc), mpf, kpf, mpd, kpd), "conv_packed_dims")
+            taps = desc.KH * desc.KW
+            w = _req(weight.detach(), "conv weight")
+            self.wf = torch.empty(taps * kpf.value * mpf.value, dtype=torch.float32, device=w.device)
+            self.wd = torch.empty(taps * kpd.value * mpd.value, dtype=torch.float32, device=w.device)
+            check(L.mcdseg_conv_pack_weights(ctypes.byref(desc), _p(w), _p(self.wf), _p(self.wd), _stream()), "conv_pack_weights")
+            self.mpf = mpf.value
+            self.key = key
+        return self.wf, self.wd, self.mpf
+
+
+# ------------------------------------------------------------------------------------------------ raw launchers
+def _conv_fprop(desc, x, wf, bias, want_stats, mpf):
+    L = lib()
+    y = torch.empty((desc.N, desc.Cout, desc.Ho, desc.Wo), dtype=torch.float32, device=x.device)
+    part, rows = None, 0
+    if want_stats:
+        rows = L.mcdseg_conv_stat_rows(ctypes.byref(desc))
+        part = torch.empty(rows * 3 * mpf, dtype=torch.float32, device=x.device)
+    check(L.mcdseg_conv_fprop(ctypes.byref(desc), _p(x), _p(wf), _p(bias), _p(y), _p(part), _stream()), "conv_fprop")
+    return y, part, rows
+
+
+def _conv_dgrad(desc, dy, wd):
+    dx = torch.empty((desc.N, desc.Cin, desc.H, desc.W), dtype=torch.float32, device=dy.device)
+    check(lib().mcdseg_conv_dgrad(ctypes.byref(desc), _p(dy), _p(wd), _p(dx), _stream()), "conv_dgrad")
+    return dx
+
+
+def _conv_wgrad(desc, x, dy):
+    L = lib()
+    nbytes = L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(desc))
+    ws = _ws(nbytes, x.device)
+    dw = torch.empty((desc.Cout, desc.Cin, desc.KH, desc.KW), dtype=torch.float32, device=x.device)
+    check(L.mcdseg_conv_wgrad(ctypes.byref(desc), _p(x), _p(dy), _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
+          "conv_wgrad")
+    return dw
+
+
+def _channel_reduce(dy, y, z, mean, rstd, relu):
+    """(dgamma, dbeta) of a BN (z given) or just the per-channel sum of dy (z None)."""
+    L = lib()
+    n, c = dy.shape[0], dy.shape[1]
+    hw = dy.shape[2] * dy.shape[3]
+    ws = _ws(L.mcdseg_bn_bwd_workspace_bytes(n, c, hw), dy.device)
+    dgamma = torch.empty(c, dtype=torch.float32, device=dy.device) if z is not None else None
+    dbeta = torch.empty(c, dtype=torch.float32, device=dy.device)
+    check(L.mcdseg_bn_bwd_reduce(_p(dy), _p(y), _p(z), _p(mean), _p(rstd), _p(dgamma), _p(dbeta), n, c, hw, int(relu), _p(ws),
+                                 ctypes.c_size_t(ws.numel() * 4), _stream()), "bn_bwd_reduce")
+    return dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------------ conv + BN + act
+class _ConvBNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, running_mean, running_var, nbt, packed, geom, training, momentum,
+                eps, relu):
+        L = lib()
+        x = _req(x, "conv input")
+        residual = _req(residual, "residual")
+        stride, pad, dil = geom
+        desc = conv_desc(x.shape, weight.shape, stride, pad, dil)
+        wf, wd, mpf = packed.get(weight, desc)
+        z, part, rows = _conv_fprop(desc, x, wf, None, training, mpf)
+        c = desc.Cout
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        if training:
+            track = running_mean is not None
+            check(L.mcdseg_bn_stats_finalize(_p(part), rows, c, mpf, _p(mean), _p(rstd), _p(running_mean) if track else None,
+                                             _p(running_var) if track else None, _p(nbt) if track else None,
+                                             float(momentum), float(eps), _stream()), "bn_stats_finalize")
+        else:
+            check(L.mcdseg_bn_eval_stats(_p(running_mean), _p(running_var), c, float(eps), _p(mean), _p(rstd), _stream()),
+                  "bn_eval_stats")
+        y = torch.empty_like(z)
+        hw = desc.Ho * desc.Wo
+        check(L.mcdseg_bn_apply(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), _p(y), desc.N, c, hw, int(relu),
+                                _stream()), "bn_apply")
+        ctx.desc, ctx.wd, ctx.relu, ctx.training, ctx.has_res = desc, wd, relu, training, residual is not None
+        ctx.save_for_backward(x, z, y, mean, rstd, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = lib()
+        x, z, y, mean, rstd, gamma = ctx.saved_tensors
+        desc = ctx.desc
+        dy = _req(dy, "grad_output")
+        n, c, hw = desc.N, desc.Cout, desc.Ho * desc.Wo
+        dgamma, dbeta = _channel_reduce(dy, y if ctx.relu else None, z, mean, rstd, ctx.relu)
+        dz = torch.empty_like(z)
+        dres = None
+        if ctx.has_res and ctx.needs_input_grad[4]:
+            dres = torch.empty_like(z) if ctx.relu else dy
+        check(L.mcdseg_bn_bwd_apply(_p(dy), _p(y) if ctx.relu else None, _p(z), _p(mean), _p(rstd), _p(gamma), _p(dgamma),
+                                    _p(dbeta), _p(dz), _p(dres) if (dres is not None and ctx.relu) else None, n, c, hw,
+                                    int(ctx.relu), int(ctx.training), _stream()), "bn_bwd_apply")
+        dx = _conv_dgrad(desc, dz, ctx.wd) if ctx.needs_input_grad[0] else None
+        dw = _conv_wgrad(desc, x, dz) if ctx.needs_input_grad[1] else None
+        return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres,
+                None, None, None, None, None, None, None, None, None)
+
+
+def conv_bn_act(x, conv, bn, relu=True, residual=None):
+    """y = act(bn(conv(x)) + residual) with the HIP kernels; ``conv``/``bn`` are the parameter-holding modules."""
+    if conv.bias is not None:
+        raise NotImplementedError("mcdseg: conv+BN fusion expects a bias-free convolution")
+    geom = (conv.stride[0], conv.padding[0], conv.dilation[0])
+    training = bn.training
+    track = bn.track_running_stats and bn.running_mean is not None
+    if not training and not track:
+        raise NotImplementedError("mcdseg: eval-mode BatchNorm needs running statistics")
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn.running_mean if track else None,
+                            bn.running_var if track else None, bn.num_batches_tracked if track else None, conv._packed, geom,
+                            training, momentum, bn.eps, relu)
+
+
+# ------------------------------------------------------------------------------------------------ conv (+bias)
+class _Conv2dBias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, packed, geom):
+        x = _req(x, "conv input")
+        desc = conv_desc(x.shape, weight.shape, *geom)
+        wf, wd, mpf = packed.get(weight, desc)
+        y, _, _ = _conv_fprop(desc, x, wf, _req(bias, "conv bias"), False, mpf)
+        ctx.desc, ctx.wd, ctx.has_bias = desc, wd, bias is not None
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _req(dy, "grad_output")
+        dx = _conv_dgrad(ctx.desc, dy, ctx.wd) if ctx.needs_input_grad[0] else None
+        dw = _conv_wgrad(ctx.desc, x, dy) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            _, db = _channel_reduce(dy, None, None, None, None, False)
+        return dx, dw, db, None, None
+
+
+def conv2d_bias(x, conv):
+    geom = (conv.stride[0], conv.padding[0], conv.dilation[0])
+    return _Conv2dBias.apply(x, conv.weight, conv.bias, conv._packed, geom)
+
+
+# ------------------------------------------------------------------------------------------------ x8 up-sampler
+def _up8_bwd_input(dy, w, n, c, hi, wi):
+    dx = torch.empty((n, c, hi, wi), dtype=torch.float32, device=dy.device)
+    check(lib().mcdseg_up8_bwd_input(_p(dy), _p(w), _p(dx), n, c, hi, wi, _stream()), "up8_bwd_input")
+    return dx
+
+
+def _up8_bwd_weight(dy, x, n, c, hi, wi):
+    L = lib()
+    ws = _ws(L.mcdseg_up8_bwd_weight_workspace_bytes(n, c, hi, wi), dy.device)
+    dw = torch.empty((c, 1, 16, 16), dtype=torch.float32, device=dy.device)
+    check(L.mcdseg_up8_bwd_weight(_p(dy), _p(x), _p(dw), n, c, hi, wi, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
+          "up8_bwd_weight")
+    return dw
+
+
+def _check_up(x, w):
+    if x.dim() != 4 or tuple(w.shape) != (x.shape[1], 1, 16, 16):
+        raise ValueError("mcdseg: up8 expects x [N,C,H,W] and w [C,1,16,16], got %s / %s" % (tuple(x.shape), tuple(w.shape)))
+
+
+class _Up8(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x, w = _req(x, "up8 input"), _req(w, "up8 weight")
+        _check_up(x, w)
+        n, c, hi, wi = x.shape
+        y = torch.empty((n, c, 8 * hi, 8 * wi), dtype=torch.float32, device=x.device)
+        check(lib().mcdseg_up8_fwd(_p(x), _p(w), None, None, _p(y), n, c, hi, wi, _stream()), "up8_fwd")
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _req(dy, "grad_output")
+        n, c, hi, wi = x.shape
+        dx = _up8_bwd_input(dy, w, n, c, hi, wi) if ctx.needs_input_grad[0] else None
+        dw = _up8_bwd_weight(dy, x, n, c, hi, wi) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+class _Up8Dual(torch.autograd.Function):
+    """up(x1, w1) + up(x2, w2) in one pass over the full-resolution output."""
+
+    @staticmethod
+    def forward(ctx, x1, w1, x2, w2):
+        x1, w1, x2, w2 = _req(x1, "up8 input"), _req(w1, "up8 weight"), _req(x2, "up8 input"), _req(w2, "up8 weight")
+        _check_up(x1, w1), _check_up(x2, w2)
+        if x1.shape != x2.shape:
+            raise ValueError("mcdseg: up8_dual inputs differ in shape")
+        n, c, hi, wi = x1.shape
+        y = torch.empty((n, c, 8 * hi, 8 * wi), dtype=torch.float32, device=x1.device)
+        check(lib().mcdseg_up8_fwd(_p(x1), _p(w1), _p(x2), _p(w2), _p(y), n, c, hi, wi, _stream()), "up8_fwd")
+        ctx.save_for_backward(x1, w1, x2, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, w1, x2, w2 = ctx.saved_tensors
+        dy = _req(dy, "grad_output")
+        n, c, hi, wi = x1.shape
+        need = ctx.needs_input_grad
+        return (_up8_bwd_input(dy, w1, n, c, hi, wi) if need[0] else None, _up8_bwd_weight(dy, x1, n, c, hi, wi) if need[1] else None,
+                _up8_bwd_input(dy, w2, n, c, hi, wi) if need[2] else None, _up8_bwd_weight(dy, x2, n, c, hi, wi) if need[3] else None)
+
+
+def up8(x, w):
+    return _Up8.apply(x, w)
+
+
+def up8_dual(x1, w1, x2, w2):
+    return _Up8Dual.apply(x1, w1, x2, w2)
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def mcd_losses(z1, z2, labels, class_weight, ignore_index=-100, ce_coef=0.0, diff_coef=0.0, want_grad=True):
+    """One fused pass.  Returns (losses[4] = CE1, CE2, Diff, sum w[y]; g1; g2) where
+    g_k = ce_coef * dCE_k/dz_k + diff_coef * dDiff/dz_k (None when not requested)."""
+    L = lib()
+    z1 = _req(z1, "logits")
+    z2 = _req(z2, "logits")
+    if z1.dim() != 4 or (z2 is not None and z2.shape != z1.shape):
+        raise ValueError("mcdseg: logits must be [N,C,H,W] and of equal shape")
+    n, c, h, w = z1.shape
+    if labels is not None:
+        labels = _req(labels, "labels", torch.int64)
+        if tuple(labels.shape) != (n, h, w):
+            raise ValueError("mcdseg: labels must be [N,H,W] = %s, got %s" % ((n, h, w), tuple(labels.shape)))
+    class_weight = _req(class_weight, "class weights")
+    if class_weight is not None and class_weight.numel() != c:
+        raise ValueError("mcdseg: class weight has %d entries for %d classes" % (class_weight.numel(), c))
+    losses = torch.empty(4, dtype=torch.float32, device=z1.device)
+    g1 = torch.empty_like(z1) if want_grad else None
+    g2 = torch.empty_like(z2) if (want_grad and z2 is not None) else None
+    ws = _ws(L.mcdseg_loss_workspace_bytes(n, h * w), z1.device)
+    check(L.mcdseg_softmax_ce_l1(_p(z1), _p(z2), _p(labels), _p(class_weight), int(ignore_index), float(ce_coef), float(diff_coef),
+                                 _p(g1), _p(g2), _p(losses), n, c, h * w, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
+          "softmax_ce_l1")
+    return losses, g1, g2
+
+
+def _scale_(g, s):
+    check(lib().mcdseg_scale_by_device_scalar(_p(g), _p(s), g.numel(), _stream()), "scale_by_device_scalar")
+    return g
+
+
+class _CrossEntropy2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, labels, class_weight, ignore_index, size_average):
+        losses, g, _ = mcd_losses(z, None, labels, class_weight, ignore_index, ce_coef=1.0, want_grad=ctx.needs_input_grad[0])
+        ctx.g = g
+        ctx.size_average = size_average
+        ctx.wsum = losses[3:4]
+        return losses[0].clone() if size_average else losses[0] * losses[3]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g, ctx.g = ctx.g, None
+        s = _req(grad_out.reshape(1), "grad_output")
+        if not ctx.size_average:
+            s = s * ctx.wsum
+        return _scale_(g, s), None, None, None, None
+
+
+class _Diff2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z1, z2):
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        losses, g1, g2 = mcd_losses(z1, z2, None, None, diff_coef=1.0, want_grad=need)
+        ctx.g = (g1, g2)
+        return losses[2].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (g1, g2), ctx.g = ctx.g, None
+        s = _req(grad_out.reshape(1), "grad_output")
+        return _scale_(g1, s), _scale_(g2, s)
+
+
+def cross_entropy2d(z, labels, class_weight=None, ignore_index=-100, size_average=True):
+    return _CrossEntropy2d.apply(z, labels, class_weight, ignore_index, size_average)
+
+
+def diff2d(z1, z2):
+    return _Diff2d.apply(z1, z2)
+
+
+# ------------------------------------------------------------------------------------------------ optimizer kernel
+def sgd_momentum_flat_(p, g, v, lr, momentum, weight_decay, grad_scale=1.0):
+    for t, name in ((p, "params"), (g, "grads"), (v, "momentum")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("mcdseg: flat SGD needs contiguous fp32 GPU buffers (%s)" % name)
+    check(lib().mcdseg_sgd_momentum_flat(_p(p), _p(g), _p(v), p.numel(), float(lr), float(momentum), float(weight_decay),
+                                         float(grad_scale), _stream()), "sgd_momentum_flat")
+    bump_weight_epoch()

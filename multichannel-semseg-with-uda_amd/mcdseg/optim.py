@@ -1,0 +1,148 @@
+"""Flat-buffer SGD (momentum + weight decay) driven by one HIP kernel per step.
+
+Drop-in for ``torch.optim.SGD`` as the reference configures it (models/model_util.py:289-292:
+dampening 0, no Nesterov): same constructor arguments, ``param_groups``, ``zero_grad``, ``step`` and a
+``state_dict`` in torch's own layout (``state[i]['momentum_buffer']`` + ``param_groups``), so
+checkpoints interchange with the reference (adapt_trainer.py:232-245, 29-59).
+
+Parameters are re-homed, on first use, into one contiguous fp32 buffer (each ``p.data`` becomes a view
+of it); momentum lives in a second flat buffer and gradients are gathered into a third, which is also
+the single payload of the data-parallel all-reduce (``mcdseg.dist``).  Parameters whose ``grad`` is
+None are skipped exactly as torch does (no weight decay, no momentum update).
+"""
+import torch
+
+from . import dist as mdist
+from . import ops
+
+_ALIGN = 64  # floats; keeps every view 256-byte aligned for the float4 kernels
+
+
+class FlatSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0):
+        if lr < 0 or momentum < 0 or weight_decay < 0:
+            raise ValueError("FlatSGD: negative hyper-parameter")
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, dampening=0, nesterov=False))
+        self._flat = None
+
+    # ------------------------------------------------------------------ flat storage
+    def _all_params(self):
+        seen, out = set(), []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    out.append(p)
+        return out
+
+    def _flatten(self):
+        params = self._all_params()
+        if not params:
+            raise ValueError("FlatSGD: no parameters")
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatSGD: parameters must be on the GPU before the first step (no CPU fallback)")
+        offs, total = [], 0
+        for p in params:
+            if p.device != dev or p.dtype != torch.float32:
+                raise RuntimeError("FlatSGD: all parameters must be fp32 on one device")
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        fp = torch.zeros(total, dtype=torch.float32, device=dev)
+        fv = torch.zeros(total, dtype=torch.float32, device=dev)
+        fg = torch.zeros(total, dtype=torch.float32, device=dev)
+        views = {}
+        for p, o in zip(params, offs):
+            n = p.numel()
+            pv = fp[o:o + n].view(p.shape)
+            pv.copy_(p.data)
+            p.data = pv
+            vv = fv[o:o + n].view(p.shape)
+            st = self.state.get(p)
+            if st and st.get("momentum_buffer") is not None:
+                vv.copy_(st["momentum_buffer"])
+                st["momentum_buffer"] = vv
+            views[id(p)] = (o, n, vv, fg[o:o + n].view(p.shape))
+        self._flat = dict(p=fp, v=fv, g=fg, params=params, offs=offs, views=views, total=total)
+        ops.bump_weight_epoch()
+
+    def _ensure_flat(self):
+        if self._flat is None:
+            self._flatten()
+            return
+        # .cuda()/.to()/load_state_dict(assign) may have re-homed a parameter: rebuild if any view moved
+        fl = self._flat
+        for p in fl["params"]:
+            o, n, _, _ = fl["views"][id(p)]
+            if p.data_ptr() != fl["p"].data_ptr() + 4 * o:
+                self._flat = None
+                self._flatten()
+                return
+
+    # ------------------------------------------------------------------ torch.optim API
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._ensure_flat()
+        fl = self._flat
+        group_of = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                group_of[id(p)] = group
+        # maximal runs of consecutive parameters that have a gradient and share hyper-parameters
+        runs, cur = [], None
+        for p in fl["params"]:
+            g = group_of[id(p)]
+            if p.grad is None:
+                cur = None
+                continue
+            key = (g["lr"], g["momentum"], g["weight_decay"])
+            if cur is None or cur["key"] != key:
+                cur = dict(key=key, params=[])
+                runs.append(cur)
+            cur["params"].append(p)
+        world = mdist.world_size()
+        for run in runs:
+            ps = run["params"]
+            gviews = [fl["views"][id(p)][3] for p in ps]
+            grads = [p.grad if p.grad.dtype == torch.float32 else p.grad.float() for p in ps]
+            torch._foreach_copy_(gviews, grads)
+            o0 = fl["views"][id(ps[0])][0]
+            o1, n1 = fl["views"][id(ps[-1])][0], fl["views"][id(ps[-1])][1]
+            lo, hi = o0, o1 + n1
+            gflat = fl["g"][lo:hi]
+            if world > 1:
+                mdist.all_reduce_sum_(gflat)
+            lr, mu, wd = run["key"]
+            ops.sgd_momentum_flat_(fl["p"][lo:hi], gflat, fl["v"][lo:hi], lr, mu, wd, 1.0 / world)
+            if mu != 0:
+                for p in ps:
+                    self.state[p]["momentum_buffer"] = fl["views"][id(p)][2]
+        return loss
+
+    def state_dict(self):
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            if "momentum_buffer" in st and st["momentum_buffer"] is not None:
+                st["momentum_buffer"] = st["momentum_buffer"].clone()  # detach from the flat storage
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        if self._flat is not None:
+            fl = self._flat
+            fl["v"].zero_()
+            for p in fl["params"]:
+                st = self.state.get(p)
+                if st and st.get("momentum_buffer") is not None:
+                    vv = fl["views"][id(p)][2]
+                    vv.copy_(st["momentum_buffer"])
+                    st["momentum_buffer"] = vv
+
+    def flat_buffers(self):
+        """(params, grads, momentum) flat tensors -- for tests and the bench's byte accounting."""
+        self._ensure_flat()
+        return self._flat["p"], self._flat["g"], self._flat["v"]

@@ -1,0 +1,137 @@
+"""Segmentation wrappers around the DRN trunk (reference: models/dilated_fcn.py).
+
+  DRNSeg                              :68-110   trunk + seg + up (source-only training, cfg1)
+  DRNSegBase                = G       :217-250  trunk + 1x1 ``seg`` (ver1) / trunk only (ver2)
+  DRNSegPixelClassifier     = F1/F2   :340-366  learned x8 depthwise transposed-conv up-sampler
+  FusionDRNSegPixelClassifier         :431-470  fuse features, one up-sampler
+  ScoreFusionDRNSegPixelClassifier    :473-491  one up-sampler per modality, fuse scores
+
+State-dict keys follow the reference: ``base.<stage>...``, ``seg.{weight,bias}``,
+``up.weight`` / ``up1.weight`` / ``up2.weight``.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from mcdseg import ops
+
+from . import drn
+from .drn import Conv2d, FusedSequential
+from .fusion import AddFusion, ConcatFusion, get_fusion_model
+
+
+def _trunk(model_name, pretrained, input_ch):
+    ctor = drn.__dict__.get(model_name)
+    if ctor is None or not model_name.startswith("drn_"):
+        raise NotImplementedError("unknown DRN variant %r" % (model_name,))
+    model = ctor(pretrained=pretrained, num_classes=0, input_ch=input_ch)
+    return FusedSequential(*model.trunk()), model.out_dim
+
+
+def _seg_head(cin, n_class):
+    seg = Conv2d(cin, n_class, kernel_size=1, bias=True)
+    n = seg.kernel_size[0] * seg.kernel_size[1] * seg.out_channels
+    seg.weight.data.normal_(0, math.sqrt(2.0 / n))
+    seg.bias.data.zero_()
+    return seg
+
+
+class Up8(nn.ConvTranspose2d):
+    """ConvTranspose2d(C, C, 16, stride 8, padding 4, groups=C, bias=False) -- parameters in torch's layout and
+    default initialisation (the reference leaves ``fill_up_weights`` commented out, :93), HIP kernels for the maths."""
+
+    def __init__(self, n_class):
+        super().__init__(n_class, n_class, 16, stride=8, padding=4, output_padding=0, groups=n_class, bias=False)
+
+    def forward(self, x, output_size=None):
+        return ops.up8(x, self.weight)
+
+
+def _up(cin, n_class, use_torch_up=False):
+    if use_torch_up:
+        raise NotImplementedError("use_torch_up (bilinear) is not on the MCD hot path")
+    if cin != n_class:
+        raise NotImplementedError("ConcatFusion up-sampler (2C -> C grouped transposed conv) is not on the MCD hot path")
+    return Up8(n_class)
+
+
+class DRNSeg(nn.Module):
+    def __init__(self, model_name, n_class, input_ch=3, pretrained_model=None, pretrained=True, use_torch_up=False):
+        super().__init__()
+        self.base, out_dim = _trunk(model_name, pretrained, input_ch)
+        if pretrained_model is not None:
+            self.base.load_state_dict({k.replace("module.", ""): v for k, v in pretrained_model.items()}, strict=False)
+        self.seg = _seg_head(out_dim, n_class)
+        self.up = _up(n_class, n_class, use_torch_up)
+
+    def forward(self, x):
+        return self.up(self.seg(self.base(x)))
+
+    def optim_parameters(self, memo=None):
+        yield from self.base.parameters()
+        yield from self.seg.parameters()
+
+
+class DRNSegBase(nn.Module):
+    def __init__(self, model_name, n_class, pretrained=True, input_ch=3, ver="ver1"):
+        super().__init__()
+        self.base, out_dim = _trunk(model_name, pretrained, input_ch)
+        self.ver = ver
+        if ver == "ver1":
+            self.seg = _seg_head(out_dim, n_class)
+        elif ver == "ver2":
+            print("ver2 will be used")
+
+    def forward(self, x):
+        x = self.base(x)
+        return x if self.ver == "ver2" else self.seg(x)
+
+    def optim_parameters(self, memo=None):
+        yield from self.base.parameters()
+        yield from self.seg.parameters()
+
+
+class DRNSegPixelClassifier(nn.Module):
+    def __init__(self, n_class, use_torch_up=False, dropout=False, ver="ver1"):
+        super().__init__()
+        self.dropout = dropout
+        self.ver = ver
+        if ver == "ver2":
+            self.seg = _seg_head(512, n_class)
+        self.up = _up(n_class, n_class, use_torch_up)
+
+    def forward(self, x):
+        if self.ver == "ver2":
+            x = self.seg(x)
+        return self.up(x)
+
+
+class FusionDRNSegPixelClassifier(nn.Module):
+    def __init__(self, fusion_type, n_class, use_torch_up=False, ver="ver1"):
+        super().__init__()
+        self.fusion = get_fusion_model(fusion_type, n_class if ver == "ver1" else 512)
+        self.ver = ver
+        self.up = _up(2 * n_class if isinstance(self.fusion, ConcatFusion) else n_class, n_class, use_torch_up)
+        if ver == "ver2":
+            self.seg = _seg_head(512, n_class)
+
+    def forward(self, x1, x2):
+        h = self.fusion(x1, x2)
+        if self.ver == "ver2":
+            h = self.seg(h)
+        return self.up(h)
+
+
+class ScoreFusionDRNSegPixelClassifier(nn.Module):
+    def __init__(self, fusion_type, n_class):
+        super().__init__()
+        self.fusion = get_fusion_model(fusion_type, n_class)
+        self.up1 = Up8(n_class)
+        self.up2 = Up8(n_class)
+
+    def forward(self, x1, x2):
+        if isinstance(self.fusion, AddFusion):
+            # up1(x1) + up2(x2) in one pass over the full-resolution tensor
+            return ops.up8_dual(x1, self.up1.weight, x2, self.up2.weight)
+        return self.fusion(self.up1(x1), self.up2(x2))

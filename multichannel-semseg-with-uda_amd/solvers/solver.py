@@ -1,0 +1,138 @@
+"""The three-step Maximum-Classifier-Discrepancy update as a solver object.
+
+The reference has no working solver (``solvers/solver.py`` there is dead LSGAN code); the update is
+written inline in each trainer.  ``MCDSolver.step`` follows ``adapt_trainer.py:155-220`` and
+``MFNetMCDSolver.step`` follows ``adapt_mfnet_trainer.py:174-244``:
+
+  A  G, F1, F2 <- min  CE(F1(G(xs)), ys) + CE(F2(G(xs)), ys)
+  B  F1, F2    <- min  CE1 + CE2 (source)  -  Diff(F1(G(xt)), F2(G(xt)))
+  C  G         <- min  Diff(target) * num_multiply_d_loss          (num_k times)
+
+Differences from running the same statements through the drop-in modules -- none of them changes a
+result:
+  * each phase evaluates its loss terms and both logit gradients with ONE fused kernel launch
+    (``mcdseg.ops.mcd_losses``) instead of separate CE / CE / Diff criteria;
+  * step B never back-propagates through G: only ``optimizer_f.step()`` follows and the generator
+    gradients are zeroed before any use (adapt_trainer.py:187-205), so G runs without saving
+    activations there -- its BatchNorm running statistics still move on every forward (7 per step);
+  * step C does not form the (unused) classifier weight gradients.
+"""
+import torch
+
+from mcdseg import ops
+
+
+def _params(modules):
+    seen, out = set(), []
+    for m in modules:
+        for p in m.parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+    return out
+
+
+class _frozen:
+    """temporarily mark parameters as not requiring grad (their gradient would be discarded anyway)"""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+
+    def __enter__(self):
+        for p in self.params:
+            p.requires_grad_(False)
+
+    def __exit__(self, *exc):
+        for p in self.params:
+            p.requires_grad_(True)
+
+
+class MCDSolver:
+    def __init__(self, model_g, model_f1, model_f2, optimizer_g, optimizer_f, criterion, criterion_d, num_k=4,
+                 num_multiply_d_loss=1):
+        self.g, self.f1, self.f2 = model_g, model_f1, model_f2
+        self.opt_g, self.opt_f = optimizer_g, optimizer_f
+        self.class_weight = getattr(criterion, "weight", None)
+        self.ignore_index = getattr(criterion, "ignore_index", -100)
+        if type(criterion_d).__name__ != "Diff2d":
+            raise NotImplementedError("the fused solver implements d_loss='diff' (loss.py:93-100)")
+        self.num_k = num_k
+        self.mult = float(num_multiply_d_loss)
+
+    # -- hooks the MFNet variant overrides
+    def _features(self, x):
+        return (self.g(x),)
+
+    def _heads(self, feats):
+        return self.f1(*feats), self.f2(*feats)
+
+    def _generators(self):
+        return [self.g]
+
+    def _ce(self, o1, o2, labels, want_grad=True):
+        return ops.mcd_losses(o1, o2, labels, self.class_weight, self.ignore_index, ce_coef=1.0, want_grad=want_grad)
+
+    def step(self, src_imgs, src_lbls, tgt_imgs):
+        # ---- A: generator and classifiers on source
+        self.opt_g.zero_grad()
+        self.opt_f.zero_grad()
+        o1, o2 = self._heads(self._features(src_imgs))
+        losses, g1, g2 = self._ce(o1, o2, src_lbls)
+        torch.autograd.backward([o1, o2], [g1, g2])
+        c_loss = losses[0] + losses[1]
+        del o1, o2, g1, g2
+        self.opt_g.step()
+        self.opt_f.step()
+
+        # ---- B: classifiers only (generator forward without a tape)
+        self.opt_g.zero_grad()
+        self.opt_f.zero_grad()
+        with torch.no_grad():
+            feats = self._features(src_imgs)
+        o1, o2 = self._heads(feats)
+        _, g1, g2 = self._ce(o1, o2, src_lbls)
+        torch.autograd.backward([o1, o2], [g1, g2])
+        with torch.no_grad():
+            feats = self._features(tgt_imgs)
+        o1, o2 = self._heads(feats)
+        _, g1, g2 = ops.mcd_losses(o1, o2, None, None, diff_coef=-1.0)
+        torch.autograd.backward([o1, o2], [g1, g2])
+        del o1, o2, g1, g2, feats
+        self.opt_f.step()
+        self._after_b()
+
+        # ---- C: generator only, num_k times
+        d_last = None
+        with _frozen(_params([self.f1, self.f2])):
+            for _ in range(self.num_k):
+                self.opt_g.zero_grad()
+                o1, o2 = self._heads(self._features(tgt_imgs))
+                losses, g1, g2 = ops.mcd_losses(o1, o2, None, None, diff_coef=self.mult)
+                torch.autograd.backward([o1, o2], [g1, g2])
+                d_last = losses[2] * self.mult
+                del o1, o2, g1, g2
+                self.opt_g.step()
+        d_loss = d_last / self.num_k  # only the last inner loss is logged (adapt_trainer.py:214)
+        return c_loss, d_loss
+
+    def _after_b(self):
+        pass
+
+
+class MFNetMCDSolver(MCDSolver):
+    """Two modality encoders (RGB: channels 0-2, HHA/depth: the rest), classifiers take both feature maps."""
+
+    def __init__(self, model_g_3ch, model_g_1ch, model_f1, model_f2, optimizer_g, optimizer_f, criterion, criterion_d,
+                 num_k=4):
+        super().__init__(model_g_3ch, model_f1, model_f2, optimizer_g, optimizer_f, criterion, criterion_d, num_k=num_k,
+                         num_multiply_d_loss=1)  # adapt_mfnet_trainer.py:226-235 applies no multiplier
+        self.g_3ch, self.g_1ch = model_g_3ch, model_g_1ch
+
+    def _features(self, x):
+        return self.g_3ch(x[:, :3, :, :]), self.g_1ch(x[:, 3:, :, :])
+
+    def _generators(self):
+        return [self.g_3ch, self.g_1ch]
+
+    def _after_b(self):
+        self.opt_f.zero_grad()  # adapt_mfnet_trainer.py:222

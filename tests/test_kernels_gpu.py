@@ -1,0 +1,292 @@
+"""GPU: every HIP kernel (through the C ABI) against a plain fp64 PyTorch-CPU statement of the same op,
+and the loss kernel against the oracle's closed forms and the golden vectors."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _maxerr(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((got - ref).abs().max()), float(ref.abs().max()) + 1e-30
+
+
+def _assert_close(got, ref, rtol, what):
+    err, scale = _maxerr(got, ref)
+    assert err <= rtol * scale, "%s: max err %.3e vs scale %.3e (rel %.2e > %.1e)" % (what, err, scale, err / scale, rtol)
+
+
+# (Cin, Cout, k, stride, dil, H, W, N, bias)  -- every conv geometry of drn_d_38 / drn_d_105 / MFNet stems
+CONV_CASES = [
+    (6, 16, 7, 1, 1, 20, 28, 2, False),     # 6-ch stem (K padded 6 -> 8)
+    (3, 16, 7, 1, 1, 18, 22, 1, False),     # MFNet stems
+    (1, 16, 7, 1, 1, 9, 13, 2, False),
+    (16, 16, 3, 1, 1, 20, 28, 2, False),    # layer1
+    (16, 32, 3, 2, 1, 21, 27, 2, False),    # layer2, stride 2, odd size
+    (32, 64, 3, 2, 1, 20, 28, 2, False),    # layer3 first block
+    (32, 64, 1, 2, 1, 20, 28, 2, False),    # 1x1 stride-2 shortcut
+    (64, 64, 3, 1, 1, 12, 20, 3, False),
+    (64, 128, 3, 2, 1, 12, 20, 2, False),
+    (128, 256, 3, 1, 2, 12, 15, 2, False),  # dilation 2
+    (256, 256, 3, 1, 2, 9, 12, 2, False),
+    (128, 256, 1, 1, 1, 9, 12, 2, False),   # 1x1 projection
+    (256, 512, 3, 1, 4, 10, 12, 2, False),  # dilation 4
+    (512, 512, 3, 1, 4, 8, 12, 2, False),
+    (512, 512, 3, 1, 1, 8, 12, 1, False),
+    (512, 41, 1, 1, 1, 8, 12, 2, True),     # seg head with bias (M padded 41 -> 64)
+    (64, 256, 1, 1, 1, 7, 9, 2, False),     # bottleneck 1x1s
+    (256, 64, 1, 1, 1, 7, 9, 2, False),
+    (40, 24, 3, 1, 1, 11, 13, 2, True),     # ragged channel counts
+]
+
+
+def _conv_inputs(case, seed):
+    cin, cout, k, s, d, h, w, n, bias = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (k * k * cout)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1 if bias else None
+    pad = d * (k // 2)
+    return x, wt, b, s, pad, d
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c[:5])))
+def test_conv_fprop_dgrad_wgrad(case):
+    dev = _dev()
+    from mcdseg import ops
+    x, wt, b, s, pad, d = _conv_inputs(case, 7)
+    desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
+    packed = ops.PackedWeights()
+    xg, wg = x.to(dev), wt.to(dev)
+    wf, wd, mpf = packed.get(wg, desc)
+    y, _, _ = ops._conv_fprop(desc, xg, wf, b.to(dev) if b is not None else None, False, mpf)
+    x64 = x.double().requires_grad_()
+    w64 = wt.double().requires_grad_()
+    ref = F.conv2d(x64, w64, b.double() if b is not None else None, stride=s, padding=pad, dilation=d)
+    _assert_close(y, ref, 2e-5, "fprop")
+    gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(8))
+    gx_ref, gw_ref = torch.autograd.grad(ref, [x64, w64], gy.double())
+    dx = ops._conv_dgrad(desc, gy.to(dev), wd)
+    _assert_close(dx, gx_ref, 2e-5, "dgrad")
+    dw = ops._conv_wgrad(desc, xg, gy.to(dev))
+    _assert_close(dw, gw_ref, 2e-5, "wgrad")
+
+
+def test_conv_rejects_bad_geometry():
+    dev = _dev()
+    from mcdseg import ops
+    from mcdseg._lib import ConvDesc, lib
+    import ctypes
+    x = torch.zeros(1, 4, 8, 8, device=dev)
+    bad = ConvDesc(1, 4, 8, 8, 8, 3, 3, 1, 1, 1, 9, 9)  # wrong Ho/Wo
+    y = torch.zeros(1, 8, 9, 9, device=dev)
+    rc = lib().mcdseg_conv_fprop(ctypes.byref(bad), ops._p(x), ops._p(x), None, ops._p(y), None, ops._stream())
+    assert rc != 0 and b"Ho/Wo" in lib().mcdseg_last_error()
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops._req(torch.zeros(2), "cpu tensor")
+
+
+@pytest.mark.parametrize("cfg", [
+    # Cin, Cout, k, stride, dil, H, W, N, relu, residual, train
+    (16, 16, 3, 1, 1, 20, 28, 2, True, False, True),
+    (16, 32, 3, 2, 1, 21, 27, 2, True, False, True),
+    (64, 64, 3, 1, 1, 12, 20, 3, True, True, True),
+    (128, 256, 1, 1, 1, 9, 12, 2, False, False, True),
+    (256, 256, 3, 1, 2, 9, 12, 2, True, True, True),
+    (512, 512, 3, 1, 4, 8, 12, 2, True, True, True),
+    (64, 64, 3, 1, 1, 12, 20, 2, True, True, False),   # eval-mode BN (fix_bn / inference)
+    (40, 24, 3, 1, 1, 11, 13, 2, False, True, True),   # HW % 4 != 0 -> scalar paths
+], ids=lambda c: "x".join(map(str, c)))
+def test_conv_bn_act_fwd_bwd(cfg):
+    dev = _dev()
+    from mcdseg import ops
+    from models.drn import BatchNorm2d, Conv2d
+    cin, cout, k, s, d, h, w, n, relu, use_res, train = cfg
+    g = torch.Generator().manual_seed(11)
+    pad = d * (k // 2)
+    conv = Conv2d(cin, cout, k, stride=s, padding=pad, dilation=d, bias=False)
+    bn = BatchNorm2d(cout)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (k * k * cout)) ** 0.5)
+        bn.weight.copy_(1 + 0.2 * torch.randn(cout, generator=g))
+        bn.bias.copy_(0.1 * torch.randn(cout, generator=g))
+        bn.running_mean.copy_(0.05 * torch.randn(cout, generator=g))
+        bn.running_var.copy_(1 + 0.1 * torch.rand(cout, generator=g))
+    x = torch.randn(n, cin, h, w, generator=g) + 0.3
+    ho, wo = (h + 2 * pad - d * (k - 1) - 1) // s + 1, (w + 2 * pad - d * (k - 1) - 1) // s + 1
+    res = torch.randn(n, cout, ho, wo, generator=g) if use_res else None
+    gy = torch.randn(n, cout, ho, wo, generator=g)
+
+    # fp64 reference on CPU
+    x64 = x.double().requires_grad_()
+    w64 = conv.weight.detach().double().requires_grad_()
+    ga64 = bn.weight.detach().double().requires_grad_()
+    be64 = bn.bias.detach().double().requires_grad_()
+    r64 = res.double().requires_grad_() if use_res else None
+    rm, rv = bn.running_mean.double().clone(), bn.running_var.double().clone()
+    z = F.conv2d(x64, w64, None, s, pad, d)
+    o = F.batch_norm(z, rm, rv, ga64, be64, training=train, momentum=0.1, eps=1e-5)
+    if use_res:
+        o = o + r64
+    if relu:
+        o = F.relu(o)
+    ins = [x64, w64, ga64, be64] + ([r64] if use_res else [])
+    grads = torch.autograd.grad(o, ins, gy.double())
+
+    conv.to(dev), bn.to(dev)
+    bn.train(train)
+    xg = x.to(dev).requires_grad_()
+    rg = res.to(dev).requires_grad_() if use_res else None
+    y = ops.conv_bn_act(xg, conv, bn, relu=relu, residual=rg)
+    _assert_close(y, o, 3e-5, "forward")
+    if train:
+        _assert_close(bn.running_mean, rm, 1e-5, "running_mean")
+        _assert_close(bn.running_var, rv, 1e-5, "running_var")
+        assert int(bn.num_batches_tracked) == 1
+    else:
+        assert int(bn.num_batches_tracked) == 0
+    y.backward(gy.to(dev))
+    got = [xg.grad, conv.weight.grad, bn.weight.grad, bn.bias.grad] + ([rg.grad] if use_res else [])
+    for name, a, b in zip(["dx", "dw", "dgamma", "dbeta", "dres"], got, grads):
+        _assert_close(a, b, 1e-4, name)
+
+
+@pytest.mark.parametrize("shape", [(2, 41, 8, 12), (1, 5, 3, 7), (3, 16, 6, 10)])
+def test_up8_fwd_bwd(shape):
+    dev = _dev()
+    from mcdseg import ops
+    n, c, hi, wi = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, c, hi, wi, generator=g)
+    w = torch.randn(c, 1, 16, 16, generator=g) * 0.1
+    x2 = torch.randn(n, c, hi, wi, generator=g)
+    w2 = torch.randn(c, 1, 16, 16, generator=g) * 0.1
+    gy = torch.randn(n, c, 8 * hi, 8 * wi, generator=g)
+    t = [v.double().requires_grad_() for v in (x, w, x2, w2)]
+    ref = F.conv_transpose2d(t[0], t[1], stride=8, padding=4, groups=c)
+    ref2 = ref + F.conv_transpose2d(t[2], t[3], stride=8, padding=4, groups=c)
+    gr = torch.autograd.grad(ref, t[:2], gy.double(), retain_graph=True)
+    gr2 = torch.autograd.grad(ref2, t, gy.double())
+    d = [v.to(dev).requires_grad_() for v in (x, w, x2, w2)]
+    y = ops.up8(d[0], d[1])
+    _assert_close(y, ref, 1e-5, "up8 fwd")
+    y.backward(gy.to(dev))
+    _assert_close(d[0].grad, gr[0], 2e-5, "up8 dx")
+    _assert_close(d[1].grad, gr[1], 2e-5, "up8 dw")
+    for v in d:
+        v.grad = None
+    y2 = ops.up8_dual(*d)
+    _assert_close(y2, ref2, 1e-5, "up8_dual fwd")
+    y2.backward(gy.to(dev))
+    for name, a, b in zip(("dx1", "dw1", "dx2", "dw2"), [v.grad for v in d], gr2):
+        _assert_close(a, b, 2e-5, "up8_dual " + name)
+
+
+def test_loss_kernel_against_golden_and_closed_forms(golden):
+    dev = _dev()
+    from mcdseg import ops
+    from oracle import ref_loss
+    fx = golden.npz("loss_small.npz")
+    z1 = torch.from_numpy(fx["z1"]).to(dev)
+    z2 = torch.from_numpy(fx["z2"]).to(dev)
+    y = torch.from_numpy(fx["y"]).to(dev)
+    w = torch.from_numpy(fx["w"]).to(dev)
+    # fused: CE on both heads + discrepancy, coefficients as in step B (CE - Diff)
+    losses, g1, g2 = ops.mcd_losses(z1, z2, y, w, ce_coef=1.0, diff_coef=-1.0)
+    ls = losses.cpu().numpy()
+    ce2, gce2 = ref_loss.ce_and_grad(fx["z2"], fx["y"], fx["w"])
+    assert abs(ls[0] - float(fx["ce"])) <= 1e-6 * float(fx["ce"])
+    assert abs(ls[1] - ce2) <= 2e-6 * ce2
+    assert abs(ls[2] - float(fx["diff"])) <= 2e-6 * float(fx["diff"])
+    assert abs(ls[3] - float(fx["w"][fx["y"]].sum())) < 1e-3
+    ref1 = fx["g_ce"].astype(np.float64) - fx["g_d1"]
+    ref2 = gce2 - fx["g_d2"]
+    assert np.abs(g1.cpu().numpy() - ref1).max() <= 1e-6 * np.abs(ref1).max()
+    assert np.abs(g2.cpu().numpy() - ref2).max() <= 1e-6 * np.abs(ref2).max()
+    # autograd-facing single-purpose paths
+    a = z1.clone().requires_grad_()
+    ce = ops.cross_entropy2d(a, y, torch.from_numpy(fx["wfull"]).to(dev))
+    (3.0 * ce).backward()
+    l64, g64 = ref_loss.ce_and_grad(fx["z1"], fx["y"], fx["wfull"])
+    assert abs(float(ce) - float(fx["ce_w"])) <= 1e-6 * float(fx["ce_w"])
+    assert np.abs(a.grad.cpu().numpy() - 3.0 * g64).max() <= 1e-6 * np.abs(3.0 * g64).max()
+    a = z1.clone().requires_grad_()
+    b = z2.clone().requires_grad_()
+    dd = ops.diff2d(a, b)
+    (-dd).backward()
+    assert abs(float(dd) - float(fx["diff"])) <= 2e-6 * float(fx["diff"])
+    assert np.abs(a.grad.cpu().numpy() + fx["g_d1"]).max() <= 1e-6 * np.abs(fx["g_d1"]).max()
+    assert np.abs(b.grad.cpu().numpy() + fx["g_d2"]).max() <= 1e-6 * np.abs(fx["g_d2"]).max()
+
+
+@pytest.mark.parametrize("c,shape", [(41, (2, 9, 13)), (20, (1, 16, 16)), (14, (3, 5, 7)), (3, (2, 4, 4))])
+def test_loss_kernel_edge_cases(c, shape):
+    """ignore_index pixels, all-background batches (W = 0 in the reference gives nan), sum reduction."""
+    dev = _dev()
+    from mcdseg import ops
+    from oracle import ref_loss
+    n, h, w = shape
+    rs = np.random.RandomState(c)
+    z = (2 * rs.standard_normal((n, c, h, w))).astype(np.float32)
+    y = rs.randint(0, c, size=(n, h, w)).astype(np.int64)
+    y[0, 0, :2] = -100
+    cw = rs.uniform(0.5, 1.5, c).astype(np.float32)
+    l64, g64 = ref_loss.ce_and_grad(z, y, cw)
+    zt = torch.from_numpy(z).to(dev).requires_grad_()
+    loss = ops.cross_entropy2d(zt, torch.from_numpy(y).to(dev), torch.from_numpy(cw).to(dev))
+    loss.backward()
+    assert abs(float(loss) - l64) <= 2e-6 * abs(l64)
+    assert np.abs(zt.grad.cpu().numpy() - g64).max() <= 2e-6 * np.abs(g64).max()
+    assert float(zt.grad[0, :, 0, :2].abs().max()) == 0.0
+    zt.grad = None
+    s = ops.cross_entropy2d(zt, torch.from_numpy(y).to(dev), torch.from_numpy(cw).to(dev), size_average=False)
+    W = float(cw[y[y >= 0]].sum())
+    assert abs(float(s) - l64 * W) <= 3e-6 * abs(l64 * W)
+    # identical heads: zero discrepancy, zero gradient
+    d = ops.diff2d(zt.detach().clone().requires_grad_(), zt.detach().clone().requires_grad_())
+    assert float(d) == 0.0
+    with pytest.raises(RuntimeError, match="48 classes"):
+        ops.mcd_losses(torch.zeros(1, 64, 2, 2, device=dev), None, None, None)
+    with pytest.raises(ValueError):
+        ops.mcd_losses(zt.detach(), None, torch.zeros(n, h + 1, w, dtype=torch.int64, device=dev), None, ce_coef=1.0)
+
+
+def test_sgd_kernel_and_flat_optimizer():
+    dev = _dev()
+    from mcdseg.optim import FlatSGD
+    g = torch.Generator().manual_seed(3)
+    shapes = [(16, 6, 7, 7), (16,), (16,), (33, 5, 3, 3), (41, 1, 16, 16), (7,)]
+    ref_params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    our_params = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref_params]
+    ref = torch.optim.SGD(ref_params, lr=1e-2, momentum=0.9, weight_decay=2e-3)
+    ours = FlatSGD(our_params, lr=1e-2, momentum=0.9, weight_decay=2e-3)
+    for step in range(4):
+        ref.zero_grad(), ours.zero_grad()
+        for i, (a, b) in enumerate(zip(ref_params, our_params)):
+            if step == 2 and i == 3:
+                continue  # a parameter without gradient is skipped by torch -- and by us
+            gr = torch.randn(a.shape, generator=g)
+            a.grad = gr.clone()
+            b.grad = gr.to(dev)
+        ref.step(), ours.step()
+        if step == 1:  # checkpoint round trip in torch's layout (adapt_trainer.py:29-59, 232-245)
+            sd = ours.state_dict()
+            assert sorted(sd.keys()) == ["param_groups", "state"]
+            assert set(sd["state"][0].keys()) == {"momentum_buffer"}
+            ref.load_state_dict({"state": {k: {"momentum_buffer": v["momentum_buffer"].cpu()} for k, v in sd["state"].items()},
+                                 "param_groups": ref.state_dict()["param_groups"]})
+            ours.load_state_dict(sd)
+    for a, b in zip(ref_params, our_params):
+        _assert_close(b, a, 2e-6, "param")
+        _assert_close(ours.state[b]["momentum_buffer"], ref.state[a]["momentum_buffer"], 2e-6, "momentum")
+    fp, fg, fv = ours.flat_buffers()
+    assert all(p.data_ptr() >= fp.data_ptr() and p.data_ptr() < fp.data_ptr() + 4 * fp.numel() for p in our_params)

@@ -1,0 +1,295 @@
+"""GPU: the HIP product path (models/, loss.py, mcdseg.optim) against the golden vectors captured from
+the reference and against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from recipe import checksum, fill_state_, make_batch, state_checksums
+
+pytestmark = pytest.mark.gpu
+NC = 41
+
+
+@pytest.fixture(autouse=True)
+def _no_pretrained(monkeypatch):
+    monkeypatch.setenv("MCDSEG_PRETRAINED", "0")
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _mcd_models(dev, train=True):
+    from models.model_util import get_models
+    g, f1, f2 = get_models("drn_d_38", 6, NC)
+    for m, seed in ((g, 11), (f1, 12), (f2, 13)):
+        fill_state_(m, seed)
+        m.to(dev)
+        m.train(train)
+    return g, f1, f2
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_forward_small_vs_reference(golden, mode):
+    """logits within 1e-3 of the reference (north_star), argmax label maps identical wherever the
+    reference's own top-1/top-2 margin exceeds 2x that tolerance."""
+    dev = _dev()
+    fx = golden.npz("fwd_small.npz")
+    g, f1, f2 = _mcd_models(dev, train=(mode == "train"))
+    src, _, _ = make_batch(21, 2, 6, 64, 96, NC)
+    with torch.no_grad():
+        feat = g(src.to(dev))
+        o1, o2 = f1(feat), f2(feat)
+    ref = fx["feat_" + mode]
+    err = np.abs(feat.cpu().numpy() - ref).max()
+    assert err <= 1e-3, "feat max abs err %.3e" % err
+    assert err <= 2e-5 * np.abs(ref).max(), "feat err %.3e beyond fp32 re-association noise (scale %.3e)" % (err, np.abs(ref).max())
+    sub = o1[:, :, ::4, ::4].cpu().numpy()
+    assert np.abs(sub - fx["logits1_sub_" + mode]).max() <= 1e-3
+    assert abs(checksum(o2)[1] - fx["logits2_cs_" + mode][1]) <= 1e-5 * fx["logits2_cs_" + mode][1]
+    pred = o1[:, :NC - 1].argmax(1).cpu().numpy()  # adapt_tester.py:121-124
+    safe = fx["margin1_" + mode] > 2e-3
+    assert safe.mean() > 0.97
+    assert (pred == fx["argmax1_" + mode])[safe].all()
+    assert (pred != fx["argmax1_" + mode]).mean() < 0.005
+    if mode == "train":
+        sd = g.state_dict()
+        for k in fx.files:
+            if k.startswith("rs/"):
+                np.testing.assert_allclose(sd[k[3:]].cpu().numpy(), fx[k], rtol=2e-5, atol=1e-6)
+        assert int(sd["base.8.1.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("which", ["ce", "diff"])
+def test_backward_small_vs_reference(golden, which):
+    """Gradients: |g - g64| <= max(1e-3 * scale-free abs bound, k * the reference's own fp32 noise |g32 - g64|)
+    (train-mode BN backward leaves 1-3 % fp32 noise in the reference itself)."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, Diff2d
+    fx = golden.npz("bwd_small.npz")
+    g, f1, f2 = _mcd_models(dev)
+    src, lbl, tgt = make_batch(21, 2, 6, 64, 96, NC)
+    feat = g((src if which == "ce" else tgt).to(dev))
+    a, b = f1(feat), f2(feat)
+    if which == "ce":
+        w = torch.ones(NC)
+        w[NC - 1] = 0
+        crit = CrossEntropyLoss2d(w.to(dev))
+        loss = crit(a, lbl.to(dev)) + crit(b, lbl.to(dev))
+    else:
+        loss = Diff2d()(a, b)
+    loss.backward()
+    l64 = float(fx[which + "/loss64"])
+    assert abs(float(loss) - l64) <= 5e-6 * abs(l64)
+    named = dict(g.named_parameters())
+    report = []
+    for key in fx.files:
+        if not key.startswith(which + "/f64/"):
+            continue
+        name = key.split("/", 2)[2]
+        if name in named:
+            got = named[name].grad
+            got = got if got.numel() <= 40000 else got.reshape(got.shape[0], -1)[:16, :288]
+        elif name == "up1":
+            got = f1.up.weight.grad
+        elif name == "up2":
+            got = f2.up.weight.grad
+        elif name == "bn_gamma_all":
+            got = torch.cat([p.grad.reshape(-1) for k, p in named.items() if p.dim() == 1 and k.endswith("weight")])
+        elif name == "bn_beta_all":
+            got = torch.cat([p.grad.reshape(-1) for k, p in named.items() if p.dim() == 1 and k.endswith("bias") and not k.startswith("seg")])
+        else:
+            continue
+        g64 = fx[key]
+        noise = np.abs(fx[key.replace("/f64/", "/f32/")] - g64).max()
+        err = np.abs(got.double().cpu().numpy() - g64).max()
+        scale = np.abs(g64).max()
+        report.append((name, err, noise, scale))
+        assert err <= max(1e-3 * max(scale, 1e-3), 4 * noise), "%s: err %.3e, reference fp32 noise %.3e, scale %.3e" % (name, err, noise, scale)
+    assert len(report) >= 12
+
+
+def _check_state(mod, ref_cs, rtol):
+    got = state_checksums(mod)
+    assert got.keys() == ref_cs.keys()
+    bad = [(k, got[k][1], l2) for k, (s, l2) in ref_cs.items() if abs(got[k][1] - l2) > rtol * max(abs(l2), 1e-6)]
+    assert not bad, bad[:5]
+
+
+def test_three_step_small_vs_reference(golden):
+    """2 iterations of the A/B/C update through the drop-in API, statement for statement as
+    adapt_trainer.py:155-220, compared with the reference's trace."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, get_prob_distance_criterion
+    from models.model_util import get_optimizer
+    tr = golden.json("traces.json")["mcd_small"]
+    g, f1, f2 = _mcd_models(dev)
+    n, ch, h, w = tr["shape"]
+    s, l, t = (v.to(dev) for v in make_batch(tr["seed_batch"], n, ch, h, w, NC))
+    og = get_optimizer(g.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    of = get_optimizer(list(f1.parameters()) + list(f2.parameters()), "sgd", 1e-3, 0.9, 2e-5)
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    criterion = CrossEntropyLoss2d(cw.to(dev))
+    criterion_d = get_prob_distance_criterion("diff")
+    for it in tr["iters"]:
+        og.zero_grad(); of.zero_grad()
+        out = g(s)
+        loss = criterion(f1(out), l) + criterion(f2(out), l)
+        loss.backward()
+        c_loss = float(loss)
+        og.step(); of.step()
+        og.zero_grad(); of.zero_grad()
+        out = g(s)
+        loss = criterion(f1(out), l) + criterion(f2(out), l)
+        out = g(t)
+        loss = loss - criterion_d(f1(out), f2(out))
+        loss.backward()
+        of.step()
+        for _ in range(4):
+            og.zero_grad()
+            out = g(t)
+            loss = criterion_d(f1(out), f2(out)) * 1
+            loss.backward()
+            og.step()
+        d_loss = float(loss) / 4
+        assert abs(c_loss - it["c_loss"]) <= 1e-4 * it["c_loss"], (c_loss, it)
+        assert abs(d_loss - it["d_loss"]) <= 2e-3 * it["d_loss"], (d_loss, it)
+    _check_state(g, tr["g"], 3e-4), _check_state(f1, tr["f1"], 3e-4), _check_state(f2, tr["f2"], 3e-4)
+    assert int(g.state_dict()["base.0.1.num_batches_tracked"]) == tr["nbt"] == 14
+    sd = og.state_dict()
+    assert sorted(sd.keys()) == tr["opt_g_state_keys"]
+    assert sorted(sd["param_groups"][0].keys()) >= [k for k in tr["opt_g_group_keys"] if k in ("lr", "momentum", "weight_decay", "params")]
+    first = next(iter(g.parameters()))
+    mom = checksum(og.state[first]["momentum_buffer"])
+    assert abs(mom[1] - tr["mom_g_first"][1]) <= 2e-2 * tr["mom_g_first"][1]
+
+
+def test_solver_matches_drop_in_loop(golden):
+    """The fused solver (one loss kernel per phase, step-B generator backward elided) gives the same trace."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, get_prob_distance_criterion
+    from models.model_util import get_optimizer
+    from solvers.solver import MCDSolver
+    tr = golden.json("traces.json")["mcd_small"]
+    g, f1, f2 = _mcd_models(dev)
+    n, ch, h, w = tr["shape"]
+    s, l, t = (v.to(dev) for v in make_batch(tr["seed_batch"], n, ch, h, w, NC))
+    og = get_optimizer(g.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    of = get_optimizer(list(f1.parameters()) + list(f2.parameters()), "sgd", 1e-3, 0.9, 2e-5)
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    solver = MCDSolver(g, f1, f2, og, of, CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff"), num_k=4)
+    for it in tr["iters"]:
+        c_loss, d_loss = solver.step(s, l, t)
+        assert abs(float(c_loss) - it["c_loss"]) <= 1e-4 * it["c_loss"]
+        assert abs(float(d_loss) - it["d_loss"]) <= 2e-3 * it["d_loss"]
+    _check_state(g, tr["g"], 3e-4), _check_state(f1, tr["f1"], 3e-4), _check_state(f2, tr["f2"], 3e-4)
+    assert int(g.state_dict()["base.0.1.num_batches_tracked"]) == 14
+
+
+def test_mfnet_vs_reference(golden):
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, get_prob_distance_criterion
+    from models.model_util import get_models, get_optimizer
+    from solvers.solver import MFNetMCDSolver
+    tr = golden.json("traces.json")["mfnet_small"]
+    fx = golden.npz("mfnet_small.npz")
+    ms = get_models("drn_d_38", 6, NC, method="MFNet-ScoreAddFusion")
+    for m, seed in zip(ms, (51, 52, 53, 54)):
+        fill_state_(m, seed)
+        m.to(dev).train()
+    n, ch, h, w = tr["shape"]
+    s, l, t = (v.to(dev) for v in make_batch(tr["seed_batch"], n, ch, h, w, NC))
+    with torch.no_grad():
+        a, b = ms[0](s[:, :3]), ms[1](s[:, 3:])
+        o = ms[2](a, b)
+    assert np.abs(a.cpu().numpy() - fx["feat_rgb"]).max() <= 2e-5 * np.abs(fx["feat_rgb"]).max()
+    assert np.abs(b.cpu().numpy() - fx["feat_hha"]).max() <= 2e-5 * np.abs(fx["feat_hha"]).max()
+    assert np.abs(o[:, :, ::4, ::4].cpu().numpy() - fx["logits1_sub"]).max() <= 1e-3
+    for m, seed in zip(ms, (51, 52, 53, 54)):
+        fill_state_(m, seed)
+    og = get_optimizer(list(ms[0].parameters()) + list(ms[1].parameters()), "sgd", 1e-3, 0.9, 2e-5)
+    of = get_optimizer(list(ms[2].parameters()) + list(ms[3].parameters()), "sgd", 1e-3, 0.9, 2e-5)
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    solver = MFNetMCDSolver(ms[0], ms[1], ms[2], ms[3], og, of, CrossEntropyLoss2d(cw.to(dev)),
+                            get_prob_distance_criterion("diff"), num_k=4)
+    c_loss, d_loss = solver.step(s, l, t)
+    assert abs(float(c_loss) - tr["c_loss"]) <= 1e-4 * tr["c_loss"]
+    assert abs(float(d_loss) - tr["d_loss"]) <= 2e-3 * tr["d_loss"]
+    _check_state(ms[0], tr["g_3ch"], 3e-4), _check_state(ms[1], tr["g_1ch"], 3e-4), _check_state(ms[2], tr["f1"], 3e-4)
+
+
+def test_source_step_cfg1_vs_reference(golden):
+    """BASELINE config 1 (source_trainer, DRNSeg in DataParallel, 2x6x240x320) on the HIP path."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d
+    from models.model_util import get_full_model, get_optimizer
+    tr = golden.json("traces.json")["source_240x320"]
+    m = get_full_model("drn_d_38", "50", NC, 6)
+    assert next(iter(m.state_dict())).startswith("module.")
+    fill_state_(m, 61)
+    m.to(dev).train()
+    n, ch, h, w = tr["shape"]
+    s, l, _ = (v.to(dev) for v in make_batch(tr["seed_batch"], n, ch, h, w, NC))
+    opt = get_optimizer(m.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    opt.zero_grad()
+    preds = m(s)
+    loss = CrossEntropyLoss2d(cw.to(dev))(preds, l)
+    loss.backward()
+    opt.step()
+    assert abs(float(loss) - tr["loss"]) <= 1e-5 * tr["loss"]
+    assert abs(checksum(preds)[1] - tr["logits_cs"][1]) <= 1e-5 * tr["logits_cs"][1]
+    _check_state(m, tr["state"], 3e-4)
+
+
+def test_full_resolution_vs_oracle_and_properties():
+    """BASELINE config 2 geometry (6x480x640): one image against the CPU oracle, then size-independent
+    properties at N = 4: BN output statistics, up-sampler linearity, loss symmetries."""
+    dev = _dev()
+    from oracle import ref_models
+    from mcdseg import ops
+    g, f1, f2 = _mcd_models(dev)
+    og, of1, _ = ref_models.get_models("drn_d_38", 6, NC)
+    fill_state_(og, 11), fill_state_(of1, 12)
+    og.train(), of1.train()
+    src, lbl, tgt = make_batch(77, 1, 6, 480, 640, NC)
+    with torch.no_grad():
+        ref_feat = og(src)
+        ref_logits = of1(ref_feat)
+        feat = g(src.to(dev))
+        logits = f1(feat)
+    err = float((feat.cpu() - ref_feat).abs().max())
+    assert err <= 1e-3, "feat err %.3e" % err
+    lerr = float((logits.cpu() - ref_logits).abs().max())
+    assert lerr <= 1e-3, "logit err %.3e" % lerr
+    top2 = ref_logits[:, :NC - 1].topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 2e-3
+    same = logits[:, :NC - 1].argmax(1).cpu() == ref_logits[:, :NC - 1].argmax(1)
+    assert bool(same[safe].all()) and float((~same).float().mean()) < 0.01
+    # properties at a larger batch
+    x = torch.randn(4, 6, 480, 640, generator=torch.Generator().manual_seed(5)).to(dev)
+    with torch.no_grad():
+        h = g.base[0](x)  # stem: conv7x7 + BN(train) + ReLU; pre-ReLU statistics are (beta, gamma^2) per channel
+        fa, fb = g(x), g(2 * x[:, :, :, :])
+        la, lb = f1(fa), f2(fa)
+        assert la.shape == (4, NC, 480, 640)
+        # up-sampler is linear: up(a + 2b) = up(a) + 2 up(b)
+        lin = ops.up8(fa + 2 * fb, f1.up.weight) - (ops.up8(fa, f1.up.weight) + 2 * ops.up8(fb, f1.up.weight))
+        assert float(lin.abs().max()) <= 1e-4 * float(la.abs().max() + 1)
+        # discrepancy is symmetric, zero on identical heads; softmax shift invariance of both losses
+        d_ab = ops.diff2d(la, lb)
+        assert abs(float(d_ab) - float(ops.diff2d(lb, la))) <= 1e-7
+        assert float(ops.diff2d(la, la)) == 0.0
+        lab = torch.randint(0, NC, (4, 480, 640), generator=torch.Generator().manual_seed(6)).to(dev)
+        cw = torch.ones(NC, device=dev)
+        cw[NC - 1] = 0
+        c0 = float(ops.cross_entropy2d(la, lab, cw))
+        c1 = float(ops.cross_entropy2d(la + 3.0, lab, cw))
+        assert abs(c0 - c1) <= 2e-5 * abs(c0)
+    assert h.shape == (4, 16, 480, 640) and float(h.min()) >= 0.0
