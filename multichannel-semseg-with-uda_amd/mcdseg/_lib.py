@@ -67,7 +67,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC,
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC,
            "-o", LIB_PATH + ".tmp"] + srcs
     if verbose:
         print(" ".join(cmd))
@@ -85,6 +85,13 @@ def lib():
                 if not os.path.exists(LIB_PATH):
                     raise RuntimeError("libmcdseg.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                                        "-- the HIP kernels are the only implementation, there is no fallback" % LIB_PATH)
+                # PyTorch-ROCm bundles its own libamdhip64.so; the kernels must run in THAT runtime instance (they
+                # are launched on torch's streams), so it has to be resident before libmcdseg.so resolves its
+                # libamdhip64.so.7 dependency -- otherwise /opt/rocm's copy is loaded as a second, device-less runtime.
+                import torch
+                bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+                if os.path.exists(bundled):
+                    ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
                 handle = ctypes.CDLL(LIB_PATH)
                 for name, (res, args) in _SIGNATURES.items():
                     fn = getattr(handle, name)

@@ -27,6 +27,35 @@ def bump_weight_epoch():
     WEIGHT_EPOCH += 1
 
 
+# Optional launch timer (bench.py): an object with ``wants(name) -> bool`` and ``add(name, work, start, stop)``.
+# When set, the named kernel launches are bracketed by HIP events recorded on the launch stream.
+LAUNCH_TIMER = None
+
+
+class _timed:
+    def __init__(self, name, work):
+        self.on = LAUNCH_TIMER is not None and LAUNCH_TIMER.wants(name)
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if self.on:
+            self.t0 = torch.cuda.Event(enable_timing=True)
+            self.t1 = torch.cuda.Event(enable_timing=True)
+            self.t0.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.t1.record()
+            LAUNCH_TIMER.add(self.name, self.work, self.t0, self.t1)
+
+
+def conv_work(desc):
+    """(algorithmic FLOPs, algorithmic bytes) of one conv pass: 2*MACs; input read once + output written once."""
+    macs = desc.N * desc.Ho * desc.Wo * desc.Cout * desc.Cin * desc.KH * desc.KW
+    byts = 4 * (desc.N * desc.Cin * desc.H * desc.W + desc.N * desc.Cout * desc.Ho * desc.Wo)
+    return 2 * macs, byts
+
+
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -92,13 +121,15 @@ def _conv_fprop(desc, x, wf, bias, want_stats, mpf):
     if want_stats:
         rows = L.mcdseg_conv_stat_rows(ctypes.byref(desc))
         part = torch.empty(rows * 3 * mpf, dtype=torch.float32, device=x.device)
-    check(L.mcdseg_conv_fprop(ctypes.byref(desc), _p(x), _p(wf), _p(bias), _p(y), _p(part), _stream()), "conv_fprop")
+    with _timed("conv_fprop", conv_work(desc)):
+        check(L.mcdseg_conv_fprop(ctypes.byref(desc), _p(x), _p(wf), _p(bias), _p(y), _p(part), _stream()), "conv_fprop")
     return y, part, rows
 
 
 def _conv_dgrad(desc, dy, wd):
     dx = torch.empty((desc.N, desc.Cin, desc.H, desc.W), dtype=torch.float32, device=dy.device)
-    check(lib().mcdseg_conv_dgrad(ctypes.byref(desc), _p(dy), _p(wd), _p(dx), _stream()), "conv_dgrad")
+    with _timed("conv_dgrad", conv_work(desc)):
+        check(lib().mcdseg_conv_dgrad(ctypes.byref(desc), _p(dy), _p(wd), _p(dx), _stream()), "conv_dgrad")
     return dx
 
 
@@ -107,8 +138,9 @@ def _conv_wgrad(desc, x, dy):
     nbytes = L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(desc))
     ws = _ws(nbytes, x.device)
     dw = torch.empty((desc.Cout, desc.Cin, desc.KH, desc.KW), dtype=torch.float32, device=x.device)
-    check(L.mcdseg_conv_wgrad(ctypes.byref(desc), _p(x), _p(dy), _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
-          "conv_wgrad")
+    with _timed("conv_wgrad", conv_work(desc)):
+        check(L.mcdseg_conv_wgrad(ctypes.byref(desc), _p(x), _p(dy), _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
+              "conv_wgrad")
     return dw
 
 
@@ -317,9 +349,12 @@ def mcd_losses(z1, z2, labels, class_weight, ignore_index=-100, ce_coef=0.0, dif
     g1 = torch.empty_like(z1) if want_grad else None
     g2 = torch.empty_like(z2) if (want_grad and z2 is not None) else None
     ws = _ws(L.mcdseg_loss_workspace_bytes(n, h * w), z1.device)
-    check(L.mcdseg_softmax_ce_l1(_p(z1), _p(z2), _p(labels), _p(class_weight), int(ignore_index), float(ce_coef), float(diff_coef),
-                                 _p(g1), _p(g2), _p(losses), n, c, h * w, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
-          "softmax_ce_l1")
+    nz = (1 if z2 is None else 2) * n * c * h * w
+    byts = 4 * nz * (2 if want_grad else 1) + (8 * n * h * w if labels is not None else 0)
+    with _timed("softmax_ce_l1", (0, byts)):
+        check(L.mcdseg_softmax_ce_l1(_p(z1), _p(z2), _p(labels), _p(class_weight), int(ignore_index), float(ce_coef),
+                                     float(diff_coef), _p(g1), _p(g2), _p(losses), n, c, h * w, _p(ws),
+                                     ctypes.c_size_t(ws.numel() * 4), _stream()), "softmax_ce_l1")
     return losses, g1, g2
 
 
