@@ -50,7 +50,7 @@ class LaunchTimer:
         self.enabled = False
 
     def wants(self, name):
-        return self.enabled and name in self.names
+        return self.enabled and any(name.startswith(n) for n in self.names)
 
     def add(self, name, work, t0, t1):
         self.records.append((name, work, t0, t1))
@@ -141,7 +141,7 @@ def main():
     solver, models = build_hip(args, dev)
     src, lbl, tgt = (t.to(dev) for t in synthetic_batch(args.batch, args.input_ch, args.height, args.width, args.n_class,
                                                         1234 + rank))
-    timer = LaunchTimer(["conv_fprop", "conv_dgrad", "conv_wgrad", "softmax_ce_l1"])
+    timer = LaunchTimer(["conv_gemm_kernel", "softmax_ce_l1_kernel"])
     ops.LAUNCH_TIMER = timer
 
     for _ in range(args.warmup):
@@ -173,12 +173,12 @@ def main():
             k["avg_ms"] = k["ms"] / max(k["launches"], 1)
             k["tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
             k["gbs"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
-        conv = [kern[k] for k in ("conv_fprop", "conv_dgrad") if k in kern]
-        dom = max(conv, key=lambda k: k["ms"]) if conv else None
-        dom_name = [k for k in ("conv_fprop", "conv_dgrad") if k in kern and kern[k] is dom][0] if dom else None
+        convs = {k: v for k, v in kern.items() if k.startswith("conv_gemm_kernel")}
+        dom_name = max(convs, key=lambda k: convs[k]["ms"]) if convs else None
         roofline = None
-        if dom:
-            roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (%s, f32 MFMA 32x32x2 implicit GEMM)" % dom_name,
+        if dom_name:
+            dom = convs[dom_name]
+            roofline = {"bound": "mfma", "kernel": dom_name + " (implicit-GEMM conv on v_mfma_f32_32x32x2_f32)",
                         "achieved": round(dom["tflops"], 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(dom["tflops"] / PEAK_FP32_TFLOPS, 4), "traffic": None,
                         "launches": dom["launches"], "avg_launch_ms": round(dom["avg_ms"], 4),

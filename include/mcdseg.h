@@ -66,10 +66,12 @@ int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy
  * fused with ReLU and the residual add of BasicBlock/Bottleneck (models/drn.py:43-59, 80-100)
  * ---------------------------------------------------------------------------------------------- */
 /* Merge the conv epilogue partials -> mean[C], rstd[C]; update running_mean/var (unbiased var) and
- * ++num_batches_tracked when those pointers are non-NULL. */
+ * ++num_batches_tracked when those pointers are non-NULL.  workspace: 8-byte aligned scratch. */
+size_t mcdseg_bn_stats_workspace_bytes(int64_t rows, int32_t C);
 int mcdseg_bn_stats_finalize(const float* stat_partials, int64_t rows, int32_t C, int32_t Mp,
                              float* mean, float* rstd, float* running_mean, float* running_var,
-                             int64_t* num_batches_tracked, float momentum, float eps, void* stream);
+                             int64_t* num_batches_tracked, float momentum, float eps,
+                             void* workspace, size_t workspace_bytes, void* stream);
 /* eval mode: mean = running_mean, rstd = 1/sqrt(running_var+eps) */
 int mcdseg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps,
                          float* mean, float* rstd, void* stream);

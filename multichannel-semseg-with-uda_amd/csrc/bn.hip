@@ -13,57 +13,69 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// finalize: block = 32 channels x 32 row-groups.  Two passes over the partial rows (both cached):
-// pass 1 total count and mean, pass 2 M2 about that mean -- no divisions in the inner loops.
-__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __restrict__ part, int64_t rows, int C, int Mp,
-                                                                  float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                                  float* __restrict__ running_mean,
-                                                                  float* __restrict__ running_var, int64_t* nbt,
-                                                                  float momentum, float eps) {
-  __shared__ double sh_a[32][33];
-  __shared__ double sh_b[32][33];
+// finalize, two stages.  Stage 1: grid (C/32, S); a block of 32 channels x 8 row-groups folds its slice of the
+// partial rows into fp64 (sum n, sum n*mean, sum M2 + n*mean^2).  Stage 2: one thread per channel merges the
+// S slices: mean = S1/N, var = (Q - S1^2/N)/N -- in fp64 the subtraction costs ~1e-16 * mean^2/var, far below
+// fp32 resolution, while the fp32 data itself was centred per wave (shifted form) in the conv epilogue.
+int stats_slices(int64_t rows) {
+  int64_t s = rows / 64;
+  return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+}
+
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ part, int64_t rows, int C, int Mp,
+                                                               double* __restrict__ out) {
+  __shared__ double sh[3][8][33];
   const int cx = threadIdx.x & 31;
   const int g = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
-  const bool cv = c < C;
-  double cnt = 0.0, wsum = 0.0;
-  if (cv) {
-    for (int64_t r = g; r < rows; r += 32) {
+  const int S = gridDim.y;
+  const int64_t per = (rows + S - 1) / S;
+  const int64_t r0 = blockIdx.y * per;
+  int64_t r1 = r0 + per;
+  if (r1 > rows) r1 = rows;
+  double n = 0.0, s1 = 0.0, q = 0.0;
+  if (c < C) {
+    for (int64_t r = r0 + g; r < r1; r += 8) {
       const float* row = part + (size_t)r * 3 * Mp;
-      const double n = (double)row[c];
-      cnt += n;
-      wsum += n * (double)row[Mp + c];
+      const double cnt = (double)row[c];
+      const double mu = (double)row[Mp + c];
+      n += cnt;
+      s1 += cnt * mu;
+      q += (double)row[2 * (size_t)Mp + c] + cnt * mu * mu;
     }
   }
-  sh_a[g][cx] = cnt;
-  sh_b[g][cx] = wsum;
+  sh[0][g][cx] = n;
+  sh[1][g][cx] = s1;
+  sh[2][g][cx] = q;
   __syncthreads();
-  double tot_n = 0.0, tot_s = 0.0;
-  for (int k = 0; k < 32; ++k) {
-    tot_n += sh_a[k][cx];
-    tot_s += sh_b[k][cx];
+  if (g < 3 && c < C) {
+    double t = 0.0;
+    for (int k = 0; k < 8; ++k) t += sh[g][k][cx];
+    out[((size_t)blockIdx.y * 3 + g) * C + c] = t;
   }
-  const double mean = tot_n > 0.0 ? tot_s / tot_n : 0.0;
-  __syncthreads();
-  double m2 = 0.0;
-  if (cv) {
-    for (int64_t r = g; r < rows; r += 32) {
-      const float* row = part + (size_t)r * 3 * Mp;
-      const double n = (double)row[c];
-      const double d = (double)row[Mp + c] - mean;
-      m2 += (double)row[2 * (size_t)Mp + c] + n * d * d;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ sl, int S, int C,
+                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var, int64_t* nbt,
+                                                                float momentum, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    double n = 0.0, s1 = 0.0, q = 0.0;
+    for (int k = 0; k < S; ++k) {
+      n += sl[((size_t)k * 3 + 0) * C + c];
+      s1 += sl[((size_t)k * 3 + 1) * C + c];
+      q += sl[((size_t)k * 3 + 2) * C + c];
     }
-  }
-  sh_a[g][cx] = m2;
-  __syncthreads();
-  if (g == 0 && cv) {
-    double tot_m2 = 0.0;
-    for (int k = 0; k < 32; ++k) tot_m2 += sh_a[k][cx];
-    const double var = tot_n > 0.0 ? tot_m2 / tot_n : 0.0;
+    const double mean = n > 0.0 ? s1 / n : 0.0;
+    double m2 = q - s1 * mean;
+    if (m2 < 0.0) m2 = 0.0;
+    const double var = n > 0.0 ? m2 / n : 0.0;
     mean_out[c] = (float)mean;
     rstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
     if (running_mean != nullptr) {
-      const double unbiased = tot_n > 1.0 ? tot_m2 / (tot_n - 1.0) : var;
+      const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
       running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
       running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
     }
@@ -275,14 +287,26 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
+extern "C" size_t mcdseg_bn_stats_workspace_bytes(int64_t rows, int32_t C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return (size_t)stats_slices(rows) * 3 * C * sizeof(double);
+}
+
 extern "C" int mcdseg_bn_stats_finalize(const float* stat_partials, int64_t rows, int32_t C, int32_t Mp, float* mean, float* rstd,
                                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
-                                        float eps, void* stream) {
-  MCD_REQUIRE(stat_partials && mean && rstd, "bn_stats_finalize: null pointer");
+                                        float eps, void* workspace, size_t workspace_bytes, void* stream) {
+  MCD_REQUIRE(stat_partials && mean && rstd && workspace, "bn_stats_finalize: null pointer");
   MCD_REQUIRE(rows > 0 && C > 0 && Mp >= C, "bn_stats_finalize: bad dims rows=%lld C=%d Mp=%d", (long long)rows, C, Mp);
   MCD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize: running stats must come in pairs");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, (hipStream_t)stream, stat_partials, rows, C,
-                     Mp, mean, rstd, running_mean, running_var, num_batches_tracked, momentum, eps);
+  MCD_REQUIRE(workspace_bytes >= mcdseg_bn_stats_workspace_bytes(rows, C), "bn_stats_finalize: workspace too small");
+  MCD_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "bn_stats_finalize: workspace must be 8-byte aligned");
+  const int S = stats_slices(rows);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ceil_div(C, 32), S), dim3(256), 0, st, stat_partials, rows, C, Mp,
+                     (double*)workspace);
+  MCD_LAUNCH_CHECK("bn_stats_partial");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const double*)workspace, S, C, mean,
+                     rstd, running_mean, running_var, num_batches_tracked, momentum, eps);
   MCD_LAUNCH_CHECK("bn_stats_finalize");
   return 0;
 }

@@ -32,10 +32,12 @@ struct ConvGemmParams {
   int Mp, Kp;
   int KH, KW, stride, pad, dil;
   int P;           // N*Hd*Wd
+  int src_bytes, wp_bytes;  // buffer-descriptor ranges (< 2 GiB)
+  int ablate;      // timing-only ablation bits (mcdseg_debug_ablate): 1 no global loads, 2 no LDS stores, 4 no barriers
 };
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool DGRAD>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
+__global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGemmParams p) {
   constexpr int BM = 32 * WM * WAVES_M;
   constexpr int BN = 32 * WN * WAVES_N;
   constexpr int NT = 256;
@@ -56,8 +58,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
   const int wave = t >> 6;
   const int wm = wave / WAVES_N;
   const int wn = wave % WAVES_N;
-  const int tile_n = blockIdx.x;
-  const int tile_m = blockIdx.y;
+  // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an L2), so
+  // id -> (xcd = b % 8, slot = b / 8).  Inside one XCD consecutive slots walk the M tiles of one pixel tile
+  // first (they gather the same activations: one HBM/MALL fetch, then L2 hits), and every XCD owns a contiguous
+  // range of pixel tiles (neighbouring tiles share their halo rows).  Placement only affects speed.
+  const int m_tiles = p.Mp / BM;
+  const int n_tiles = (p.P + BN - 1) / BN;
+  const int per_xcd = (n_tiles + 7) >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int tile_m = slot % m_tiles;
+  const int tile_n = xcd * per_xcd + slot / m_tiles;
+  if (tile_n >= n_tiles) return;
 
   // ---- this thread's gather pixel
   const int bj = t % BN;
@@ -73,53 +85,74 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
     py = rem / p.Wd;
     px = rem - py * p.Wd;
   }
-  const float* src_n = p.src + (size_t)pn * p.Cs * HWs;
+  // Gathers go through buffer loads: the 128-bit descriptor and the per-load channel offset live in SGPRs, the
+  // per-lane part is ONE 32-bit byte offset recomputed per tap, and a lane whose tap falls into the zero padding
+  // (or past the last pixel) gets an offset beyond num_records -- the hardware range check returns 0 for it.
+  // No exec-mask juggling, no 64-bit address arithmetic in the K loop.
+  constexpr unsigned OOB = 0x80000000u;  // tensors are < 2 GiB (checked on the host), so this is out of range
+  const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wp_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.wp_bytes, 0x00020000);
+  const unsigned pix_base = (unsigned)pn * (unsigned)p.Cs * (unsigned)HWs;
+  const int brg_u = __builtin_amdgcn_readfirstlane(brg);  // wave-uniform (BN >= 64)
+  const bool ragged = p.Kp != p.Cs;
 
   // ---- K-step state of the loader (one step ahead of the MFMAs)
   int l_tap = 0, l_c0 = 0, l_ky = 0, l_kx = 0;
-  int l_off = 0;
-  bool l_ok = false;
+  unsigned l_voff = OOB;
   auto tap_geom = [&]() {
+    bool ok;
+    int off;
     if (!DGRAD) {
       const int sy = py * p.stride + l_ky * p.dil - p.pad;
       const int sx = px * p.stride + l_kx * p.dil - p.pad;
-      l_ok = pv && sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws;
-      l_off = sy * p.Ws + sx;
+      ok = pv && sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws;
+      off = sy * p.Ws + sx;
     } else {
       const int ty = py + p.pad - l_ky * p.dil;
       const int tx = px + p.pad - l_kx * p.dil;
-      bool ok = pv && ty >= 0 && tx >= 0;
+      ok = pv && ty >= 0 && tx >= 0;
       int sy = ty, sx = tx;
       if (p.stride != 1) {
         sy = ty / p.stride;
         sx = tx / p.stride;
         ok = ok && (sy * p.stride == ty) && (sx * p.stride == tx);
       }
-      l_ok = ok && sy < p.Hs && sx < p.Ws;
-      l_off = sy * p.Ws + sx;
+      ok = ok && sy < p.Hs && sx < p.Ws;
+      off = sy * p.Ws + sx;
     }
+    l_voff = ok ? (pix_base + (unsigned)off) * 4u : OOB;
   };
   tap_geom();
 
-  float breg[B_ITERS];
-  float4 areg[A_ITERS];
+  // weight slab: per-thread constant offsets inside the [BK][BM] slab, per-step uniform base in soffset
+  unsigned a_voff[A_ITERS];
 #pragma unroll
-  for (int i = 0; i < A_ITERS; ++i) areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < A_ITERS; ++i) {
+    const int idx = t + i * NT;
+    const int k = idx / (BM / 4);
+    const int m4 = idx - k * (BM / 4);
+    a_voff[i] = (A_EXACT || idx < A_VECS) ? ((unsigned)k * (unsigned)p.Mp + (unsigned)m4 * 4u) * 4u : OOB;
+  }
+
+  float breg[B_ITERS];
+  f32x4 areg[A_ITERS];
   auto load_regs = [&]() {
+    const int c_base = l_c0 + brg_u;
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
-      const int c = l_c0 + brg + i * RPP;
-      float v = 0.f;
-      if (l_ok && c < p.Cs) v = src_n[(size_t)c * HWs + l_off];
-      breg[i] = v;
+      const int c = c_base + i * RPP;
+      // channels of the zero-padded K tail: a scalar offset past every record (voffset + soffset never wraps)
+      const int soff = (!ragged || c < p.Cs) ? c * HWs * 4 : 0x7FFFFFFF;
+      breg[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src_rs, l_voff, soff, 0));
     }
-    const float* wrow = p.wp + ((size_t)l_tap * p.Kp + l_c0) * p.Mp + tile_m * BM;
+    const int a_soff = ((l_tap * p.Kp + l_c0) * p.Mp + tile_m * BM) * 4;
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
-      const int idx = t + i * NT;
-      const int k = idx / (BM / 4);
-      const int m4 = idx - k * (BM / 4);
-      if (A_EXACT || idx < A_VECS) areg[i] = *reinterpret_cast<const float4*>(wrow + (size_t)k * p.Mp + m4 * 4);
+      const auto q = __builtin_amdgcn_raw_buffer_load_b128(wp_rs, a_voff[i], a_soff, 0);
+      areg[i][0] = __uint_as_float(q[0]);
+      areg[i][1] = __uint_as_float(q[1]);
+      areg[i][2] = __uint_as_float(q[2]);
+      areg[i][3] = __uint_as_float(q[3]);
     }
   };
   auto store_lds = [&](int buf) {
@@ -130,21 +163,26 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       const int idx = t + i * NT;
-      if (A_EXACT || idx < A_VECS) *reinterpret_cast<float4*>(adst + idx * 4) = areg[i];
+      if (A_EXACT || idx < A_VECS) *reinterpret_cast<f32x4*>(adst + idx * 4) = areg[i];
     }
   };
+  // K order: channel chunk OUTER, tap INNER -- the KH*KW shifted re-reads of one 16-channel activation slab
+  // are back to back, so all but the first come from L1/L2 instead of MALL/HBM.
+  const int taps = p.KH * p.KW;
   auto advance = [&]() {
-    l_c0 += BK;
-    if (l_c0 >= p.Kp) {
-      l_c0 = 0;
-      ++l_tap;
-      ++l_kx;
-      if (l_kx == p.KW) {
-        l_kx = 0;
-        ++l_ky;
-      }
-      tap_geom();
+    ++l_tap;
+    ++l_kx;
+    if (l_kx == p.KW) {
+      l_kx = 0;
+      ++l_ky;
     }
+    if (l_tap == taps) {
+      l_tap = 0;
+      l_kx = 0;
+      l_ky = 0;
+      l_c0 += BK;
+    }
+    tap_geom();
   };
 
   f32x16 acc[WM][WN];
@@ -155,7 +193,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nsteps = p.KH * p.KW * (p.Kp / BK);
+  const int nsteps = taps * (p.Kp / BK);
   load_regs();
   store_lds(0);
   __syncthreads();
@@ -167,25 +205,36 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
     const bool more = (s + 1) < nsteps;
     if (more) {
       advance();
-      load_regs();
+      if (!(p.ablate & 1)) load_regs();
     }
     const float* a_base = As + cur * BK * BM + wm * (32 * WM) + l31;
     const float* b_base = Bs + cur * BK * BN + wn * (32 * WN) + l31;
+    // fragments of k-pair ks+1 are read from LDS while the MFMAs of k-pair ks run
+    float a[2][WM], b[2][WN];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const int kr = kk + lh;
-      float a[WM], b[WN];
+    for (int i = 0; i < WM; ++i) a[0][i] = a_base[lh * BM + i * 32];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = a_base[kr * BM + i * 32];
+    for (int j = 0; j < WN; ++j) b[0][j] = b_base[lh * BN + j * 32];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[j] = b_base[kr * BN + j * 32];
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      const int cb = ks & 1;
+      if (ks + 1 < BK / 2) {
+        const int kr = 2 * (ks + 1) + lh;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[cb ^ 1][i] = a_base[kr * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b[cb ^ 1][j] = b_base[kr * BN + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of the NEXT k-pair ahead of these MFMAs
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][i], b[cb][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) store_lds(cur ^ 1);
-    __syncthreads();
+    if (more && !(p.ablate & 2)) store_lds(cur ^ 1);
+    if (!(p.ablate & 4)) __syncthreads();
   }
 
   // ---- epilogue.  acc[i][j][r] = D[row][col], row = (r&3) + 8*(r>>2) + 4*lh, col = l31 of the 32x32 tile
@@ -299,15 +348,16 @@ int check_desc(const mcdseg_conv_desc* d, const char* who) {
   MCD_REQUIRE(ho == d->Ho && wo == d->Wo, "%s: Ho/Wo (%d,%d) do not match geometry (%d,%d)", who, d->Ho, d->Wo, ho, wo);
   MCD_REQUIRE((int64_t)d->N * d->Ho * d->Wo < (1ll << 31) && (int64_t)d->N * d->H * d->W < (1ll << 31),
               "%s: pixel count exceeds int32", who);
-  MCD_REQUIRE((int64_t)d->Cin * d->H * d->W < (1ll << 31) && (int64_t)d->Cout * d->Ho * d->Wo < (1ll << 31),
-              "%s: per-image tensor exceeds int32", who);
+  MCD_REQUIRE((int64_t)d->N * d->Cin * d->H * d->W * 4 < (1ll << 31) && (int64_t)d->N * d->Cout * d->Ho * d->Wo * 4 < (1ll << 31),
+              "%s: activation tensor must stay below 2 GiB (32-bit buffer offsets); split the batch", who);
   return 0;
 }
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, bool DGRAD>
 void launch_cfg(const ConvGemmParams& p, int bk, hipStream_t st) {
   constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
-  dim3 grid(ceil_div(p.P, BN), p.Mp / BM);
+  const int n_tiles = ceil_div(p.P, BN);
+  dim3 grid(8 * ceil_div(n_tiles, 8) * (p.Mp / BM));
   if (bk == 8)
     hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, WAVES_M, WAVES_N, 8, DGRAD>), grid, dim3(256), 0, st, p);
   else
@@ -330,7 +380,12 @@ void launch(const ConvGemmParams& p, hipStream_t st) {
 int bn_for(int M) { return mcd_bm(M) == 128 ? 128 : 256; }
 int waves_n_for(int M) { return mcd_bm(M) == 128 ? 2 : 4; }
 
+int g_ablate = 0;
+
 }  // namespace
+
+// Timing-only ablation switch for kernel development (results are WRONG when non-zero).
+extern "C" void mcdseg_debug_ablate(int bits) { g_ablate = bits; }
 
 extern "C" int mcdseg_conv_packed_dims(const mcdseg_conv_desc* d, int32_t* Mp_f, int32_t* Kp_f, int32_t* Mp_d, int32_t* Kp_d) {
   MCD_REQUIRE(d != nullptr, "conv_packed_dims: null descriptor");
@@ -377,6 +432,9 @@ extern "C" int mcdseg_conv_fprop(const mcdseg_conv_desc* d, const float* x, cons
   p.Kp = mcd_kp(d->Cin);
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
   p.P = d->N * d->Ho * d->Wo;
+  p.src_bytes = (int)((int64_t)d->N * d->Cin * d->H * d->W * 4);
+  p.wp_bytes = (int)((int64_t)d->KH * d->KW * p.Kp * p.Mp * 4);
+  p.ablate = g_ablate;
   launch<false>(p, (hipStream_t)stream);
   MCD_LAUNCH_CHECK("conv_fprop");
   return 0;
@@ -398,6 +456,9 @@ extern "C" int mcdseg_conv_dgrad(const mcdseg_conv_desc* d, const float* dy, con
   p.Kp = mcd_kp(d->Cout);
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
   p.P = d->N * d->H * d->W;
+  p.src_bytes = (int)((int64_t)d->N * d->Cout * d->Ho * d->Wo * 4);
+  p.wp_bytes = (int)((int64_t)d->KH * d->KW * p.Kp * p.Mp * 4);
+  p.ablate = g_ablate;
   launch<true>(p, (hipStream_t)stream);
   MCD_LAUNCH_CHECK("conv_dgrad");
   return 0;

@@ -12,8 +12,7 @@
 
 namespace {
 
-constexpr int BKP = 32;        // pixels per K-step
-constexpr int LDP = BKP + 1;   // padded LDS row
+constexpr int BKP_MAX = 32;    // pixels per K-step: 16 for the 128x128 tile (4 workgroups/CU), else 32
 
 struct WgradParams {
   const float* x;
@@ -22,7 +21,8 @@ struct WgradParams {
   int N, Cin, H, W, Cout, Ho, Wo;
   int KH, KW, stride, pad, dil;
   int co_p, ci_p;
-  int chunk, chunks_per_img;
+  int chunk, chunks_per_img, splits;
+  int x_bytes, dy_bytes;
 };
 
 struct WgradPlan {
@@ -52,9 +52,9 @@ WgradPlan make_plan(const mcdseg_conv_desc* d) {
   const int hw = d->Ho * d->Wo;
   int cpi = (int)ceil_div64(want_splits, d->N);
   if (cpi < 1) cpi = 1;
-  int chunk = round_up(ceil_div(hw, cpi), BKP);
-  if (chunk < 8 * BKP) chunk = 8 * BKP;  // at least 8 K-steps of work per workgroup
-  if (chunk > round_up(hw, BKP)) chunk = round_up(hw, BKP);
+  int chunk = round_up(ceil_div(hw, cpi), BKP_MAX);
+  if (chunk < 8 * BKP_MAX) chunk = 8 * BKP_MAX;  // at least 8 K-steps of work per workgroup
+  if (chunk > round_up(hw, BKP_MAX)) chunk = round_up(hw, BKP_MAX);
   pl.chunk = chunk;
   pl.chunks_per_img = ceil_div(hw, chunk);
   pl.splits = d->N * pl.chunks_per_img;
@@ -62,12 +62,13 @@ WgradPlan make_plan(const mcdseg_conv_desc* d) {
   return pl;
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_wgrad_kernel(WgradParams p) {
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BKP>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 3 : 1)) void conv_wgrad_kernel(WgradParams p) {
+  constexpr int LDP = BKP + 1;  // padded LDS row
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int BM = 32 * WM * WAVES_M;
   constexpr int BN = 32 * WN * WAVES_N;
-  constexpr int RP = NT / 32;  // rows staged per pass
+  constexpr int RP = NT / BKP;  // rows staged per pass
   constexpr int A_ITERS = BM / RP;
   constexpr int B_ITERS = BN / RP;
 
@@ -82,11 +83,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_wgrad_kernel(Wgra
   const int wn = wave % WAVES_N;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  const int tile_co = blockIdx.x;
+  // XCD-aware order (ids b, b+8 share an L2): an XCD owns whole pixel splits; inside a split the tap index
+  // runs fastest, then the ci tile, then the co tile -- workgroups that stream the same dY rows / the same
+  // (shifted) X rows are resident together and advance through the pixels in step, so the streams are fetched
+  // once per XCD and re-used from L2.
   const int ci_tiles = p.ci_p / BN;
-  const int tap = blockIdx.y / ci_tiles;
-  const int tile_ci = blockIdx.y - tap * ci_tiles;
-  const int split = blockIdx.z;
+  const int co_tiles = p.co_p / BM;
+  const int T_ = p.KH * p.KW;
+  const int per_split = co_tiles * ci_tiles * T_;
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int split = (slot / per_split) * 8 + xcd;
+  if (split >= p.splits) return;
+  int rem = slot % per_split;
+  const int tap = rem % T_;
+  rem /= T_;
+  const int tile_ci = rem % ci_tiles;
+  const int tile_co = rem / ci_tiles;
   const int n = split / p.chunks_per_img;
   const int chunk_id = split - n * p.chunks_per_img;
   const int ky = tap / p.KW;
@@ -97,37 +110,41 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_wgrad_kernel(Wgra
   int r_end = r_begin + p.chunk;
   if (r_end > HoWo) r_end = HoWo;
 
-  const int sk = t & 31;
-  const int srg = t >> 5;
-  const float* dy_n = p.dy + (size_t)n * p.Cout * HoWo;
-  const float* x_n = p.x + (size_t)n * p.Cin * HW;
-  const int co0 = tile_co * BM + srg;
-  const int ci0 = tile_ci * BN + srg;
+  const int sk = t % BKP;
+  const int srg = t / BKP;
+  // Buffer loads (descriptor + per-row offset in SGPRs, one 32-bit per-lane offset per K-step): a lane past the
+  // end of its pixel chunk, or whose tap falls into the zero padding, uses an offset beyond num_records and reads 0.
+  // Rows of the zero-padded tile tail (co >= Cout / ci >= Cin) are NOT masked: they alias finite data of the next
+  // image (or read 0 past the tensor end) and only feed slab rows/columns the reduction never reads.
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t dy_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const int a_soff0 = (n * p.Cout + tile_co * BM) * HoWo * 4;
+  const int b_soff0 = (n * p.Cin + tile_ci * BN) * HW * 4;
+  const int a_sstep = RP * HoWo * 4;
+  const int b_sstep = RP * HW * 4;
+  const unsigned a_row = (unsigned)srg * (unsigned)HoWo;
+  const unsigned b_row = (unsigned)srg * (unsigned)HW;
 
   float areg[A_ITERS], breg[B_ITERS];
   auto load_regs = [&](int r0) {
     const int r = r0 + sk;
     const bool rv = r < r_end;
-    int xoff = 0;
-    bool xv = false;
+    unsigned a_voff = OOB, b_voff = OOB;
     if (rv) {
+      a_voff = (a_row + (unsigned)r) * 4u;
       const int oy = r / p.Wo;
       const int ox = r - oy * p.Wo;
       const int iy = oy * p.stride + ky * p.dil - p.pad;
       const int ix = ox * p.stride + kx * p.dil - p.pad;
-      xv = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      xoff = iy * p.W + ix;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) b_voff = (b_row + (unsigned)(iy * p.W + ix)) * 4u;
     }
 #pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-      const int co = co0 + i * RP;
-      areg[i] = (rv && co < p.Cout) ? dy_n[(size_t)co * HoWo + r] : 0.f;
-    }
+    for (int i = 0; i < A_ITERS; ++i)
+      areg[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dy_rs, a_voff, a_soff0 + i * a_sstep, 0));
 #pragma unroll
-    for (int i = 0; i < B_ITERS; ++i) {
-      const int ci = ci0 + i * RP;
-      breg[i] = (xv && ci < p.Cin) ? x_n[(size_t)ci * HW + xoff] : 0.f;
-    }
+    for (int i = 0; i < B_ITERS; ++i)
+      breg[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rs, b_voff, b_soff0 + i * b_sstep, 0));
   };
   auto store_lds = [&](int buf) {
     float* a = As + buf * BM * LDP;
@@ -158,17 +175,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_wgrad_kernel(Wgra
     if (more) load_regs(r_begin + (s + 1) * BKP);
     const float* a_base = As + cur * BM * LDP + (wm * 32 * WM + l31) * LDP + lh;
     const float* b_base = Bs + cur * BN * LDP + (wn * 32 * WN + l31) * LDP + lh;
+    // fragments of pixel-pair ks+1 are read from LDS while the MFMAs of pixel-pair ks run
+    float a[2][WM], b[2][WN];
 #pragma unroll
-    for (int kk = 0; kk < BKP; kk += 2) {
-      float a[WM], b[WN];
+    for (int i = 0; i < WM; ++i) a[0][i] = a_base[i * 32 * LDP];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = a_base[i * 32 * LDP + kk];
+    for (int j = 0; j < WN; ++j) b[0][j] = b_base[j * 32 * LDP];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[j] = b_base[j * 32 * LDP + kk];
+    for (int ks = 0; ks < BKP / 2; ++ks) {
+      const int cb = ks & 1;
+      if (ks + 1 < BKP / 2) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[cb ^ 1][i] = a_base[i * 32 * LDP + 2 * (ks + 1)];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b[cb ^ 1][j] = b_base[j * 32 * LDP + 2 * (ks + 1)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][i], b[cb][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) store_lds(cur ^ 1);
     __syncthreads();
@@ -216,25 +244,30 @@ extern "C" int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, cons
                                  size_t workspace_bytes, void* stream) {
   MCD_REQUIRE(d && x && dy && dw && workspace, "conv_wgrad: null pointer");
   MCD_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0, "conv_wgrad: bad dims");
+  MCD_REQUIRE(((int64_t)d->N * d->Cin + 128) * d->H * d->W * 4 < (1ll << 31) && ((int64_t)d->N * d->Cout + 128) * d->Ho * d->Wo * 4 < (1ll << 31),
+              "conv_wgrad: activation tensor must stay below 2 GiB (32-bit buffer offsets); split the batch");
   const WgradPlan pl = make_plan(d);
   MCD_REQUIRE(workspace_bytes >= (size_t)pl.slab_floats * sizeof(float), "conv_wgrad: workspace too small (%zu < %zu)",
               workspace_bytes, (size_t)pl.slab_floats * sizeof(float));
-  MCD_REQUIRE(pl.splits <= 65535, "conv_wgrad: too many splits (%d)", pl.splits);
   const int T = d->KH * d->KW;
   WgradParams p;
   p.x = x; p.dy = dy; p.slab = (float*)workspace;
   p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.Ho = d->Ho; p.Wo = d->Wo;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
-  p.co_p = pl.co_p; p.ci_p = pl.ci_p; p.chunk = pl.chunk; p.chunks_per_img = pl.chunks_per_img;
-  dim3 grid(pl.co_p / pl.bm, (pl.ci_p / pl.bn) * T, pl.splits);
-  MCD_REQUIRE(grid.y <= 65535, "conv_wgrad: grid.y too large");
+  p.co_p = pl.co_p; p.ci_p = pl.ci_p; p.chunk = pl.chunk; p.chunks_per_img = pl.chunks_per_img; p.splits = pl.splits;
+  p.x_bytes = (int)((int64_t)d->N * d->Cin * d->H * d->W * 4);
+  p.dy_bytes = (int)((int64_t)d->N * d->Cout * d->Ho * d->Wo * 4);
+  const int64_t per_split = (int64_t)(pl.co_p / pl.bm) * (pl.ci_p / pl.bn) * T;
+  const int64_t nwg = 8 * ceil_div64(pl.splits, 8) * per_split;
+  MCD_REQUIRE(nwg < (1ll << 31), "conv_wgrad: grid too large");
+  dim3 grid((unsigned)nwg);
   hipStream_t st = (hipStream_t)stream;
   if (pl.cfg == 0)
-    hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 2, 2, 16>), grid, dim3(256), 0, st, p);
   else if (pl.cfg == 1)
-    hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 2>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 2, 32>), grid, dim3(256), 0, st, p);
   else
-    hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 1>), grid, dim3(64), 0, st, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 1, 32>), grid, dim3(64), 0, st, p);
   MCD_LAUNCH_CHECK("conv_wgrad");
   const int64_t total = (int64_t)T * d->Cout * d->Cin;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,

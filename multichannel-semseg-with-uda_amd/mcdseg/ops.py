@@ -12,6 +12,7 @@ mirror the ATen call sites of the reference's hot path:
   mcd_losses       both of the above in one fused kernel            adapt_trainer.py:163-212
 """
 import ctypes
+import os
 
 import torch
 
@@ -54,6 +55,18 @@ def conv_work(desc):
     macs = desc.N * desc.Ho * desc.Wo * desc.Cout * desc.Cin * desc.KH * desc.KW
     byts = 4 * (desc.N * desc.Cin * desc.H * desc.W + desc.N * desc.Cout * desc.Ho * desc.Wo)
     return 2 * macs, byts
+
+
+def gemm_kernel_name(m, k, dgrad):
+    """Template instantiation conv_fprop / conv_dgrad dispatch to (same rule as csrc/common.h mcd_bm / mcd_bk)."""
+    bm = 32 if m <= 32 else (64 if m <= 64 else 128)
+    cfg = {128: "2, 2, 2, 2", 64: "2, 2, 1, 4", 32: "1, 2, 1, 4"}[bm]
+    return "conv_gemm_kernel<%s, %d, %s>" % (cfg, 8 if k <= 8 else 16, "true" if dgrad else "false")
+
+
+def wgrad_kernel_name(cout, cin):
+    lo = min(cout, cin)
+    return "conv_wgrad_kernel<%s>" % ("2, 2, 2, 2, 16" if lo > 64 else ("1, 1, 2, 2, 32" if lo > 32 else "1, 1, 1, 1, 32"))
 
 
 def _p(t):
@@ -121,14 +134,14 @@ def _conv_fprop(desc, x, wf, bias, want_stats, mpf):
     if want_stats:
         rows = L.mcdseg_conv_stat_rows(ctypes.byref(desc))
         part = torch.empty(rows * 3 * mpf, dtype=torch.float32, device=x.device)
-    with _timed("conv_fprop", conv_work(desc)):
+    with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False), conv_work(desc)):
         check(L.mcdseg_conv_fprop(ctypes.byref(desc), _p(x), _p(wf), _p(bias), _p(y), _p(part), _stream()), "conv_fprop")
     return y, part, rows
 
 
 def _conv_dgrad(desc, dy, wd):
     dx = torch.empty((desc.N, desc.Cin, desc.H, desc.W), dtype=torch.float32, device=dy.device)
-    with _timed("conv_dgrad", conv_work(desc)):
+    with _timed(gemm_kernel_name(desc.Cin, desc.Cout, True), conv_work(desc)):
         check(lib().mcdseg_conv_dgrad(ctypes.byref(desc), _p(dy), _p(wd), _p(dx), _stream()), "conv_dgrad")
     return dx
 
@@ -138,10 +151,37 @@ def _conv_wgrad(desc, x, dy):
     nbytes = L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(desc))
     ws = _ws(nbytes, x.device)
     dw = torch.empty((desc.Cout, desc.Cin, desc.KH, desc.KW), dtype=torch.float32, device=x.device)
-    with _timed("conv_wgrad", conv_work(desc)):
+    with _timed(wgrad_kernel_name(desc.Cout, desc.Cin), conv_work(desc)):
         check(L.mcdseg_conv_wgrad(ctypes.byref(desc), _p(x), _p(dy), _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
               "conv_wgrad")
     return dw
+
+
+# dgrad and wgrad of one layer are independent: launching wgrad on a second HIP stream lets its workgroups fill
+# the CUs that idle in the last (partial) round of dgrad's tiles, and vice versa.
+OVERLAP_WGRAD = os.environ.get("MCDSEG_OVERLAP_WGRAD", "1") != "0"
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+def _conv_backward(desc, x, dy, wd, need_dx, need_dw):
+    if not (need_dx and need_dw and OVERLAP_WGRAD):
+        return (_conv_dgrad(desc, dy, wd) if need_dx else None), (_conv_wgrad(desc, x, dy) if need_dw else None)
+    main = torch.cuda.current_stream()
+    side = _side_stream(dy.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        dw = _conv_wgrad(desc, x, dy)
+    dx = _conv_dgrad(desc, dy, wd)
+    main.wait_stream(side)
+    dw.record_stream(main)
+    return dx, dw
 
 
 def _channel_reduce(dy, y, z, mean, rstd, relu):
@@ -174,9 +214,11 @@ class _ConvBNAct(torch.autograd.Function):
         rstd = torch.empty(c, dtype=torch.float32, device=x.device)
         if training:
             track = running_mean is not None
+            ws = torch.empty(L.mcdseg_bn_stats_workspace_bytes(rows, c) // 8 + 1, dtype=torch.float64, device=x.device)
             check(L.mcdseg_bn_stats_finalize(_p(part), rows, c, mpf, _p(mean), _p(rstd), _p(running_mean) if track else None,
                                              _p(running_var) if track else None, _p(nbt) if track else None,
-                                             float(momentum), float(eps), _stream()), "bn_stats_finalize")
+                                             float(momentum), float(eps), _p(ws), ctypes.c_size_t(ws.numel() * 8), _stream()),
+                  "bn_stats_finalize")
         else:
             check(L.mcdseg_bn_eval_stats(_p(running_mean), _p(running_var), c, float(eps), _p(mean), _p(rstd), _stream()),
                   "bn_eval_stats")
@@ -203,8 +245,7 @@ class _ConvBNAct(torch.autograd.Function):
         check(L.mcdseg_bn_bwd_apply(_p(dy), _p(y) if ctx.relu else None, _p(z), _p(mean), _p(rstd), _p(gamma), _p(dgamma),
                                     _p(dbeta), _p(dz), _p(dres) if (dres is not None and ctx.relu) else None, n, c, hw,
                                     int(ctx.relu), int(ctx.training), _stream()), "bn_bwd_apply")
-        dx = _conv_dgrad(desc, dz, ctx.wd) if ctx.needs_input_grad[0] else None
-        dw = _conv_wgrad(desc, x, dz) if ctx.needs_input_grad[1] else None
+        dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres,
                 None, None, None, None, None, None, None, None, None)
 
@@ -240,8 +281,7 @@ class _Conv2dBias(torch.autograd.Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         dy = _req(dy, "grad_output")
-        dx = _conv_dgrad(ctx.desc, dy, ctx.wd) if ctx.needs_input_grad[0] else None
-        dw = _conv_wgrad(ctx.desc, x, dy) if ctx.needs_input_grad[1] else None
+        dx, dw = _conv_backward(ctx.desc, x, dy, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             _, db = _channel_reduce(dy, None, None, None, None, False)
@@ -351,7 +391,7 @@ def mcd_losses(z1, z2, labels, class_weight, ignore_index=-100, ce_coef=0.0, dif
     ws = _ws(L.mcdseg_loss_workspace_bytes(n, h * w), z1.device)
     nz = (1 if z2 is None else 2) * n * c * h * w
     byts = 4 * nz * (2 if want_grad else 1) + (8 * n * h * w if labels is not None else 0)
-    with _timed("softmax_ce_l1", (0, byts)):
+    with _timed("softmax_ce_l1_kernel<48, %s>" % ("true" if z2 is not None else "false") if c > 24 else "softmax_ce_l1_kernel", (0, byts)):
         check(L.mcdseg_softmax_ce_l1(_p(z1), _p(z2), _p(labels), _p(class_weight), int(ignore_index), float(ce_coef),
                                      float(diff_coef), _p(g1), _p(g2), _p(losses), n, c, h * w, _p(ws),
                                      ctypes.c_size_t(ws.numel() * 4), _stream()), "softmax_ce_l1")
