@@ -112,11 +112,19 @@ int mcdseg_up8_bwd_weight(const float* dy, const float* x, float* dw, int32_t N,
  *   losses[3] = sum_i w[y_i]
  *   g1 = ce_coef * dCE1/dz1 + diff_coef * dDiff/dz1,   g2 likewise for z2.
  * Any of z2 / labels / g1 / g2 may be NULL (single-head CE, discrepancy only, loss values only).
+ * wsum_in (device scalar, may be NULL) overrides the CE normaliser sum_i w[y_i]: under data parallelism the
+ * caller passes the all-reduced sum over all shards so that averaged per-rank gradients equal the gradient
+ * of the reference's single global weighted mean (nn.DataParallel gathers logits before the loss).
  * ---------------------------------------------------------------------------------------------- */
 size_t mcdseg_loss_workspace_bytes(int32_t N, int32_t HW);
 int mcdseg_softmax_ce_l1(const float* z1, const float* z2, const int64_t* labels, const float* class_weight,
-                         int64_t ignore_index, float ce_coef, float diff_coef, float* g1, float* g2, float* losses,
+                         int64_t ignore_index, float ce_coef, float diff_coef, const float* wsum_in,
+                         float* g1, float* g2, float* losses,
                          int32_t N, int32_t C, int32_t HW, void* workspace, size_t workspace_bytes, void* stream);
+/* out[0] = sum_i w[labels_i] over P pixels (ignore_index and out-of-range labels contribute 0) */
+size_t mcdseg_label_weight_sum_workspace_bytes(int64_t P);
+int mcdseg_label_weight_sum(const int64_t* labels, const float* class_weight, int64_t ignore_index, int32_t C, int64_t P,
+                            float* out, void* workspace, size_t workspace_bytes, void* stream);
 /* buf[i] *= *scale (device scalar) -- applies autograd's upstream scalar without a host sync */
 int mcdseg_scale_by_device_scalar(float* buf, const float* scale, int64_t n, void* stream);
 

@@ -31,14 +31,14 @@ __global__ __launch_bounds__(256) void label_wsum_kernel(const int64_t* __restri
   if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-__global__ __launch_bounds__(256) void wsum_finalize_kernel(const float* __restrict__ part, int n, float* __restrict__ losses) {
+__global__ __launch_bounds__(256) void wsum_finalize_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) s += (double)part[i];
   __shared__ double sh[4];
   s = wave_sum_d(s);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) losses[3] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+  if (threadIdx.x == 0) *out = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
 }
 
 template <int NCMAX, bool TWO>
@@ -203,9 +203,25 @@ extern "C" size_t mcdseg_loss_workspace_bytes(int32_t N, int32_t HW) {
   return (size_t)(ceil_div64(P, LOSS_BLOCK) * 3 + wsum_blocks(P)) * sizeof(float);
 }
 
+extern "C" size_t mcdseg_label_weight_sum_workspace_bytes(int64_t P) { return P > 0 ? (size_t)wsum_blocks(P) * sizeof(float) : 0; }
+
+extern "C" int mcdseg_label_weight_sum(const int64_t* labels, const float* class_weight, int64_t ignore_index, int32_t C, int64_t P,
+                                       float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  MCD_REQUIRE(labels && out && workspace && C > 0 && P > 0, "label_weight_sum: bad arguments");
+  const int wb = wsum_blocks(P);
+  MCD_REQUIRE(workspace_bytes >= (size_t)wb * sizeof(float), "label_weight_sum: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(label_wsum_kernel, dim3(wb), dim3(256), 0, st, labels, class_weight, ignore_index, C, P, (float*)workspace);
+  MCD_LAUNCH_CHECK("label_wsum");
+  hipLaunchKernelGGL(wsum_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, wb, out);
+  MCD_LAUNCH_CHECK("wsum_finalize");
+  return 0;
+}
+
 extern "C" int mcdseg_softmax_ce_l1(const float* z1, const float* z2, const int64_t* labels, const float* class_weight,
-                                    int64_t ignore_index, float ce_coef, float diff_coef, float* g1, float* g2, float* losses,
-                                    int32_t N, int32_t C, int32_t HW, void* workspace, size_t workspace_bytes, void* stream) {
+                                    int64_t ignore_index, float ce_coef, float diff_coef, const float* wsum_in, float* g1, float* g2,
+                                    float* losses, int32_t N, int32_t C, int32_t HW, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
   MCD_REQUIRE(z1 && losses && workspace, "softmax_ce_l1: null pointer");
   MCD_REQUIRE(N > 0 && C > 0 && HW > 0, "softmax_ce_l1: bad dims");
   MCD_REQUIRE(C <= 48, "softmax_ce_l1: at most 48 classes are kept in registers (got %d)", C);
@@ -218,10 +234,13 @@ extern "C" int mcdseg_softmax_ce_l1(const float* z1, const float* z2, const int6
   float* part = (float*)workspace;
   float* wpart = part + nblk * 3;
   const int wb = wsum_blocks(P);
-  if (labels != nullptr) {
+  if (wsum_in != nullptr) {
+    // normaliser supplied by the caller (data parallel: the all-reduced sum of w[y] over every rank's shard)
+    (void)hipMemcpyAsync(losses + 3, wsum_in, sizeof(float), hipMemcpyDeviceToDevice, st);
+  } else if (labels != nullptr) {
     hipLaunchKernelGGL(label_wsum_kernel, dim3(wb), dim3(256), 0, st, labels, class_weight, ignore_index, C, P, wpart);
     MCD_LAUNCH_CHECK("label_wsum");
-    hipLaunchKernelGGL(wsum_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)wpart, wb, losses);
+    hipLaunchKernelGGL(wsum_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)wpart, wb, losses + 3);
     MCD_LAUNCH_CHECK("wsum_finalize");
   } else {
     (void)hipMemsetAsync(losses + 3, 0, sizeof(float), st);

@@ -369,7 +369,31 @@ def up8_dual(x1, w1, x2, w2):
 
 
 # ------------------------------------------------------------------------------------------------ losses
-def mcd_losses(z1, z2, labels, class_weight, ignore_index=-100, ce_coef=0.0, diff_coef=0.0, want_grad=True):
+def label_weight_sum(labels, class_weight, n_class, ignore_index=-100):
+    """device scalar sum_i w[labels_i]"""
+    L = lib()
+    labels = _req(labels, "labels", torch.int64)
+    class_weight = _req(class_weight, "class weights")
+    out = torch.empty(1, dtype=torch.float32, device=labels.device)
+    ws = _ws(L.mcdseg_label_weight_sum_workspace_bytes(labels.numel()), labels.device)
+    check(L.mcdseg_label_weight_sum(_p(labels), _p(class_weight), int(ignore_index), int(n_class), labels.numel(), _p(out), _p(ws),
+                                    ctypes.c_size_t(ws.numel() * 4), _stream()), "label_weight_sum")
+    return out
+
+
+def ce_normaliser(labels, class_weight, n_class, ignore_index=-100):
+    """CE normaliser for this rank: None (kernel computes the local sum) for single-process runs; under data
+    parallelism the all-reduced sum divided by world size, so that the optimizer's 1/world gradient average
+    reproduces the reference's one global weighted mean."""
+    from . import dist as mdist
+    if not mdist.is_distributed():
+        return None
+    w = label_weight_sum(labels, class_weight, n_class, ignore_index)
+    mdist.all_reduce_sum_(w)
+    return w / mdist.world_size()
+
+
+def mcd_losses(z1, z2, labels, class_weight, ignore_index=-100, ce_coef=0.0, diff_coef=0.0, want_grad=True, wsum=None):
     """One fused pass.  Returns (losses[4] = CE1, CE2, Diff, sum w[y]; g1; g2) where
     g_k = ce_coef * dCE_k/dz_k + diff_coef * dDiff/dz_k (None when not requested)."""
     L = lib()
@@ -385,6 +409,9 @@ def mcd_losses(z1, z2, labels, class_weight, ignore_index=-100, ce_coef=0.0, dif
     class_weight = _req(class_weight, "class weights")
     if class_weight is not None and class_weight.numel() != c:
         raise ValueError("mcdseg: class weight has %d entries for %d classes" % (class_weight.numel(), c))
+    if labels is not None and ce_coef != 0.0 and wsum is None:
+        wsum = ce_normaliser(labels, class_weight, c, ignore_index)
+    wsum = _req(wsum, "CE normaliser")
     losses = torch.empty(4, dtype=torch.float32, device=z1.device)
     g1 = torch.empty_like(z1) if want_grad else None
     g2 = torch.empty_like(z2) if (want_grad and z2 is not None) else None
@@ -393,7 +420,7 @@ def mcd_losses(z1, z2, labels, class_weight, ignore_index=-100, ce_coef=0.0, dif
     byts = 4 * nz * (2 if want_grad else 1) + (8 * n * h * w if labels is not None else 0)
     with _timed("softmax_ce_l1_kernel<48, %s>" % ("true" if z2 is not None else "false") if c > 24 else "softmax_ce_l1_kernel", (0, byts)):
         check(L.mcdseg_softmax_ce_l1(_p(z1), _p(z2), _p(labels), _p(class_weight), int(ignore_index), float(ce_coef),
-                                     float(diff_coef), _p(g1), _p(g2), _p(losses), n, c, h * w, _p(ws),
+                                     float(diff_coef), _p(wsum), _p(g1), _p(g2), _p(losses), n, c, h * w, _p(ws),
                                      ctypes.c_size_t(ws.numel() * 4), _stream()), "softmax_ce_l1")
     return losses, g1, g2
 

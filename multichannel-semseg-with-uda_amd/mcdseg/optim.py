@@ -19,6 +19,10 @@ _ALIGN = 64  # floats; keeps every view 256-byte aligned for the float4 kernels
 
 
 class FlatSGD(torch.optim.Optimizer):
+    # The update kernel is HIP-only.  Tests of the host-side logic (flat layout, run detection, the gloo
+    # all-reduce of the data-parallel path) clear this flag and substitute a reference update for the kernel.
+    _require_gpu = True
+
     def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0):
         if lr < 0 or momentum < 0 or weight_decay < 0:
             raise ValueError("FlatSGD: negative hyper-parameter")
@@ -40,7 +44,7 @@ class FlatSGD(torch.optim.Optimizer):
         if not params:
             raise ValueError("FlatSGD: no parameters")
         dev = params[0].device
-        if dev.type != "cuda":
+        if dev.type != "cuda" and self._require_gpu:
             raise RuntimeError("FlatSGD: parameters must be on the GPU before the first step (no CPU fallback)")
         offs, total = [], 0
         for p in params:

@@ -1,0 +1,157 @@
+"""CPU: the C-ABI library loads and exports every symbol of include/mcdseg.h; host-side logic (flags, helpers,
+factory, checkpoint layout) behaves like the reference's.  No kernel is launched here."""
+import argparse
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(autouse=True)
+def _no_pretrained(monkeypatch):
+    monkeypatch.setenv("MCDSEG_PRETRAINED", "0")
+
+
+def test_library_exports_every_header_symbol():
+    import mcdseg
+    from mcdseg import _lib
+    mcdseg.build()
+    header = open(os.path.join(ROOT, "include", "mcdseg.h")).read()
+    declared = set(re.findall(r"\b(mcdseg_[a-z0-9_]+)\s*\(", header))
+    declared.discard("mcdseg_conv_desc")
+    assert declared, "no declarations parsed"
+    L = mcdseg.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), "libmcdseg.so does not export %s" % name
+    assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
+    assert L.mcdseg_version() == 100
+    assert isinstance(L.mcdseg_last_error(), bytes)
+    # every source is written for gfx950 directly: no CUDA shims / dual paths
+    for src in _lib.sources():
+        text = open(src).read()
+        assert "__HIP_PLATFORM" not in text and "cuda_runtime" not in text and "hipify" not in text.lower()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "multichannel-semseg-with-uda_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), os.path.join(dirpath, f)
+
+
+def test_ops_refuse_cpu_tensors():
+    from mcdseg import ops
+    from models.model_util import get_models
+    g, f1, _ = get_models("drn_d_38", 6, 41)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        g(torch.zeros(1, 6, 16, 16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        f1(torch.zeros(1, 41, 2, 2))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.mcd_losses(torch.zeros(1, 3, 2, 2), None, None, None)
+
+
+def test_parser_defaults_match_reference():
+    # argmyparse.py:35-137 of the reference
+    import argmyparse
+    a = argmyparse.get_da_mcd_training_parser().parse_args(["suncg", "nyu"])
+    assert (a.net, a.opt, a.lr, a.momentum, a.weight_decay, a.batch_size) == ("drn_d_38", "sgd", 1e-3, 0.9, 2e-5, 1)
+    assert (a.num_k, a.num_multiply_d_loss, a.d_loss, a.method, a.input_ch) == (4, 1, "diff", "MCD", 3)
+    assert (a.epochs, a.max_iter, a.savename, a.base_outdir, a.background_id) == (40, 5000, "normal", "train_output", 255)
+    assert not a.uses_one_classifier and not a.fix_bn and not a.adjust_lr and a.train_img_shape is None
+    a = argmyparse.add_additional_params_to_args(a)
+    assert a.n_class == 41 and a.train_img_shape == [640, 480]  # W, H (datasets.py:561, 1021-1022)
+    s = argmyparse.get_src_only_training_parser().parse_args(["suncg", "--input_ch", "6", "-b", "2", "--train_img_shape", "320", "240"])
+    assert s.train_img_shape == [320, 240] and s.split == "train"
+    assert "drn_d_38_ver2" in argmyparse.AVAILABLE_NET_LIST and "drn_d_105_ver2_fusenet" in argmyparse.AVAILABLE_NET_LIST
+    with pytest.raises(SystemExit):
+        argmyparse.get_da_mcd_training_parser().parse_args(["suncg", "nyu", "--input_ch", "5"])
+
+
+def test_dataset_helpers():
+    import datasets
+    assert datasets.__file__.startswith(os.path.join(ROOT, "multichannel-semseg-with-uda_amd"))
+    assert [datasets.get_n_class(d) for d in ("suncg", "nyu", "gta", "city16", "sun")] == [41, 41, 20, 16, 14]
+    assert datasets.get_img_shape("city", True) == [1024, 512] and datasets.get_img_shape("nyu", True) == [640, 480]
+    with pytest.raises(AssertionError):
+        datasets.check_src_tgt_ok("synthia", "city")
+    with pytest.raises(NotImplementedError):
+        datasets.get_dataset("suncg", "train", None, None, False)
+    a = datasets.SyntheticRGBD(4, 6, [32, 24], 41, seed=3)
+    b = datasets.SyntheticRGBD(4, 6, [32, 24], 41, seed=3)
+    img, lbl = a[2]
+    assert img.shape == (6, 24, 32) and lbl.shape == (24, 32) and lbl.dtype == torch.int64
+    assert torch.equal(img, b[2][0]) and int(lbl.max()) <= 40 and not torch.equal(img, a[1][0])
+    cat = datasets.ConcatDataset(a, datasets.SyntheticRGBD(3, 6, [32, 24], 41, seed=4))
+    assert len(cat) == 3 and len(cat[0]) == 2
+
+
+def test_util_helpers(tmp_path):
+    import util
+    w = util.get_class_weight_from_file(41)
+    assert float(w.sum()) == 40 and float(w[40]) == 0 and float(util.get_class_weight_from_file(41, add_bg_loss=True)[40]) == 1
+    csv = tmp_path / "w.csv"
+    csv.write_text("class_id,weight\n1,2.0\n0,0.5\n2,1.0\n")
+    assert util.get_class_weight_from_file(3, str(csv)).tolist() == [0.5, 2.0, 0.0]
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    assert util.adjust_learning_rate(opt, 1e-3, 0.1, 0, 40) == 1e-3
+    assert util.adjust_learning_rate(opt, 1e-3, 0.1, 20, 40) == pytest.approx(1e-4)
+    assert util.adjust_learning_rate(opt, 1e-3, 0.1, 30, 40) == pytest.approx(1e-5) and opt.param_groups[0]["lr"] == pytest.approx(1e-5)
+    fn = tmp_path / "p.json"
+    util.save_dic_to_json({"a": 1, "ns": argparse.Namespace(x=1)}, str(fn), verbose=False)
+    assert '"a": 1' in fn.read_text()
+    util.check_if_done(str(fn))  # stdin is not a TTY under pytest: must not block
+
+
+def test_factory_errors_and_quirks():
+    from models import model_util
+    with pytest.raises(NotImplementedError):
+        model_util.get_models("fcn", 6, 41)
+    with pytest.raises(NotImplementedError):
+        model_util.get_full_model("psp", "50", 41, 6)
+    assert isinstance(model_util.get_models("drn_d_38", 6, 41, method="DANN"), NotImplementedError)  # model_util.py:281
+    with pytest.raises(NotImplementedError):
+        model_util.get_optimizer([torch.nn.Parameter(torch.zeros(1))], "rmsprop", 1e-3, 0.9, 0)
+    import loss
+    assert loss.DiscrepancyLoss is loss.Diff2d
+    assert isinstance(loss.get_prob_distance_criterion("diff"), loss.Diff2d)
+    with pytest.raises(NotImplementedError):
+        loss.get_prob_distance_criterion("jsd")
+    g = model_util.get_models("drn_d_38", 6, 41)[0]
+    w = g.base[0][0].weight.data
+    assert torch.equal(w[:, 3:6], w[:, :3])  # models/drn.py:285-288
+    g.train()
+    model_util.fix_batchnorm_when_training(g)
+    assert not g.base[5][0].bn1.training and g.base[5][0].training
+
+
+def test_checkpoint_layout_roundtrips_with_torch_modules(golden, tmp_path):
+    """state_dicts and the optimizer state use the reference's layout: they load into plain-torch modules of the
+    same architecture (the oracle, pinned to the reference's key set) and back."""
+    import util
+    from models.model_util import get_models, get_optimizer
+    from oracle import ref_models
+    g, f1, f2 = get_models("drn_d_38", 6, 41)
+    ks = golden.json("keys_shapes.json")
+    assert {k: list(v.shape) for k, v in g.state_dict().items()} == ks["MCD/drn_d_38/6ch/G"]
+    og = get_optimizer(g.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    args = argparse.Namespace(net="drn_d_38", uses_one_classifier=False)
+    save_dic = {"epoch": 1, "args": args, "g_state_dict": g.state_dict(), "f1_state_dict": f1.state_dict(),
+                "f2_state_dict": f2.state_dict(), "optimizer_g": og.state_dict(), "optimizer_f": og.state_dict()}
+    fn = str(tmp_path / "MCD-normal-drn_d_38-1.pth.tar")
+    util.save_checkpoint(save_dic, False, fn)
+    ck = util.load_checkpoint(fn)
+    assert sorted(ck.keys()) == ["args", "epoch", "f1_state_dict", "f2_state_dict", "g_state_dict", "optimizer_f", "optimizer_g"]
+    rg, rf1, _ = ref_models.get_models("drn_d_38", 6, 41)
+    rg.load_state_dict(ck["g_state_dict"])  # strict
+    rf1.load_state_dict(ck["f1_state_dict"])
+    g.load_state_dict(rg.state_dict())
+    ref_opt = ref_models.get_optimizer(rg.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    ref_opt.load_state_dict(ck["optimizer_g"])
+    assert ref_opt.state_dict()["param_groups"][0]["momentum"] == 0.9
+    og.load_state_dict(ref_opt.state_dict())

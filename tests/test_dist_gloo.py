@@ -1,0 +1,87 @@
+"""CPU, world_size 2 over gloo: the data-parallel path of the flat optimizer (one all-reduce of the flat gradient
+buffer, 1/world folded into the update) and the global CE normaliser.  The HIP update kernel is replaced by a
+reference formula here -- what is under test is the host-side distributed logic."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _ref_sgd_(p, g, v, lr, mu, wd, gs=1.0):
+    v.mul_(mu).add_(g * gs + wd * p)
+    p.sub_(lr * v)
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "multichannel-semseg-with-uda_amd"))
+    from mcdseg import dist as mdist
+    from mcdseg import ops
+    from mcdseg.optim import FlatSGD
+    r, w, _ = mdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and mdist.is_distributed() and mdist.world_size() == world
+    ops.sgd_momentum_flat_ = lambda p, g, v, lr, mu, wd, gs=1.0: _ref_sgd_(p, g, v, lr, mu, wd, gs)
+    FlatSGD._require_gpu = False
+    gen = torch.Generator().manual_seed(0)
+    shapes = [(8, 3, 3, 3), (8,), (5, 7)]
+    params = [torch.nn.Parameter(torch.randn(s, generator=gen)) for s in shapes]
+    ref = [p.detach().clone() for p in params]
+    refv = [torch.zeros_like(p) for p in ref]
+    opt = FlatSGD(params, lr=0.1, momentum=0.9, weight_decay=0.01)
+    for step in range(3):
+        grads_all = [[torch.randn(s, generator=torch.Generator().manual_seed(100 * step + 10 * k + i)) for i, s in enumerate(shapes)]
+                     for k in range(world)]
+        opt.zero_grad()
+        for p, g in zip(params, grads_all[rank]):
+            p.grad = g.clone()
+        opt.step()
+        for i in range(len(ref)):
+            gavg = sum(grads_all[k][i] for k in range(world)) / world
+            _ref_sgd_(ref[i], gavg, refv[i], 0.1, 0.9, 0.01)
+    for p, q in zip(params, ref):
+        assert torch.allclose(p.detach(), q, rtol=1e-5, atol=1e-6), float((p.detach() - q).abs().max())
+    # every rank holds the same replica
+    flat = opt.flat_buffers()[0].clone()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    torch.distributed.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], t) for t in gathered)
+    # global CE normaliser: sum over ranks / world
+    local = torch.tensor([10.0 + rank])
+    mdist.all_reduce_sum_(local)
+    assert float(local) == sum(10.0 + k for k in range(world))
+    mdist.barrier()
+    torch.distributed.destroy_process_group()
+    open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+
+
+def test_flat_sgd_data_parallel_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
+
+
+def test_single_process_helpers():
+    from mcdseg import dist as mdist
+    assert mdist.world_size() == 1 and mdist.rank() == 0 and not mdist.is_distributed()
+    t = torch.ones(3)
+    assert mdist.all_reduce_sum_(t) is t and float(t.sum()) == 3
+    mdist.barrier()
+    env = {k: os.environ.pop(k, None) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    try:
+        assert mdist.init_from_env() == (0, 1, 0)
+    finally:
+        for k, v in env.items():
+            if v is not None:
+                os.environ[k] = v

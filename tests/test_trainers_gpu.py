@@ -1,0 +1,69 @@
+"""GPU: the entry points (adapt_trainer / adapt_mfnet_trainer / source_trainer) end to end on synthetic data:
+CLI, output layout, checkpoint dict layout of the reference, resume."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+COMMON = ["--input_ch", "6", "-b", "2", "--train_img_shape", "96", "64", "--synthetic", "--synthetic_len", "4",
+          "--no_pretrained", "--no_tflog", "--epochs", "1", "--max_iter", "10"]
+
+
+@pytest.mark.parametrize("solver", ["fused", "dropin"])
+def test_adapt_trainer_checkpoint_and_resume(tmp_path, solver):
+    _need_gpu()
+    import adapt_trainer
+    import util
+    out = str(tmp_path / "out")
+    assert adapt_trainer.main(["suncg", "nyu", "--base_outdir", out, "--solver", solver] + COMMON) == 0
+    d = os.path.join(out, "suncg-train2nyu-train_6ch")
+    ck_fn = os.path.join(d, "pth", "MCD-normal-drn_d_38-1.pth.tar")
+    assert os.path.exists(ck_fn) and os.path.exists(os.path.join(d, "param-MCD-normal-drn_d_38.json"))
+    ck = util.load_checkpoint(ck_fn)
+    assert sorted(ck.keys()) == ["args", "epoch", "f1_state_dict", "f2_state_dict", "g_state_dict", "optimizer_f", "optimizer_g"]
+    assert ck["epoch"] == 1 and ck["args"].n_class == 41 and ck["args"].start_epoch == 1
+    assert len(ck["g_state_dict"]) == 248 and list(ck["f1_state_dict"].keys()) == ["up.weight"]
+    assert int(ck["g_state_dict"]["base.0.1.num_batches_tracked"]) == 14  # 2 iterations x 7 forwards
+    assert len(ck["optimizer_g"]["state"]) == len(ck["optimizer_g"]["param_groups"][0]["params"])
+    assert all(torch.isfinite(v).all() for v in ck["g_state_dict"].values())
+    # resume for one more epoch: the pickled args replace the CLI ones, epochs comes from the checkpoint
+    ck["args"].epochs = 2
+    util.save_checkpoint(ck, False, ck_fn)
+    assert adapt_trainer.main(["suncg", "nyu", "--resume", ck_fn] + COMMON) == 0
+    ck2 = util.load_checkpoint(os.path.join(d, "pth", "MCD-normal-drn_d_38-2.pth.tar"))
+    assert ck2["epoch"] == 2 and int(ck2["g_state_dict"]["base.0.1.num_batches_tracked"]) == 28
+
+
+def test_adapt_mfnet_trainer(tmp_path):
+    _need_gpu()
+    import adapt_mfnet_trainer
+    import util
+    out = str(tmp_path / "out")
+    assert adapt_mfnet_trainer.main(["suncg", "nyu", "--base_outdir", out, "--method_detail", "MFNet-ScoreAddFusion"] + COMMON) == 0
+    ck = util.load_checkpoint(os.path.join(out, "suncg-train2nyu-train_6ch_MFNet", "pth", "MFNet-ScoreAddFusion-normal-drn_d_38-1.pth.tar"))
+    assert sorted(ck.keys()) == ["args", "epoch", "f1_state_dict", "f2_state_dict", "g_1ch_state_dict", "g_3ch_state_dict",
+                                 "optimizer_f", "optimizer_g"]
+    assert sorted(ck["f1_state_dict"].keys()) == ["up1.weight", "up2.weight"]
+    assert list(ck["g_3ch_state_dict"]["base.0.0.weight"].shape) == [16, 3, 7, 7]
+
+
+def test_source_trainer_cfg1(tmp_path):
+    _need_gpu()
+    import source_trainer
+    import util
+    out = str(tmp_path / "out")
+    args = ["suncg", "--base_outdir", out, "--input_ch", "6", "-b", "2", "--train_img_shape", "320", "240", "--synthetic",
+            "--synthetic_len", "2", "--no_pretrained", "--no_tflog", "--epochs", "1"]
+    assert source_trainer.main(args) == 0
+    ck = util.load_checkpoint(os.path.join(out, "suncg-train_only_6ch", "pth", "normal-drn_d_38-1.pth.tar"))
+    assert sorted(ck.keys()) == ["args", "epoch", "optimizer", "state_dict"]
+    assert all(k.startswith("module.") for k in ck["state_dict"])  # DataParallel prefix (model_util.py:36-37)
+    assert "module.up.weight" in ck["state_dict"] and "module.seg.bias" in ck["state_dict"]
