@@ -174,7 +174,9 @@ def main():
             k["tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
             k["gbs"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
         convs = {k: v for k, v in kern.items() if k.startswith("conv_gemm_kernel")}
-        dom_name = max(convs, key=lambda k: convs[k]["ms"]) if convs else None
+        # dominant kernel = the instantiation carrying the most algorithmic FLOPs of the step (the forward 128x128
+        # tile: 7 forward passes vs 5 backward); its launches run alone on the stream, so the event pairs are clean
+        dom_name = max(convs, key=lambda k: convs[k]["flops"]) if convs else None
         roofline = None
         if dom_name:
             dom = convs[dom_name]
