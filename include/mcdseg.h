@@ -129,6 +129,17 @@ int mcdseg_label_weight_sum(const int64_t* labels, const float* class_weight, in
 int mcdseg_scale_by_device_scalar(float* buf, const float* scale, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Multitask decoder (BASELINE config 4; models/dilated_fcn.py:661-739)
+ *   bilinear x8 up-sampling with align_corners = False (nn.Upsample(scale_factor=8, mode='bilinear'), :676)
+ *   loss[0] = mean((pred-target)^2), grad = 2 (pred-target) / n            (F.mse_loss, :712-714)
+ * ---------------------------------------------------------------------------------------------- */
+int mcdseg_bilinear8_fwd(const float* x, float* y, int32_t N, int32_t C, int32_t Hi, int32_t Wi, void* stream);
+int mcdseg_bilinear8_bwd(const float* dy, float* dx, int32_t N, int32_t C, int32_t Hi, int32_t Wi, void* stream);
+size_t mcdseg_mse_workspace_bytes(int64_t n);
+int mcdseg_mse(const float* pred, const float* target, float* grad, float* loss, int64_t n,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * SGD with momentum + weight decay on flat buffers (torch.optim.SGD via models/model_util.py:289-292)
  *   d = g*grad_scale + wd*p ; v = mu*v + d ; p -= lr*v        (v starts at 0, so the first v = d)
  * ---------------------------------------------------------------------------------------------- */

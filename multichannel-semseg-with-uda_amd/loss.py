@@ -14,12 +14,24 @@ import torch.nn as nn
 from mcdseg import ops
 
 
+class _ClassWeights(nn.Module):
+    """holds the class-weight vector where the reference's ``nn.NLLLoss2d`` holds it: buffer ``weight``"""
+
+    def __init__(self, weight):
+        super().__init__()
+        self.register_buffer("weight", weight)
+
+
 class CrossEntropyLoss2d(nn.Module):
     def __init__(self, weight=None, size_average=True, ignore_index=-100):
         super().__init__()
-        self.weight = weight
+        self.nll_loss = _ClassWeights(weight)  # state-dict key ``nll_loss.weight`` as in the reference (loss.py:10)
         self.size_average = size_average
         self.ignore_index = ignore_index
+
+    @property
+    def weight(self):
+        return self.nll_loss.weight
 
     def forward(self, inputs, targets):
         w = self.weight

@@ -50,6 +50,10 @@ _SIGNATURES = {
                              [c_void_p, c_size_t, c_void_p]),
     "mcdseg_label_weight_sum_workspace_bytes": (c_size_t, [c_i64]),
     "mcdseg_label_weight_sum": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mcdseg_bilinear8_fwd": (c_int, [c_void_p, c_void_p] + [c_i32] * 4 + [c_void_p]),
+    "mcdseg_bilinear8_bwd": (c_int, [c_void_p, c_void_p] + [c_i32] * 4 + [c_void_p]),
+    "mcdseg_mse_workspace_bytes": (c_size_t, [c_i64]),
+    "mcdseg_mse": (c_int, [c_void_p] * 4 + [c_i64, c_void_p, c_size_t, c_void_p]),
     "mcdseg_scale_by_device_scalar": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "mcdseg_sgd_momentum_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_float, c_void_p]),
 }

@@ -159,7 +159,7 @@ def _conv_wgrad(desc, x, dy):
 
 # dgrad and wgrad of one layer are independent: launching wgrad on a second HIP stream lets its workgroups fill
 # the CUs that idle in the last (partial) round of dgrad's tiles, and vice versa.
-OVERLAP_WGRAD = os.environ.get("MCDSEG_OVERLAP_WGRAD", "1") != "0"
+OVERLAP_WGRAD = os.environ.get("MCDSEG_OVERLAP_WGRAD", "0") != "0"  # measured: -2 % when on (both kernels are MFMA-bound)
 _SIDE = {}
 
 
@@ -200,15 +200,15 @@ def _channel_reduce(dy, y, z, mean, rstd, relu):
 # ------------------------------------------------------------------------------------------------ conv + BN + act
 class _ConvBNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, running_mean, running_var, nbt, packed, geom, training, momentum,
-                eps, relu):
+    def forward(ctx, x, weight, gamma, beta, residual, conv_bias, running_mean, running_var, nbt, packed, geom, training,
+                momentum, eps, relu):
         L = lib()
         x = _req(x, "conv input")
         residual = _req(residual, "residual")
         stride, pad, dil = geom
         desc = conv_desc(x.shape, weight.shape, stride, pad, dil)
         wf, wd, mpf = packed.get(weight, desc)
-        z, part, rows = _conv_fprop(desc, x, wf, None, training, mpf)
+        z, part, rows = _conv_fprop(desc, x, wf, _req(conv_bias, "conv bias"), training, mpf)
         c = desc.Cout
         mean = torch.empty(c, dtype=torch.float32, device=x.device)
         rstd = torch.empty(c, dtype=torch.float32, device=x.device)
@@ -227,6 +227,7 @@ class _ConvBNAct(torch.autograd.Function):
         check(L.mcdseg_bn_apply(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), _p(y), desc.N, c, hw, int(relu),
                                 _stream()), "bn_apply")
         ctx.desc, ctx.wd, ctx.relu, ctx.training, ctx.has_res = desc, wd, relu, training, residual is not None
+        ctx.has_bias = conv_bias is not None
         ctx.save_for_backward(x, z, y, mean, rstd, gamma)
         return y
 
@@ -246,21 +247,24 @@ class _ConvBNAct(torch.autograd.Function):
                                     _p(dbeta), _p(dz), _p(dres) if (dres is not None and ctx.relu) else None, n, c, hw,
                                     int(ctx.relu), int(ctx.training), _stream()), "bn_bwd_apply")
         dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres,
+        dbias = None
+        if ctx.has_bias and ctx.needs_input_grad[5]:
+            # a bias in front of train-mode BN has zero gradient up to rounding (BN removes the channel mean);
+            # it is still formed, as autograd does in the reference (CBR, models/dilated_fcn.py:632-644)
+            _, dbias = _channel_reduce(dz, None, None, None, None, False)
+        return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres, dbias,
                 None, None, None, None, None, None, None, None, None)
 
 
 def conv_bn_act(x, conv, bn, relu=True, residual=None):
     """y = act(bn(conv(x)) + residual) with the HIP kernels; ``conv``/``bn`` are the parameter-holding modules."""
-    if conv.bias is not None:
-        raise NotImplementedError("mcdseg: conv+BN fusion expects a bias-free convolution")
     geom = (conv.stride[0], conv.padding[0], conv.dilation[0])
     training = bn.training
     track = bn.track_running_stats and bn.running_mean is not None
     if not training and not track:
         raise NotImplementedError("mcdseg: eval-mode BatchNorm needs running statistics")
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    return _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn.running_mean if track else None,
+    return _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, residual, conv.bias, bn.running_mean if track else None,
                             bn.running_var if track else None, bn.num_batches_tracked if track else None, conv._packed, geom,
                             training, momentum, bn.eps, relu)
 
@@ -366,6 +370,56 @@ def up8(x, w):
 
 def up8_dual(x1, w1, x2, w2):
     return _Up8Dual.apply(x1, w1, x2, w2)
+
+
+# ------------------------------------------------------------------------------------------------ multitask decoder
+class _Bilinear8(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, "bilinear8 input")
+        n, c, hi, wi = x.shape
+        y = torch.empty((n, c, 8 * hi, 8 * wi), dtype=torch.float32, device=x.device)
+        check(lib().mcdseg_bilinear8_fwd(_p(x), _p(y), n, c, hi, wi, _stream()), "bilinear8_fwd")
+        ctx.shape = (n, c, hi, wi)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _req(dy, "grad_output")
+        n, c, hi, wi = ctx.shape
+        dx = torch.empty((n, c, hi, wi), dtype=torch.float32, device=dy.device)
+        check(lib().mcdseg_bilinear8_bwd(_p(dy), _p(dx), n, c, hi, wi, _stream()), "bilinear8_bwd")
+        return dx
+
+
+def bilinear8(x):
+    """nn.Upsample(scale_factor=8, mode='bilinear') with align_corners=False"""
+    return _Bilinear8.apply(x)
+
+
+class _MSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        L = lib()
+        pred, target = _req(pred, "mse input"), _req(target, "mse target")
+        if pred.shape != target.shape:
+            raise ValueError("mcdseg: mse_loss shapes differ: %s vs %s" % (tuple(pred.shape), tuple(target.shape)))
+        n = pred.numel()
+        grad = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        ws = _ws(L.mcdseg_mse_workspace_bytes(n), pred.device)
+        check(L.mcdseg_mse(_p(pred), _p(target), _p(grad), _p(loss), n, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()), "mse")
+        ctx.g = grad
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g, ctx.g = ctx.g, None
+        return _scale_(g, _req(grad_out.reshape(1), "grad_output")), None
+
+
+def mse_loss(pred, target):
+    return _MSE.apply(pred, target)
 
 
 # ------------------------------------------------------------------------------------------------ losses

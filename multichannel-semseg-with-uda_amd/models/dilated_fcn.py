@@ -13,11 +13,12 @@ import math
 
 import torch
 import torch.nn as nn
+from torch.nn import Parameter
 
 from mcdseg import ops
 
 from . import drn
-from .drn import Conv2d, FusedSequential
+from .drn import BatchNorm2d, Conv2d, FusedSequential
 from .fusion import AddFusion, ConcatFusion, get_fusion_model
 
 
@@ -135,3 +136,97 @@ class ScoreFusionDRNSegPixelClassifier(nn.Module):
             # up1(x1) + up2(x2) in one pass over the full-resolution tensor
             return ops.up8_dual(x1, self.up1.weight, x2, self.up2.weight)
         return self.fusion(self.up1(x1), self.up2(x2))
+
+
+# ------------------------------------------------------------------------------------------------ multitask (cfg4)
+class MultiTaskEncoder(nn.Module):
+    """DRN trunk on the RGB channels (models/dilated_fcn.py:554-566)."""
+
+    def __init__(self, model_name, pretrained=True, input_ch=3):
+        super().__init__()
+        self.base, _ = _trunk(model_name, pretrained, input_ch)
+
+    def forward(self, x):
+        return self.base(x)
+
+
+class CBR(nn.Module):
+    """conv (with bias) - BN - ReLU as one fused HIP group (models/dilated_fcn.py:632-644)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True):
+        super().__init__()
+        self.conv = Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, dilation=dilation,
+                           groups=groups, bias=bias)
+        self.bn = BatchNorm2d(out_channels)
+
+    def forward(self, x):
+        return ops.conv_bn_act(x, self.conv, self.bn, relu=True)
+
+
+class ThreeLayerDecoder(nn.Module):
+    def __init__(self, output_ch, input_ch=512):
+        super().__init__()
+        self.cbr1 = CBR(input_ch, 512, kernel_size=3, padding=1)
+        self.cbr2 = CBR(512, 512, kernel_size=1)
+        self.conv3 = Conv2d(512, output_ch, kernel_size=1)
+
+    def forward(self, x):
+        return self.conv3(self.cbr2(self.cbr1(x)))
+
+
+class _Bilinear8(nn.Module):
+    """nn.Upsample(scale_factor=8, mode='bilinear') (align_corners=False) on the HIP kernel; holds no parameters, so
+    the decoder's state_dict is unchanged."""
+
+    def forward(self, x):
+        return ops.bilinear8(x)
+
+
+class MCDMultiTaskDecoder(nn.Module):
+    """Two segmentation heads + one HHA-regression head on 512-ch features, x8 bilinear up-sampling, learned
+    log-variance task weights ``exp(-s) * L + s`` (models/dilated_fcn.py:661-739)."""
+
+    def __init__(self, n_class, depth_ch, semseg_criterion=None, discrepancy_criterion=None):
+        super().__init__()
+        self.s_semsegcls = Parameter(torch.ones(1))
+        self.s_deprgr = Parameter(torch.ones(1))
+        self.semsegcls_dec1 = ThreeLayerDecoder(n_class)
+        self.semsegcls_dec2 = ThreeLayerDecoder(n_class)
+        self.deprgr_dec = ThreeLayerDecoder(depth_ch)
+        self.semseg_criterion = semseg_criterion
+        self.discrepancy_criterion = discrepancy_criterion
+        self.upsample = _Bilinear8()
+
+    def semseg_forward(self, x):
+        return self.upsample(self.semsegcls_dec1(x)), self.upsample(self.semsegcls_dec2(x))
+
+    def depth_forward(self, x):
+        return self.upsample(self.deprgr_dec(x))
+
+    def forward(self, x):
+        pred_semseg1, pred_semseg2 = self.semseg_forward(x)
+        return pred_semseg1, pred_semseg2, self.depth_forward(x)
+
+    def get_cls_descrepancy(self, x):
+        pred_semseg1, pred_semseg2 = self.semseg_forward(x)
+        return self.discrepancy_criterion(pred_semseg1, pred_semseg2)
+
+    def get_semseg_loss(self, x, gt_semseg, separately_returning=False):
+        pred_semseg1, pred_semseg2 = self.semseg_forward(x)
+        loss1 = self.semseg_criterion(pred_semseg1, gt_semseg)
+        loss2 = self.semseg_criterion(pred_semseg2, gt_semseg)
+        return (loss1, loss2) if separately_returning else loss1 + loss2
+
+    def get_depth_loss(self, x, gt_dep):
+        return ops.mse_loss(self.depth_forward(x), gt_dep)
+
+    def get_loss(self, x, gt_semseg, gt_dep, separately_returning=False):
+        loss1, loss2 = self.get_semseg_loss(x, gt_semseg, separately_returning=True)
+        s = self.s_semsegcls
+        semseg_loss = ((torch.exp(-s) * loss1 + s) + (torch.exp(-s) * loss2 + s)) / 2
+        depreg_loss = torch.exp(-self.s_deprgr) * self.get_depth_loss(x, gt_dep) + self.s_deprgr
+        return (semseg_loss, depreg_loss) if separately_returning else semseg_loss + depreg_loss
+
+    def get_task_weights(self):
+        import numpy as np
+        return (np.sqrt(np.exp(2 * self.s_semsegcls.data.cpu().numpy())), np.sqrt(np.exp(2 * self.s_deprgr.data.cpu().numpy())))

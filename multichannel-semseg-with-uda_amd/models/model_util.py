@@ -66,6 +66,23 @@ def get_models(net_name, input_ch, n_class, res="50", method="MCD", is_data_para
     return _wrap(model_list, is_data_parallel)
 
 
+def get_multitask_models(net_name, input_ch, n_class, semseg_criterion=None, discrepancy_criterion=None,
+                         is_data_parallel=False, is_src_only=False):
+    """RGB encoder + MCD multitask decoder (models/model_util.py:81-99); the source-only decoder variant is not on
+    the hot path."""
+    if "drn" not in net_name:
+        raise NotImplementedError("Only FCN (Including Dilated FCN), SegNet, PSPNet UNet are supported!")
+    if is_src_only:
+        raise NotImplementedError("MultiTaskDecoder (source-only) is outside the MCD hot path")
+    from models.dilated_fcn import MCDMultiTaskDecoder, MultiTaskEncoder
+    model_enc = MultiTaskEncoder(model_name=net_name, input_ch=3, pretrained=_pretrained_default())  # RGB is 3 channel
+    model_dec = MCDMultiTaskDecoder(n_class=n_class, depth_ch=input_ch - 3, semseg_criterion=semseg_criterion,
+                                    discrepancy_criterion=discrepancy_criterion)
+    if is_data_parallel:
+        return _wrap(model_enc, True), _wrap(model_dec, True)
+    return model_enc, model_dec
+
+
 def get_optimizer(model_parameters, opt, lr, momentum, weight_decay):
     params = [p for p in model_parameters if p.requires_grad]
     if opt == "sgd":

@@ -136,3 +136,57 @@ class MFNetMCDSolver(MCDSolver):
 
     def _after_b(self):
         self.opt_f.zero_grad()  # adapt_mfnet_trainer.py:222
+
+
+class MultiTaskMCDSolver:
+    """Three-step update of the multitask variant (segmentation + HHA regression decoders on an RGB encoder),
+    following ``adapt_multitask_trainer.py:166-239`` through the decoder's own loss methods.
+
+    Elisions that change no result: step B only steps the decoder optimizer, so the encoder runs there without a
+    tape; the ``semseg_forward(src_fet)`` whose result the reference throws away (``:208``) still runs -- it moves
+    the BatchNorm running statistics of both segmentation decoders -- but builds no graph."""
+
+    def __init__(self, model_enc, model_dec, optimizer_enc, optimizer_dec, num_k=4, num_multiply_d_loss=1):
+        self.enc, self.dec = model_enc, model_dec
+        self.opt_enc, self.opt_dec = optimizer_enc, optimizer_dec
+        self.num_k, self.mult = num_k, num_multiply_d_loss
+
+    def step(self, src_imgs, src_gt_semseg, tgt_imgs):
+        enc, dec = self.enc, self.dec
+        src_rgbs, src_depths = src_imgs[:, :3, :, :], src_imgs[:, 3:, :, :].contiguous()
+        tgt_rgbs, tgt_depths = tgt_imgs[:, :3, :, :], tgt_imgs[:, 3:, :, :].contiguous()
+
+        self.opt_enc.zero_grad()
+        self.opt_dec.zero_grad()
+        src_fet = enc(src_rgbs)
+        tgt_fet = enc(tgt_rgbs)
+        src_semseg_loss, src_depth_loss = dec.get_loss(src_fet, src_gt_semseg, src_depths, separately_returning=True)
+        tgt_depth_loss = dec.get_depth_loss(tgt_fet, tgt_depths)
+        loss = src_semseg_loss + src_depth_loss + tgt_depth_loss
+        loss.backward()
+        c_loss = loss.detach()
+        self.opt_enc.step()
+        self.opt_dec.step()
+
+        self.opt_enc.zero_grad()
+        self.opt_dec.zero_grad()
+        with torch.no_grad():
+            src_fet = enc(src_rgbs)
+            dec.semseg_forward(src_fet)
+        src_semseg_loss, src_depth_loss = dec.get_loss(src_fet, src_gt_semseg, src_depths, separately_returning=True)
+        with torch.no_grad():
+            tgt_fet = enc(tgt_rgbs)
+        tgt_depth_loss = dec.get_depth_loss(tgt_fet, tgt_depths)
+        tgt_discrepancy = dec.get_cls_descrepancy(tgt_fet)
+        loss = src_semseg_loss + src_depth_loss + tgt_depth_loss - tgt_discrepancy
+        loss.backward()
+        self.opt_dec.step()
+        parts = (src_semseg_loss.detach(), src_depth_loss.detach(), tgt_depth_loss.detach())
+
+        for _ in range(self.num_k):
+            self.opt_enc.zero_grad()
+            tgt_fet = enc(tgt_rgbs)
+            loss = dec.get_cls_descrepancy(tgt_fet) * self.mult
+            loss.backward()
+            self.opt_enc.step()
+        return c_loss, loss.detach() / self.num_k, parts

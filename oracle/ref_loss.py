@@ -18,15 +18,19 @@ import torch.nn.functional as F
 
 
 class CrossEntropyLoss2d(nn.Module):
+    """The class weights live in the ``nll_loss`` sub-module as a buffer (key ``nll_loss.weight``), as in the
+    reference -- that key shows up in ``MCDMultiTaskDecoder.state_dict()`` (51 tensors)."""
+
     def __init__(self, weight=None, size_average=True, ignore_index=-100):
         super().__init__()
-        self.weight = weight
-        self.reduction = "mean" if size_average else "sum"
-        self.ignore_index = ignore_index
+        self.nll_loss = nn.NLLLoss(weight, ignore_index=ignore_index, reduction="mean" if size_average else "sum")
+
+    @property
+    def weight(self):
+        return self.nll_loss.weight
 
     def forward(self, inputs, targets):
-        return F.nll_loss(F.log_softmax(inputs, dim=1), targets, weight=self.weight,
-                          ignore_index=self.ignore_index, reduction=self.reduction)
+        return self.nll_loss(F.log_softmax(inputs, dim=1), targets)
 
 
 class Diff2d(nn.Module):

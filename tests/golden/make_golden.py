@@ -362,6 +362,78 @@ def main():
                              "logits_cs": checksum(preds), "state": state_checksums(rfull)}
     print("  source: loss %.6f" % float(loss))
 
+    # ---------------------------------------------------------------- H. drn_d_105 (Bottleneck, cfg5 trunk), small
+    r105 = ref_get_models(ref_mu, dfcn, "drn_d_105", 6, NC, "MCD")
+    o105 = o_models.get_models("drn_d_105", 6, NC)
+    for i, seed in enumerate((71, 72, 73)):
+        fill_state_(r105[i], seed), fill_state_(o105[i], seed)
+        r105[i].train(), o105[i].train()
+    s, l, t = make_batch(45, 2, 6, H, W, NC)
+    for m in list(r105) + list(o105):
+        m.zero_grad()
+    rfeat = r105[0](s); rl = crit(r105[1](rfeat), l) + crit(r105[2](rfeat), l); rl.backward()
+    ofeat = o105[0](s); ol = o_loss.CrossEntropyLoss2d(w)(o105[1](ofeat), l) + o_loss.CrossEntropyLoss2d(w)(o105[2](ofeat), l); ol.backward()
+    close(ofeat, rfeat, 1e-5, "d105 feat")
+    assert abs(float(ol) - float(rl)) < 1e-5 * float(rl)
+    named = dict(r105[0].named_parameters())
+    d105 = {"feat": rfeat.detach().numpy(), "loss": np.array(float(rl)),
+            "g/base.0.0.weight": named["base.0.0.weight"].grad.numpy(), "g/seg.weight": named["seg.weight"].grad.numpy(),
+            "g/base.5.11.conv2.weight_sub": named["base.5.11.conv2.weight"].grad.reshape(256, -1)[:16, :288].numpy(),
+            "g/base.7.0.weight_sub": named["base.7.0.weight"].grad.reshape(512, -1)[:16, :288].numpy()}
+    np.savez_compressed(os.path.join(HERE, "d105_small.npz"), **d105)
+    out["d105_small"] = {"seed_batch": 45, "shape": [2, 6, H, W], "loss": float(rl), "grad_cs": {k: checksum(p.grad) for k, p in named.items()}}
+    print("  d105: loss %.6f" % float(rl))
+
+    # ---------------------------------------------------------------- I. multitask (cfg4): encoder + MCD multitask decoder
+    from oracle import ref_multitask as o_mt
+    r_enc = dfcn.MultiTaskEncoder(model_name="drn_d_38", pretrained=False, input_ch=3)
+    r_dec = dfcn.MCDMultiTaskDecoder(n_class=NC, depth_ch=3, semseg_criterion=crit, discrepancy_criterion=critd)
+    o_enc, o_dec = o_mt.get_multitask_models("drn_d_38", 6, NC, o_loss.CrossEntropyLoss2d(w), o_loss.Diff2d())
+    ks_mt = {"enc": keys_shapes(r_enc), "dec": keys_shapes(r_dec)}
+    assert keys_shapes(o_enc) == ks_mt["enc"] and keys_shapes(o_dec) == ks_mt["dec"]
+    for a, b, seed in ((r_enc, o_enc, 81), (r_dec, o_dec, 82)):
+        fill_state_(a, seed), fill_state_(b, seed)
+        a.train(), b.train()
+    s, l, t = make_batch(46, 2, 6, H, W, NC)
+    with torch.no_grad():
+        rf = r_enc(s[:, :3]); ra, rb, rd = r_dec(rf)
+        of_ = o_enc(s[:, :3]); oa, ob, od = o_dec(of_)
+    close(oa, ra, 1e-5, "mt seg1"), close(od, rd, 1e-5, "mt depth")
+    mt = {"fet": rf.numpy(), "seg1_sub": ra[:, :, ::4, ::4].numpy().copy(), "seg2_cs": np.array(checksum(rb)), "dep": rd.numpy()}
+    np.savez_compressed(os.path.join(HERE, "multitask_small.npz"), **mt)
+    for a, b, seed in ((r_enc, o_enc, 81), (r_dec, o_dec, 82)):
+        fill_state_(a, seed), fill_state_(b, seed)
+    r_oe = ref_mu.get_optimizer(r_enc.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    r_od = ref_mu.get_optimizer(r_dec.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    o_oe = o_models.get_optimizer(o_enc.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    o_od = o_models.get_optimizer(o_dec.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    # adapt_multitask_trainer.py:166-239 on the reference modules
+    sr, sd, tr_, td = s[:, :3, :, :], s[:, 3:, :, :], t[:, :3, :, :], t[:, 3:, :, :]
+    r_oe.zero_grad(); r_od.zero_grad()
+    src_fet = r_enc(sr); tgt_fet = r_enc(tr_)
+    ssl, sdl = r_dec.get_loss(src_fet, l, sd, separately_returning=True)
+    tdl = r_dec.get_depth_loss(tgt_fet, td)
+    loss = ssl + sdl + tdl; loss.backward(); c_loss = float(loss); r_oe.step(); r_od.step()
+    r_oe.zero_grad(); r_od.zero_grad()
+    src_fet = r_enc(sr); r_dec.semseg_forward(src_fet)
+    ssl, sdl = r_dec.get_loss(src_fet, l, sd, separately_returning=True)
+    tgt_fet = r_enc(tr_); tdl = r_dec.get_depth_loss(tgt_fet, td)
+    disc = r_dec.get_cls_descrepancy(tgt_fet)
+    loss = ssl + sdl + tdl - disc; loss.backward(); r_od.step()
+    for _ in range(4):
+        r_oe.zero_grad(); tgt_fet = r_enc(tr_); disc = r_dec.get_cls_descrepancy(tgt_fet); loss = disc * 1; loss.backward(); r_oe.step()
+    d_loss = float(loss) / 4
+    oc, od_, parts = o_mt.multitask_mcd_step(o_enc, o_dec, o_oe, o_od, s, l, t)
+    assert abs(oc - c_loss) < 1e-4 * abs(c_loss) and abs(od_ - d_loss) < 1e-3 * abs(d_loss) + 1e-7, (oc, c_loss, od_, d_loss)
+    out["multitask_small"] = {"shape": [2, 6, H, W], "seed_batch": 46, "c_loss": c_loss, "d_loss": d_loss,
+                              "parts": [float(ssl), float(sdl), float(tdl)], "enc": state_checksums(r_enc),
+                              "dec": state_checksums(r_dec), "keys_shapes": ks_mt,
+                              "nbt_enc": int(r_enc.state_dict()["base.0.1.num_batches_tracked"]),
+                              "nbt_seg": int(r_dec.state_dict()["semsegcls_dec1.cbr1.bn.num_batches_tracked"]),
+                              "nbt_dep": int(r_dec.state_dict()["deprgr_dec.cbr1.bn.num_batches_tracked"])}
+    print("  multitask: c_loss %.6f d_loss %.8f nbt enc/seg/dep %d/%d/%d" % (c_loss, d_loss, out["multitask_small"]["nbt_enc"],
+          out["multitask_small"]["nbt_seg"], out["multitask_small"]["nbt_dep"]))
+
     out["init_stats"] = init_stats
     out["torch_version"] = torch.__version__
     with open(os.path.join(HERE, "traces.json"), "w") as fh:

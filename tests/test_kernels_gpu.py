@@ -291,3 +291,67 @@ def test_sgd_kernel_and_flat_optimizer():
         _assert_close(ours.state[b]["momentum_buffer"], ref.state[a]["momentum_buffer"], 2e-6, "momentum")
     fp, fg, fv = ours.flat_buffers()
     assert all(p.data_ptr() >= fp.data_ptr() and p.data_ptr() < fp.data_ptr() + 4 * fp.numel() for p in our_params)
+
+
+@pytest.mark.parametrize("shape", [(2, 41, 8, 12), (1, 3, 5, 7), (2, 3, 1, 9)])
+def test_bilinear8_fwd_bwd(shape):
+    dev = _dev()
+    from mcdseg import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(shape, generator=g)
+    x64 = x.double().requires_grad_()
+    ref = F.interpolate(x64, scale_factor=8, mode="bilinear", align_corners=False)
+    gy = torch.randn(ref.shape, generator=g)
+    (gx,) = torch.autograd.grad(ref, x64, gy.double())
+    xd = x.to(dev).requires_grad_()
+    y = ops.bilinear8(xd)
+    _assert_close(y, ref, 2e-6, "bilinear8 fwd")
+    y.backward(gy.to(dev))
+    _assert_close(xd.grad, gx, 1e-5, "bilinear8 bwd")
+
+
+@pytest.mark.parametrize("n", [2 * 3 * 64 * 96, 1001])
+def test_mse(n):
+    dev = _dev()
+    from mcdseg import ops
+    g = torch.Generator().manual_seed(n)
+    p, t = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    p64 = p.double().requires_grad_()
+    ref = F.mse_loss(p64, t.double())
+    (gp,) = torch.autograd.grad(3.0 * ref, p64)
+    pd = p.to(dev).requires_grad_()
+    loss = ops.mse_loss(pd, t.to(dev))
+    (3.0 * loss).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * float(ref)
+    _assert_close(pd.grad, gp, 2e-6, "mse grad")
+
+
+def test_conv_bias_bn_relu():
+    """CBR of the multitask decoders (models/dilated_fcn.py:632-644): conv WITH bias, then BN, then ReLU."""
+    dev = _dev()
+    from mcdseg import ops
+    from models.drn import BatchNorm2d, Conv2d
+    g = torch.Generator().manual_seed(21)
+    conv, bn = Conv2d(48, 40, 3, padding=1, bias=True), BatchNorm2d(40)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.05)
+        conv.bias.copy_(torch.randn(40, generator=g))
+        bn.weight.copy_(1 + 0.2 * torch.randn(40, generator=g))
+        bn.bias.copy_(0.1 * torch.randn(40, generator=g))
+    x = torch.randn(2, 48, 10, 12, generator=g)
+    gy = torch.randn(2, 40, 10, 12, generator=g)
+    t = [v.detach().double().requires_grad_() for v in (x, conv.weight, conv.bias, bn.weight, bn.bias)]
+    rm, rv = torch.zeros(40, dtype=torch.float64), torch.ones(40, dtype=torch.float64)
+    o = F.relu(F.batch_norm(F.conv2d(t[0], t[1], t[2], padding=1), rm, rv, t[3], t[4], training=True, momentum=0.1, eps=1e-5))
+    grads = torch.autograd.grad(o, t, gy.double())
+    conv.to(dev), bn.to(dev)
+    xd = x.to(dev).requires_grad_()
+    y = ops.conv_bn_act(xd, conv, bn, relu=True)
+    _assert_close(y, o, 3e-5, "forward")
+    _assert_close(bn.running_mean, rm, 1e-5, "running_mean (includes the conv bias)")
+    y.backward(gy.to(dev))
+    for name, a, b in zip(["dx", "dw", "dgamma", "dbeta"], [xd.grad, conv.weight.grad, bn.weight.grad, bn.bias.grad],
+                          [grads[0], grads[1], grads[3], grads[4]]):
+        _assert_close(a, b, 1e-4, name)
+    # d(bias) vanishes analytically (BN removes the channel mean): both are rounding noise around zero
+    assert float(conv.bias.grad.abs().max()) <= 1e-4 * float(grads[1].abs().max()) * 120

@@ -294,3 +294,70 @@ def test_full_resolution_vs_oracle_and_properties():
         c1 = float(ops.cross_entropy2d(la + 3.0, lab, cw))
         assert abs(c0 - c1) <= 2e-5 * abs(c0)
     assert h.shape == (4, 16, 480, 640) and float(h.min()) >= 0.0
+
+
+def test_d105_bottleneck_vs_reference(golden):
+    """drn_d_105 (Bottleneck blocks; BASELINE config 5 trunk) forward + CE backward against the reference."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d
+    from models.model_util import get_models
+    fx = golden.npz("d105_small.npz")
+    tr = golden.json("traces.json")["d105_small"]
+    g, f1, f2 = get_models("drn_d_105", 6, NC)
+    for m, seed in ((g, 71), (f1, 72), (f2, 73)):
+        fill_state_(m, seed)
+        m.to(dev).train()
+    n, ch, h, w = tr["shape"]
+    s, l, _ = (v.to(dev) for v in make_batch(tr["seed_batch"], n, ch, h, w, NC))
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    crit = CrossEntropyLoss2d(cw.to(dev))
+    feat = g(s)
+    loss = crit(f1(feat), l) + crit(f2(feat), l)
+    loss.backward()
+    err = np.abs(feat.detach().cpu().numpy() - fx["feat"]).max()
+    assert err <= 1e-3 and err <= 5e-5 * np.abs(fx["feat"]).max(), err
+    assert abs(float(loss) - tr["loss"]) <= 1e-5 * tr["loss"]
+    named = dict(g.named_parameters())
+    for key, name in (("g/seg.weight", "seg.weight"), ("g/base.0.0.weight", "base.0.0.weight")):
+        ref = fx[key]
+        got = named[name].grad.cpu().numpy()
+        assert np.abs(got - ref).max() <= max(1e-3, 0.1 * np.abs(ref).max()), name  # fp32 reference gradient: noise floor ~ few %
+    cs = tr["grad_cs"]
+    got = named["seg.weight"].grad.double().norm().item()
+    assert abs(got - cs["seg.weight"][1]) <= 1e-3 * cs["seg.weight"][1]
+
+
+def test_multitask_cfg4_vs_reference(golden):
+    """BASELINE config 4: RGB encoder + MCD multitask decoder (bilinear x8, MSE on HHA, learned task weights)."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, Diff2d
+    from models.model_util import get_multitask_models, get_optimizer
+    from solvers.solver import MultiTaskMCDSolver
+    tr = golden.json("traces.json")["multitask_small"]
+    fx = golden.npz("multitask_small.npz")
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    enc, dec = get_multitask_models("drn_d_38", 6, NC, CrossEntropyLoss2d(cw), Diff2d())
+    assert {k: list(v.shape) for k, v in dec.state_dict().items()} == tr["keys_shapes"]["dec"]
+    fill_state_(enc, 81), fill_state_(dec, 82)
+    enc.to(dev).train(), dec.to(dev).train()
+    n, ch, h, w = tr["shape"]
+    s, l, t = (v.to(dev) for v in make_batch(tr["seed_batch"], n, ch, h, w, NC))
+    with torch.no_grad():
+        fet = enc(s[:, :3])
+        a, b, d = dec(fet)
+    assert np.abs(fet.cpu().numpy() - fx["fet"]).max() <= 2e-5 * np.abs(fx["fet"]).max()
+    assert np.abs(a[:, :, ::4, ::4].cpu().numpy() - fx["seg1_sub"]).max() <= 5e-5 * np.abs(fx["seg1_sub"]).max()
+    assert np.abs(d.cpu().numpy() - fx["dep"]).max() <= 5e-5 * np.abs(fx["dep"]).max()
+    fill_state_(enc, 81), fill_state_(dec, 82)
+    oe = get_optimizer(enc.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    od = get_optimizer(dec.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    c, dl, parts = MultiTaskMCDSolver(enc, dec, oe, od, num_k=4).step(s, l, t)
+    assert abs(float(c) - tr["c_loss"]) <= 1e-4 * tr["c_loss"]
+    assert abs(float(dl) - tr["d_loss"]) <= 5e-3 * tr["d_loss"]
+    assert all(abs(float(p) - q) <= 2e-3 * abs(q) for p, q in zip(parts, tr["parts"]))
+    _check_state(enc, tr["enc"], 5e-4), _check_state(dec, tr["dec"], 2e-3)
+    sd = dec.state_dict()
+    assert int(enc.state_dict()["base.0.1.num_batches_tracked"]) == 8
+    assert int(sd["semsegcls_dec1.cbr1.bn.num_batches_tracked"]) == 8 and int(sd["deprgr_dec.cbr1.bn.num_batches_tracked"]) == 4

@@ -212,3 +212,55 @@ def test_source_step_cfg1(golden):
     loss = ref_mcd.source_step(m, opt, ref_loss.CrossEntropyLoss2d(ref_loss.class_weights(NC)), s, l)
     assert abs(loss - tr["loss"]) < 1e-5 * tr["loss"]
     _check_state(m, tr["state"])
+
+
+def test_d105_bottleneck_small(golden):
+    """drn_d_105 (Bottleneck blocks, the cfg5 trunk): forward features and selected gradients."""
+    fx = golden.npz("d105_small.npz")
+    tr = golden.json("traces.json")["d105_small"]
+    g, f1, f2 = ref_models.get_models("drn_d_105", 6, NC)
+    for m, seed in ((g, 71), (f1, 72), (f2, 73)):
+        fill_state_(m, seed)
+        m.train()
+    n, ch, h, w = tr["shape"]
+    s, l, _ = make_batch(tr["seed_batch"], n, ch, h, w, NC)
+    crit = ref_loss.CrossEntropyLoss2d(ref_loss.class_weights(NC))
+    feat = g(s)
+    loss = crit(f1(feat), l) + crit(f2(feat), l)
+    loss.backward()
+    np.testing.assert_allclose(feat.detach().numpy(), fx["feat"], rtol=0, atol=1e-5 * np.abs(fx["feat"]).max())
+    assert abs(float(loss) - tr["loss"]) < 1e-5 * tr["loss"]
+    named = dict(g.named_parameters())
+    np.testing.assert_allclose(named["seg.weight"].grad.numpy(), fx["g/seg.weight"], rtol=0, atol=1e-5 * np.abs(fx["g/seg.weight"]).max())
+
+
+def test_multitask_cfg4(golden):
+    from oracle import ref_multitask
+    tr = golden.json("traces.json")["multitask_small"]
+    fx = golden.npz("multitask_small.npz")
+    crit = ref_loss.CrossEntropyLoss2d(ref_loss.class_weights(NC))
+    enc, dec = ref_multitask.get_multitask_models("drn_d_38", 6, NC, crit, ref_loss.Diff2d())
+    assert {k: list(v.shape) for k, v in enc.state_dict().items()} == tr["keys_shapes"]["enc"]
+    assert {k: list(v.shape) for k, v in dec.state_dict().items()} == tr["keys_shapes"]["dec"]
+    assert len(dec.state_dict()) == 51 and "semseg_criterion.nll_loss.weight" in dec.state_dict()
+    fill_state_(enc, 81), fill_state_(dec, 82)
+    enc.train(), dec.train()
+    n, ch, h, w = tr["shape"]
+    s, l, t = make_batch(tr["seed_batch"], n, ch, h, w, NC)
+    with torch.no_grad():
+        fet = enc(s[:, :3])
+        a, b, d = dec(fet)
+    np.testing.assert_allclose(fet.numpy(), fx["fet"], rtol=0, atol=1e-5 * np.abs(fx["fet"]).max())
+    np.testing.assert_allclose(a[:, :, ::4, ::4].numpy(), fx["seg1_sub"], rtol=0, atol=1e-5 * np.abs(fx["seg1_sub"]).max())
+    np.testing.assert_allclose(d.numpy(), fx["dep"], rtol=0, atol=1e-5 * np.abs(fx["dep"]).max())
+    fill_state_(enc, 81), fill_state_(dec, 82)
+    oe = ref_models.get_optimizer(enc.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    od = ref_models.get_optimizer(dec.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    c, dl, parts = ref_multitask.multitask_mcd_step(enc, dec, oe, od, s, l, t)
+    assert abs(c - tr["c_loss"]) < 1e-4 * tr["c_loss"] and abs(dl - tr["d_loss"]) < 1e-3 * tr["d_loss"]
+    assert all(abs(p - q) < 1e-3 * abs(q) for p, q in zip(parts, tr["parts"]))
+    _check_state(enc, tr["enc"]), _check_state(dec, tr["dec"], rtol=1e-3)
+    sd = dec.state_dict()
+    assert int(enc.state_dict()["base.0.1.num_batches_tracked"]) == tr["nbt_enc"] == 8
+    assert int(sd["semsegcls_dec1.cbr1.bn.num_batches_tracked"]) == tr["nbt_seg"] == 8
+    assert int(sd["deprgr_dec.cbr1.bn.num_batches_tracked"]) == tr["nbt_dep"] == 4

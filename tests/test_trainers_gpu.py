@@ -67,3 +67,15 @@ def test_source_trainer_cfg1(tmp_path):
     assert sorted(ck.keys()) == ["args", "epoch", "optimizer", "state_dict"]
     assert all(k.startswith("module.") for k in ck["state_dict"])  # DataParallel prefix (model_util.py:36-37)
     assert "module.up.weight" in ck["state_dict"] and "module.seg.bias" in ck["state_dict"]
+
+
+def test_adapt_multitask_trainer(tmp_path):
+    _need_gpu()
+    import adapt_multitask_trainer
+    import util
+    out = str(tmp_path / "out")
+    assert adapt_multitask_trainer.main(["suncg", "nyu", "--base_outdir", out] + COMMON) == 0
+    ck = util.load_checkpoint(os.path.join(out, "suncg-train2nyu-train_6ch_MCDmultitask", "pth", "MCD-normal-drn_d_38-1.pth.tar"))
+    assert sorted(ck.keys()) == ["args", "dec_state_dict", "enc_state_dict", "epoch", "optimizer_dec", "optimizer_enc"]
+    assert len(ck["dec_state_dict"]) == 51 and "s_semsegcls" in ck["dec_state_dict"]
+    assert list(ck["dec_state_dict"]["deprgr_dec.conv3.weight"].shape) == [3, 512, 1, 1]
