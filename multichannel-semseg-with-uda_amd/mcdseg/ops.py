@@ -127,34 +127,63 @@ class PackedWeights:
 
 
 # ------------------------------------------------------------------------------------------------ raw launchers
+# The kernels address one conv operand with 32-bit buffer offsets, so a single launch takes operands below 2 GiB
+# (+ a tile of slack).  Larger batches (cfg5: 32 x 720 x 1280) are cut along N on the host: conv is independent per
+# image, the BN partial rows of the pieces are simply concatenated, weight gradients of the pieces are summed.
+MAX_CONV_BYTES = int(os.environ.get("MCDSEG_MAX_CONV_BYTES", str((1 << 31) - (1 << 26))))
+
+
+def _sub_desc(desc, n):
+    return ConvDesc(n, desc.Cin, desc.H, desc.W, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad, desc.dil, desc.Ho, desc.Wo)
+
+
+def _batch_pieces(desc):
+    per_img = 4 * max((desc.Cin + 128) * desc.H * desc.W, (desc.Cout + 128) * desc.Ho * desc.Wo)
+    step = max(1, MAX_CONV_BYTES // per_img)
+    if step >= desc.N:
+        return [(0, desc.N)]
+    return [(i, min(i + step, desc.N)) for i in range(0, desc.N, step)]
+
+
 def _conv_fprop(desc, x, wf, bias, want_stats, mpf):
     L = lib()
     y = torch.empty((desc.N, desc.Cout, desc.Ho, desc.Wo), dtype=torch.float32, device=x.device)
-    part, rows = None, 0
+    pieces = _batch_pieces(desc)
+    descs = [desc if len(pieces) == 1 else _sub_desc(desc, b - a) for a, b in pieces]
+    part, rows, row_off = None, 0, [0]
     if want_stats:
-        rows = L.mcdseg_conv_stat_rows(ctypes.byref(desc))
+        for d in descs:
+            row_off.append(row_off[-1] + L.mcdseg_conv_stat_rows(ctypes.byref(d)))
+        rows = row_off[-1]
         part = torch.empty(rows * 3 * mpf, dtype=torch.float32, device=x.device)
-    with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False), conv_work(desc)):
-        check(L.mcdseg_conv_fprop(ctypes.byref(desc), _p(x), _p(wf), _p(bias), _p(y), _p(part), _stream()), "conv_fprop")
+    for i, ((a, b), d) in enumerate(zip(pieces, descs)):
+        pp = None if part is None else ctypes.c_void_p(part.data_ptr() + 4 * row_off[i] * 3 * mpf)
+        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False), conv_work(d)):
+            check(L.mcdseg_conv_fprop(ctypes.byref(d), _p(x[a:b]), _p(wf), _p(bias), _p(y[a:b]), pp, _stream()), "conv_fprop")
     return y, part, rows
 
 
 def _conv_dgrad(desc, dy, wd):
     dx = torch.empty((desc.N, desc.Cin, desc.H, desc.W), dtype=torch.float32, device=dy.device)
-    with _timed(gemm_kernel_name(desc.Cin, desc.Cout, True), conv_work(desc)):
-        check(lib().mcdseg_conv_dgrad(ctypes.byref(desc), _p(dy), _p(wd), _p(dx), _stream()), "conv_dgrad")
+    for a, b in _batch_pieces(desc):
+        d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
+        with _timed(gemm_kernel_name(desc.Cin, desc.Cout, True), conv_work(d)):
+            check(lib().mcdseg_conv_dgrad(ctypes.byref(d), _p(dy[a:b]), _p(wd), _p(dx[a:b]), _stream()), "conv_dgrad")
     return dx
 
 
 def _conv_wgrad(desc, x, dy):
     L = lib()
-    nbytes = L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(desc))
-    ws = _ws(nbytes, x.device)
-    dw = torch.empty((desc.Cout, desc.Cin, desc.KH, desc.KW), dtype=torch.float32, device=x.device)
-    with _timed(wgrad_kernel_name(desc.Cout, desc.Cin), conv_work(desc)):
-        check(L.mcdseg_conv_wgrad(ctypes.byref(desc), _p(x), _p(dy), _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
-              "conv_wgrad")
-    return dw
+    total = None
+    for a, b in _batch_pieces(desc):
+        d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
+        ws = _ws(L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(d)), x.device)
+        dw = torch.empty((desc.Cout, desc.Cin, desc.KH, desc.KW), dtype=torch.float32, device=x.device)
+        with _timed(wgrad_kernel_name(desc.Cout, desc.Cin), conv_work(d)):
+            check(L.mcdseg_conv_wgrad(ctypes.byref(d), _p(x[a:b]), _p(dy[a:b]), _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4),
+                                      _stream()), "conv_wgrad")
+        total = dw if total is None else total.add_(dw)
+    return total
 
 
 # dgrad and wgrad of one layer are independent: launching wgrad on a second HIP stream lets its workgroups fill

@@ -355,3 +355,31 @@ def test_conv_bias_bn_relu():
         _assert_close(a, b, 1e-4, name)
     # d(bias) vanishes analytically (BN removes the channel mean): both are rounding noise around zero
     assert float(conv.bias.grad.abs().max()) <= 1e-4 * float(grads[1].abs().max()) * 120
+
+
+def test_conv_batch_split_for_large_operands(monkeypatch):
+    """Operands above the 2 GiB launch limit (cfg5) are cut along N on the host; exercised here with a tiny limit."""
+    dev = _dev()
+    from mcdseg import ops
+    from models.drn import BatchNorm2d, Conv2d
+    g = torch.Generator().manual_seed(2)
+    conv, bn = Conv2d(24, 40, 3, padding=2, dilation=2, bias=False).to(dev), BatchNorm2d(40).to(dev)
+    x = torch.randn(5, 24, 12, 14, generator=g).to(dev).requires_grad_()
+    gy = torch.randn(5, 40, 12, 14, generator=g).to(dev)
+
+    def run():
+        bn.running_mean.zero_(), bn.running_var.fill_(1), bn.num_batches_tracked.zero_()
+        for t in (x, conv.weight, bn.weight, bn.bias):
+            t.grad = None
+        y = ops.conv_bn_act(x, conv, bn, relu=True)
+        y.backward(gy)
+        return [t.detach().clone() for t in (y, x.grad, conv.weight.grad, bn.weight.grad, bn.bias.grad, bn.running_var)]
+
+    whole = run()
+    per_img = 4 * (40 + 128) * 12 * 14
+    monkeypatch.setattr(ops, "MAX_CONV_BYTES", 2 * per_img)  # -> pieces of 2, 2, 1 images
+    desc = ops.conv_desc(x.shape, conv.weight.shape, 1, 2, 2)
+    assert ops._batch_pieces(desc) == [(0, 2), (2, 4), (4, 5)]
+    split = run()
+    for name, a, b in zip(["y", "dx", "dw", "dgamma", "dbeta", "running_var"], split, whole):
+        _assert_close(a, b, 2e-6, name)
