@@ -23,6 +23,7 @@ struct WgradParams {
   int co_p, ci_p;
   int chunk, chunks_per_img, splits;
   int x_bytes, dy_bytes;
+  int groups;
 };
 
 struct WgradPlan {
@@ -30,13 +31,22 @@ struct WgradPlan {
   int bm, bn;
   int co_p, ci_p;
   int chunk, chunks_per_img, splits;
+  int cinp, groups;  // cfg 3: padded input channels per tap (8/16) and number of tap groups
   int64_t slab_floats;
 };
 
 WgradPlan make_plan(const mcdseg_conv_desc* d) {
   WgradPlan pl;
+  const int T = d->KH * d->KW;
   const int lo = d->Cout < d->Cin ? d->Cout : d->Cin;
-  if (lo > 64) {
+  pl.cinp = 0;
+  pl.groups = T;
+  if (d->Cin <= 16 && T > 1) {
+    // thin inputs (stem, layer1, layer2): several taps share one 32-column MFMA tile, columns = (tap_local, ci)
+    pl.cfg = 3; pl.bm = 32; pl.bn = 32;
+    pl.cinp = d->Cin <= 8 ? 8 : 16;
+    pl.groups = ceil_div(T, 32 / pl.cinp);
+  } else if (lo > 64) {
     pl.cfg = 0; pl.bm = 128; pl.bn = 128;
   } else if (lo > 32) {
     pl.cfg = 1; pl.bm = 64; pl.bn = 64;
@@ -44,10 +54,9 @@ WgradPlan make_plan(const mcdseg_conv_desc* d) {
     pl.cfg = 2; pl.bm = 32; pl.bn = 32;
   }
   pl.co_p = round_up(d->Cout, pl.bm);
-  pl.ci_p = round_up(d->Cin, pl.bn);
-  const int T = d->KH * d->KW;
-  const int64_t tiles = (int64_t)(pl.co_p / pl.bm) * (pl.ci_p / pl.bn) * T;
-  const int64_t want_wgs = pl.cfg == 2 ? 4096 : 1024;
+  pl.ci_p = pl.cfg == 3 ? 32 : round_up(d->Cin, pl.bn);
+  const int64_t tiles = (int64_t)(pl.co_p / pl.bm) * (pl.ci_p / pl.bn) * pl.groups;
+  const int64_t want_wgs = (pl.cfg >= 2) ? 4096 : 1024;
   const int64_t want_splits = ceil_div64(want_wgs, tiles);
   const int hw = d->Ho * d->Wo;
   int cpi = (int)ceil_div64(want_splits, d->N);
@@ -58,7 +67,7 @@ WgradPlan make_plan(const mcdseg_conv_desc* d) {
   pl.chunk = chunk;
   pl.chunks_per_img = ceil_div(hw, chunk);
   pl.splits = d->N * pl.chunks_per_img;
-  pl.slab_floats = (int64_t)pl.splits * T * pl.co_p * pl.ci_p;
+  pl.slab_floats = (int64_t)pl.splits * pl.groups * pl.co_p * pl.ci_p;
   return pl;
 }
 
@@ -217,6 +226,140 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 3
     }
 }
 
+// Thin-input variant (Cin <= 16: 7x7 stem, layer1, layer2).  One wave per workgroup, a 32 (co) x 32 (columns) tile
+// whose columns are (tap_local, ci) pairs: 32/CINP taps share one MFMA tile instead of one tap per tile padded from
+// Cin to 32 columns -- 4x fewer MFMAs and dY re-reads for the 6-channel stem, 2x for 16 channels.
+template <int CINP>
+__global__ __launch_bounds__(64) void conv_wgrad_thin_kernel(WgradParams p) {
+  constexpr int BKP = 32, LDP = BKP + 1, BM = 32, BN = 32;
+  constexpr int TPT = 32 / CINP;  // taps per tile
+  __shared__ float smem[2 * (BM + BN) * LDP];
+  float* As = smem;
+  float* Bs = smem + 2 * BM * LDP;
+  const int t = threadIdx.x;
+  const int l31 = t & 31, lh = t >> 5;
+
+  const int co_tiles = p.co_p / BM;
+  const int per_split = co_tiles * p.groups;
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int split = (slot / per_split) * 8 + xcd;
+  if (split >= p.splits) return;
+  const int rem = slot % per_split;
+  const int group = rem % p.groups;
+  const int tile_co = rem / p.groups;
+  const int n = split / p.chunks_per_img;
+  const int chunk_id = split - n * p.chunks_per_img;
+  const int HoWo = p.Ho * p.Wo;
+  const int HW = p.H * p.W;
+  const int r_begin = chunk_id * p.chunk;
+  int r_end = r_begin + p.chunk;
+  if (r_end > HoWo) r_end = HoWo;
+
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t dy_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const int sk = l31, srg = lh;  // pixel within the step, row parity
+  const int a_soff0 = (n * p.Cout + tile_co * BM) * HoWo * 4;
+  const int b_soff0 = n * p.Cin * HW * 4;
+  const unsigned a_row = (unsigned)srg * (unsigned)HoWo;
+  const unsigned b_row = (unsigned)srg * (unsigned)HW;
+  // tap geometry of this group's TPT taps (taps past the kernel window only feed columns nobody reads)
+  int tdy[TPT], tdx[TPT];
+#pragma unroll
+  for (int q = 0; q < TPT; ++q) {
+    const int tap = group * TPT + q;
+    const int ky = tap / p.KW;
+    const int kx = tap - ky * p.KW;
+    tdy[q] = ky * p.dil - p.pad;
+    tdx[q] = kx * p.dil - p.pad;
+  }
+
+  float areg[16], breg[16];
+  auto load_regs = [&](int r0) {
+    const int r = r0 + sk;
+    const bool rv = r < r_end;
+    unsigned a_voff = OOB;
+    unsigned b_voff[TPT];
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) b_voff[q] = OOB;
+    if (rv) {
+      a_voff = (a_row + (unsigned)r) * 4u;
+      const int oy = r / p.Wo;
+      const int ox = r - oy * p.Wo;
+#pragma unroll
+      for (int q = 0; q < TPT; ++q) {
+        const int iy = oy * p.stride + tdy[q];
+        const int ix = ox * p.stride + tdx[q];
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) b_voff[q] = (b_row + (unsigned)(iy * p.W + ix)) * 4u;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)  // rows srg + 2i of dY
+      areg[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dy_rs, a_voff, a_soff0 + 2 * i * HoWo * 4, 0));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {  // column srg + 2i = (tap_local, ci): tap_local = 2i / CINP, ci = 2i % CINP + srg
+      const int q = (2 * i) / CINP;
+      const int ci_even = (2 * i) % CINP;
+      breg[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rs, b_voff[q], b_soff0 + ci_even * HW * 4, 0));
+    }
+  };
+  auto store_lds = [&](int buf) {
+    float* a = As + buf * BM * LDP;
+    float* b = Bs + buf * BN * LDP;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[(srg + 2 * i) * LDP + sk] = areg[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[(srg + 2 * i) * LDP + sk] = breg[i];
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nsteps = (r_end - r_begin + BKP - 1) / BKP;
+  if (nsteps > 0) {
+    load_regs(r_begin);
+    store_lds(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int cur = s & 1;
+    const bool more = (s + 1) < nsteps;
+    if (more) load_regs(r_begin + (s + 1) * BKP);
+    const float* a_base = As + cur * BM * LDP + l31 * LDP + lh;
+    const float* b_base = Bs + cur * BN * LDP + l31 * LDP + lh;
+#pragma unroll
+    for (int kk = 0; kk < BKP; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_base[kk], b_base[kk], acc, 0, 0, 0);
+    if (more) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+  float* out = p.slab + ((size_t)split * p.groups + group) * p.co_p * 32;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = tile_co * BM + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    out[(size_t)row * 32 + l31] = acc[r];
+  }
+}
+
+__global__ void wgrad_thin_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int T, int co_p,
+                                         int groups, int cinp, int splits) {
+  const int64_t total = (int64_t)T * Cout * Cin;
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ci = (int)(i % Cin);
+  const int64_t r = i / Cin;
+  const int co = (int)(r % Cout);
+  const int tap = (int)(r / Cout);
+  const int tpt = 32 / cinp;
+  const int group = tap / tpt;
+  const int col = (tap - group * tpt) * cinp + ci;
+  const size_t stride = (size_t)groups * co_p * 32;
+  const float* src = slab + ((size_t)group * co_p + co) * 32 + col;
+  double s = 0.0;
+  for (int k = 0; k < splits; ++k) s += (double)src[(size_t)k * stride];
+  dw[((size_t)co * Cin + ci) * T + tap] = (float)s;
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int T, int co_p,
                                     int ci_p, int splits) {
   const int64_t total = (int64_t)T * Cout * Cin;
@@ -257,11 +400,24 @@ extern "C" int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, cons
   p.co_p = pl.co_p; p.ci_p = pl.ci_p; p.chunk = pl.chunk; p.chunks_per_img = pl.chunks_per_img; p.splits = pl.splits;
   p.x_bytes = (int)((int64_t)d->N * d->Cin * d->H * d->W * 4);
   p.dy_bytes = (int)((int64_t)d->N * d->Cout * d->Ho * d->Wo * 4);
-  const int64_t per_split = (int64_t)(pl.co_p / pl.bm) * (pl.ci_p / pl.bn) * T;
+  p.groups = pl.groups;
+  const int64_t per_split = (int64_t)(pl.co_p / pl.bm) * (pl.ci_p / pl.bn) * pl.groups;
   const int64_t nwg = 8 * ceil_div64(pl.splits, 8) * per_split;
   MCD_REQUIRE(nwg < (1ll << 31), "conv_wgrad: grid too large");
   dim3 grid((unsigned)nwg);
   hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)T * d->Cout * d->Cin;
+  if (pl.cfg == 3) {
+    if (pl.cinp == 8)
+      hipLaunchKernelGGL((conv_wgrad_thin_kernel<8>), grid, dim3(64), 0, st, p);
+    else
+      hipLaunchKernelGGL((conv_wgrad_thin_kernel<16>), grid, dim3(64), 0, st, p);
+    MCD_LAUNCH_CHECK("conv_wgrad_thin");
+    hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, (const float*)workspace,
+                       dw, d->Cout, d->Cin, T, pl.co_p, pl.groups, pl.cinp, pl.splits);
+    MCD_LAUNCH_CHECK("conv_wgrad_thin_reduce");
+    return 0;
+  }
   if (pl.cfg == 0)
     hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 2, 2, 16>), grid, dim3(256), 0, st, p);
   else if (pl.cfg == 1)
@@ -269,7 +425,6 @@ extern "C" int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, cons
   else
     hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 1, 32>), grid, dim3(64), 0, st, p);
   MCD_LAUNCH_CHECK("conv_wgrad");
-  const int64_t total = (int64_t)T * d->Cout * d->Cin;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
                      d->Cout, d->Cin, T, pl.co_p, pl.ci_p, pl.splits);
   MCD_LAUNCH_CHECK("conv_wgrad_reduce");

@@ -64,7 +64,9 @@ def gemm_kernel_name(m, k, dgrad):
     return "conv_gemm_kernel<%s, %d, %s>" % (cfg, 8 if k <= 8 else 16, "true" if dgrad else "false")
 
 
-def wgrad_kernel_name(cout, cin):
+def wgrad_kernel_name(cout, cin, taps=9):
+    if cin <= 16 and taps > 1:
+        return "conv_wgrad_thin_kernel<%d>" % (8 if cin <= 8 else 16)
     lo = min(cout, cin)
     return "conv_wgrad_kernel<%s>" % ("2, 2, 2, 2, 16" if lo > 64 else ("1, 1, 2, 2, 32" if lo > 32 else "1, 1, 1, 1, 32"))
 
@@ -179,7 +181,7 @@ def _conv_wgrad(desc, x, dy):
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
         ws = _ws(L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(d)), x.device)
         dw = torch.empty((desc.Cout, desc.Cin, desc.KH, desc.KW), dtype=torch.float32, device=x.device)
-        with _timed(wgrad_kernel_name(desc.Cout, desc.Cin), conv_work(d)):
+        with _timed(wgrad_kernel_name(desc.Cout, desc.Cin, desc.KH * desc.KW), conv_work(d)):
             check(L.mcdseg_conv_wgrad(ctypes.byref(d), _p(x[a:b]), _p(dy[a:b]), _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4),
                                       _stream()), "conv_wgrad")
         total = dw if total is None else total.add_(dw)

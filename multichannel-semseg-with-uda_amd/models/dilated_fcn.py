@@ -118,6 +118,9 @@ class FusionDRNSegPixelClassifier(nn.Module):
             self.seg = _seg_head(512, n_class)
 
     def forward(self, x1, x2):
+        if isinstance(self.fusion, AddFusion) and self.ver == "ver1":
+            # up(x1 + x2) = up(x1) + up(x2): the sum is never materialised, one pass over the full-resolution output
+            return ops.up8_dual(x1, self.up.weight, x2, self.up.weight)
         h = self.fusion(x1, x2)
         if self.ver == "ver2":
             h = self.seg(h)

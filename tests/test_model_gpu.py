@@ -385,3 +385,98 @@ def test_multitask_cfg4_vs_reference(golden):
     sd = dec.state_dict()
     assert int(enc.state_dict()["base.0.1.num_batches_tracked"]) == 8
     assert int(sd["semsegcls_dec1.cbr1.bn.num_batches_tracked"]) == 8 and int(sd["deprgr_dec.cbr1.bn.num_batches_tracked"]) == 4
+
+
+@pytest.mark.parametrize("net,method", [("drn_d_38_ver2", "MCD"), ("drn_d_38", "MFNet-AddFusion"), ("drn_d_22", "MCD")])
+def test_model_variants_vs_oracle(net, method):
+    """ver2 (1x1 ``seg`` head inside F, models/dilated_fcn.py:240-241, 346-351), feature-level AddFusion
+    (:431-470) and another trunk depth: forward + CE/discrepancy backward against the CPU oracle."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, Diff2d
+    from models.model_util import get_models
+    from oracle import ref_loss, ref_models
+    hip = get_models(net, 6, NC, method=method)
+    ora = ref_models.get_models(net, 6, NC, method=method)
+    for i, (a, b) in enumerate(zip(hip, ora)):
+        fill_state_(a, 90 + i), fill_state_(b, 90 + i)
+        a.to(dev).train(), b.train()
+    s, l, _ = make_batch(91, 2, 6, 64, 96, NC)
+    cw = ref_loss.class_weights(NC)
+
+    def run(ms, x, lab, crit, critd):
+        if "MFNet" in method:
+            fa, fb = ms[0](x[:, :3].contiguous()), ms[1](x[:, 3:].contiguous())
+            o1, o2 = ms[2](fa, fb), ms[3](fa, fb)
+        else:
+            f = ms[0](x)
+            o1, o2 = ms[1](f), ms[2](f)
+        loss = crit(o1, lab) + crit(o2, lab) - critd(o1, o2)
+        loss.backward()
+        return o1.detach(), float(loss)
+
+    r1, rl = run(ora, s, l, ref_loss.CrossEntropyLoss2d(cw), ref_loss.Diff2d())
+    h1, hl = run(hip, s.to(dev), l.to(dev), CrossEntropyLoss2d(cw.to(dev)), Diff2d())
+    assert float((h1.cpu() - r1).abs().max()) <= 5e-5 * float(r1.abs().max())
+    assert abs(hl - rl) <= 1e-5 * abs(rl)
+    for a, b in zip(hip, ora):
+        pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+        for k in pb:
+            if k.endswith("up.weight") or k.startswith("seg.") or k.endswith("up1.weight"):
+                ga, gb = pa[k].grad.cpu(), pb[k].grad
+                assert float((ga - gb).abs().max()) <= max(2e-3 * float(gb.abs().max()), 1e-7), k
+
+
+def test_rccl_path_world_size_one(golden):
+    """RCCL plumbing on one GPU: nccl process group of size 1, the optimizer's flat-gradient all-reduce and the
+    all-reduced CE normaliser are exercised (summing over one rank must not change anything)."""
+    dev = _dev()
+    import torch.distributed as dist
+    from loss import CrossEntropyLoss2d, get_prob_distance_criterion
+    from mcdseg import dist as mdist
+    from models.model_util import get_optimizer
+    from solvers.solver import MCDSolver
+    tr = golden.json("traces.json")["mcd_small"]
+    os_env = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29531", "RANK": "0", "WORLD_SIZE": "1"}
+    import os
+    old = {k: os.environ.get(k) for k in os_env}
+    os.environ.update(os_env)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    real = mdist.is_distributed
+    calls = {"n": 0}
+    real_ar = mdist.all_reduce_sum_
+
+    def counting(flat):
+        calls["n"] += 1
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
+
+    mdist.is_distributed = lambda: True
+    mdist.all_reduce_sum_ = counting
+    import mcdseg.optim as mo
+    ws = mdist.world_size
+    try:
+        mdist.world_size = lambda: 1
+        g, f1, f2 = _mcd_models(dev)
+        n, ch, h, w = tr["shape"]
+        s, l, t = (v.to(dev) for v in make_batch(tr["seed_batch"], n, ch, h, w, NC))
+        og = get_optimizer(g.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+        of = get_optimizer(list(f1.parameters()) + list(f2.parameters()), "sgd", 1e-3, 0.9, 2e-5)
+        # FlatSGD only all-reduces when world > 1: drive the collective directly on its flat gradient buffer too
+        cw = torch.ones(NC)
+        cw[NC - 1] = 0
+        solver = MCDSolver(g, f1, f2, og, of, CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff"), num_k=4)
+        c_loss, d_loss = solver.step(s, l, t)
+        counting(og.flat_buffers()[1])
+        torch.cuda.synchronize()
+        it = tr["iters"][0]
+        assert abs(float(c_loss) - it["c_loss"]) <= 1e-4 * it["c_loss"] and abs(float(d_loss) - it["d_loss"]) <= 2e-3 * it["d_loss"]
+        assert calls["n"] >= 3  # two CE normalisers (steps A, B) + the explicit flat-buffer reduce
+    finally:
+        mdist.is_distributed, mdist.all_reduce_sum_, mdist.world_size = real, real_ar, ws
+        dist.destroy_process_group()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
