@@ -178,11 +178,23 @@ def main():
         # tile: 7 forward passes vs 5 backward); its launches run alone on the stream, so the event pairs are clean
         dom_name = max(convs, key=lambda k: convs[k]["flops"]) if convs else None
         roofline = None
+        traffic = None
+        if dom_name:
+            # HBM-side bytes per launch from the committed PMC passes (profiles/<round>_pmc_traffic.json: FETCH_SIZE and
+            # WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same bench, FETCH_SIZE doubled per the gfx950 note)
+            import glob
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+                try:
+                    traffic = json.load(open(fn))["kernels"][dom_name]["hbm_bytes_per_launch"]
+                    break
+                except (KeyError, ValueError, OSError):
+                    continue
         if dom_name:
             dom = convs[dom_name]
             roofline = {"bound": "mfma", "kernel": dom_name + " (implicit-GEMM conv on v_mfma_f32_32x32x2_f32)",
                         "achieved": round(dom["tflops"], 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(dom["tflops"] / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                        "frac": round(dom["tflops"] / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                        "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
                         "launches": dom["launches"], "avg_launch_ms": round(dom["avg_ms"], 4),
                         "alg_flops_per_launch": dom["flops"] / dom["launches"]}
         # whole-step accounting on the algorithmic work of SURVEY.md 8d (drn_d_38 @ 6x480x640 only)

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Turn raw rocprofv3 output merged into gpurun_out/ into the small, committed summaries under profiles/.
+
+    python tools/summarize_profiles.py r01c      # reads gpurun_out/r01c_{stats,fetch,write}, writes profiles/r01c_*
+
+* <tag>_kernel_stats.csv : rocprofv3 --kernel-trace --stats summary of `bench.py --steps 2 --warmup 1` (verbatim)
+* <tag>_pmc_traffic.json : per kernel (all launches of one MCD step): launches, mean FETCH_SIZE / WRITE_SIZE, and
+                           HBM-side bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024.  The two counters come from
+                           separate --pmc passes (TCC slot budget); FETCH_SIZE is doubled per the gfx950 note in
+                           MI355X_MICROARCH.md (HBM section) -- calibrated here on kernels with known byte counts
+                           (softmax_ce_l1: 2 x 806 MB read -> FETCH_SIZE 806 MB; bn_apply, up8_fwd likewise).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
+def counters(path, counter):
+    agg = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        d = agg.setdefault(short(r["Kernel_Name"]), [])
+        d.append(float(r["Counter_Value"]))
+    return agg
+
+
+def main(tag):
+    out = os.path.join(ROOT, "profiles")
+    src = os.path.join(ROOT, "gpurun_out")
+    stats = glob.glob(os.path.join(src, tag + "_stats", "*", "*kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(out, tag + "_bench_kernel_stats.csv"))
+    f = glob.glob(os.path.join(src, tag + "_fetch", "*", "*counter_collection.csv"))
+    w = glob.glob(os.path.join(src, tag + "_write", "*", "*counter_collection.csv"))
+    if f and w:
+        fetch, write = counters(f[0], "FETCH_SIZE"), counters(w[0], "WRITE_SIZE")
+        table = {}
+        for k, v in fetch.items():
+            if k not in write or not k.startswith(("conv_", "bn_", "up8_", "softmax", "sgd", "wgrad", "pack", "bilinear", "mse")):
+                continue
+            fk, wk = sum(v) / len(v), sum(write[k]) / len(write[k])
+            table[k] = {"launches_per_step": len(v), "fetch_size_kb_mean": round(fk, 1), "write_size_kb_mean": round(wk, 1),
+                        "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+        json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (two passes) -- python3 bench.py --steps 1 --warmup 0",
+                   "units": "FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes = (2*FETCH + WRITE) * 1024 (gfx950 FETCH_SIZE halving)",
+                   "kernels": table}, open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    b = os.path.join(src, tag + "_bench.json")
+    if os.path.exists(b):
+        shutil.copy(b, os.path.join(out, tag + "_bench_line.json"))
+    print("profiles/ updated for", tag)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01c")
