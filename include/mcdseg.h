@@ -54,6 +54,10 @@ int64_t mcdseg_conv_stat_rows(const mcdseg_conv_desc* d);
  * (fused epilogue; nn.BatchNorm2d call sites models/drn.py:34,38,129,179,202). */
 int mcdseg_conv_fprop(const mcdseg_conv_desc* d, const float* x, const float* wp_fprop, const float* bias,
                       float* y, float* stat_partials, void* stream);
+/* Inference form (eval-mode BatchNorm folded into the epilogue, adapt_tester.py:87-104):
+ * y = act(scale[c] * conv(x, w) + shift[c] (+ residual)), act = ReLU if relu != 0.  No bn_apply pass. */
+int mcdseg_conv_fprop_affine(const mcdseg_conv_desc* d, const float* x, const float* wp_fprop, const float* scale,
+                             const float* shift, const float* residual, int32_t relu, float* y, void* stream);
 /* dx = conv_transpose(dy, w)   (autograd of the same call sites) */
 int mcdseg_conv_dgrad(const mcdseg_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* stream);
 /* dw = x (*) dy ; split over pixels into slabs in `workspace`, then reduced in a fixed order. */
@@ -75,6 +79,10 @@ int mcdseg_bn_stats_finalize(const float* stat_partials, int64_t rows, int32_t C
 /* eval mode: mean = running_mean, rstd = 1/sqrt(running_var+eps) */
 int mcdseg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps,
                          float* mean, float* rstd, void* stream);
+/* eval-mode BN as an affine map: scale = gamma/sqrt(running_var+eps), shift = beta + (conv_bias - running_mean)*scale
+ * (conv_bias may be NULL) -- feeds mcdseg_conv_fprop_affine */
+int mcdseg_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                          const float* conv_bias, int32_t C, float eps, float* scale, float* shift, void* stream);
 /* y = act(gamma*(z-mean)*rstd + beta (+ residual)), act = ReLU if relu != 0 */
 int mcdseg_bn_apply(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                     const float* residual, float* y, int32_t N, int32_t C, int32_t HW, int32_t relu, void* stream);
@@ -125,6 +133,12 @@ int mcdseg_softmax_ce_l1(const float* z1, const float* z2, const int64_t* labels
 size_t mcdseg_label_weight_sum_workspace_bytes(int64_t P);
 int mcdseg_label_weight_sum(const int64_t* labels, const float* class_weight, int64_t ignore_index, int32_t C, int64_t P,
                             float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* Inference tail (adapt_tester.py:101-124; util.py:44-48): o = z1, or (z1+z2)/2 when z2 != NULL;
+ * labels[n,hw] = argmax_{c < C_used} o (uint8; the background channel is excluded by C_used = C-1 unless it was trained);
+ * entropy[0] = -mean_{n,c,hw} p log(p + 1e-6), p = softmax over all C classes. */
+size_t mcdseg_predict_workspace_bytes(int32_t N, int32_t HW);
+int mcdseg_predict_labels(const float* z1, const float* z2, uint8_t* labels, float* entropy, int32_t N, int32_t C,
+                          int32_t C_used, int32_t HW, void* workspace, size_t workspace_bytes, void* stream);
 /* buf[i] *= *scale (device scalar) -- applies autograd's upstream scalar without a host sync */
 int mcdseg_scale_by_device_scalar(float* buf, const float* scale, int64_t n, void* stream);
 

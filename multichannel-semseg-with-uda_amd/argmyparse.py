@@ -94,3 +94,21 @@ def get_da_mcd_training_parser():
                         choices=["jsd", "mysymkl", "spatial_jsd", "symkl", "diff", "nmlsymkl", "strange_kl", "mis_symkl"])
     parser.add_argument("--uses_one_classifier", action="store_true", help="separate f1, f2")
     return parser
+
+
+def get_da_mcd_testing_parser():
+    """flags of the reference's testers (argmyparse.py:146-160)"""
+    parser = argparse.ArgumentParser(description="Adapt tester for validation data")
+    parser.add_argument("tgt_dataset", type=str, choices=AVAILABLE_DATASET_LIST)
+    parser.add_argument("trained_checkpoint", type=str, metavar="PTH.TAR")
+    parser.add_argument("--split", type=str, default="val", help="'val' or 'test') is used")
+    parser.add_argument("--outdir", type=str, default="test_output", help="output directory")
+    parser.add_argument("--test_img_shape", default=None, nargs=2, type=int, help="W H")
+    parser.add_argument("--saves_prob", action="store_true", help="whether you save probability tensors")
+    parser.add_argument("--use_f2", action="store_true", help="whether you use f2")
+    g = parser.add_argument_group("MI355X build")
+    g.add_argument("--synthetic", action="store_true")
+    g.add_argument("--synthetic_len", type=int, default=4)
+    g.add_argument("--seed", type=int, default=4321)
+    g.add_argument("-b", "--batch_size", type=int, default=1)
+    return parser

@@ -92,6 +92,19 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* 
   }
 }
 
+// eval-mode BatchNorm as a per-channel affine map (folded into the conv epilogue at inference):
+//   scale = gamma / sqrt(running_var + eps), shift = beta + (conv_bias - running_mean) * scale
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                                      const float* __restrict__ rv, const float* __restrict__ conv_bias, int C, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float a = gamma[c] * (float)(1.0 / sqrt((double)rv[c] + (double)eps));
+    scale[c] = a;
+    shift[c] = beta[c] + ((conv_bias ? conv_bias[c] : 0.f) - rm[c]) * a;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // apply: grid.x = plane (n*C + c), grid.y = chunk of the plane; float4 when HW % 4 == 0.
 template <bool VEC>
@@ -317,6 +330,15 @@ extern "C" int mcdseg_bn_eval_stats(const float* running_mean, const float* runn
   hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean, running_var,
                      C, eps, mean, rstd);
   MCD_LAUNCH_CHECK("bn_eval_stats");
+  return 0;
+}
+
+extern "C" int mcdseg_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                     const float* conv_bias, int32_t C, float eps, float* scale, float* shift, void* stream) {
+  MCD_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "bn_eval_affine: bad arguments");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                     running_var, conv_bias, C, eps, scale, shift);
+  MCD_LAUNCH_CHECK("bn_eval_affine");
   return 0;
 }
 

@@ -26,6 +26,10 @@ struct ConvGemmParams {
   const float* bias;
   float* dst;
   float* stats;
+  const float* ep_scale;  // inference epilogue: y = act(scale[m]*acc + shift[m] + residual)
+  const float* ep_shift;
+  const float* ep_res;
+  int ep_relu;
   int N;
   int Cs, Hs, Ws;  // source tensor (gathered)
   int M, Hd, Wd;   // destination tensor
@@ -253,6 +257,19 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGemmParams p) {
       }
   }
 
+  if (!DGRAD && p.ep_scale != nullptr) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float sc = (m < p.M) ? p.ep_scale[m] : 0.f;
+        const float sh = (m < p.M) ? p.ep_shift[m] : 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j][r] = fmaf(acc[i][j][r], sc, sh);
+      }
+  }
+
   bool colv[WN];
   size_t dbase[WN];
 #pragma unroll
@@ -274,7 +291,14 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGemmParams p) {
       if (m < p.M) {
 #pragma unroll
         for (int j = 0; j < WN; ++j)
-          if (colv[j]) p.dst[dbase[j] + (size_t)m * HWd] = acc[i][j][r];
+          if (colv[j]) {
+            float v = acc[i][j][r];
+            if (!DGRAD && p.ep_scale != nullptr) {
+              if (p.ep_res != nullptr) v += p.ep_res[dbase[j] + (size_t)m * HWd];
+              if (p.ep_relu) v = fmaxf(v, 0.f);
+            }
+            p.dst[dbase[j] + (size_t)m * HWd] = v;
+          }
       }
     }
 
@@ -415,11 +439,28 @@ extern "C" int64_t mcdseg_conv_stat_rows(const mcdseg_conv_desc* d) {
   return ceil_div64(P, bn_for(d->Cout)) * waves_n_for(d->Cout);
 }
 
+static int conv_fprop_impl(const mcdseg_conv_desc* d, const float* x, const float* wp_fprop, const float* bias, float* y,
+                           float* stat_partials, const float* ep_scale, const float* ep_shift, const float* ep_res, int ep_relu,
+                           void* stream);
+
 extern "C" int mcdseg_conv_fprop(const mcdseg_conv_desc* d, const float* x, const float* wp_fprop, const float* bias, float* y,
                                  float* stat_partials, void* stream) {
+  return conv_fprop_impl(d, x, wp_fprop, bias, y, stat_partials, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int mcdseg_conv_fprop_affine(const mcdseg_conv_desc* d, const float* x, const float* wp_fprop, const float* scale,
+                                        const float* shift, const float* residual, int32_t relu, float* y, void* stream) {
+  MCD_REQUIRE(scale && shift, "conv_fprop_affine: null scale/shift");
+  return conv_fprop_impl(d, x, wp_fprop, nullptr, y, nullptr, scale, shift, residual, relu, stream);
+}
+
+static int conv_fprop_impl(const mcdseg_conv_desc* d, const float* x, const float* wp_fprop, const float* bias, float* y,
+                           float* stat_partials, const float* ep_scale, const float* ep_shift, const float* ep_res, int ep_relu,
+                           void* stream) {
   if (int rc = check_desc(d, "conv_fprop")) return rc;
   MCD_REQUIRE(x && wp_fprop && y, "conv_fprop: null pointer");
   ConvGemmParams p;
+  p.ep_scale = ep_scale; p.ep_shift = ep_shift; p.ep_res = ep_res; p.ep_relu = ep_relu;
   p.src = x;
   p.wp = wp_fprop;
   p.bias = bias;
@@ -444,6 +485,7 @@ extern "C" int mcdseg_conv_dgrad(const mcdseg_conv_desc* d, const float* dy, con
   if (int rc = check_desc(d, "conv_dgrad")) return rc;
   MCD_REQUIRE(dy && wp_dgrad && dx, "conv_dgrad: null pointer");
   ConvGemmParams p;
+  p.ep_scale = nullptr; p.ep_shift = nullptr; p.ep_res = nullptr; p.ep_relu = 0;
   p.src = dy;
   p.wp = wp_dgrad;
   p.bias = nullptr;

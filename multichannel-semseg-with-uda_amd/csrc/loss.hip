@@ -167,6 +167,71 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
   }
 }
 
+// Inference tail (adapt_tester.py:101-124, util.py:44-48): o = z1 or (z1 + z2)/2; label = argmax over the first C_used
+// classes (the background channel is excluded unless it was trained); entropy term = sum_c p_c log(p_c + 1e-6) over ALL classes.
+template <int NCMAX>
+__global__ __launch_bounds__(256) void predict_kernel(const float* __restrict__ z1, const float* __restrict__ z2,
+                                                      uint8_t* __restrict__ labels, float* __restrict__ part, int C, int C_used,
+                                                      int HW, int64_t P) {
+  const int64_t pix = blockIdx.x * (int64_t)LOSS_BLOCK + threadIdx.x;
+  float ent = 0.f;
+  if (pix < P) {
+    const int64_t n = pix / HW;
+    const int hw = (int)(pix - n * HW);
+    const size_t base = (size_t)n * C * HW + hw;
+    float a[NCMAX];
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c) {
+      float v = -INFINITY;
+      if (c < C) {
+        v = z1[base + (size_t)c * HW];
+        if (z2 != nullptr) v = (v + z2[base + (size_t)c * HW]) / 2.f;
+      }
+      a[c] = v;
+    }
+    float m = a[0], mu = a[0];
+    int best = 0;
+#pragma unroll
+    for (int c = 1; c < NCMAX; ++c) {
+      m = fmaxf(m, a[c]);
+      if (c < C_used && a[c] > mu) {
+        mu = a[c];
+        best = c;
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c) {
+      a[c] = (c < C) ? expf(a[c] - m) : 0.f;
+      s += a[c];
+    }
+    const float r = 1.f / s;
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c)
+      if (c < C) {
+        const float pc = a[c] * r;
+        ent += pc * logf(pc + 1e-6f);
+      }
+    labels[pix] = (uint8_t)best;
+  }
+  __shared__ float sh[4];
+  ent = wave_sum(ent);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ent;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void predict_finalize_kernel(const float* __restrict__ part, int64_t nblk, double neg_inv_m,
+                                                               float* __restrict__ out) {
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < nblk; i += 256) s += (double)part[i];
+  __shared__ double sh[4];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) * neg_inv_m);
+}
+
 __global__ void scale_by_device_scalar_kernel(float* __restrict__ buf, const float* __restrict__ scale, int64_t n4, int64_t n) {
   const float s = *scale;
   float4* b4 = reinterpret_cast<float4*>(buf);
@@ -260,6 +325,30 @@ extern "C" int mcdseg_softmax_ce_l1(const float* z1, const float* z2, const int6
   MCD_LAUNCH_CHECK("softmax_ce_l1");
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nblk, losses, inv_m);
   MCD_LAUNCH_CHECK("loss_finalize");
+  return 0;
+}
+
+extern "C" size_t mcdseg_predict_workspace_bytes(int32_t N, int32_t HW) {
+  return (N > 0 && HW > 0) ? (size_t)ceil_div64((int64_t)N * HW, LOSS_BLOCK) * sizeof(float) : 0;
+}
+
+extern "C" int mcdseg_predict_labels(const float* z1, const float* z2, uint8_t* labels, float* entropy, int32_t N, int32_t C,
+                                     int32_t C_used, int32_t HW, void* workspace, size_t workspace_bytes, void* stream) {
+  MCD_REQUIRE(z1 && labels && entropy && workspace, "predict_labels: null pointer");
+  MCD_REQUIRE(N > 0 && HW > 0 && C > 0 && C <= 48 && C_used > 0 && C_used <= C && C_used <= 256, "predict_labels: bad dims");
+  MCD_REQUIRE(workspace_bytes >= mcdseg_predict_workspace_bytes(N, HW), "predict_labels: workspace too small");
+  const int64_t P = (int64_t)N * HW;
+  const int64_t nblk = ceil_div64(P, LOSS_BLOCK);
+  hipStream_t st = (hipStream_t)stream;
+  if (C <= 16)
+    hipLaunchKernelGGL(predict_kernel<16>, dim3((unsigned)nblk), dim3(LOSS_BLOCK), 0, st, z1, z2, labels, (float*)workspace, C, C_used, HW, P);
+  else if (C <= 24)
+    hipLaunchKernelGGL(predict_kernel<24>, dim3((unsigned)nblk), dim3(LOSS_BLOCK), 0, st, z1, z2, labels, (float*)workspace, C, C_used, HW, P);
+  else
+    hipLaunchKernelGGL(predict_kernel<48>, dim3((unsigned)nblk), dim3(LOSS_BLOCK), 0, st, z1, z2, labels, (float*)workspace, C, C_used, HW, P);
+  MCD_LAUNCH_CHECK("predict_labels");
+  hipLaunchKernelGGL(predict_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, nblk, -1.0 / ((double)P * (double)C), entropy);
+  MCD_LAUNCH_CHECK("predict_finalize");
   return 0;
 }
 

@@ -287,10 +287,34 @@ class _ConvBNAct(torch.autograd.Function):
                 None, None, None, None, None, None, None, None, None)
 
 
+def _conv_bn_act_inference(x, conv, bn, relu, residual):
+    """eval-mode BN folded into the conv epilogue: one kernel, no z / bn_apply pass, nothing kept for backward"""
+    L = lib()
+    x = _req(x, "conv input")
+    residual = _req(residual, "residual")
+    desc = conv_desc(x.shape, conv.weight.shape, conv.stride[0], conv.padding[0], conv.dilation[0])
+    wf, _, _ = conv._packed.get(conv.weight, desc)
+    c = desc.Cout
+    scale = torch.empty(c, dtype=torch.float32, device=x.device)
+    shift = torch.empty(c, dtype=torch.float32, device=x.device)
+    check(L.mcdseg_bn_eval_affine(_p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(conv.bias), c,
+                                  float(bn.eps), _p(scale), _p(shift), _stream()), "bn_eval_affine")
+    y = torch.empty((desc.N, c, desc.Ho, desc.Wo), dtype=torch.float32, device=x.device)
+    for a, b in _batch_pieces(desc):
+        d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
+        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False), conv_work(d)):
+            check(L.mcdseg_conv_fprop_affine(ctypes.byref(d), _p(x[a:b]), _p(wf), _p(scale), _p(shift),
+                                             _p(residual[a:b]) if residual is not None else None, int(relu), _p(y[a:b]), _stream()),
+                  "conv_fprop_affine")
+    return y
+
+
 def conv_bn_act(x, conv, bn, relu=True, residual=None):
     """y = act(bn(conv(x)) + residual) with the HIP kernels; ``conv``/``bn`` are the parameter-holding modules."""
     geom = (conv.stride[0], conv.padding[0], conv.dilation[0])
     training = bn.training
+    if not training and not torch.is_grad_enabled() and bn.track_running_stats and bn.running_mean is not None:
+        return _conv_bn_act_inference(x, conv, bn, relu, residual)
     track = bn.track_running_stats and bn.running_mean is not None
     if not training and not track:
         raise NotImplementedError("mcdseg: eval-mode BatchNorm needs running statistics")
@@ -508,6 +532,21 @@ def mcd_losses(z1, z2, labels, class_weight, ignore_index=-100, ce_coef=0.0, dif
                                      float(diff_coef), _p(wsum), _p(g1), _p(g2), _p(losses), n, c, h * w, _p(ws),
                                      ctypes.c_size_t(ws.numel() * 4), _stream()), "softmax_ce_l1")
     return losses, g1, g2
+
+
+def predict_labels(z1, z2=None, n_used=None):
+    """Inference tail of adapt_tester.py:101-124: (uint8 label map [N,H,W] = argmax over the first ``n_used`` classes
+    of z1 or (z1+z2)/2, mean entropy scalar as util.calc_entropy defines it)."""
+    L = lib()
+    z1, z2 = _req(z1, "logits"), _req(z2, "logits")
+    n, c, h, w = z1.shape
+    n_used = c if n_used is None else int(n_used)
+    labels = torch.empty((n, h, w), dtype=torch.uint8, device=z1.device)
+    ent = torch.empty(1, dtype=torch.float32, device=z1.device)
+    ws = _ws(L.mcdseg_predict_workspace_bytes(n, h * w), z1.device)
+    check(L.mcdseg_predict_labels(_p(z1), _p(z2), _p(labels), _p(ent), n, c, n_used, h * w, _p(ws), ctypes.c_size_t(ws.numel() * 4),
+                                  _stream()), "predict_labels")
+    return labels, ent.reshape(())
 
 
 def _scale_(g, s):

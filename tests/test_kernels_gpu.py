@@ -383,3 +383,38 @@ def test_conv_batch_split_for_large_operands(monkeypatch):
     split = run()
     for name, a, b in zip(["y", "dx", "dw", "dgamma", "dbeta", "running_var"], split, whole):
         _assert_close(a, b, 2e-6, name)
+
+
+def test_folded_bn_inference_and_predict_tail():
+    dev = _dev()
+    from mcdseg import ops
+    from models.drn import BatchNorm2d, Conv2d
+    g = torch.Generator().manual_seed(31)
+    conv, bn = Conv2d(24, 40, 3, padding=2, dilation=2, bias=True), BatchNorm2d(40)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.08)
+        conv.bias.copy_(torch.randn(40, generator=g) * 0.2)
+        bn.weight.copy_(1 + 0.2 * torch.randn(40, generator=g)), bn.bias.copy_(0.1 * torch.randn(40, generator=g))
+        bn.running_mean.copy_(0.1 * torch.randn(40, generator=g)), bn.running_var.copy_(0.5 + torch.rand(40, generator=g))
+    x = torch.randn(3, 24, 9, 11, generator=g)
+    res = torch.randn(3, 40, 9, 11, generator=g)
+    ref = F.relu(F.batch_norm(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=2, dilation=2),
+                              bn.running_mean.double(), bn.running_var.double(), bn.weight.double(), bn.bias.double(), training=False,
+                              eps=1e-5) + res.double())
+    conv.to(dev), bn.to(dev).eval()
+    with torch.no_grad():
+        y = ops.conv_bn_act(x.to(dev), conv, bn, relu=True, residual=res.to(dev))   # folded path (no grad, eval)
+    _assert_close(y, ref, 2e-5, "folded conv+BN+residual+ReLU")
+    xg = x.to(dev).requires_grad_()
+    y2 = ops.conv_bn_act(xg, conv, bn, relu=True, residual=res.to(dev))              # eval BN with a tape (fix_bn training)
+    _assert_close(y2, ref, 2e-5, "eval-mode BN, autograd path")
+    # argmax / entropy tail
+    z1 = torch.randn(2, 41, 7, 9, generator=g) * 2
+    z2 = torch.randn(2, 41, 7, 9, generator=g) * 2
+    lab, ent = ops.predict_labels(z1.to(dev), z2.to(dev), 40)
+    o = (z1 + z2) / 2
+    assert torch.equal(lab.cpu(), o[:, :40].argmax(1).to(torch.uint8))
+    p = torch.softmax(o.double(), dim=1)
+    assert abs(float(ent) - float(-(p * torch.log(p + 1e-6)).mean())) <= 1e-5
+    lab1, _ = ops.predict_labels(z1.to(dev), None, 41)
+    assert torch.equal(lab1.cpu(), z1.argmax(1).to(torch.uint8))

@@ -79,3 +79,44 @@ def test_adapt_multitask_trainer(tmp_path):
     assert sorted(ck.keys()) == ["args", "dec_state_dict", "enc_state_dict", "epoch", "optimizer_dec", "optimizer_enc"]
     assert len(ck["dec_state_dict"]) == 51 and "s_semsegcls" in ck["dec_state_dict"]
     assert list(ck["dec_state_dict"]["deprgr_dec.conv3.weight"].shape) == [3, 512, 1, 1]
+
+
+def test_adapt_tester_label_maps_match_oracle(tmp_path):
+    """Train one synthetic epoch, run the tester (folded-BN inference + argmax/entropy kernel) and compare the written
+    label PNGs and the entropy with the CPU oracle evaluating the same checkpoint (adapt_tester.py:87-126)."""
+    _need_gpu()
+    import numpy as np
+    from PIL import Image
+    import adapt_tester
+    import adapt_trainer
+    import util
+    from datasets import SyntheticRGBD
+    from oracle import ref_models
+    out = str(tmp_path / "out")
+    assert adapt_trainer.main(["suncg", "nyu", "--base_outdir", out] + COMMON) == 0
+    ck_fn = os.path.join(out, "suncg-train2nyu-train_6ch", "pth", "MCD-normal-drn_d_38-1.pth.tar")
+    label_dir, ent = adapt_tester.main(["nyu", ck_fn, "--outdir", str(tmp_path / "test"), "--synthetic", "--synthetic_len", "3",
+                                        "--use_f2", "--test_img_shape", "96", "64"])
+    ck = util.load_checkpoint(ck_fn)
+    g, f1, f2 = ref_models.get_models("drn_d_38", 6, 41)
+    g.load_state_dict(ck["g_state_dict"]), f1.load_state_dict(ck["f1_state_dict"]), f2.load_state_dict(ck["f2_state_dict"])
+    for m in (g, f1, f2):
+        m.eval()
+    ds = SyntheticRGBD(3, 6, [96, 64], 41, seed=4321, test=True)
+    ents, agree, safe_total = [], 0, 0
+    for i in range(3):
+        img, _, name = ds[i]
+        with torch.no_grad():
+            o = (f1(g(img[None])) + f2(g(img[None]))) / 2
+        p = torch.softmax(o, dim=1)
+        ents.append(float(-(p * torch.log(p + 1e-6)).mean()))
+        top2 = o[0, :40].topk(2, dim=0).values
+        safe = ((top2[0] - top2[1]) > 2e-3).numpy()
+        got = np.array(Image.open(os.path.join(label_dir, name)))
+        ref = o[0, :40].argmax(0).numpy().astype(np.uint8)
+        assert got.shape == ref.shape == (64, 96) and got.max() <= 39
+        assert (got == ref)[safe].all()
+        agree += int((got == ref).sum())
+        safe_total += got.size
+    assert agree / safe_total > 0.995
+    assert abs(ent - sum(ents) / 3) <= 1e-4 * abs(sum(ents) / 3)
