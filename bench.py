@@ -179,7 +179,8 @@ def main():
         dom_name = max(convs, key=lambda k: convs[k]["flops"]) if convs else None
         roofline = None
         traffic = None
-        if dom_name:
+        default_cfg = (args.net, args.batch, args.height, args.width, args.input_ch) == ("drn_d_38", 16, 480, 640, 6)
+        if dom_name and default_cfg:  # the PMC passes were taken on exactly this workload
             # HBM-side bytes per launch from the committed PMC passes (profiles/<round>_pmc_traffic.json: FETCH_SIZE and
             # WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same bench, FETCH_SIZE doubled per the gfx950 note)
             import glob

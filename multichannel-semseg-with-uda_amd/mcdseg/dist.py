@@ -35,8 +35,10 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
+        backend = os.environ.get("MCDSEG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if os.environ.get("MCDSEG_SINGLE_DEVICE") == "1":
+        local = 0  # test rigs with fewer GPUs than ranks (gloo only: RCCL refuses two ranks on one device)
+    if torch.cuda.is_available():
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend)
