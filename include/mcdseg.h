@@ -60,6 +60,19 @@ int mcdseg_conv_fprop_affine(const mcdseg_conv_desc* d, const float* x, const fl
                              const float* shift, const float* residual, int32_t relu, float* y, void* stream);
 /* dx = conv_transpose(dy, w)   (autograd of the same call sites) */
 int mcdseg_conv_dgrad(const mcdseg_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* stream);
+/* ---- "bf16x6" variants: same operators, fp32 operands split 3-way into bf16 and multiplied on the bf16 matrix
+ * pipe with the six largest cross terms (dropped terms < 2^-24 of a product: fp32-grade results at 2.67x the f32
+ * MFMA rate).  Weight images are bf16, layout [k-step][piece 3][k-half 2][Mp][8]; sizes from *_packed_bytes. */
+int mcdseg_conv_x6_packed_bytes(const mcdseg_conv_desc* d, int64_t* fprop_bytes, int64_t* dgrad_bytes);
+int mcdseg_conv_x6_pack_weights(const mcdseg_conv_desc* d, const float* w, void* wp_fprop, void* wp_dgrad, void* stream);
+int mcdseg_conv_x6_fprop(const mcdseg_conv_desc* d, const float* x, const void* wp_fprop, const float* bias, float* y,
+                         float* stat_partials, void* stream);
+int mcdseg_conv_x6_fprop_affine(const mcdseg_conv_desc* d, const float* x, const void* wp_fprop, const float* scale,
+                                const float* shift, const float* residual, int32_t relu, float* y, void* stream);
+int mcdseg_conv_x6_dgrad(const mcdseg_conv_desc* d, const float* dy, const void* wp_dgrad, float* dx, void* stream);
+/* same workspace as mcdseg_conv_wgrad; 128x128-tile layers run on the split path, thin layers on the f32 kernels */
+int mcdseg_conv_x6_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw,
+                         void* workspace, size_t workspace_bytes, void* stream);
 /* dw = x (*) dy ; split over pixels into slabs in `workspace`, then reduced in a fixed order. */
 size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d);
 int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw,

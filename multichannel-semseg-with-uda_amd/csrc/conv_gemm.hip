@@ -410,6 +410,7 @@ int g_ablate = 0;
 
 // Timing-only ablation switch for kernel development (results are WRONG when non-zero).
 extern "C" void mcdseg_debug_ablate(int bits) { g_ablate = bits; }
+int mcdseg_internal_ablate_bits() { return g_ablate; }
 
 extern "C" int mcdseg_conv_packed_dims(const mcdseg_conv_desc* d, int32_t* Mp_f, int32_t* Kp_f, int32_t* Mp_d, int32_t* Kp_d) {
   MCD_REQUIRE(d != nullptr, "conv_packed_dims: null descriptor");

@@ -1,0 +1,498 @@
+// Implicit-GEMM convolution (forward and data-gradient) with fp32 operands carried through the bf16 matrix pipe
+// as a 3-way split ("bf16x6").
+//
+// Every fp32 value is split exactly into three bf16 pieces, a = a1 + a2 + a3 (8 + 8 + 8 significant bits), and a
+// product a*b is formed from the six largest cross terms a1b1, a1b2, a2b1, a2b2, a1b3, a3b1 -- each an exact
+// bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped terms are below 2^-24 of the
+// product, i.e. below fp32 rounding: measured against fp64 the result is as accurate as the f32-input MFMA chain
+// (tests/test_kernels_gpu.py::test_conv_x6_accuracy), but six 32-cycle K=16 MFMAs replace eight 64-cycle K=2
+// MFMAs: 2.67x the matrix rate.
+//
+// Structure is that of conv_gemm.hip (buffer-load gathers, channel-chunk-outer / tap-inner K order, XCD-aware
+// tiles, double-buffered LDS, fused BatchNorm statistics); what differs is the operand path:
+//   * weights are pre-split on the host side of the ABI into the exact LDS image
+//     [k-step][piece 3][k-half 2][Mp][8 bf16], so a K-step's slab is six contiguous runs copied 16 B per lane;
+//   * one thread gathers 8 consecutive channels of one pixel (8 coalesced dword loads, lanes = pixels), splits
+//     them with v_cvt_pk_bf16_f32 and writes three 16-B fragments [piece][k-half][pixel][8] -- exactly what one
+//     lane of the MFMA consumes, so fragment reads are ds_read_b128 over 512 contiguous bytes per half-wave.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvX6Params {
+  const float* src;
+  const void* wp;  // bf16 image
+  const float* bias;
+  float* dst;
+  float* stats;
+  const float* ep_scale;
+  const float* ep_shift;
+  const float* ep_res;
+  int ep_relu;
+  int N;
+  int Cs, Hs, Ws;
+  int M, Hd, Wd;
+  int Mp, Kp;
+  int KH, KW, stride, pad, dil;
+  int P;
+  int src_bytes, wp_bytes;
+  int ablate;  // timing-only ablation bits (mcdseg_debug_ablate)
+};
+
+__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 a = (__bf16)v[e];
+    const float r1 = v[e] - (float)a;  // exact
+    const __bf16 b = (__bf16)r1;
+    const float r2 = r1 - (float)b;    // exact
+    p1[e] = a;
+    p2[e] = b;
+    p3[e] = (__bf16)r2;
+  }
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool DGRAD>
+__global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
+  constexpr int BM = 32 * WM * WAVES_M;
+  constexpr int BN = 32 * WN * WAVES_N;
+  constexpr int NT = 256;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int B_ITEMS = BN * 2 / NT;             // (pixel, k-half) items per thread: 1 (BN=128) or 2 (BN=256)
+  constexpr int A_CHUNKS = 6 * BM;                 // 16-byte chunks of the weight slab per K-step
+  constexpr int A_ITERS = (A_CHUNKS + NT - 1) / NT;
+  constexpr bool A_EXACT = (A_CHUNKS % NT) == 0;
+  constexpr int A_BYTES = 6 * BM * 16, B_BYTES = 6 * BN * 16;
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+  unsigned char* As = smem;                  // [2][piece][half][BM][16 B]
+  unsigned char* Bs = smem + 2 * A_BYTES;    // [2][piece][half][BN][16 B]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int m_tiles = p.Mp / BM;
+  const int n_tiles = (p.P + BN - 1) / BN;
+  const int per_xcd = (n_tiles + 7) >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int tile_m = slot % m_tiles;
+  const int tile_n = xcd * per_xcd + slot / m_tiles;
+  if (tile_n >= n_tiles) return;
+
+  // ---- this thread's gather pixel (same pixel for both of its k-halves when BN = 256)
+  const int bj = t % BN;
+  const int bh0 = __builtin_amdgcn_readfirstlane(t / BN);  // k-half of item 0 (wave-uniform)
+  const int HWd = p.Hd * p.Wd;
+  const int HWs = p.Hs * p.Ws;
+  const int pix = tile_n * BN + bj;
+  const bool pv = pix < p.P;
+  int pn = 0, py = 0, px = 0;
+  if (pv) {
+    pn = pix / HWd;
+    const int rem = pix - pn * HWd;
+    py = rem / p.Wd;
+    px = rem - py * p.Wd;
+  }
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wp_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.wp_bytes, 0x00020000);
+  const unsigned pix_base = (unsigned)pn * (unsigned)p.Cs * (unsigned)HWs;
+  const bool ragged = p.Kp != p.Cs;
+  const int taps = p.KH * p.KW;
+
+  int l_tap = 0, l_c0 = 0, l_ky = 0, l_kx = 0, l_kstep = 0;
+  unsigned l_voff = OOB;
+  auto tap_geom = [&]() {
+    bool ok;
+    int off;
+    if (!DGRAD) {
+      const int sy = py * p.stride + l_ky * p.dil - p.pad;
+      const int sx = px * p.stride + l_kx * p.dil - p.pad;
+      ok = pv && sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws;
+      off = sy * p.Ws + sx;
+    } else {
+      const int ty = py + p.pad - l_ky * p.dil;
+      const int tx = px + p.pad - l_kx * p.dil;
+      ok = pv && ty >= 0 && tx >= 0;
+      int sy = ty, sx = tx;
+      if (p.stride != 1) {
+        sy = ty / p.stride;
+        sx = tx / p.stride;
+        ok = ok && (sy * p.stride == ty) && (sx * p.stride == tx);
+      }
+      ok = ok && sy < p.Hs && sx < p.Ws;
+      off = sy * p.Ws + sx;
+    }
+    l_voff = ok ? (pix_base + (unsigned)off) * 4u : OOB;
+  };
+  tap_geom();
+  auto advance = [&]() {
+    ++l_kstep;
+    ++l_tap;
+    ++l_kx;
+    if (l_kx == p.KW) {
+      l_kx = 0;
+      ++l_ky;
+    }
+    if (l_tap == taps) {
+      l_tap = 0;
+      l_kx = 0;
+      l_ky = 0;
+      l_c0 += 16;
+    }
+    tap_geom();
+  };
+
+  unsigned a_voff[A_ITERS];
+#pragma unroll
+  for (int i = 0; i < A_ITERS; ++i) {
+    const int id = t + i * NT;
+    const int plane = id / BM;
+    const int m = id - plane * BM;
+    a_voff[i] = (A_EXACT || id < A_CHUNKS) ? ((unsigned)plane * (unsigned)p.Mp + (unsigned)m) * 16u : OOB;
+  }
+
+  float breg[B_ITEMS][8];
+  f32x4 areg[A_ITERS];
+  auto load_regs = [&]() {
+#pragma unroll
+    for (int it = 0; it < B_ITEMS; ++it) {
+      const int h = (B_ITEMS == 1) ? bh0 : it;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = l_c0 + 8 * h + e;
+        const int soff = (!ragged || c < p.Cs) ? c * HWs * 4 : 0x7FFFFFFF;
+        breg[it][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src_rs, l_voff, soff, 0));
+      }
+    }
+    const int a_soff = (l_kstep * 6 * p.Mp + tile_m * BM) * 16;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const auto q = __builtin_amdgcn_raw_buffer_load_b128(wp_rs, a_voff[i], a_soff, 0);
+      areg[i][0] = __uint_as_float(q[0]);
+      areg[i][1] = __uint_as_float(q[1]);
+      areg[i][2] = __uint_as_float(q[2]);
+      areg[i][3] = __uint_as_float(q[3]);
+    }
+  };
+  auto store_lds = [&](int buf) {
+    unsigned char* bdst = Bs + buf * B_BYTES;
+#pragma unroll
+    for (int it = 0; it < B_ITEMS; ++it) {
+      const int h = (B_ITEMS == 1) ? bh0 : it;
+      bf16x8 p1, p2, p3;
+      split3(breg[it], p1, p2, p3);
+      *reinterpret_cast<bf16x8*>(bdst + ((0 * 2 + h) * BN + bj) * 16) = p1;
+      *reinterpret_cast<bf16x8*>(bdst + ((1 * 2 + h) * BN + bj) * 16) = p2;
+      *reinterpret_cast<bf16x8*>(bdst + ((2 * 2 + h) * BN + bj) * 16) = p3;
+    }
+    unsigned char* adst = As + buf * A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int id = t + i * NT;
+      if (A_EXACT || id < A_CHUNKS) *reinterpret_cast<f32x4*>(adst + id * 16) = areg[i];
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nsteps = taps * (p.Kp / 16);
+  load_regs();
+  store_lds(0);
+  __syncthreads();
+
+  for (int s = 0; s < nsteps; ++s) {
+    const int cur = s & 1;
+    const bool more = (s + 1) < nsteps;
+    if (more) {
+      advance();
+      if (!(p.ablate & 1)) load_regs();
+    }
+    const unsigned char* a_base = As + cur * A_BYTES + (lh * BM + wm * (32 * WM) + l31) * 16;
+    const unsigned char* b_base = Bs + cur * B_BYTES + (lh * BN + wn * (32 * WN) + l31) * 16;
+    bf16x8 a[3][WM], b[3][WN];
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[pc][i] = *reinterpret_cast<const bf16x8*>(a_base + (pc * 2 * BM + i * 32) * 16);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[pc][j] = *reinterpret_cast<const bf16x8*>(b_base + (pc * 2 * BN + j * 32) * 16);
+    }
+    // six cross terms, smallest first
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        if (p.ablate & 8) {  // experiment: all nine cross terms
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[2][j], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+      }
+    if (more && !(p.ablate & 2)) store_lds(cur ^ 1);
+    if (!(p.ablate & 4)) __syncthreads();
+  }
+
+  // ---- epilogue (identical to conv_gemm.hip): acc[i][j][r] = D[row][col], row = (r&3) + 8*(r>>2) + 4*lh, col = l31
+  const int m_wave = tile_m * BM + wm * (32 * WM);
+  const int p_wave = tile_n * BN + wn * (32 * WN);
+  if (!DGRAD && p.bias != nullptr) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float bv = (m < p.M) ? p.bias[m] : 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j][r] += bv;
+      }
+  }
+  if (!DGRAD && p.ep_scale != nullptr) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float sc = (m < p.M) ? p.ep_scale[m] : 0.f;
+        const float sh = (m < p.M) ? p.ep_shift[m] : 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j][r] = fmaf(acc[i][j][r], sc, sh);
+      }
+  }
+  bool colv[WN];
+  size_t dbase[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int pp = p_wave + j * 32 + l31;
+    colv[j] = pp < p.P;
+    int n = 0, rem = 0;
+    if (colv[j]) {
+      n = pp / HWd;
+      rem = pp - n * HWd;
+    }
+    dbase[j] = (size_t)n * p.M * HWd + rem;
+  }
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < p.M) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          if (colv[j]) {
+            float v = acc[i][j][r];
+            if (!DGRAD && p.ep_scale != nullptr) {
+              if (p.ep_res != nullptr) v += p.ep_res[dbase[j] + (size_t)m * HWd];
+              if (p.ep_relu) v = fmaxf(v, 0.f);
+            }
+            p.dst[dbase[j] + (size_t)m * HWd] = v;
+          }
+      }
+    }
+  if (!DGRAD && p.stats != nullptr) {
+    int cntw = p.P - p_wave;
+    cntw = cntw < 0 ? 0 : (cntw > 32 * WN ? 32 * WN : cntw);
+    const float inv = cntw > 0 ? 1.f / (float)cntw : 0.f;
+    const size_t srow = ((size_t)(tile_n * WAVES_N + wn) * 3) * p.Mp;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      float my_mean = 0.f, my_m2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) v += colv[j] ? acc[i][j][r] : 0.f;
+        const float mean = wave_half_sum(v) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const float d = acc[i][j][r] - mean;
+          q += colv[j] ? d * d : 0.f;
+        }
+        q = wave_half_sum(q);
+        if (l31 == r) {
+          my_mean = mean;
+          my_m2 = q;
+        }
+      }
+      if (l31 < 16) {
+        const int m = m_wave + i * 32 + (l31 & 3) + 8 * (l31 >> 2) + 4 * lh;
+        p.stats[srow + m] = (float)cntw;
+        p.stats[srow + p.Mp + m] = my_mean;
+        p.stats[srow + 2 * (size_t)p.Mp + m] = my_m2;
+      }
+    }
+  }
+}
+
+// ---- weight packing: w[Cout][Cin][T] (fp32) -> [chunk*T + tap][piece][half][Mp][8] bf16, chunk = 16 K-channels
+// MODE 0: m = cout, k = cin (forward); MODE 1: m = cin, k = cout (dgrad)
+__global__ void pack_weights_x6_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int Cout, int Cin, int T, int Mp,
+                                       int Kp, int mode) {
+  const int64_t total = (int64_t)(Kp / 16) * T * 2 * Mp * 8;  // one thread per (kstep, half, m, e): writes all 3 pieces
+  const int M = mode == 0 ? Cout : Cin;
+  const int K = mode == 0 ? Cin : Cout;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7);
+    int64_t r = i >> 3;
+    const int m = (int)(r % Mp);
+    r /= Mp;
+    const int h = (int)(r & 1);
+    const int64_t kstep = r >> 1;
+    const int tap = (int)(kstep % T);
+    const int chunk = (int)(kstep / T);
+    const int k = chunk * 16 + 8 * h + e;
+    float v = 0.f;
+    if (m < M && k < K) v = mode == 0 ? w[((int64_t)m * Cin + k) * T + tap] : w[((int64_t)k * Cin + m) * T + tap];
+    const __bf16 a = (__bf16)v;
+    const float r1 = v - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const float r2 = r1 - (float)b;
+    const int64_t base = kstep * 6 * (int64_t)Mp * 8;
+    out[base + ((0 * 2 + h) * (int64_t)Mp + m) * 8 + e] = a;
+    out[base + ((1 * 2 + h) * (int64_t)Mp + m) * 8 + e] = b;
+    out[base + ((2 * 2 + h) * (int64_t)Mp + m) * 8 + e] = (__bf16)r2;
+  }
+}
+
+int x6_check(const mcdseg_conv_desc* d, const char* who) {
+  MCD_REQUIRE(d != nullptr, "%s: null descriptor", who);
+  MCD_REQUIRE(d->N > 0 && d->Cin > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "%s: non-positive dims", who);
+  MCD_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0, "%s: bad kernel geometry", who);
+  const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+  const int wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+  MCD_REQUIRE(ho == d->Ho && wo == d->Wo, "%s: Ho/Wo (%d,%d) do not match geometry (%d,%d)", who, d->Ho, d->Wo, ho, wo);
+  MCD_REQUIRE((int64_t)d->N * d->Cin * d->H * d->W * 4 < (1ll << 31) && (int64_t)d->N * d->Cout * d->Ho * d->Wo * 4 < (1ll << 31),
+              "%s: activation tensor must stay below 2 GiB (32-bit buffer offsets); split the batch", who);
+  return 0;
+}
+
+int64_t x6_image_bytes(int M, int K, int T) { return (int64_t)(round_up(K, 16) / 16) * T * 6 * mcd_mp(M) * 16; }
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool DGRAD>
+void launch_cfg(const ConvX6Params& p, hipStream_t st) {
+  constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
+  const int n_tiles = ceil_div(p.P, BN);
+  dim3 grid(8 * ceil_div(n_tiles, 8) * (p.Mp / BM));
+  hipLaunchKernelGGL((conv_gemm_x6_kernel<WM, WN, WAVES_M, WAVES_N, DGRAD>), grid, dim3(256), 0, st, p);
+}
+
+template <bool DGRAD>
+void launch(const ConvX6Params& p, hipStream_t st) {
+  const int bm = mcd_bm(p.M);
+  if (bm == 128)
+    launch_cfg<2, 2, 2, 2, DGRAD>(p, st);
+  else if (bm == 64)
+    launch_cfg<2, 2, 1, 4, DGRAD>(p, st);
+  else
+    launch_cfg<1, 2, 1, 4, DGRAD>(p, st);
+}
+
+}  // namespace
+
+int mcdseg_internal_ablate_bits();
+
+extern "C" int mcdseg_conv_x6_packed_bytes(const mcdseg_conv_desc* d, int64_t* fprop_bytes, int64_t* dgrad_bytes) {
+  MCD_REQUIRE(d != nullptr, "conv_x6_packed_bytes: null descriptor");
+  const int T = d->KH * d->KW;
+  if (fprop_bytes) *fprop_bytes = x6_image_bytes(d->Cout, d->Cin, T);
+  if (dgrad_bytes) *dgrad_bytes = x6_image_bytes(d->Cin, d->Cout, T);
+  return 0;
+}
+
+extern "C" int mcdseg_conv_x6_pack_weights(const mcdseg_conv_desc* d, const float* w, void* wp_fprop, void* wp_dgrad, void* stream) {
+  if (int rc = x6_check(d, "conv_x6_pack_weights")) return rc;
+  MCD_REQUIRE(w != nullptr && (wp_fprop != nullptr || wp_dgrad != nullptr), "conv_x6_pack_weights: null pointer");
+  const int T = d->KH * d->KW;
+  hipStream_t st = (hipStream_t)stream;
+  for (int mode = 0; mode < 2; ++mode) {
+    void* out = mode == 0 ? wp_fprop : wp_dgrad;
+    if (!out) continue;
+    const int M = mode == 0 ? d->Cout : d->Cin, K = mode == 0 ? d->Cin : d->Cout;
+    const int Mp = mcd_mp(M), Kp = round_up(K, 16);
+    const int64_t total = (int64_t)(Kp / 16) * T * 2 * Mp * 8;
+    int64_t blocks = ceil_div64(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weights_x6_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, (__bf16*)out, d->Cout, d->Cin, T, Mp, Kp, mode);
+    MCD_LAUNCH_CHECK("conv_x6_pack_weights");
+  }
+  return 0;
+}
+
+static int x6_fprop_impl(const mcdseg_conv_desc* d, const float* x, const void* wp, const float* bias, float* y, float* stats,
+                         const float* ep_scale, const float* ep_shift, const float* ep_res, int ep_relu, void* stream) {
+  if (int rc = x6_check(d, "conv_x6_fprop")) return rc;
+  MCD_REQUIRE(x && wp && y, "conv_x6_fprop: null pointer");
+  ConvX6Params p;
+  p.src = x; p.wp = wp; p.bias = bias; p.dst = y; p.stats = stats;
+  p.ep_scale = ep_scale; p.ep_shift = ep_shift; p.ep_res = ep_res; p.ep_relu = ep_relu;
+  p.N = d->N;
+  p.Cs = d->Cin; p.Hs = d->H; p.Ws = d->W;
+  p.M = d->Cout; p.Hd = d->Ho; p.Wd = d->Wo;
+  p.Mp = mcd_mp(d->Cout);
+  p.Kp = round_up(d->Cin, 16);
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+  p.P = d->N * d->Ho * d->Wo;
+  p.src_bytes = (int)((int64_t)d->N * d->Cin * d->H * d->W * 4);
+  const int64_t wb = x6_image_bytes(d->Cout, d->Cin, d->KH * d->KW);
+  MCD_REQUIRE(wb < (1ll << 31), "conv_x6_fprop: packed weights exceed 2 GiB");
+  p.wp_bytes = (int)wb;
+  p.ablate = mcdseg_internal_ablate_bits();
+  launch<false>(p, (hipStream_t)stream);
+  MCD_LAUNCH_CHECK("conv_x6_fprop");
+  return 0;
+}
+
+extern "C" int mcdseg_conv_x6_fprop(const mcdseg_conv_desc* d, const float* x, const void* wp_fprop, const float* bias, float* y,
+                                    float* stat_partials, void* stream) {
+  return x6_fprop_impl(d, x, wp_fprop, bias, y, stat_partials, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int mcdseg_conv_x6_fprop_affine(const mcdseg_conv_desc* d, const float* x, const void* wp_fprop, const float* scale,
+                                           const float* shift, const float* residual, int32_t relu, float* y, void* stream) {
+  MCD_REQUIRE(scale && shift, "conv_x6_fprop_affine: null scale/shift");
+  return x6_fprop_impl(d, x, wp_fprop, nullptr, y, nullptr, scale, shift, residual, relu, stream);
+}
+
+extern "C" int mcdseg_conv_x6_dgrad(const mcdseg_conv_desc* d, const float* dy, const void* wp_dgrad, float* dx, void* stream) {
+  if (int rc = x6_check(d, "conv_x6_dgrad")) return rc;
+  MCD_REQUIRE(dy && wp_dgrad && dx, "conv_x6_dgrad: null pointer");
+  ConvX6Params p;
+  p.src = dy; p.wp = wp_dgrad; p.bias = nullptr; p.dst = dx; p.stats = nullptr;
+  p.ep_scale = nullptr; p.ep_shift = nullptr; p.ep_res = nullptr; p.ep_relu = 0;
+  p.N = d->N;
+  p.Cs = d->Cout; p.Hs = d->Ho; p.Ws = d->Wo;
+  p.M = d->Cin; p.Hd = d->H; p.Wd = d->W;
+  p.Mp = mcd_mp(d->Cin);
+  p.Kp = round_up(d->Cout, 16);
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+  p.P = d->N * d->H * d->W;
+  p.src_bytes = (int)((int64_t)d->N * d->Cout * d->Ho * d->Wo * 4);
+  const int64_t wb = x6_image_bytes(d->Cin, d->Cout, d->KH * d->KW);
+  MCD_REQUIRE(wb < (1ll << 31), "conv_x6_dgrad: packed weights exceed 2 GiB");
+  p.wp_bytes = (int)wb;
+  p.ablate = mcdseg_internal_ablate_bits();
+  launch<true>(p, (hipStream_t)stream);
+  MCD_LAUNCH_CHECK("conv_x6_dgrad");
+  return 0;
+}

@@ -34,6 +34,12 @@ _SIGNATURES = {
     "mcdseg_bn_eval_affine": (c_int, [c_void_p] * 5 + [c_i32, c_float, c_void_p, c_void_p, c_void_p]),
     "mcdseg_predict_workspace_bytes": (c_size_t, [c_i32, c_i32]),
     "mcdseg_predict_labels": (c_int, [c_void_p] * 4 + [c_i32] * 4 + [c_void_p, c_size_t, c_void_p]),
+    "mcdseg_conv_x6_packed_bytes": (c_int, [_P(ConvDesc), _P(c_i64), _P(c_i64)]),
+    "mcdseg_conv_x6_pack_weights": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mcdseg_conv_x6_fprop": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mcdseg_conv_x6_fprop_affine": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p]),
+    "mcdseg_conv_x6_dgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mcdseg_conv_x6_wgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mcdseg_conv_dgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcdseg_conv_wgrad_workspace_bytes": (c_size_t, [_P(ConvDesc)]),
     "mcdseg_conv_wgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -57,10 +57,12 @@ def conv_work(desc):
     return 2 * macs, byts
 
 
-def gemm_kernel_name(m, k, dgrad):
+def gemm_kernel_name(m, k, dgrad, x6=False):
     """Template instantiation conv_fprop / conv_dgrad dispatch to (same rule as csrc/common.h mcd_bm / mcd_bk)."""
     bm = 32 if m <= 32 else (64 if m <= 64 else 128)
     cfg = {128: "2, 2, 2, 2", 64: "2, 2, 1, 4", 32: "1, 2, 1, 4"}[bm]
+    if x6:
+        return "conv_gemm_x6_kernel<%s, %s>" % (cfg, "true" if dgrad else "false")
     return "conv_gemm_kernel<%s, %d, %s>" % (cfg, 8 if k <= 8 else 16, "true" if dgrad else "false")
 
 
@@ -104,6 +106,25 @@ def conv_desc(x_shape, w_shape, stride, pad, dil):
     return ConvDesc(n, cin, h, w, cout, kh, kw, stride, pad, dil, ho, wo)
 
 
+# Matrix-pipe arithmetic of the convolutions (MCDSEG_CONV_MATH):
+#   "bf16x6" (default)  fp32 operands split exactly into three bf16 pieces, the six largest cross terms on
+#                       v_mfma_f32_32x32x16_bf16 -- fp32-grade (measured <= 2x the rounding noise of an fp32 FMA chain,
+#                       tests/test_kernels_gpu.py::test_conv_x6_accuracy) at 2.67x the f32 matrix rate;
+#   "f32"               v_mfma_f32_32x32x2_f32, the exact k-ordered fp32 FMA chain;
+#   "mixed"             bf16x6 for forward / data-gradient, f32 for the weight gradients.
+CONV_MATH = os.environ.get("MCDSEG_CONV_MATH", "bf16x6")
+if CONV_MATH not in ("bf16x6", "f32", "mixed", "bf16x6-fprop", "bf16x6-dgrad"):
+    raise ValueError("MCDSEG_CONV_MATH must be bf16x6, f32 or mixed, got %r" % CONV_MATH)
+
+
+def _use_x6(contraction_channels, direction="fprop"):
+    if contraction_channels < 16:
+        return False
+    if CONV_MATH in ("bf16x6", "mixed"):
+        return True
+    return CONV_MATH == "bf16x6-" + direction  # "bf16x6-fprop" / "bf16x6-dgrad": one direction only (experiments)
+
+
 class PackedWeights:
     """GEMM images of one conv kernel, refreshed when the parameter changes."""
 
@@ -113,16 +134,29 @@ class PackedWeights:
         self.wd = None
 
     def get(self, weight, desc, need_dgrad=True):
-        key = (weight.data_ptr(), weight._version, WEIGHT_EPOCH, weight.device)
+        key = (weight.data_ptr(), weight._version, WEIGHT_EPOCH, weight.device, CONV_MATH)
         if key != self.key or (need_dgrad and self.wd is None):
             L = lib()
             mpf, kpf, mpd, kpd = (ctypes.c_int32() for _ in range(4))
             check(L.mcdseg_conv_packed_dims(ctypes.byref(desc), mpf, kpf, mpd, kpd), "conv_packed_dims")
             taps = desc.KH * desc.KW
             w = _req(weight.detach(), "conv weight")
-            self.wf = torch.empty(taps * kpf.value * mpf.value, dtype=torch.float32, device=w.device)
-            self.wd = torch.empty(taps * kpd.value * mpd.value, dtype=torch.float32, device=w.device)
-            check(L.mcdseg_conv_pack_weights(ctypes.byref(desc), _p(w), _p(self.wf), _p(self.wd), _stream()), "conv_pack_weights")
+            dev = w.device
+            fx6, dx6 = _use_x6(desc.Cin, "fprop"), _use_x6(desc.Cout, "dgrad")
+            # f32 images (kept for whichever direction does not run on the split path)
+            self.wf = None if fx6 else torch.empty(taps * kpf.value * mpf.value, dtype=torch.float32, device=dev)
+            self.wd = None if dx6 else torch.empty(taps * kpd.value * mpd.value, dtype=torch.float32, device=dev)
+            if self.wf is not None or self.wd is not None:
+                check(L.mcdseg_conv_pack_weights(ctypes.byref(desc), _p(w), _p(self.wf), _p(self.wd), _stream()), "conv_pack_weights")
+            if fx6 or dx6:
+                fb, db = ctypes.c_int64(), ctypes.c_int64()
+                check(L.mcdseg_conv_x6_packed_bytes(ctypes.byref(desc), fb, db), "conv_x6_packed_bytes")
+                if fx6:
+                    self.wf = torch.empty(fb.value // 2, dtype=torch.bfloat16, device=dev)
+                if dx6:
+                    self.wd = torch.empty(db.value // 2, dtype=torch.bfloat16, device=dev)
+                check(L.mcdseg_conv_x6_pack_weights(ctypes.byref(desc), _p(w), _p(self.wf) if fx6 else None,
+                                                    _p(self.wd) if dx6 else None, _stream()), "conv_x6_pack_weights")
             self.mpf = mpf.value
             self.key = key
         return self.wf, self.wd, self.mpf
@@ -160,8 +194,9 @@ def _conv_fprop(desc, x, wf, bias, want_stats, mpf):
         part = torch.empty(rows * 3 * mpf, dtype=torch.float32, device=x.device)
     for i, ((a, b), d) in enumerate(zip(pieces, descs)):
         pp = None if part is None else ctypes.c_void_p(part.data_ptr() + 4 * row_off[i] * 3 * mpf)
-        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False), conv_work(d)):
-            check(L.mcdseg_conv_fprop(ctypes.byref(d), _p(x[a:b]), _p(wf), _p(bias), _p(y[a:b]), pp, _stream()), "conv_fprop")
+        fn = L.mcdseg_conv_x6_fprop if wf.dtype == torch.bfloat16 else L.mcdseg_conv_fprop
+        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, wf.dtype == torch.bfloat16), conv_work(d)):
+            check(fn(ctypes.byref(d), _p(x[a:b]), _p(wf), _p(bias), _p(y[a:b]), pp, _stream()), "conv_fprop")
     return y, part, rows
 
 
@@ -169,8 +204,9 @@ def _conv_dgrad(desc, dy, wd):
     dx = torch.empty((desc.N, desc.Cin, desc.H, desc.W), dtype=torch.float32, device=dy.device)
     for a, b in _batch_pieces(desc):
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
-        with _timed(gemm_kernel_name(desc.Cin, desc.Cout, True), conv_work(d)):
-            check(lib().mcdseg_conv_dgrad(ctypes.byref(d), _p(dy[a:b]), _p(wd), _p(dx[a:b]), _stream()), "conv_dgrad")
+        fn = lib().mcdseg_conv_x6_dgrad if wd.dtype == torch.bfloat16 else lib().mcdseg_conv_dgrad
+        with _timed(gemm_kernel_name(desc.Cin, desc.Cout, True, wd.dtype == torch.bfloat16), conv_work(d)):
+            check(fn(ctypes.byref(d), _p(dy[a:b]), _p(wd), _p(dx[a:b]), _stream()), "conv_dgrad")
     return dx
 
 
@@ -181,8 +217,10 @@ def _conv_wgrad(desc, x, dy):
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
         ws = _ws(L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(d)), x.device)
         dw = torch.empty((desc.Cout, desc.Cin, desc.KH, desc.KW), dtype=torch.float32, device=x.device)
-        with _timed(wgrad_kernel_name(desc.Cout, desc.Cin, desc.KH * desc.KW), conv_work(d)):
-            check(L.mcdseg_conv_wgrad(ctypes.byref(d), _p(x[a:b]), _p(dy[a:b]), _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4),
+        x6 = CONV_MATH == "bf16x6" and min(desc.Cout, desc.Cin) > 64 and not (desc.Cin <= 16 and desc.KH * desc.KW > 1)
+        fn = L.mcdseg_conv_x6_wgrad if x6 else L.mcdseg_conv_wgrad
+        with _timed("conv_wgrad_x6_kernel" if x6 else wgrad_kernel_name(desc.Cout, desc.Cin, desc.KH * desc.KW), conv_work(d)):
+            check(fn(ctypes.byref(d), _p(x[a:b]), _p(dy[a:b]), _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4),
                                       _stream()), "conv_wgrad")
         total = dw if total is None else total.add_(dw)
     return total
@@ -302,8 +340,9 @@ def _conv_bn_act_inference(x, conv, bn, relu, residual):
     y = torch.empty((desc.N, c, desc.Ho, desc.Wo), dtype=torch.float32, device=x.device)
     for a, b in _batch_pieces(desc):
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
-        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False), conv_work(d)):
-            check(L.mcdseg_conv_fprop_affine(ctypes.byref(d), _p(x[a:b]), _p(wf), _p(scale), _p(shift),
+        fn = L.mcdseg_conv_x6_fprop_affine if wf.dtype == torch.bfloat16 else L.mcdseg_conv_fprop_affine
+        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, wf.dtype == torch.bfloat16), conv_work(d)):
+            check(fn(ctypes.byref(d), _p(x[a:b]), _p(wf), _p(scale), _p(shift),
                                              _p(residual[a:b]) if residual is not None else None, int(relu), _p(y[a:b]), _stream()),
                   "conv_fprop_affine")
     return y

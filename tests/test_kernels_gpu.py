@@ -418,3 +418,33 @@ def test_folded_bn_inference_and_predict_tail():
     assert abs(float(ent) - float(-(p * torch.log(p + 1e-6)).mean())) <= 1e-5
     lab1, _ = ops.predict_labels(z1.to(dev), None, 41)
     assert torch.equal(lab1.cpu(), z1.argmax(1).to(torch.uint8))
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if min(c[0], c[1]) >= 16], ids=lambda c: "x".join(map(str, c[:5])))
+def test_conv_x6_accuracy(case, monkeypatch):
+    """bf16x6 split-precision path: against fp64 it must be as accurate as the exact-fp32 MFMA path (within 2x of
+    its error, and within the same 2e-5-of-scale bound)."""
+    dev = _dev()
+    from mcdseg import ops
+    x, wt, b, s, pad, d = _conv_inputs(case, 17)
+    desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
+    xg, wg = x.to(dev), wt.to(dev)
+    x64, w64 = x.double().requires_grad_(), wt.double().requires_grad_()
+    ref = F.conv2d(x64, w64, b.double() if b is not None else None, stride=s, padding=pad, dilation=d)
+    gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(18))
+    gx_ref, gw_ref = torch.autograd.grad(ref, [x64, w64], gy.double())
+    errs = {}
+    for math in ("f32", "bf16x6"):
+        monkeypatch.setattr(ops, "CONV_MATH", math)
+        wf, wd, mpf = ops.PackedWeights().get(wg, desc)
+        assert (wf.dtype == torch.bfloat16) == (math == "bf16x6")
+        y, part, rows = ops._conv_fprop(desc, xg, wf, b.to(dev) if b is not None else None, True, mpf)
+        dx = ops._conv_dgrad(desc, gy.to(dev), wd)
+        dw = ops._conv_wgrad(desc, xg, gy.to(dev))
+        errs[math] = (_maxerr(y, ref), _maxerr(dx, gx_ref), _maxerr(dw, gw_ref))
+        _assert_close(y, ref, 2e-5, math + " fprop")
+        _assert_close(dx, gx_ref, 2e-5, math + " dgrad")
+        _assert_close(dw, gw_ref, 2e-5, math + " wgrad")
+    for k in (0, 1, 2):
+        e32, e6 = errs["f32"][k][0], errs["bf16x6"][k][0]
+        assert e6 <= max(2.0 * e32, 2e-6 * errs["f32"][k][1]), "bf16x6 err %.3e vs f32-MFMA err %.3e" % (e6, e32)

@@ -62,12 +62,19 @@ def test_forward_small_vs_reference(golden, mode):
         assert int(sd["base.8.1.num_batches_tracked"]) == 1
 
 
+@pytest.mark.parametrize("math,k_noise", [("f32", 4.0), ("bf16x6", 8.0)])
 @pytest.mark.parametrize("which", ["ce", "diff"])
-def test_backward_small_vs_reference(golden, which):
-    """Gradients: |g - g64| <= max(1e-3 * scale-free abs bound, k * the reference's own fp32 noise |g32 - g64|)
-    (train-mode BN backward leaves 1-3 % fp32 noise in the reference itself)."""
+def test_backward_small_vs_reference(golden, which, math, k_noise, monkeypatch):
+    """Gradients against the reference's fp64 gradients: |g - g64| <= max(1e-3 * max(scale, 1e-3), k * |g32_ref - g64|).
+    Train-mode BN backward leaves 1-3 % fp32 noise in the reference's OWN conv-weight gradients,
+    so the yardstick is the reference's fp32-vs-fp64 deviation.  Measured worst ratios: exact f32 MFMA chain 1.7 (CE) /
+    2.2 (discrepancy); bf16x6 split path 1.8 / 4.2 -- its matrix-pipe accumulation carries about twice the rounding
+    noise of an FMA chain (unchanged when all nine cross terms are kept), all of it far below the 1e-3 of north_star
+    (absolute errors here are <= 3e-6).  k = 4 for the f32 path, 8 for the split path."""
     dev = _dev()
     from loss import CrossEntropyLoss2d, Diff2d
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "CONV_MATH", math)
     fx = golden.npz("bwd_small.npz")
     g, f1, f2 = _mcd_models(dev)
     src, lbl, tgt = make_batch(21, 2, 6, 64, 96, NC)
@@ -107,7 +114,8 @@ def test_backward_small_vs_reference(golden, which):
         err = np.abs(got.double().cpu().numpy() - g64).max()
         scale = np.abs(g64).max()
         report.append((name, err, noise, scale))
-        assert err <= max(1e-3 * max(scale, 1e-3), 4 * noise), "%s: err %.3e, reference fp32 noise %.3e, scale %.3e" % (name, err, noise, scale)
+        assert err <= 1e-3, name  # north_star: gradients within 1e-3
+        assert err <= max(1e-3 * max(scale, 1e-3), k_noise * noise), "%s: err %.3e, reference fp32 noise %.3e, scale %.3e" % (name, err, noise, scale)
     assert len(report) >= 12
 
 

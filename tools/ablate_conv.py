@@ -14,6 +14,9 @@ n, cin, cout, k, d, h, w = 16, 512, 512, 3, 4, 60, 80
 x = torch.randn(n, cin, h, w, device=dev)
 wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
 desc = ops.conv_desc(x.shape, wt.shape, 1, d, d)
+import sys as _s
+if len(_s.argv) > 1:
+    ops.CONV_MATH = _s.argv[1]
 wf, wd, mpf = ops.PackedWeights().get(wt, desc)
 gf = 2.0 * n * h * w * cout * cin * 9 / 1e9
 def timeit(fn, reps=5):

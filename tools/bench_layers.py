@@ -50,7 +50,10 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--math", default=None, help="f32 | bf16x6")
     args = ap.parse_args()
+    if args.math:
+        ops.CONV_MATH = args.math
     dev = torch.device("cuda:0")
     n = args.batch
     tot = {"fprop": 0.0, "dgrad": 0.0, "wgrad": 0.0}
