@@ -34,11 +34,16 @@ os.environ.setdefault("MCDSEG_PRETRAINED", "0")
 import torch  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector = fp32-input MFMA (MI355X_MICROARCH.md, chip-level table)
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md, chip-level table; the 5 PF figure is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec
 # algorithmic work per image-pass (one image through G+F1+F2 forward+backward incl. loss), drn_d_38 6x480x640
 # (SURVEY.md section 8d / BASELINE.md section 3): 781.5 GFLOP, 1.94 GB
 GF_FWD_PER_IMG = 260.5
 GB_FWD_PER_IMG, GB_BWD_PER_IMG = 0.71, 1.23
+
+
+DTYPE_LABEL = {"f32": "f32", "bf16x6": "f32 (operands split 3-way into bf16, 6 cross terms on the bf16 MFMA pipe, fp32 accumulate)",
+               "mixed": "f32 (bf16x6 split for forward/dgrad, f32 MFMA for wgrad)"}
 
 
 class LaunchTimer:
@@ -141,7 +146,7 @@ def main():
     solver, models = build_hip(args, dev)
     src, lbl, tgt = (t.to(dev) for t in synthetic_batch(args.batch, args.input_ch, args.height, args.width, args.n_class,
                                                         1234 + rank))
-    timer = LaunchTimer(["conv_gemm_kernel", "softmax_ce_l1_kernel"])
+    timer = LaunchTimer(["conv_gemm_kernel", "conv_gemm_x6_kernel", "softmax_ce_l1_kernel"])
     ops.LAUNCH_TIMER = timer
 
     for _ in range(args.warmup):
@@ -173,7 +178,7 @@ def main():
             k["avg_ms"] = k["ms"] / max(k["launches"], 1)
             k["tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
             k["gbs"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
-        convs = {k: v for k, v in kern.items() if k.startswith("conv_gemm_kernel")}
+        convs = {k: v for k, v in kern.items() if k.startswith("conv_gemm")}
         # dominant kernel = the instantiation carrying the most algorithmic FLOPs of the step (the forward 128x128
         # tile: 7 forward passes vs 5 backward); its launches run alone on the stream, so the event pairs are clean
         dom_name = max(convs, key=lambda k: convs[k]["flops"]) if convs else None
@@ -192,9 +197,16 @@ def main():
                     continue
         if dom_name:
             dom = convs[dom_name]
-            roofline = {"bound": "mfma", "kernel": dom_name + " (implicit-GEMM conv on v_mfma_f32_32x32x2_f32)",
-                        "achieved": round(dom["tflops"], 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(dom["tflops"] / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+            x6 = "x6" in dom_name
+            # bf16x6: every algorithmic fp32 MAC is executed as six bf16 MACs on v_mfma_f32_32x32x16_bf16, so the kernel is
+            # priced in EXECUTED bf16 FLOPs against the dense bf16 MFMA peak; the f32 kernel against the f32 MFMA peak
+            mult, peak = (6.0, PEAK_BF16_TFLOPS) if x6 else (1.0, PEAK_FP32_TFLOPS)
+            roofline = {"bound": "mfma",
+                        "kernel": dom_name + (" (implicit-GEMM conv, fp32 operands as 3-way bf16 split, 6 cross terms on "
+                                              "v_mfma_f32_32x32x16_bf16)" if x6 else " (implicit-GEMM conv on v_mfma_f32_32x32x2_f32)"),
+                        "achieved": round(mult * dom["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(mult * dom["tflops"] / peak, 4), "traffic": traffic,
+                        "alg_tflops_fp32_equivalent": round(dom["tflops"], 2),
                         "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
                         "launches": dom["launches"], "avg_launch_ms": round(dom["avg_ms"], 4),
                         "alg_flops_per_launch": dom["flops"] / dom["launches"]}
@@ -212,11 +224,11 @@ def main():
         line = {
             "metric": "RGB-D img/s (6x480x640) MCD train step, drn_d_38", "value": round(value, 3), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_LABEL.get(ops.CONV_MATH, ops.CONV_MATH), "data": "synthetic",
             "config": {"workload": "adapt_trainer MCD early-fusion %s %d-ch, bs=%d/GPU synthetic %dx%d, full A+B+C step (num_k=4)"
                                    % (args.net, args.input_ch, args.batch, args.height, args.width),
                        "pairs_per_gpu": args.batch, "global_pairs": args.batch * world, "parallelism": "dp%d" % world,
-                       "n_class": args.n_class, "c_loss": c_loss, "d_loss": d_loss},
+                       "n_class": args.n_class, "conv_math": ops.CONV_MATH, "c_loss": c_loss, "d_loss": d_loss},
             "roofline": roofline,
             "step_accounting": step_acc,
             "kernels": {k: {"launches": v["launches"], "ms_total": round(v["ms"], 2), "avg_ms": round(v["avg_ms"], 4),

@@ -400,7 +400,9 @@ void launch_cfg(const ConvX6Params& p, hipStream_t st) {
 template <bool DGRAD>
 void launch(const ConvX6Params& p, hipStream_t st) {
   const int bm = mcd_bm(p.M);
-  if (bm == 128)
+  if (bm == 128 && (p.ablate & 16))
+    launch_cfg<2, 4, 2, 2, DGRAD>(p, st);  // experiment: 128 x 256 tile, 64 x 128 per wave
+  else if (bm == 128)
     launch_cfg<2, 2, 2, 2, DGRAD>(p, st);
   else if (bm == 64)
     launch_cfg<2, 2, 1, 4, DGRAD>(p, st);
