@@ -65,11 +65,16 @@ int mcdseg_conv_dgrad(const mcdseg_conv_desc* d, const float* dy, const float* w
  * MFMA rate).  Weight images are bf16, layout [k-step][piece 3][k-half 2][Mp][8]; sizes from *_packed_bytes. */
 int mcdseg_conv_x6_packed_bytes(const mcdseg_conv_desc* d, int64_t* fprop_bytes, int64_t* dgrad_bytes);
 int mcdseg_conv_x6_pack_weights(const mcdseg_conv_desc* d, const float* w, void* wp_fprop, void* wp_dgrad, void* stream);
-int mcdseg_conv_x6_fprop(const mcdseg_conv_desc* d, const float* x, const void* wp_fprop, const float* bias, float* y,
-                         float* stat_partials, void* stream);
-int mcdseg_conv_x6_fprop_affine(const mcdseg_conv_desc* d, const float* x, const void* wp_fprop, const float* scale,
-                                const float* shift, const float* residual, int32_t relu, float* y, void* stream);
-int mcdseg_conv_x6_dgrad(const mcdseg_conv_desc* d, const float* dy, const void* wp_dgrad, float* dx, void* stream);
+/* x_cb / dy_cb (may be NULL): the gathered operand already split by its producer into the channel-blocked layout
+ * [piece 3][N][C/8][H*W][8 bf16] (mcdseg_bn_apply_cb / mcdseg_bn_bwd_apply_cb); C must be divisible by 8.  With it the
+ * K loop does no conversion and loads 3 x 16 B per pixel and 8-channel group instead of 8 dwords. */
+int mcdseg_conv_x6_fprop(const mcdseg_conv_desc* d, const float* x, const void* x_cb, const void* wp_fprop,
+                         const float* bias, float* y, float* stat_partials, void* stream);
+int mcdseg_conv_x6_fprop_affine(const mcdseg_conv_desc* d, const float* x, const void* x_cb, const void* wp_fprop,
+                                const float* scale, const float* shift, const float* residual, int32_t relu, float* y,
+                                void* stream);
+int mcdseg_conv_x6_dgrad(const mcdseg_conv_desc* d, const float* dy, const void* dy_cb, const void* wp_dgrad, float* dx,
+                         void* stream);
 /* same workspace as mcdseg_conv_wgrad; 128x128-tile layers run on the split path, thin layers on the f32 kernels */
 int mcdseg_conv_x6_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw,
                          void* workspace, size_t workspace_bytes, void* stream);
@@ -99,6 +104,15 @@ int mcdseg_bn_eval_affine(const float* gamma, const float* beta, const float* ru
 /* y = act(gamma*(z-mean)*rstd + beta (+ residual)), act = ReLU if relu != 0 */
 int mcdseg_bn_apply(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                     const float* residual, float* y, int32_t N, int32_t C, int32_t HW, int32_t relu, void* stream);
+/* Same as mcdseg_bn_apply / mcdseg_bn_bwd_apply, additionally emitting the exact 3-way bf16 split of the produced
+ * tensor in the channel-blocked layout [piece 3][N][C/8][HW][8 bf16] (3*N*C*HW*2 bytes) consumed by the bf16x6
+ * convolutions; C must be divisible by 8. */
+int mcdseg_bn_apply_cb(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       const float* residual, float* y, void* y_cb, int32_t N, int32_t C, int32_t HW, int32_t relu,
+                       void* stream);
+int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
+                           const float* gamma, const float* dgamma, const float* dbeta, float* dz, float* dres,
+                           void* dz_cb, int32_t N, int32_t C, int32_t HW, int32_t relu, int32_t train, void* stream);
 /* Backward.  dy is the gradient w.r.t. y; y (the saved forward output) supplies the ReLU mask when
  * relu != 0.  reduce: dgamma[c] = sum dy_m*xhat, dbeta[c] = sum dy_m.  With z == NULL only dbeta is
  * produced (used for the conv bias gradient, models/dilated_fcn.py:227). */

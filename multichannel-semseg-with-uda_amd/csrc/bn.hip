@@ -288,6 +288,91 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// "cb" variants: besides the fp32 tensor, emit its exact 3-way bf16 split in the channel-blocked layout
+//   cb[piece 3][N][C/8][HW][8 bf16]
+// which is what the bf16x6 convolution consumes as its gathered operand (one 16-B fragment per pixel and 8-channel
+// group, consecutive pixels contiguous).  Splitting here -- once, in an HBM-bound kernel whose VALU is idle -- instead
+// of inside the convolution's K loop (where every activation is re-split for each of the 9 taps and 4 M-tiles and the
+// conversion competes with MFMA issue slots) is worth ~1.3x on the convolution.  One thread = one pixel x 8 channels:
+// loads and fp32 stores are pixel-contiguous per channel, the three 16-B split stores are contiguous across lanes.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3_store(const float (&v)[8], __bf16* __restrict__ cb, size_t piece_stride, size_t idx16) {
+  bf16x8_t p1, p2, p3;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 a = (__bf16)v[e];
+    const float r1 = v[e] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    p1[e] = a;
+    p2[e] = b;
+    p3[e] = (__bf16)(r1 - (float)b);
+  }
+  *reinterpret_cast<bf16x8_t*>(cb + idx16 * 8) = p1;
+  *reinterpret_cast<bf16x8_t*>(cb + piece_stride + idx16 * 8) = p2;
+  *reinterpret_cast<bf16x8_t*>(cb + 2 * piece_stride + idx16 * 8) = p3;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_cb_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ res,
+                                                          float* __restrict__ y, __bf16* __restrict__ cb, int N, int C, int HW,
+                                                          int relu) {
+  const int C8 = C >> 3;
+  const int ng = blockIdx.y;  // n * C8 + g
+  const int g = ng % C8;
+  const int n = ng / C8;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= HW) return;
+  const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = 8 * g + e;
+    const float a = gamma[c] * rstd[c];
+    const float b = beta[c] - mean[c] * a;
+    float t = fmaf(z[base + (size_t)e * HW], a, b);
+    if (res) t += res[base + (size_t)e * HW];
+    if (relu) t = fmaxf(t, 0.f);
+    v[e] = t;
+    y[base + (size_t)e * HW] = t;
+  }
+  split3_store(v, cb, (size_t)N * C * HW, (size_t)ng * HW + pix);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_cb_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                              const float* __restrict__ z, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                              float* __restrict__ dz, float* __restrict__ dres,
+                                                              __bf16* __restrict__ cb, int N, int C, int HW, int relu, int train) {
+  const int C8 = C >> 3;
+  const int ng = blockIdx.y;
+  const int g = ng % C8;
+  const int n = ng / C8;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= HW) return;
+  const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
+  const float inv_n = 1.f / ((float)N * (float)HW);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = 8 * g + e;
+    const float mu = mean[c], rs = rstd[c];
+    const float a = gamma[c] * rs;
+    const float k1 = train ? dbeta[c] * inv_n : 0.f;
+    const float k2 = train ? dgamma[c] * inv_n : 0.f;
+    float gv = dy[base + (size_t)e * HW];
+    if (relu && !(y[base + (size_t)e * HW] > 0.f)) gv = 0.f;
+    if (dres) dres[base + (size_t)e * HW] = gv;
+    const float t = a * (gv - k1 - ((z[base + (size_t)e * HW] - mu) * rs) * k2);
+    v[e] = t;
+    dz[base + (size_t)e * HW] = t;
+  }
+  split3_store(v, cb, (size_t)N * C * HW, (size_t)ng * HW + pix);
+}
+
 int plane_chunks(int HW, bool vec) {
   const int work = vec ? HW / 4 : HW;
   int chunks = ceil_div(work, 256 * 4);  // ~4 elements (float4s) per thread
@@ -355,6 +440,32 @@ extern "C" int mcdseg_bn_apply(const float* z, const float* mean, const float* r
     hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual, y, C,
                        HW, relu);
   MCD_LAUNCH_CHECK("bn_apply");
+  return 0;
+}
+
+extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  const float* residual, float* y, void* y_cb, int32_t N, int32_t C, int32_t HW, int32_t relu,
+                                  void* stream) {
+  MCD_REQUIRE(z && mean && rstd && gamma && beta && y && y_cb, "bn_apply_cb: null pointer");
+  MCD_REQUIRE(N > 0 && C > 0 && HW > 0 && (C % 8) == 0, "bn_apply_cb: C must be a positive multiple of 8");
+  MCD_REQUIRE((int64_t)N * (C / 8) <= 65535, "bn_apply_cb: N*C/8 exceeds the grid limit");
+  hipLaunchKernelGGL(bn_apply_cb_kernel, dim3(ceil_div(HW, 256), N * (C / 8)), dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma,
+                     beta, residual, y, (__bf16*)y_cb, N, C, HW, relu);
+  MCD_LAUNCH_CHECK("bn_apply_cb");
+  return 0;
+}
+
+extern "C" int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
+                                      const float* gamma, const float* dgamma, const float* dbeta, float* dz, float* dres,
+                                      void* dz_cb, int32_t N, int32_t C, int32_t HW, int32_t relu, int32_t train, void* stream) {
+  MCD_REQUIRE(dy && z && mean && rstd && gamma && dz && dz_cb, "bn_bwd_apply_cb: null pointer");
+  MCD_REQUIRE(!relu || y, "bn_bwd_apply_cb: relu mask needs y");
+  MCD_REQUIRE(!train || (dgamma && dbeta), "bn_bwd_apply_cb: train mode needs dgamma/dbeta");
+  MCD_REQUIRE(N > 0 && C > 0 && HW > 0 && (C % 8) == 0, "bn_bwd_apply_cb: C must be a positive multiple of 8");
+  MCD_REQUIRE((int64_t)N * (C / 8) <= 65535, "bn_bwd_apply_cb: N*C/8 exceeds the grid limit");
+  hipLaunchKernelGGL(bn_bwd_apply_cb_kernel, dim3(ceil_div(HW, 256), N * (C / 8)), dim3(256), 0, (hipStream_t)stream, dy, y, z, mean,
+                     rstd, gamma, dgamma, dbeta, dz, dres, (__bf16*)dz_cb, N, C, HW, relu, train);
+  MCD_LAUNCH_CHECK("bn_bwd_apply_cb");
   return 0;
 }
 

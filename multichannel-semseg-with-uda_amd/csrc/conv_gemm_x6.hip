@@ -15,6 +15,8 @@
 //   * one thread gathers 8 consecutive channels of one pixel (8 coalesced dword loads, lanes = pixels), splits
 //     them with v_cvt_pk_bf16_f32 and writes three 16-B fragments [piece][k-half][pixel][8] -- exactly what one
 //     lane of the MFMA consumes, so fragment reads are ds_read_b128 over 512 contiguous bytes per half-wave.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -23,6 +25,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct ConvX6Params {
   const float* src;
+  const void* src_cb;  // optional pre-split operand: [piece 3][N][Cs/8][Hs*Ws][8 bf16] (PRESPLIT kernels)
   const void* wp;  // bf16 image
   const float* bias;
   float* dst;
@@ -37,7 +40,7 @@ struct ConvX6Params {
   int Mp, Kp;
   int KH, KW, stride, pad, dil;
   int P;
-  int src_bytes, wp_bytes;
+  int src_bytes, wp_bytes, cb_bytes;
   int ablate;  // timing-only ablation bits (mcdseg_debug_ablate)
 };
 
@@ -54,7 +57,7 @@ __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& p1, bf16x8& 
   }
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, bool DGRAD>
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool DGRAD, bool PRESPLIT>
 __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   constexpr int BM = 32 * WM * WAVES_M;
   constexpr int BN = 32 * WN * WAVES_N;
@@ -64,6 +67,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   constexpr int A_CHUNKS = 6 * BM;                 // 16-byte chunks of the weight slab per K-step
   constexpr int A_ITERS = (A_CHUNKS + NT - 1) / NT;
   constexpr bool A_EXACT = (A_CHUNKS % NT) == 0;
+  constexpr bool A_DMA = A_EXACT;                  // weight slab by LDS-DMA when it tiles the workgroup exactly
   constexpr int A_BYTES = 6 * BM * 16, B_BYTES = 6 * BN * 16;
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
@@ -101,9 +105,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
     px = rem - py * p.Wd;
   }
   constexpr unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  // PRESPLIT: the gathered operand was split into bf16 pieces by its producer (bn_apply_cb / bn_bwd_apply_cb); a pixel's
+  // 8-channel group is one 16-B fragment, so offsets count 16-B units and a K-step needs 3 x 16-B loads and no VALU.
+  constexpr unsigned UNIT = PRESPLIT ? 16u : 4u;
+  const __amdgpu_buffer_rsrc_t src_rs = PRESPLIT ? __builtin_amdgcn_make_buffer_rsrc((void*)p.src_cb, 0, p.cb_bytes, 0x00020000)
+                                                 : __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wp_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.wp_bytes, 0x00020000);
-  const unsigned pix_base = (unsigned)pn * (unsigned)p.Cs * (unsigned)HWs;
+  const int C8 = p.Cs >> 3;
+  const int piece_stride = p.N * C8 * HWs;  // 16-B units between the three pieces
+  const unsigned pix_base = PRESPLIT ? (unsigned)pn * (unsigned)C8 * (unsigned)HWs : (unsigned)pn * (unsigned)p.Cs * (unsigned)HWs;
   const bool ragged = p.Kp != p.Cs;
   const int taps = p.KH * p.KW;
 
@@ -130,9 +140,35 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
       ok = ok && sy < p.Hs && sx < p.Ws;
       off = sy * p.Ws + sx;
     }
-    l_voff = ok ? (pix_base + (unsigned)off) * 4u : OOB;
+    l_voff = ok ? (pix_base + (unsigned)off) * UNIT : OOB;
   };
-  tap_geom();
+  // The pixel of a thread never changes.  For unit-stride geometry the gather offset of tap (ky,kx) is the thread's
+  // own base plus a tap offset that is the SAME for every thread (scalar ALU), and whether the tap falls into the zero
+  // padding is one bit of a per-thread mask computed once -- the K loop spends three VALU ops per step on addressing
+  // instead of ~25 that would compete with the MFMA issue slots.  Strided dgrad keeps the general form.
+  const bool fast_taps = taps <= 32 && (!DGRAD || p.stride == 1);
+  unsigned valid_mask = 0;
+  unsigned vbase = 0;
+  if (fast_taps) {
+    for (int q = 0; q < taps; ++q) {
+      l_ky = q / p.KW;
+      l_kx = q - l_ky * p.KW;
+      tap_geom();
+      valid_mask |= (l_voff != OOB ? 1u : 0u) << q;
+    }
+    l_ky = 0;
+    l_kx = 0;
+    vbase = DGRAD ? pix_base + (unsigned)(py * p.Ws + px) : pix_base + (unsigned)(py * p.stride * p.Ws + px * p.stride);
+  }
+  auto fast_voff = [&]() {
+    const int rel = DGRAD ? (p.pad - l_ky * p.dil) * p.Ws + (p.pad - l_kx * p.dil)
+                          : (l_ky * p.dil - p.pad) * p.Ws + (l_kx * p.dil - p.pad);  // wave-uniform
+    l_voff = ((valid_mask >> l_tap) & 1u) ? (vbase + (unsigned)rel) * UNIT : OOB;
+  };
+  if (fast_taps)
+    fast_voff();
+  else
+    tap_geom();
   auto advance = [&]() {
     ++l_kstep;
     ++l_tap;
@@ -147,7 +183,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
       l_ky = 0;
       l_c0 += 16;
     }
-    tap_geom();
+    if (fast_taps)
+      fast_voff();
+    else
+      tap_geom();
   };
 
   unsigned a_voff[A_ITERS];
@@ -159,45 +198,86 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
     a_voff[i] = (A_EXACT || id < A_CHUNKS) ? ((unsigned)plane * (unsigned)p.Mp + (unsigned)m) * 16u : OOB;
   }
 
-  float breg[B_ITEMS][8];
-  f32x4 areg[A_ITERS];
-  auto load_regs = [&]() {
+  // two register sets: gathers run TWO K-steps ahead of the MFMAs (a K-step of six K=16 MFMAs per tile is only ~800
+  // cycles, less than a MALL/HBM round trip, so one step of prefetch distance leaves the first tap of every channel
+  // chunk exposed)
+  float breg[2][B_ITEMS][PRESPLIT ? 1 : 8];
+  f32x4 bsplit[2][B_ITEMS][PRESPLIT ? 3 : 1];
+  f32x4 areg[2][A_ITERS];
+  auto load_regs = [&](auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
 #pragma unroll
     for (int it = 0; it < B_ITEMS; ++it) {
       const int h = (B_ITEMS == 1) ? bh0 : it;
+      if constexpr (PRESPLIT) {
+        const int grp = (l_c0 >> 3) + h;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          const int soff = grp < C8 ? (grp * HWs + pc * piece_stride) * 16 : 0x7FFFFFFF;
+          const auto q = __builtin_amdgcn_raw_buffer_load_b128(src_rs, l_voff, soff, 0);
+          bsplit[SET][it][pc][0] = __uint_as_float(q[0]);
+          bsplit[SET][it][pc][1] = __uint_as_float(q[1]);
+          bsplit[SET][it][pc][2] = __uint_as_float(q[2]);
+          bsplit[SET][it][pc][3] = __uint_as_float(q[3]);
+        }
+        continue;
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int c = l_c0 + 8 * h + e;
         const int soff = (!ragged || c < p.Cs) ? c * HWs * 4 : 0x7FFFFFFF;
-        breg[it][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src_rs, l_voff, soff, 0));
+        if constexpr (!PRESPLIT) breg[SET][it][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src_rs, l_voff, soff, 0));
       }
     }
     const int a_soff = (l_kstep * 6 * p.Mp + tile_m * BM) * 16;
+    if (A_DMA) return;  // the weight slab goes global -> LDS directly (dma_weights)
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       const auto q = __builtin_amdgcn_raw_buffer_load_b128(wp_rs, a_voff[i], a_soff, 0);
-      areg[i][0] = __uint_as_float(q[0]);
-      areg[i][1] = __uint_as_float(q[1]);
-      areg[i][2] = __uint_as_float(q[2]);
-      areg[i][3] = __uint_as_float(q[3]);
+      areg[SET][i][0] = __uint_as_float(q[0]);
+      areg[SET][i][1] = __uint_as_float(q[1]);
+      areg[SET][i][2] = __uint_as_float(q[2]);
+      areg[SET][i][3] = __uint_as_float(q[3]);
     }
   };
-  auto store_lds = [&](int buf) {
+  // Pre-split weights are stored in exactly the LDS image order, so a K-step's slab is moved by LDS-DMA
+  // (buffer_load_dwordx4 ... lds: wave-uniform LDS base + lane * 16 B): no VGPRs, no ds_write, no VALU.
+  auto dma_weights = [&](int buf) {
+    const int a_soff = (l_kstep * 6 * p.Mp + tile_m * BM) * 16;
+    unsigned char* adst = As + buf * A_BYTES + wave * 64 * 16;
+#if defined(__HIP_DEVICE_COMPILE__)  // the LDS address space does not exist in the host pass of this translation unit
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wp_rs, (__attribute__((address_space(3))) void*)(adst + i * NT * 16), 16, a_voff[i], a_soff, 0, 0);
+#else
+    (void)a_soff;
+    (void)adst;
+#endif
+  };
+  auto store_lds = [&](int buf, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
     unsigned char* bdst = Bs + buf * B_BYTES;
 #pragma unroll
     for (int it = 0; it < B_ITEMS; ++it) {
       const int h = (B_ITEMS == 1) ? bh0 : it;
+      if constexpr (PRESPLIT) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<f32x4*>(bdst + ((pc * 2 + h) * BN + bj) * 16) = bsplit[SET][it][pc];
+        continue;
+      }
       bf16x8 p1, p2, p3;
-      split3(breg[it], p1, p2, p3);
+      if constexpr (!PRESPLIT) split3(breg[SET][it], p1, p2, p3);
       *reinterpret_cast<bf16x8*>(bdst + ((0 * 2 + h) * BN + bj) * 16) = p1;
       *reinterpret_cast<bf16x8*>(bdst + ((1 * 2 + h) * BN + bj) * 16) = p2;
       *reinterpret_cast<bf16x8*>(bdst + ((2 * 2 + h) * BN + bj) * 16) = p3;
     }
-    unsigned char* adst = As + buf * A_BYTES;
+    if (!A_DMA) {
+      unsigned char* adst = As + buf * A_BYTES;
 #pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-      const int id = t + i * NT;
-      if (A_EXACT || id < A_CHUNKS) *reinterpret_cast<f32x4*>(adst + id * 16) = areg[i];
+      for (int i = 0; i < A_ITERS; ++i) {
+        const int id = t + i * NT;
+        if (A_EXACT || id < A_CHUNKS) *reinterpret_cast<f32x4*>(adst + id * 16) = areg[SET][i];
+      }
     }
   };
 
@@ -210,17 +290,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nsteps = taps * (p.Kp / 16);
-  load_regs();
-  store_lds(0);
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  // loader state runs two steps ahead: regs set k&1 holds the gathers of step k
+  if (A_DMA) dma_weights(0);
+  load_regs(S0{});
+  store_lds(0, S0{});
+  int l_dma_kstep = 0;  // weight DMA runs one step ahead
+  if (nsteps > 1) {
+    advance();
+    load_regs(S1{});
+  }
   __syncthreads();
 
-  for (int s = 0; s < nsteps; ++s) {
-    const int cur = s & 1;
-    const bool more = (s + 1) < nsteps;
-    if (more) {
-      advance();
-      if (!(p.ablate & 1)) load_regs();
-    }
+  auto mfma_step = [&](int cur) {
     const unsigned char* a_base = As + cur * A_BYTES + (lh * BM + wm * (32 * WM) + l31) * 16;
     const unsigned char* b_base = Bs + cur * B_BYTES + (lh * BN + wn * (32 * WN) + l31) * 16;
     bf16x8 a[3][WM], b[3][WN];
@@ -236,11 +319,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
     for (int i = 0; i < WM; ++i)
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
-        if (p.ablate & 8) {  // experiment: all nine cross terms
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[2][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[1][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[2][j], acc[i][j], 0, 0, 0);
-        }
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
@@ -248,8 +326,38 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
       }
-    if (more && !(p.ablate & 2)) store_lds(cur ^ 1);
-    if (!(p.ablate & 4)) __syncthreads();
+  };
+  // one K-step s (cur = s & 1): gathers of step s+2 go to the register set that step s just vacated, the weight slab of
+  // step s+1 is DMA'd into the LDS buffer released by the previous barrier, MFMAs of step s, then step s+1's gathers
+  // (loaded one step earlier) are split and written to LDS.
+  auto k_step = [&](int s, auto cur_c) {
+    constexpr int CUR = decltype(cur_c)::value;
+    using SAME = std::integral_constant<int, CUR>;
+    using OTHER = std::integral_constant<int, CUR ^ 1>;
+    if (A_DMA && s + 1 < nsteps) {
+      ++l_dma_kstep;
+      const int a_soff = (l_dma_kstep * 6 * p.Mp + tile_m * BM) * 16;
+      unsigned char* adst = As + (CUR ^ 1) * A_BYTES + wave * 64 * 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+      for (int i = 0; i < A_ITERS; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wp_rs, (__attribute__((address_space(3))) void*)(adst + i * NT * 16), 16, a_voff[i], a_soff, 0, 0);
+#else
+      (void)a_soff;
+      (void)adst;
+#endif
+    }
+    if (s + 2 < nsteps) {
+      advance();
+      load_regs(SAME{});
+    }
+    mfma_step(CUR);
+    if (s + 1 < nsteps) store_lds(CUR ^ 1, OTHER{});
+    __syncthreads();
+  };
+  for (int s = 0; s < nsteps; s += 2) {
+    k_step(s, S0{});
+    if (s + 1 < nsteps) k_step(s + 1, S1{});
   }
 
   // ---- epilogue (identical to conv_gemm.hip): acc[i][j][r] = D[row][col], row = (r&3) + 8*(r>>2) + 4*lh, col = l31
@@ -394,15 +502,16 @@ void launch_cfg(const ConvX6Params& p, hipStream_t st) {
   constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
   const int n_tiles = ceil_div(p.P, BN);
   dim3 grid(8 * ceil_div(n_tiles, 8) * (p.Mp / BM));
-  hipLaunchKernelGGL((conv_gemm_x6_kernel<WM, WN, WAVES_M, WAVES_N, DGRAD>), grid, dim3(256), 0, st, p);
+  if (p.src_cb != nullptr)
+    hipLaunchKernelGGL((conv_gemm_x6_kernel<WM, WN, WAVES_M, WAVES_N, DGRAD, true>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_gemm_x6_kernel<WM, WN, WAVES_M, WAVES_N, DGRAD, false>), grid, dim3(256), 0, st, p);
 }
 
 template <bool DGRAD>
 void launch(const ConvX6Params& p, hipStream_t st) {
   const int bm = mcd_bm(p.M);
-  if (bm == 128 && (p.ablate & 16))
-    launch_cfg<2, 4, 2, 2, DGRAD>(p, st);  // experiment: 128 x 256 tile, 64 x 128 per wave
-  else if (bm == 128)
+  if (bm == 128)
     launch_cfg<2, 2, 2, 2, DGRAD>(p, st);
   else if (bm == 64)
     launch_cfg<2, 2, 1, 4, DGRAD>(p, st);
@@ -441,11 +550,23 @@ extern "C" int mcdseg_conv_x6_pack_weights(const mcdseg_conv_desc* d, const floa
   return 0;
 }
 
-static int x6_fprop_impl(const mcdseg_conv_desc* d, const float* x, const void* wp, const float* bias, float* y, float* stats,
-                         const float* ep_scale, const float* ep_shift, const float* ep_res, int ep_relu, void* stream) {
+static int x6_cb_bytes(int N, int C, int HW, const void* cb, int* out) {
+  *out = 0;
+  if (cb == nullptr) return 0;
+  MCD_REQUIRE((C % 8) == 0, "conv_x6: a pre-split operand needs a channel count divisible by 8 (got %d)", C);
+  const int64_t b = (int64_t)3 * N * C * HW * 2;
+  MCD_REQUIRE(b < (1ll << 31), "conv_x6: pre-split operand exceeds 2 GiB; split the batch");
+  *out = (int)b;
+  return 0;
+}
+
+static int x6_fprop_impl(const mcdseg_conv_desc* d, const float* x, const void* x_cb, const void* wp, const float* bias, float* y,
+                         float* stats, const float* ep_scale, const float* ep_shift, const float* ep_res, int ep_relu, void* stream) {
   if (int rc = x6_check(d, "conv_x6_fprop")) return rc;
-  MCD_REQUIRE(x && wp && y, "conv_x6_fprop: null pointer");
+  MCD_REQUIRE((x || x_cb) && wp && y, "conv_x6_fprop: null pointer");
   ConvX6Params p;
+  if (int rc = x6_cb_bytes(d->N, d->Cin, d->H * d->W, x_cb, &p.cb_bytes)) return rc;
+  p.src_cb = x_cb;
   p.src = x; p.wp = wp; p.bias = bias; p.dst = y; p.stats = stats;
   p.ep_scale = ep_scale; p.ep_shift = ep_shift; p.ep_res = ep_res; p.ep_relu = ep_relu;
   p.N = d->N;
@@ -465,21 +586,25 @@ static int x6_fprop_impl(const mcdseg_conv_desc* d, const float* x, const void* 
   return 0;
 }
 
-extern "C" int mcdseg_conv_x6_fprop(const mcdseg_conv_desc* d, const float* x, const void* wp_fprop, const float* bias, float* y,
-                                    float* stat_partials, void* stream) {
-  return x6_fprop_impl(d, x, wp_fprop, bias, y, stat_partials, nullptr, nullptr, nullptr, 0, stream);
+extern "C" int mcdseg_conv_x6_fprop(const mcdseg_conv_desc* d, const float* x, const void* x_cb, const void* wp_fprop,
+                                    const float* bias, float* y, float* stat_partials, void* stream) {
+  return x6_fprop_impl(d, x, x_cb, wp_fprop, bias, y, stat_partials, nullptr, nullptr, nullptr, 0, stream);
 }
 
-extern "C" int mcdseg_conv_x6_fprop_affine(const mcdseg_conv_desc* d, const float* x, const void* wp_fprop, const float* scale,
-                                           const float* shift, const float* residual, int32_t relu, float* y, void* stream) {
+extern "C" int mcdseg_conv_x6_fprop_affine(const mcdseg_conv_desc* d, const float* x, const void* x_cb, const void* wp_fprop,
+                                           const float* scale, const float* shift, const float* residual, int32_t relu, float* y,
+                                           void* stream) {
   MCD_REQUIRE(scale && shift, "conv_x6_fprop_affine: null scale/shift");
-  return x6_fprop_impl(d, x, wp_fprop, nullptr, y, nullptr, scale, shift, residual, relu, stream);
+  return x6_fprop_impl(d, x, x_cb, wp_fprop, nullptr, y, nullptr, scale, shift, residual, relu, stream);
 }
 
-extern "C" int mcdseg_conv_x6_dgrad(const mcdseg_conv_desc* d, const float* dy, const void* wp_dgrad, float* dx, void* stream) {
+extern "C" int mcdseg_conv_x6_dgrad(const mcdseg_conv_desc* d, const float* dy, const void* dy_cb, const void* wp_dgrad, float* dx,
+                                    void* stream) {
   if (int rc = x6_check(d, "conv_x6_dgrad")) return rc;
-  MCD_REQUIRE(dy && wp_dgrad && dx, "conv_x6_dgrad: null pointer");
+  MCD_REQUIRE((dy || dy_cb) && wp_dgrad && dx, "conv_x6_dgrad: null pointer");
   ConvX6Params p;
+  if (int rc = x6_cb_bytes(d->N, d->Cout, d->Ho * d->Wo, dy_cb, &p.cb_bytes)) return rc;
+  p.src_cb = dy_cb;
   p.src = dy; p.wp = wp_dgrad; p.bias = nullptr; p.dst = dx; p.stats = nullptr;
   p.ep_scale = nullptr; p.ep_shift = nullptr; p.ep_res = nullptr; p.ep_relu = 0;
   p.N = d->N;

@@ -113,6 +113,9 @@ def conv_desc(x_shape, w_shape, stride, pad, dil):
 #   "f32"               v_mfma_f32_32x32x2_f32, the exact k-ordered fp32 FMA chain;
 #   "mixed"             bf16x6 for forward / data-gradient, f32 for the weight gradients.
 CONV_MATH = os.environ.get("MCDSEG_CONV_MATH", "bf16x6")
+# producers (BN apply / BN backward apply) also emit the 3-way bf16 split of what they write, so the convolution that
+# gathers it does not re-split every activation inside its K loop (MCDSEG_PRESPLIT=0 turns this off)
+PRESPLIT = os.environ.get("MCDSEG_PRESPLIT", "1") != "0"
 if CONV_MATH not in ("bf16x6", "f32", "mixed", "bf16x6-fprop", "bf16x6-dgrad"):
     raise ValueError("MCDSEG_CONV_MATH must be bf16x6, f32 or mixed, got %r" % CONV_MATH)
 
@@ -181,10 +184,12 @@ def _batch_pieces(desc):
     return [(i, min(i + step, desc.N)) for i in range(0, desc.N, step)]
 
 
-def _conv_fprop(desc, x, wf, bias, want_stats, mpf):
+def _conv_fprop(desc, x, wf, bias, want_stats, mpf, x_cb=None):
     L = lib()
     y = torch.empty((desc.N, desc.Cout, desc.Ho, desc.Wo), dtype=torch.float32, device=x.device)
     pieces = _batch_pieces(desc)
+    if len(pieces) > 1:
+        x_cb = None  # the piece-major split layout cannot be sliced along N
     descs = [desc if len(pieces) == 1 else _sub_desc(desc, b - a) for a, b in pieces]
     part, rows, row_off = None, 0, [0]
     if want_stats:
@@ -194,20 +199,39 @@ def _conv_fprop(desc, x, wf, bias, want_stats, mpf):
         part = torch.empty(rows * 3 * mpf, dtype=torch.float32, device=x.device)
     for i, ((a, b), d) in enumerate(zip(pieces, descs)):
         pp = None if part is None else ctypes.c_void_p(part.data_ptr() + 4 * row_off[i] * 3 * mpf)
-        fn = L.mcdseg_conv_x6_fprop if wf.dtype == torch.bfloat16 else L.mcdseg_conv_fprop
         with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, wf.dtype == torch.bfloat16), conv_work(d)):
-            check(fn(ctypes.byref(d), _p(x[a:b]), _p(wf), _p(bias), _p(y[a:b]), pp, _stream()), "conv_fprop")
+            if wf.dtype == torch.bfloat16:
+                check(L.mcdseg_conv_x6_fprop(ctypes.byref(d), _p(x[a:b]), _p(x_cb), _p(wf), _p(bias), _p(y[a:b]), pp, _stream()),
+                      "conv_x6_fprop")
+            else:
+                check(L.mcdseg_conv_fprop(ctypes.byref(d), _p(x[a:b]), _p(wf), _p(bias), _p(y[a:b]), pp, _stream()), "conv_fprop")
     return y, part, rows
 
 
-def _conv_dgrad(desc, dy, wd):
+def _conv_dgrad(desc, dy, wd, dy_cb=None):
+    L = lib()
     dx = torch.empty((desc.N, desc.Cin, desc.H, desc.W), dtype=torch.float32, device=dy.device)
-    for a, b in _batch_pieces(desc):
+    pieces = _batch_pieces(desc)
+    if len(pieces) > 1:
+        dy_cb = None
+    for a, b in pieces:
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
-        fn = lib().mcdseg_conv_x6_dgrad if wd.dtype == torch.bfloat16 else lib().mcdseg_conv_dgrad
         with _timed(gemm_kernel_name(desc.Cin, desc.Cout, True, wd.dtype == torch.bfloat16), conv_work(d)):
-            check(fn(ctypes.byref(d), _p(dy[a:b]), _p(wd), _p(dx[a:b]), _stream()), "conv_dgrad")
+            if wd.dtype == torch.bfloat16:
+                check(L.mcdseg_conv_x6_dgrad(ctypes.byref(d), _p(dy[a:b]), _p(dy_cb), _p(wd), _p(dx[a:b]), _stream()), "conv_x6_dgrad")
+            else:
+                check(L.mcdseg_conv_dgrad(ctypes.byref(d), _p(dy[a:b]), _p(wd), _p(dx[a:b]), _stream()), "conv_dgrad")
     return dx
+
+
+def _cb_wanted(channels):
+    """Emit the pre-split (channel-blocked bf16x3) companion of a tensor with this many channels?  Only when the conv
+    that gathers it runs on the split path (contraction >= 16 channels) and the layout applies (multiple of 8)."""
+    return PRESPLIT and _use_x6(channels) and channels % 8 == 0
+
+
+def _cb_alloc(n, c, hw, device):
+    return torch.empty(3 * n * c * hw, dtype=torch.bfloat16, device=device)
 
 
 def _conv_wgrad(desc, x, dy):
@@ -239,15 +263,15 @@ def _side_stream(device):
     return _SIDE[key]
 
 
-def _conv_backward(desc, x, dy, wd, need_dx, need_dw):
+def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None):
     if not (need_dx and need_dw and OVERLAP_WGRAD):
-        return (_conv_dgrad(desc, dy, wd) if need_dx else None), (_conv_wgrad(desc, x, dy) if need_dw else None)
+        return (_conv_dgrad(desc, dy, wd, dy_cb) if need_dx else None), (_conv_wgrad(desc, x, dy) if need_dw else None)
     main = torch.cuda.current_stream()
     side = _side_stream(dy.device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
         dw = _conv_wgrad(desc, x, dy)
-    dx = _conv_dgrad(desc, dy, wd)
+    dx = _conv_dgrad(desc, dy, wd, dy_cb)
     main.wait_stream(side)
     dw.record_stream(main)
     return dx, dw
@@ -270,14 +294,14 @@ def _channel_reduce(dy, y, z, mean, rstd, relu):
 class _ConvBNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, conv_bias, running_mean, running_var, nbt, packed, geom, training,
-                momentum, eps, relu):
+                momentum, eps, relu, x_cb):
         L = lib()
         x = _req(x, "conv input")
         residual = _req(residual, "residual")
         stride, pad, dil = geom
         desc = conv_desc(x.shape, weight.shape, stride, pad, dil)
         wf, wd, mpf = packed.get(weight, desc)
-        z, part, rows = _conv_fprop(desc, x, wf, _req(conv_bias, "conv bias"), training, mpf)
+        z, part, rows = _conv_fprop(desc, x, wf, _req(conv_bias, "conv bias"), training, mpf, x_cb)
         c = desc.Cout
         mean = torch.empty(c, dtype=torch.float32, device=x.device)
         rstd = torch.empty(c, dtype=torch.float32, device=x.device)
@@ -293,15 +317,23 @@ class _ConvBNAct(torch.autograd.Function):
                   "bn_eval_stats")
         y = torch.empty_like(z)
         hw = desc.Ho * desc.Wo
-        check(L.mcdseg_bn_apply(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), _p(y), desc.N, c, hw, int(relu),
-                                _stream()), "bn_apply")
+        y_cb = None
+        if _cb_wanted(c) and desc.N * (c // 8) <= 65535:
+            y_cb = _cb_alloc(desc.N, c, hw, x.device)
+            check(L.mcdseg_bn_apply_cb(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), _p(y), _p(y_cb), desc.N, c, hw,
+                                       int(relu), _stream()), "bn_apply_cb")
+        else:
+            check(L.mcdseg_bn_apply(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), _p(y), desc.N, c, hw, int(relu),
+                                    _stream()), "bn_apply")
         ctx.desc, ctx.wd, ctx.relu, ctx.training, ctx.has_res = desc, wd, relu, training, residual is not None
         ctx.has_bias = conv_bias is not None
         ctx.save_for_backward(x, z, y, mean, rstd, gamma)
-        return y
+        if y_cb is not None:
+            ctx.mark_non_differentiable(y_cb)
+        return y, y_cb
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dcb=None):
         L = lib()
         x, z, y, mean, rstd, gamma = ctx.saved_tensors
         desc = ctx.desc
@@ -312,17 +344,23 @@ class _ConvBNAct(torch.autograd.Function):
         dres = None
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = torch.empty_like(z) if ctx.relu else dy
-        check(L.mcdseg_bn_bwd_apply(_p(dy), _p(y) if ctx.relu else None, _p(z), _p(mean), _p(rstd), _p(gamma), _p(dgamma),
-                                    _p(dbeta), _p(dz), _p(dres) if (dres is not None and ctx.relu) else None, n, c, hw,
-                                    int(ctx.relu), int(ctx.training), _stream()), "bn_bwd_apply")
-        dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dz_cb = None
+        bwd_args = (_p(dy), _p(y) if ctx.relu else None, _p(z), _p(mean), _p(rstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dz),
+                    _p(dres) if (dres is not None and ctx.relu) else None)
+        if ctx.needs_input_grad[0] and ctx.wd.dtype == torch.bfloat16 and _cb_wanted(c) and n * (c // 8) <= 65535:
+            dz_cb = _cb_alloc(n, c, hw, dy.device)
+            check(L.mcdseg_bn_bwd_apply_cb(*bwd_args, _p(dz_cb), n, c, hw, int(ctx.relu), int(ctx.training), _stream()),
+                  "bn_bwd_apply_cb")
+        else:
+            check(L.mcdseg_bn_bwd_apply(*bwd_args, n, c, hw, int(ctx.relu), int(ctx.training), _stream()), "bn_bwd_apply")
+        dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz_cb)
         dbias = None
         if ctx.has_bias and ctx.needs_input_grad[5]:
             # a bias in front of train-mode BN has zero gradient up to rounding (BN removes the channel mean);
             # it is still formed, as autograd does in the reference (CBR, models/dilated_fcn.py:632-644)
             _, dbias = _channel_reduce(dz, None, None, None, None, False)
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres, dbias,
-                None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None)
 
 
 def _conv_bn_act_inference(x, conv, bn, relu, residual):
@@ -342,9 +380,11 @@ def _conv_bn_act_inference(x, conv, bn, relu, residual):
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
         fn = L.mcdseg_conv_x6_fprop_affine if wf.dtype == torch.bfloat16 else L.mcdseg_conv_fprop_affine
         with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, wf.dtype == torch.bfloat16), conv_work(d)):
-            check(fn(ctypes.byref(d), _p(x[a:b]), _p(wf), _p(scale), _p(shift),
-                                             _p(residual[a:b]) if residual is not None else None, int(relu), _p(y[a:b]), _stream()),
-                  "conv_fprop_affine")
+            args = (_p(scale), _p(shift), _p(residual[a:b]) if residual is not None else None, int(relu), _p(y[a:b]), _stream())
+            if wf.dtype == torch.bfloat16:
+                check(fn(ctypes.byref(d), _p(x[a:b]), None, _p(wf), *args), "conv_x6_fprop_affine")
+            else:
+                check(fn(ctypes.byref(d), _p(x[a:b]), _p(wf), *args), "conv_fprop_affine")
     return y
 
 
@@ -358,19 +398,30 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None):
     if not training and not track:
         raise NotImplementedError("mcdseg: eval-mode BatchNorm needs running statistics")
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    return _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, residual, conv.bias, bn.running_mean if track else None,
-                            bn.running_var if track else None, bn.num_batches_tracked if track else None, conv._packed, geom,
-                            training, momentum, bn.eps, relu)
+    y, y_cb = _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, residual, conv.bias, bn.running_mean if track else None,
+                               bn.running_var if track else None, bn.num_batches_tracked if track else None, conv._packed, geom,
+                               training, momentum, bn.eps, relu, _cb_of(x))
+    if y_cb is not None:
+        y._mcd_cb = y_cb  # the pre-split companion travels with the tensor object to the next convolution
+    return y
+
+
+def _cb_of(x):
+    """pre-split companion attached by the producer of ``x`` (None if ``x`` did not come straight from a fused BN group)"""
+    cb = getattr(x, "_mcd_cb", None)
+    if cb is not None and (not x.is_contiguous() or cb.numel() != 3 * x.numel()):
+        return None
+    return cb
 
 
 # ------------------------------------------------------------------------------------------------ conv (+bias)
 class _Conv2dBias(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, geom):
+    def forward(ctx, x, weight, bias, packed, geom, x_cb):
         x = _req(x, "conv input")
         desc = conv_desc(x.shape, weight.shape, *geom)
         wf, wd, mpf = packed.get(weight, desc)
-        y, _, _ = _conv_fprop(desc, x, wf, _req(bias, "conv bias"), False, mpf)
+        y, _, _ = _conv_fprop(desc, x, wf, _req(bias, "conv bias"), False, mpf, x_cb)
         ctx.desc, ctx.wd, ctx.has_bias = desc, wd, bias is not None
         ctx.save_for_backward(x)
         return y
@@ -383,12 +434,12 @@ class _Conv2dBias(torch.autograd.Function):
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             _, db = _channel_reduce(dy, None, None, None, None, False)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 def conv2d_bias(x, conv):
     geom = (conv.stride[0], conv.padding[0], conv.dilation[0])
-    return _Conv2dBias.apply(x, conv.weight, conv.bias, conv._packed, geom)
+    return _Conv2dBias.apply(x, conv.weight, conv.bias, conv._packed, geom, _cb_of(x))
 
 
 # ------------------------------------------------------------------------------------------------ x8 up-sampler

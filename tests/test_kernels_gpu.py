@@ -448,3 +448,36 @@ def test_conv_x6_accuracy(case, monkeypatch):
     for k in (0, 1, 2):
         e32, e6 = errs["f32"][k][0], errs["bf16x6"][k][0]
         assert e6 <= max(2.0 * e32, 2e-6 * errs["f32"][k][1]), "bf16x6 err %.3e vs f32-MFMA err %.3e" % (e6, e32)
+
+
+def test_presplit_operands_are_bitwise_equivalent(monkeypatch):
+    """Splitting an activation into bf16 pieces in its producer (bn_apply_cb / bn_bwd_apply_cb) or inside the consuming
+    convolution's K loop is the same arithmetic: results must be bit-identical, forward and backward."""
+    dev = _dev()
+    from mcdseg import ops
+    from models.drn import BatchNorm2d, Conv2d
+    monkeypatch.setattr(ops, "CONV_MATH", "bf16x6")
+    g = torch.Generator().manual_seed(41)
+    c1, b1 = Conv2d(24, 40, 3, padding=1, bias=False).to(dev), BatchNorm2d(40).to(dev)     # 40 = 2.5 x 16: ragged last chunk
+    c2, b2 = Conv2d(40, 64, 3, padding=2, dilation=2, bias=False).to(dev), BatchNorm2d(64).to(dev)
+    c3, b3 = Conv2d(64, 32, 1, stride=2, bias=False).to(dev), BatchNorm2d(32).to(dev)
+    x = torch.randn(3, 24, 14, 18, generator=g).to(dev)
+    gy = torch.randn(3, 32, 7, 9, generator=g).to(dev)
+
+    def run(presplit):
+        monkeypatch.setattr(ops, "PRESPLIT", presplit)
+        for m in (b1, b2, b3):
+            m.running_mean.zero_(), m.running_var.fill_(1)
+        xs = x.clone().requires_grad_()
+        for p in list(c1.parameters()) + list(c2.parameters()) + list(c3.parameters()):
+            p.grad = None
+        y1 = ops.conv_bn_act(xs, c1, b1, relu=True)
+        assert (getattr(y1, "_mcd_cb", None) is not None) == presplit
+        y2 = ops.conv_bn_act(y1, c2, b2, relu=True, residual=None)
+        y3 = ops.conv_bn_act(y2, c3, b3, relu=False)
+        y3.backward(gy)
+        return [t.detach().clone() for t in (y1, y2, y3, xs.grad, c1.weight.grad, c2.weight.grad, c3.weight.grad)]
+
+    a, b = run(True), run(False)
+    for name, u, v in zip(["y1", "y2", "y3", "dx", "dw1", "dw2", "dw3"], a, b):
+        assert torch.equal(u, v), "%s differs between pre-split and in-loop split (max %.3e)" % (name, float((u - v).abs().max()))

@@ -26,7 +26,7 @@ def timeit(fn, reps=5):
     for _ in range(reps): fn()
     t1.record(); torch.cuda.synchronize()
     return t0.elapsed_time(t1) / reps
-for bits, what in ((0, "full"), (16, "128x256 tile (x6 only)"), (17, "128x256, no loads"), (19, "128x256 no loads/stores"), (1, "no global loads"), (2, "no LDS stores"), (3, "no loads, no stores"), (7, "no loads/stores/barriers"), (4, "no barriers")):
+for bits, what in ((0, "full"), (32, "emulated pre-split operands (x6 only)"), (1, "no global loads"), (2, "no LDS stores"), (3, "no loads, no stores"), (7, "no loads/stores/barriers"), (4, "no barriers")):
     L.mcdseg_debug_ablate(bits)
     t = timeit(lambda: ops._conv_fprop(desc, x, wf, None, False, mpf))
     t2 = timeit(lambda: ops._conv_dgrad(desc, x, wd))
