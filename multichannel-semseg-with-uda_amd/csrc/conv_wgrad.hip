@@ -341,11 +341,14 @@ __global__ __launch_bounds__(64) void conv_wgrad_thin_kernel(WgradParams p) {
   }
 }
 
-__global__ void wgrad_thin_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int T, int co_p,
-                                         int groups, int cinp, int splits) {
+// one wave per output element: lanes stride over the splits (hundreds of them for the full-resolution layers), then a
+// wave reduction in fp64 -- fixed order, so still deterministic
+__global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout,
+                                                                int Cin, int T, int co_p, int groups, int cinp, int splits) {
   const int64_t total = (int64_t)T * Cout * Cin;
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= total) return;
+  const int lane = threadIdx.x & 63;
   const int ci = (int)(i % Cin);
   const int64_t r = i / Cin;
   const int co = (int)(r % Cout);
@@ -356,8 +359,9 @@ __global__ void wgrad_thin_reduce_kernel(const float* __restrict__ slab, float* 
   const size_t stride = (size_t)groups * co_p * 32;
   const float* src = slab + ((size_t)group * co_p + co) * 32 + col;
   double s = 0.0;
-  for (int k = 0; k < splits; ++k) s += (double)src[(size_t)k * stride];
-  dw[((size_t)co * Cin + ci) * T + tap] = (float)s;
+  for (int k = lane; k < splits; k += 64) s += (double)src[(size_t)k * stride];
+  s = wave_sum_d(s);
+  if (lane == 0) dw[((size_t)co * Cin + ci) * T + tap] = (float)s;
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int T, int co_p,
@@ -430,7 +434,7 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
     else
       hipLaunchKernelGGL((conv_wgrad_thin_kernel<16>), grid, dim3(64), 0, st, p);
     MCD_LAUNCH_CHECK("conv_wgrad_thin");
-    hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, (const float*)workspace,
+    hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3((unsigned)ceil_div64(total, 4)), dim3(256), 0, st, (const float*)workspace,
                        dw, d->Cout, d->Cin, T, pl.co_p, pl.groups, pl.cinp, pl.splits);
     MCD_LAUNCH_CHECK("conv_wgrad_thin_reduce");
     return 0;

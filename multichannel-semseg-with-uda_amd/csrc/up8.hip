@@ -109,19 +109,31 @@ __global__ __launch_bounds__(256) void up8_bwd_weight_kernel(const float* __rest
   const size_t plane = (size_t)n * C + c;
   const float* g = dy + plane * Ho * Wo;
   const float* xin = x + plane * Hi * Wi;
-  float acc = 0.f;
+  // four independent accumulators keep four row loads in flight; only the first and last input column can fall
+  // outside the output row, so the bounds test is a select on the loaded value rather than a branch
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int iy = iy_begin; iy < iy_end; ++iy) {
     const int oy = 8 * iy - 4 + ky;
     if (oy < 0 || oy >= Ho) continue;
     const float* row = g + (size_t)oy * Wo;
     const float* xrow = xin + iy * Wi;
-    for (int ix = 0; ix < Wi; ++ix) {
+    int ix = 0;
+    for (; ix + 4 <= Wi; ix += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ox = 8 * (ix + j) - 4 + kx;
+        const bool ok = ox >= 0 && ox < Wo;
+        const float gv = row[ok ? ox : 0];
+        acc[j] = fmaf(xrow[ix + j], ok ? gv : 0.f, acc[j]);
+      }
+    }
+    for (; ix < Wi; ++ix) {
       const int ox = 8 * ix - 4 + kx;
       if (ox < 0 || ox >= Wo) continue;
-      acc = fmaf(xrow[ix], row[ox], acc);
+      acc[0] = fmaf(xrow[ix], row[ox], acc[0]);
     }
   }
-  part[((size_t)nb * C + c) * 256 + threadIdx.x] = acc;
+  part[((size_t)nb * C + c) * 256 + threadIdx.x] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
 __global__ void up8_bwd_weight_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int C, int slabs) {

@@ -57,12 +57,13 @@ def conv_work(desc):
     return 2 * macs, byts
 
 
-def gemm_kernel_name(m, k, dgrad, x6=False):
-    """Template instantiation conv_fprop / conv_dgrad dispatch to (same rule as csrc/common.h mcd_bm / mcd_bk)."""
+def gemm_kernel_name(m, k, dgrad, x6=False, presplit=False):
+    """Template instantiation conv_fprop / conv_dgrad dispatch to (same rule as csrc/common.h mcd_bm / mcd_bk); the
+    string equals the kernel name rocprofv3 prints, so profiles/*_pmc_traffic.json can be keyed by it."""
     bm = 32 if m <= 32 else (64 if m <= 64 else 128)
     cfg = {128: "2, 2, 2, 2", 64: "2, 2, 1, 4", 32: "1, 2, 1, 4"}[bm]
     if x6:
-        return "conv_gemm_x6_kernel<%s, %s>" % (cfg, "true" if dgrad else "false")
+        return "conv_gemm_x6_kernel<%s, %s, %s>" % (cfg, "true" if dgrad else "false", "true" if presplit else "false")
     return "conv_gemm_kernel<%s, %d, %s>" % (cfg, 8 if k <= 8 else 16, "true" if dgrad else "false")
 
 
@@ -199,7 +200,7 @@ def _conv_fprop(desc, x, wf, bias, want_stats, mpf, x_cb=None):
         part = torch.empty(rows * 3 * mpf, dtype=torch.float32, device=x.device)
     for i, ((a, b), d) in enumerate(zip(pieces, descs)):
         pp = None if part is None else ctypes.c_void_p(part.data_ptr() + 4 * row_off[i] * 3 * mpf)
-        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, wf.dtype == torch.bfloat16), conv_work(d)):
+        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, wf.dtype == torch.bfloat16, x_cb is not None), conv_work(d)):
             if wf.dtype == torch.bfloat16:
                 check(L.mcdseg_conv_x6_fprop(ctypes.byref(d), _p(x[a:b]), _p(x_cb), _p(wf), _p(bias), _p(y[a:b]), pp, _stream()),
                       "conv_x6_fprop")
@@ -216,7 +217,7 @@ def _conv_dgrad(desc, dy, wd, dy_cb=None):
         dy_cb = None
     for a, b in pieces:
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
-        with _timed(gemm_kernel_name(desc.Cin, desc.Cout, True, wd.dtype == torch.bfloat16), conv_work(d)):
+        with _timed(gemm_kernel_name(desc.Cin, desc.Cout, True, wd.dtype == torch.bfloat16, dy_cb is not None), conv_work(d)):
             if wd.dtype == torch.bfloat16:
                 check(L.mcdseg_conv_x6_dgrad(ctypes.byref(d), _p(dy[a:b]), _p(dy_cb), _p(wd), _p(dx[a:b]), _stream()), "conv_x6_dgrad")
             else:
@@ -328,6 +329,7 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.desc, ctx.wd, ctx.relu, ctx.training, ctx.has_res = desc, wd, relu, training, residual is not None
         ctx.has_bias = conv_bias is not None
         ctx.save_for_backward(x, z, y, mean, rstd, gamma)
+        ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the non-differentiable split companion
         if y_cb is not None:
             ctx.mark_non_differentiable(y_cb)
         return y, y_cb
@@ -335,6 +337,8 @@ class _ConvBNAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dcb=None):
         L = lib()
+        if dy is None:
+            return (None,) * 16
         x, z, y, mean, rstd, gamma = ctx.saved_tensors
         desc = ctx.desc
         dy = _req(dy, "grad_output")
