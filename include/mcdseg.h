@@ -75,9 +75,11 @@ int mcdseg_conv_x6_fprop_affine(const mcdseg_conv_desc* d, const float* x, const
                                 void* stream);
 int mcdseg_conv_x6_dgrad(const mcdseg_conv_desc* d, const float* dy, const void* dy_cb, const void* wp_dgrad, float* dx,
                          void* stream);
-/* same workspace as mcdseg_conv_wgrad; 128x128-tile layers run on the split path, thin layers on the f32 kernels */
-int mcdseg_conv_x6_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw,
-                         void* workspace, size_t workspace_bytes, void* stream);
+/* same workspace as mcdseg_conv_wgrad; 128x128-tile layers run on the split path, thin layers on the f32 kernels.
+ * x_cb / dy_cb (may be NULL; used only when BOTH are given): the pre-split companions of x and dy in the layout above --
+ * the kernel then transposes 8x8 bf16 blocks in registers instead of splitting fp32 values.  x and dy stay mandatory. */
+int mcdseg_conv_x6_wgrad(const mcdseg_conv_desc* d, const float* x, const void* x_cb, const float* dy, const void* dy_cb,
+                         float* dw, void* workspace, size_t workspace_bytes, void* stream);
 /* dw = x (*) dy ; split over pixels into slabs in `workspace`, then reduced in a fixed order. */
 size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d);
 int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw,

@@ -384,19 +384,22 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 
 int mcdseg_internal_wgrad_x6_launch(const mcdseg_conv_desc* d, const float* x, const float* dy, float* slab, int co_p, int ci_p,
                                     int chunk, int chunks_per_img, int splits, hipStream_t st);
+int mcdseg_internal_wgrad_x6_cb_launch(const mcdseg_conv_desc* d, const void* x_cb, const void* dy_cb, float* slab, int co_p,
+                                       int ci_p, int chunks_per_img, int splits, hipStream_t st);
 
 static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
-                      int x6, void* stream);
+                      int x6, const void* x_cb, const void* dy_cb, void* stream);
 
 extern "C" int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,
                                  size_t workspace_bytes, void* stream) {
-  return wgrad_impl(d, x, dy, dw, workspace, workspace_bytes, 0, stream);
+  return wgrad_impl(d, x, dy, dw, workspace, workspace_bytes, 0, nullptr, nullptr, stream);
 }
 
-// bf16x6 arithmetic on the 128x128-tile plan (thin layers fall through to the f32 kernels)
-extern "C" int mcdseg_conv_x6_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
-  return wgrad_impl(d, x, dy, dw, workspace, workspace_bytes, 1, stream);
+// bf16x6 arithmetic on the 128x128-tile plan (thin layers fall through to the f32 kernels); with BOTH pre-split
+// companions the 128x128 plan reads them instead of the fp32 tensors
+extern "C" int mcdseg_conv_x6_wgrad(const mcdseg_conv_desc* d, const float* x, const void* x_cb, const float* dy, const void* dy_cb,
+                                    float* dw, void* workspace, size_t workspace_bytes, void* stream) {
+  return wgrad_impl(d, x, dy, dw, workspace, workspace_bytes, 1, x_cb, dy_cb, stream);
 }
 
 extern "C" size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d) {
@@ -405,7 +408,7 @@ extern "C" size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d) {
 }
 
 static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
-                      int x6, void* stream) {
+                      int x6, const void* x_cb, const void* dy_cb, void* stream) {
   MCD_REQUIRE(d && x && dy && dw && workspace, "conv_wgrad: null pointer");
   MCD_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0, "conv_wgrad: bad dims");
   MCD_REQUIRE(((int64_t)d->N * d->Cin + 128) * d->H * d->W * 4 < (1ll << 31) && ((int64_t)d->N * d->Cout + 128) * d->Ho * d->Wo * 4 < (1ll << 31),
@@ -439,7 +442,10 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
     MCD_LAUNCH_CHECK("conv_wgrad_thin_reduce");
     return 0;
   }
-  if (pl.cfg == 0 && x6) {
+  if (pl.cfg == 0 && x6 && x_cb && dy_cb && (d->Cin & 7) == 0 && (d->Cout & 7) == 0) {
+    if (int rc = mcdseg_internal_wgrad_x6_cb_launch(d, x_cb, dy_cb, (float*)workspace, pl.co_p, pl.ci_p, pl.chunks_per_img, pl.splits, st))
+      return rc;
+  } else if (pl.cfg == 0 && x6) {
     if (int rc = mcdseg_internal_wgrad_x6_launch(d, x, dy, (float*)workspace, pl.co_p, pl.ci_p, pl.chunk, pl.chunks_per_img, pl.splits, st))
       return rc;
   } else if (pl.cfg == 0)

@@ -183,6 +183,200 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(WgradX6Params p) 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pre-split variant: both operands arrive in the channel-blocked bf16x3 layout their producers wrote
+// ([piece 3][N][C/8][H*W][8 bf16]: mcdseg_bn_bwd_apply_cb for dY, mcdseg_bn_apply_cb for X).  One 16-B load is
+// 8 channels of one pixel; the MFMA wants 8 pixels of one channel per lane, so a thread loads the same 8-channel
+// group at 8 pixels and transposes the 8x8 block of 16-bit values in registers (32 v_perm_b32) -- 0.5 VALU per value
+// instead of ~11 for splitting an fp32 value, and no conversion at all.
+//
+// A K "super-step" is one 8 x 4 pixel tile of the output image (two K=16 MFMA depths).  The four lanes of a quad
+// take four consecutive pixels (64 contiguous bytes), and a thread's 8 in-lane k slots are j -> (row j&3,
+// column ps + 4*(j>>2)) of the tile; which pixel sits in which k slot is irrelevant as long as dY and X agree, and
+// X simply adds the tap's shift to every address.  Everything about a load except the quad-lane column is
+// wave-uniform: a wave stages one (operand, piece), the tile and tap offsets go into the SGPR offset, rows that fall
+// into the padding get an out-of-range SGPR offset, columns an out-of-range VGPR offset (hardware returns 0).
+//
+// LDS image per operand [piece 3][k-octet 4][position 128][16 B] with position = c*16 + cg for channel cg*8 + c of
+// the tile: transposed rows are written 16 B per lane with consecutive cg (conflict-free) and MFMA lane i reads
+// position blockbase + i (conflict-free); the position -> channel permutation is undone when the slab is stored.
+// Octet planes are padded by 32 B so the four quad lanes (four planes) of a write hit different banks.
+// One LDS stage (48.75 KB), two workgroups per CU: one transposes/writes while the other multiplies.
+struct WgradCbParams {
+  const void* x_cb;
+  const void* dy_cb;
+  float* slab;
+  int N, Cin, H, W, Cout, Ho, Wo;
+  int KH, KW, stride, pad, dil;
+  int co_p, ci_p;
+  int tiles_x, tiles_y, tiles_per_chunk, chunks_per_img, splits;
+  int x_cb_bytes, dy_cb_bytes;
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x6_cb_kernel(WgradCbParams p) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int WM = 2, WN = 2, WAVES_N = 2;
+  constexpr int PLANE = 130;               // 16-B units per k-octet plane (128 positions + 2 pad)
+  constexpr int PIECE = 4 * PLANE;         // four octets per super-step
+  constexpr int OP_BYTES = 3 * PIECE * 16; // one operand
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * OP_BYTES];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int ci_tiles = p.ci_p / BN;
+  const int co_tiles = p.co_p / BM;
+  const int T_ = p.KH * p.KW;
+  const int per_split = co_tiles * ci_tiles * T_;
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int split = (slot / per_split) * 8 + xcd;
+  if (split >= p.splits) return;
+  int rem = slot % per_split;
+  const int tap = rem % T_;
+  rem /= T_;
+  const int tile_ci = rem % ci_tiles;
+  const int tile_co = rem / ci_tiles;
+  const int n = split / p.chunks_per_img;
+  const int chunk_id = split - n * p.chunks_per_img;
+  const int ky = tap / p.KW;
+  const int kx = tap - ky * p.KW;
+  const int ntiles = p.tiles_x * p.tiles_y;
+  const int t_begin = chunk_id * p.tiles_per_chunk;
+  int t_end = t_begin + p.tiles_per_chunk;
+  if (t_end > ntiles) t_end = ntiles;
+
+  // ---- staging role of this wave: operand (0 = dY rows, 1 = X rows) and piece are wave-uniform
+  const int opnd = wave & 1;
+  const int pieceA = wave >> 1;  // first unit: piece 0 or 1; the piece-2 unit alternates between the wave pairs
+  const int ps = lane & 3;
+  const int cg = lane >> 2;
+  // source geometry of the staged operand: X is gathered through the conv geometry, dY is its own output grid
+  const int sH = opnd ? p.H : p.Ho;
+  const int sW = opnd ? p.W : p.Wo;
+  const int sS = opnd ? p.stride : 1;
+  const int shy = opnd ? ky * p.dil - p.pad : 0;
+  const int shx = opnd ? kx * p.dil - p.pad : 0;
+  const int sC8 = (opnd ? p.Cin : p.Cout) >> 3;
+  const int ctile = opnd ? tile_ci : tile_co;
+  const int sHW = sH * sW;
+  const int pstride = p.N * sC8 * sHW;  // 16-B units between pieces
+  // the descriptor starts `bias` bytes below the tensor so that the SGPR offset (tile + tap shift) is never negative
+  const int bias = p.pad * 16 + 16;
+  const char* sptr = (const char*)(opnd ? p.x_cb : p.dy_cb) - bias;
+  const int sbytes = (opnd ? p.x_cb_bytes : p.dy_cb_bytes) + bias;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sptr, 0, sbytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  const unsigned vconst = (ctile * 16 + cg) < sC8 ? (unsigned)(cg * sHW + ps * sS) * 16u : OOB;
+  const int sbase = (n * sC8 + ctile * 16) * sHW;  // 16-B units
+  const int lane_x = ps * sS;
+
+  u32x4 R[2][8];
+  auto issue_loads = [&](int tt, int piece, u32x4 (&dst)[8]) {
+    const int ty = tt / p.tiles_x;
+    const int tx = tt - ty * p.tiles_x;
+    unsigned voff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ux = (tx * 8 + 4 * h) * sS + shx;  // uniform
+      voff[h] = ((unsigned)(ux + lane_x) < (unsigned)sW) ? vconst : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int h = j >> 2;
+      const int iy = (ty * 4 + (j & 3)) * sS + shy;
+      const int ux = (tx * 8 + 4 * h) * sS + shx;
+      const int soff = ((unsigned)iy < (unsigned)sH) ? (piece * pstride + sbase + iy * sW + ux) * 16 + bias : 0x7FFFFFFF;
+      dst[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[h], soff, 0));
+    }
+  };
+  // 8x8 transpose of 16-bit values + eight 16-B LDS writes (one per channel of the group)
+  auto transpose_store = [&](int piece, const u32x4 (&src)[8]) {
+    unsigned char* base = smem + opnd * OP_BYTES + ((piece * 4 + ps) * PLANE + cg) * 16;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      u32x4 o;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        o[m] = __builtin_amdgcn_perm(src[2 * m + 1][c >> 1], src[2 * m][c >> 1], (c & 1) ? 0x07060302u : 0x05040100u);
+      *reinterpret_cast<u32x4*>(base + c * 16 * 16) = o;
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nsteps = t_end - t_begin;
+  if (nsteps > 0) {
+    issue_loads(t_begin, pieceA, R[0]);
+    if ((wave >> 1) == 0) issue_loads(t_begin, 2, R[1]);
+  }
+  for (int s = 0; s < nsteps; ++s) {
+    const bool extra = (wave >> 1) == (s & 1);  // this wave pair also stages piece 2 of the step
+    if (s > 0) __syncthreads();                 // all fragment reads of the previous step are done
+    transpose_store(pieceA, R[0]);
+    if (extra) transpose_store(2, R[1]);
+    if (s + 1 < nsteps) {
+      issue_loads(t_begin + s + 1, pieceA, R[0]);
+      if ((wave >> 1) == ((s + 1) & 1)) issue_loads(t_begin + s + 1, 2, R[1]);
+    }
+    __syncthreads();
+    const unsigned char* a_base = smem + (lh * PLANE + wm * 64 + l31) * 16;
+    const unsigned char* b_base = smem + OP_BYTES + (lh * PLANE + wn * 64 + l31) * 16;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 a[3][WM], b[3][WN];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          a[pc][i] = *reinterpret_cast<const bf16x8*>(a_base + (pc * PIECE + 2 * kk * PLANE + i * 32) * 16);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          b[pc][j] = *reinterpret_cast<const bf16x8*>(b_base + (pc * PIECE + 2 * kk * PLANE + j * 32) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // position -> channel: pos = c*16 + cg  <->  channel cg*8 + c
+  float* out = p.slab + ((size_t)split * T_ + tap) * p.co_p * p.ci_p;
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pa = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int row = tile_co * BM + (pa & 15) * 8 + (pa >> 4);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int pb = wn * 64 + j * 32 + l31;
+        const int col = tile_ci * BN + (pb & 15) * 8 + (pb >> 4);
+        out[(size_t)row * p.ci_p + col] = acc[i][j][r];
+      }
+    }
+}
+
 }  // namespace
 
 // launched by mcdseg_conv_wgrad (conv_wgrad.hip) when the 128x128 plan applies and bf16x6 math is requested
@@ -203,5 +397,35 @@ int mcdseg_internal_wgrad_x6_launch(const mcdseg_conv_desc* d, const float* x, c
   }
   hipLaunchKernelGGL(conv_wgrad_x6_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
   MCD_LAUNCH_CHECK("conv_wgrad_x6");
+  return 0;
+}
+
+// pre-split operands (see conv_wgrad_x6_cb_kernel); chunks_per_img / splits come from the shared plan, the pixel range
+// of a chunk is expressed in 8x4 output tiles
+int mcdseg_internal_wgrad_x6_cb_launch(const mcdseg_conv_desc* d, const void* x_cb, const void* dy_cb, float* slab, int co_p,
+                                       int ci_p, int chunks_per_img, int splits, hipStream_t st) {
+  WgradCbParams p;
+  p.x_cb = x_cb; p.dy_cb = dy_cb; p.slab = slab;
+  p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+  p.co_p = co_p; p.ci_p = ci_p; p.chunks_per_img = chunks_per_img; p.splits = splits;
+  p.tiles_x = ceil_div(d->Wo, 8);
+  p.tiles_y = ceil_div(d->Ho, 4);
+  p.tiles_per_chunk = ceil_div(p.tiles_x * p.tiles_y, chunks_per_img);
+  const int64_t xb = (int64_t)3 * d->N * d->Cin * d->H * d->W * 2, yb = (int64_t)3 * d->N * d->Cout * d->Ho * d->Wo * 2;
+  if ((d->Cin & 7) || (d->Cout & 7) || xb + 4096 >= (1ll << 31) || yb + 4096 >= (1ll << 31) || d->pad > 128) {
+    mcdseg_set_error("conv_wgrad_x6: pre-split operands need channel counts divisible by 8 and < 2 GiB per operand");
+    return -22;
+  }
+  p.x_cb_bytes = (int)xb;
+  p.dy_cb_bytes = (int)yb;
+  const int64_t per_split = (int64_t)(co_p / 128) * (ci_p / 128) * d->KH * d->KW;
+  const int64_t nwg = 8 * ceil_div64(splits, 8) * per_split;
+  if (nwg >= (1ll << 31)) {
+    mcdseg_set_error("conv_wgrad_x6: grid too large");
+    return -22;
+  }
+  hipLaunchKernelGGL(conv_wgrad_x6_cb_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
+  MCD_LAUNCH_CHECK("conv_wgrad_x6_cb");
   return 0;
 }

@@ -41,7 +41,7 @@ _SIGNATURES = {
     "mcdseg_conv_x6_dgrad": (c_int, [_P(ConvDesc)] + [c_void_p] * 5),
     "mcdseg_bn_apply_cb": (c_int, [c_void_p] * 8 + [c_i32] * 4 + [c_void_p]),
     "mcdseg_bn_bwd_apply_cb": (c_int, [c_void_p] * 11 + [c_i32] * 5 + [c_void_p]),
-    "mcdseg_conv_x6_wgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mcdseg_conv_x6_wgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mcdseg_conv_dgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcdseg_conv_wgrad_workspace_bytes": (c_size_t, [_P(ConvDesc)]),
     "mcdseg_conv_wgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

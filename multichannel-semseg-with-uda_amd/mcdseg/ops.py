@@ -235,18 +235,26 @@ def _cb_alloc(n, c, hw, device):
     return torch.empty(3 * n * c * hw, dtype=torch.bfloat16, device=device)
 
 
-def _conv_wgrad(desc, x, dy):
+def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None):
     L = lib()
     total = None
-    for a, b in _batch_pieces(desc):
+    pieces = _batch_pieces(desc)
+    if len(pieces) > 1 or x_cb is None or dy_cb is None:
+        x_cb = dy_cb = None  # the piece-major split layout cannot be sliced along N; both companions or none
+    for a, b in pieces:
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
         ws = _ws(L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(d)), x.device)
         dw = torch.empty((desc.Cout, desc.Cin, desc.KH, desc.KW), dtype=torch.float32, device=x.device)
         x6 = CONV_MATH == "bf16x6" and min(desc.Cout, desc.Cin) > 64 and not (desc.Cin <= 16 and desc.KH * desc.KW > 1)
-        fn = L.mcdseg_conv_x6_wgrad if x6 else L.mcdseg_conv_wgrad
-        with _timed("conv_wgrad_x6_kernel" if x6 else wgrad_kernel_name(desc.Cout, desc.Cin, desc.KH * desc.KW), conv_work(d)):
-            check(fn(ctypes.byref(d), _p(x[a:b]), _p(dy[a:b]), _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4),
-                                      _stream()), "conv_wgrad")
+        name = ("conv_wgrad_x6_cb_kernel" if x_cb is not None else "conv_wgrad_x6_kernel") if x6 else \
+            wgrad_kernel_name(desc.Cout, desc.Cin, desc.KH * desc.KW)
+        with _timed(name, conv_work(d)):
+            if x6:
+                check(L.mcdseg_conv_x6_wgrad(ctypes.byref(d), _p(x[a:b]), _p(x_cb), _p(dy[a:b]), _p(dy_cb), _p(dw), _p(ws),
+                                             ctypes.c_size_t(ws.numel() * 4), _stream()), "conv_x6_wgrad")
+            else:
+                check(L.mcdseg_conv_wgrad(ctypes.byref(d), _p(x[a:b]), _p(dy[a:b]), _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4),
+                                          _stream()), "conv_wgrad")
         total = dw if total is None else total.add_(dw)
     return total
 
@@ -264,14 +272,15 @@ def _side_stream(device):
     return _SIDE[key]
 
 
-def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None):
+def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None):
     if not (need_dx and need_dw and OVERLAP_WGRAD):
-        return (_conv_dgrad(desc, dy, wd, dy_cb) if need_dx else None), (_conv_wgrad(desc, x, dy) if need_dw else None)
+        return ((_conv_dgrad(desc, dy, wd, dy_cb) if need_dx else None),
+                (_conv_wgrad(desc, x, dy, x_cb, dy_cb) if need_dw else None))
     main = torch.cuda.current_stream()
     side = _side_stream(dy.device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        dw = _conv_wgrad(desc, x, dy)
+        dw = _conv_wgrad(desc, x, dy, x_cb, dy_cb)
     dx = _conv_dgrad(desc, dy, wd, dy_cb)
     main.wait_stream(side)
     dw.record_stream(main)
@@ -328,6 +337,7 @@ class _ConvBNAct(torch.autograd.Function):
                                     _stream()), "bn_apply")
         ctx.desc, ctx.wd, ctx.relu, ctx.training, ctx.has_res = desc, wd, relu, training, residual is not None
         ctx.has_bias = conv_bias is not None
+        ctx.x_cb = x_cb  # wgrad reads the input's split companion too (an input of this node: safe to hold)
         ctx.save_for_backward(x, z, y, mean, rstd, gamma)
         ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the non-differentiable split companion
         if y_cb is not None:
@@ -351,13 +361,14 @@ class _ConvBNAct(torch.autograd.Function):
         dz_cb = None
         bwd_args = (_p(dy), _p(y) if ctx.relu else None, _p(z), _p(mean), _p(rstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dz),
                     _p(dres) if (dres is not None and ctx.relu) else None)
-        if ctx.needs_input_grad[0] and ctx.wd.dtype == torch.bfloat16 and _cb_wanted(c) and n * (c // 8) <= 65535:
+        want_cb = ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and ctx.x_cb is not None)
+        if want_cb and ctx.wd.dtype == torch.bfloat16 and _cb_wanted(c) and n * (c // 8) <= 65535:
             dz_cb = _cb_alloc(n, c, hw, dy.device)
             check(L.mcdseg_bn_bwd_apply_cb(*bwd_args, _p(dz_cb), n, c, hw, int(ctx.relu), int(ctx.training), _stream()),
                   "bn_bwd_apply_cb")
         else:
             check(L.mcdseg_bn_bwd_apply(*bwd_args, n, c, hw, int(ctx.relu), int(ctx.training), _stream()), "bn_bwd_apply")
-        dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz_cb)
+        dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz_cb, ctx.x_cb)
         dbias = None
         if ctx.has_bias and ctx.needs_input_grad[5]:
             # a bias in front of train-mode BN has zero gradient up to rounding (BN removes the channel mean);

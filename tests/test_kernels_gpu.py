@@ -481,3 +481,50 @@ def test_presplit_operands_are_bitwise_equivalent(monkeypatch):
     a, b = run(True), run(False)
     for name, u, v in zip(["y1", "y2", "y3", "dx", "dw1", "dw2", "dw3"], a, b):
         assert torch.equal(u, v), "%s differs between pre-split and in-loop split (max %.3e)" % (name, float((u - v).abs().max()))
+
+
+def _split_cb(t):
+    """fp32 NCHW -> the channel-blocked bf16x3 companion [piece 3][N][C/8][H*W][8] (what bn_apply_cb writes)"""
+    n, c, h, w = t.shape
+    p1 = t.bfloat16()
+    r = t - p1.float()
+    p2 = r.bfloat16()
+    p3 = (r - p2.float()).bfloat16()
+    cb = torch.stack([p1, p2, p3]).reshape(3, n, c // 8, 8, h * w).permute(0, 1, 2, 4, 3).contiguous()
+    return cb.reshape(-1)
+
+
+# (Cin, Cout, k, stride, dil, H, W, N): 128x128-plan layers only (min(C) > 64, C % 8 == 0)
+WGRAD_CB_CASES = [
+    (128, 128, 3, 1, 1, 12, 16, 2),   # whole 8x4 tiles
+    (136, 200, 3, 1, 2, 13, 19, 2),   # ragged tiles, channel counts that are not tile multiples
+    (256, 128, 3, 1, 4, 9, 10, 1),    # dilation 4: most taps of the border tiles fall into the padding
+    (128, 256, 1, 1, 1, 11, 13, 2),   # 1x1
+    (128, 128, 3, 2, 1, 15, 17, 2),   # stride 2
+    (72, 80, 3, 1, 1, 8, 8, 3),
+    (512, 512, 3, 1, 4, 30, 40, 2),   # layer6 at 240x320: several workgroups per image along the pixels
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", WGRAD_CB_CASES, ids=lambda c: "x".join(map(str, c[:7])))
+def test_conv_wgrad_presplit_operands(case, monkeypatch):
+    """weight gradient from the pre-split companions (8x8 register transposes) = the in-loop split kernel = fp64"""
+    dev = _dev()
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "CONV_MATH", "bf16x6")
+    cin, cout, k, s, d, h, w, n = case
+    x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, s, d, h, w, n, False), 23)
+    desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
+    x64, w64 = x.double(), wt.double().requires_grad_()
+    ref = F.conv2d(x64, w64, None, stride=s, padding=pad, dilation=d)
+    gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(24))
+    (gw_ref,) = torch.autograd.grad(ref, [w64], gy.double())
+    xg, gyg = x.to(dev), gy.to(dev)
+    dw_loop = ops._conv_wgrad(desc, xg, gyg)
+    dw_cb = ops._conv_wgrad(desc, xg, gyg, _split_cb(xg), _split_cb(gyg))
+    _assert_close(dw_loop, gw_ref, 2e-5, "wgrad (in-loop split)")
+    _assert_close(dw_cb, gw_ref, 2e-5, "wgrad (pre-split operands)")
+    e_loop, e_cb = _maxerr(dw_loop, gw_ref)[0], _maxerr(dw_cb, gw_ref)[0]
+    assert e_cb <= max(2.0 * e_loop, 2e-6 * _maxerr(dw_loop, gw_ref)[1])
+

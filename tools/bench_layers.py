@@ -45,6 +45,16 @@ def timeit(fn, reps):
     return t0.elapsed_time(t1) / reps
 
 
+def split_cb(t):
+    """fp32 NCHW -> [piece 3][N][C/8][H*W][8] bf16 (the layout bn_apply_cb / bn_bwd_apply_cb write)"""
+    n, c, h, w = t.shape
+    p1 = t.bfloat16()
+    r = t - p1.float()
+    p2 = r.bfloat16()
+    p3 = (r - p2.float()).bfloat16()
+    return torch.stack([p1, p2, p3]).reshape(3, n, c // 8, 8, h * w).permute(0, 1, 2, 4, 3).contiguous().reshape(-1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
@@ -72,10 +82,18 @@ def main():
         tf = timeit(lambda: ops._conv_fprop(desc, x, wf, None, True, mpf), args.reps)
         td = timeit(lambda: ops._conv_dgrad(desc, gy, wd), args.reps)
         tw = timeit(lambda: ops._conv_wgrad(desc, x, gy), args.reps)
+        extra = ""
+        if ops.CONV_MATH == "bf16x6" and min(cin, cout) > 64 and cin % 8 == 0 and cout % 8 == 0:
+            x_cb, gy_cb = split_cb(x), split_cb(gy)
+            tf2 = timeit(lambda: ops._conv_fprop(desc, x, wf, None, True, mpf, x_cb), args.reps)
+            td2 = timeit(lambda: ops._conv_dgrad(desc, gy, wd, gy_cb), args.reps)
+            tw2 = timeit(lambda: ops._conv_wgrad(desc, x, gy, x_cb, gy_cb), args.reps)
+            extra = " | pre-split: fprop %.3f ms %.1f TF, dgrad %.3f ms %.1f TF, wgrad %.3f ms %.1f TF" % (
+                tf2, gf / tf2, td2, gf / td2, tw2, gf / tw2)
         tot["fprop"] += tf * cnt
         tot["dgrad"] += td * cnt
         tot["wgrad"] += tw * cnt
-        print("%-18s %8.1f | %9.3f %7.1f | %9.3f %7.1f | %9.3f %7.1f" % (name, gf, tf, gf / tf, td, gf / td, tw, gf / tw))
+        print("%-18s %8.1f | %9.3f %7.1f | %9.3f %7.1f | %9.3f %7.1f%s" % (name, gf, tf, gf / tf, td, gf / td, tw, gf / tw, extra))
     print("per pass (weighted by layer count): fprop %.1f ms  dgrad %.1f ms  wgrad %.1f ms" % (tot["fprop"], tot["dgrad"], tot["wgrad"]))
     if not args.only:
         # streaming kernels
