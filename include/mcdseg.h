@@ -183,6 +183,20 @@ int mcdseg_mse(const float* pred, const float* target, float* grad, float* loss,
                void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Either side of the step: input transform and evaluation histogram
+ *   normalize_u8:   ToTensor() + Normalize(mean,std) (transform.py:302-315): src uint8 [N,H,W,Cs] (HWC) ->
+ *                   dst fp32 [N,C,H,W], channels [c_off, c_off+Cs): ((u/255) - mean[c]) / std[c], IEEE division.
+ *                   mean / std: device arrays of Cs floats.  RGB and HHA = two calls with c_off 0 and 3.
+ *   relabel_u8:     ToLabel() + ReLabel(olabel -> nlabel) (transform.py:21-48, 319-325): uint8 -> int64
+ *   confusion_hist: fast_hist (eval.py:21-23): hist[n*gt + pred] += 1 for 0 <= gt < n (pred outside [0,n) is
+ *                   skipped, where numpy would fail on the reshape); hist is int64 [n*n], ACCUMULATED into.
+ * ---------------------------------------------------------------------------------------------- */
+int mcdseg_normalize_u8(const uint8_t* src, float* dst, const float* mean, const float* std, int32_t N, int32_t H, int32_t W,
+                        int32_t Cs, int32_t C, int32_t c_off, void* stream);
+int mcdseg_relabel_u8(const uint8_t* src, int64_t* dst, int64_t count, int32_t olabel, int32_t nlabel, void* stream);
+int mcdseg_confusion_hist(const int64_t* gt, const int64_t* pred, int64_t count, int32_t n, int64_t* hist, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * SGD with momentum + weight decay on flat buffers (torch.optim.SGD via models/model_util.py:289-292)
  *   d = g*grad_scale + wd*p ; v = mu*v + d ; p -= lr*v        (v starts at 0, so the first v = d)
  * ---------------------------------------------------------------------------------------------- */

@@ -49,7 +49,7 @@ def main(argv=None):
         checkpoint = load_checkpoint(args.resume)
         start_epoch = checkpoint["epoch"]
         args = checkpoint["args"]
-        for k in ("synthetic", "synthetic_len", "seed", "no_pretrained", "solver", "no_tflog", "method_detail"):
+        for k in ("synthetic", "synthetic_raw", "synthetic_len", "seed", "no_pretrained", "solver", "no_tflog", "method_detail"):
             if k not in vars(args):
                 setattr(args, k, getattr(cli, k))
         detailed_method = args.method_detail
@@ -105,9 +105,9 @@ def main(argv=None):
         c_loss_per_epoch = 0.0
         it = enumerate(train_loader)
         for ind, (source, target) in (tqdm.tqdm(it) if run.is_main else it):
-            src_imgs = source[0].to(run.device, non_blocking=True)
-            src_lbls = source[1].to(run.device, non_blocking=True)
-            tgt_imgs = target[0].to(run.device, non_blocking=True)
+            src_imgs = run.images(source[0])
+            src_lbls = run.labels(source[1])
+            tgt_imgs = run.images(target[0])
             c_loss, d_loss = solver.step(src_imgs, src_lbls, tgt_imgs)
             c_loss, d_loss = float(c_loss), float(d_loss)
             c_loss_per_epoch += c_loss

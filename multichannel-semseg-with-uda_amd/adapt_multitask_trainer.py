@@ -50,7 +50,7 @@ def main(argv=None):
         checkpoint = load_checkpoint(args.resume)
         start_epoch = checkpoint["epoch"]
         args = checkpoint["args"]
-        for k in ("synthetic", "synthetic_len", "seed", "no_pretrained", "solver", "no_tflog"):
+        for k in ("synthetic", "synthetic_raw", "synthetic_len", "seed", "no_pretrained", "solver", "no_tflog"):
             if k not in vars(args):
                 setattr(args, k, getattr(cli, k))
         criterion, criterion_d = criteria(args)
@@ -92,9 +92,9 @@ def main(argv=None):
         sums = dict(c=0.0, d=0.0, seg=0.0, sdep=0.0, tdep=0.0)
         it = enumerate(train_loader)
         for ind, (source, target) in (tqdm.tqdm(it) if run.is_main else it):
-            src_imgs = source[0].to(run.device, non_blocking=True)
-            src_gt = source[1].to(run.device, non_blocking=True)
-            tgt_imgs = target[0].to(run.device, non_blocking=True)
+            src_imgs = run.images(source[0])
+            src_gt = run.labels(source[1])
+            tgt_imgs = run.images(target[0])
             c_loss, d_loss, parts = solver.step(src_imgs, src_gt, tgt_imgs)
             c_loss, d_loss = float(c_loss), float(d_loss)
             sums["c"] += c_loss

@@ -20,6 +20,7 @@ from datasets import get_dataset
 from models.model_util import get_models
 from util import check_if_done, load_checkpoint, mkdir_if_not_exist, save_dic_to_json
 from mcdseg import ops
+from eval import ConfusionMeter
 
 
 def main(argv=None):
@@ -65,14 +66,20 @@ def main(argv=None):
     label_outdir = os.path.join(base_outdir, "label")
     mkdir_if_not_exist(label_outdir)
     total_ent, batches = 0.0, 0
+    # the reference shells out to eval.py over the written PNGs (util.py:36-41); here the confusion matrix is accumulated
+    # on the device while the label maps are still there (background = 255 in label PNGs, n_class-1 in training labels)
+    meter = ConfusionMeter(train_args.n_class, background_id=255, device=dev)
     with torch.no_grad():
-        for imgs, _, paths in loader:
+        for imgs, gts, paths in loader:
             feature = G(imgs.to(dev, non_blocking=True))
             out1 = F1(feature)
             out2 = F2(feature) if args.use_f2 else None
             labels, ent = ops.predict_labels(out1, out2, n_used)
             total_ent += float(ent)
             batches += 1
+            if torch.is_tensor(gts) and gts.dim() == 3 and tuple(gts.shape) == tuple(labels.shape):
+                gts = gts.to(dev)
+                meter.update(labels, torch.where(gts == train_args.n_class - 1, torch.full_like(gts, 255), gts))
             if args.saves_prob:
                 prob_outdir = os.path.join(base_outdir, "prob")
                 mkdir_if_not_exist(prob_outdir)
@@ -87,6 +94,10 @@ def main(argv=None):
     print("average entropy: %s" % ave_ent)
     with open(os.path.join(base_outdir, "ave_ent_%s.txt" % ave_ent), "w") as f:
         f.write(str(ave_ent))
+    if int(meter.hist.sum()) > 0:
+        summary = meter.summary()
+        save_dic_to_json(summary, os.path.join(base_outdir, "eval_result.json"), verbose=False)
+        print("pixAcc %.2f  mAcc %.2f  fwIoU %.2f  mIoU %.2f" % (summary["pixAcc"], summary["mAcc"], summary["fwIoU"], summary["mIoU"]))
     return label_outdir, ave_ent
 
 

@@ -79,7 +79,7 @@ def main(argv=None):
         start_epoch = checkpoint["epoch"]
         args = checkpoint["args"]  # the pickled namespace replaces the CLI one (adapt_trainer.py:40-43)
         args.savename = infn.split("-")[0] if "savename" not in vars(args) else args.savename
-        for k in ("synthetic", "synthetic_len", "seed", "no_pretrained", "solver", "no_tflog"):
+        for k in ("synthetic", "synthetic_raw", "synthetic_len", "seed", "no_pretrained", "solver", "no_tflog"):
             if k not in vars(args):
                 setattr(args, k, getattr(cli, k))
         model_g, model_f1, model_f2, optimizer_g, optimizer_f = build(args)
@@ -141,9 +141,9 @@ def main(argv=None):
         c_loss_per_epoch = 0.0
         it = enumerate(train_loader)
         for ind, (source, target) in (tqdm.tqdm(it) if run.is_main else it):
-            src_imgs = source[0].to(run.device, non_blocking=True)
-            src_lbls = source[1].to(run.device, non_blocking=True)
-            tgt_imgs = target[0].to(run.device, non_blocking=True)
+            src_imgs = run.images(source[0])
+            src_lbls = run.labels(source[1])
+            tgt_imgs = run.images(target[0])
             if solver is not None:
                 c_loss, d_loss = solver.step(src_imgs, src_lbls, tgt_imgs)
             else:

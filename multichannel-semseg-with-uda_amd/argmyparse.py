@@ -30,6 +30,8 @@ def add_mi355x_flags(parser):
     g = parser.add_argument_group("MI355X build")
     g.add_argument("--synthetic", action="store_true", help="seeded synthetic RGB+HHA batches instead of on-disk datasets")
     g.add_argument("--synthetic_len", type=int, default=64, help="samples per synthetic dataset")
+    g.add_argument("--synthetic_raw", action="store_true",
+                   help="synthetic uint8 HWC images + uint8 labels (background 255): ToTensor/Normalize/ReLabel run on the GPU")
     g.add_argument("--seed", type=int, default=1234)
     g.add_argument("--no_pretrained", action="store_true", help="He-normal init instead of ImageNet weights (no network)")
     g.add_argument("--solver", choices=["fused", "dropin"], default="fused",

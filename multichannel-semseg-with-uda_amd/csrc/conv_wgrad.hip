@@ -8,6 +8,7 @@
 // (32 consecutive rows, one pixel) conflict-free.  The pixel axis is split over workgroups
 // (image x chunk); every workgroup writes its partial D tile to a slab and a second kernel sums the
 // slabs in a fixed order (fp64 accumulate) -- deterministic, no float atomics.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -56,7 +57,11 @@ WgradPlan make_plan(const mcdseg_conv_desc* d) {
   pl.co_p = round_up(d->Cout, pl.bm);
   pl.ci_p = pl.cfg == 3 ? 32 : round_up(d->Cin, pl.bn);
   const int64_t tiles = (int64_t)(pl.co_p / pl.bm) * (pl.ci_p / pl.bn) * pl.groups;
-  const int64_t want_wgs = (pl.cfg >= 2) ? 4096 : 1024;
+  static const int64_t tuned_wgs = [] {
+    const char* e = getenv("MCDSEG_WGRAD_WGS");  // development knob: target workgroup count of the 128/64-tile plans
+    return e ? (int64_t)atoll(e) : (int64_t)1024;
+  }();
+  const int64_t want_wgs = (pl.cfg >= 2) ? 4096 : tuned_wgs;
   const int64_t want_splits = ceil_div64(want_wgs, tiles);
   const int hw = d->Ho * d->Wo;
   int cpi = (int)ceil_div64(want_splits, d->N);

@@ -31,22 +31,72 @@ class ConcatDataset(data.Dataset):
 
 
 class SyntheticRGBD(data.Dataset):
-    """(image [C,H,W] fp32, label [H,W] int64) generated from (seed, index)."""
+    """(image [C,H,W] fp32, label [H,W] int64) generated from (seed, index).
 
-    def __init__(self, length, input_ch, img_shape_wh, n_class, seed, test=False):
+    ``raw=True`` yields what a loader holds BEFORE the reference's transforms: a uint8 [H,W,C] image (RGB then HHA
+    bytes) and a uint8 label map whose background pixels carry ``background_id`` -- the trainer then runs
+    ToTensor/Normalize/ReLabel on the MI355X (``DeviceInputPipeline``)."""
+
+    def __init__(self, length, input_ch, img_shape_wh, n_class, seed, test=False, raw=False, background_id=255):
         self.length, self.ch, self.n_class, self.seed, self.test = length, input_ch, n_class, seed, test
         self.w, self.h = int(img_shape_wh[0]), int(img_shape_wh[1])
+        self.raw, self.background_id = raw, background_id
 
     def __len__(self):
         return self.length
 
     def __getitem__(self, i):
         g = torch.Generator().manual_seed(self.seed * 1000003 + i)
-        img = torch.randn(self.ch, self.h, self.w, generator=g)
-        lbl = torch.randint(0, self.n_class, (self.h, self.w), generator=g, dtype=torch.int64)
+        if self.raw:
+            img = torch.randint(0, 256, (self.h, self.w, self.ch), generator=g, dtype=torch.uint8)
+            lbl = torch.randint(0, self.n_class, (self.h, self.w), generator=g, dtype=torch.int64)
+            lbl = torch.where(lbl == self.n_class - 1, torch.full_like(lbl, self.background_id), lbl).to(torch.uint8)
+        else:
+            img = torch.randn(self.ch, self.h, self.w, generator=g)
+            lbl = torch.randint(0, self.n_class, (self.h, self.w), generator=g, dtype=torch.int64)
         if self.test:
             return img, lbl, "synthetic_%06d.png" % i
         return img, lbl
+
+
+IMAGENET_MEAN = [.485, .456, .406, .485, .485, .485]  # 6-channel RGB+HHA statistics of transform.py:307
+IMAGENET_STD = [.229, .224, .225, .229, .229, .229]
+CITY_MEAN = [0.290101, 0.328081, 0.286964]            # transform.py:311
+CITY_STD = [0.182954, 0.186566, 0.184475]
+
+
+class DeviceInputPipeline(object):
+    """The tensor half of ``get_img_transform`` / ``get_lbl_transform`` (transform.py:302-325) on the GPU: pinned uint8
+    batches go over PCIe as bytes (4x fewer than fp32) and one kernel each does ToTensor+Normalize (HWC->NCHW) and
+    ToLabel+ReLabel(background_id -> n_class-1).  Resizing stays with the loader (PIL), as in the reference."""
+
+    def __init__(self, input_ch, n_class, device, normalize_way="imagenet", background_id=255):
+        from mcdseg import ops
+        self._ops = ops
+        self.input_ch, self.n_class, self.device, self.background_id = input_ch, n_class, device, background_id
+        if normalize_way == "imagenet":
+            mean, std = IMAGENET_MEAN[:input_ch], IMAGENET_STD[:input_ch]
+        elif normalize_way == "city":
+            mean, std = CITY_MEAN[:input_ch], CITY_STD[:input_ch]
+        else:  # "No normalization..." (transform.py:314-315): ToTensor only
+            mean, std = [0.0] * input_ch, [1.0] * input_ch
+        self.mean = torch.tensor(mean, dtype=torch.float32, device=device)
+        self.std = torch.tensor(std, dtype=torch.float32, device=device)
+
+    def images(self, *parts):
+        """one or more uint8 [N,H,W,c_i] tensors (e.g. RGB and HHA) -> fp32 [N, sum c_i, H, W]"""
+        parts = [p.to(self.device, non_blocking=True) for p in parts]
+        n, h, w = parts[0].shape[:3]
+        c = sum(p.shape[3] for p in parts)
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=self.device)
+        off = 0
+        for p in parts:
+            self._ops.normalize_u8_(out, p, self.mean[off:off + p.shape[3]], self.std[off:off + p.shape[3]], c_off=off)
+            off += p.shape[3]
+        return out
+
+    def labels(self, lbl_u8):
+        return self._ops.relabel_u8(lbl_u8.to(self.device, non_blocking=True), self.background_id, self.n_class - 1)
 
 
 def get_dataset(dataset_name, split, img_transform, label_transform, test, input_ch=3, joint_transform=None,
@@ -57,7 +107,8 @@ def get_dataset(dataset_name, split, img_transform, label_transform, test, input
     if synthetic is None:
         raise NotImplementedError("on-disk dataset %r is outside the MI355X hot-path build; run with --synthetic"
                                   % dataset_name)
-    return SyntheticRGBD(synthetic["length"], input_ch, synthetic["img_shape"], synthetic["n_class"], synthetic["seed"], test)
+    return SyntheticRGBD(synthetic["length"], input_ch, synthetic["img_shape"], synthetic["n_class"], synthetic["seed"], test,
+                         raw=synthetic.get("raw", False), background_id=synthetic.get("background_id", 255))
 
 
 def check_src_tgt_ok(src_dataset_name, tgt_dataset_name):

@@ -66,6 +66,9 @@ _SIGNATURES = {
     "mcdseg_bilinear8_bwd": (c_int, [c_void_p, c_void_p] + [c_i32] * 4 + [c_void_p]),
     "mcdseg_mse_workspace_bytes": (c_size_t, [c_i64]),
     "mcdseg_mse": (c_int, [c_void_p] * 4 + [c_i64, c_void_p, c_size_t, c_void_p]),
+    "mcdseg_normalize_u8": (c_int, [c_void_p] * 4 + [c_i32] * 6 + [c_void_p]),
+    "mcdseg_relabel_u8": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_void_p]),
+    "mcdseg_confusion_hist": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p]),
     "mcdseg_scale_by_device_scalar": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "mcdseg_sgd_momentum_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_float, c_void_p]),
 }

@@ -654,6 +654,43 @@ def predict_labels(z1, z2=None, n_used=None):
     return labels, ent.reshape(())
 
 
+def normalize_u8_(dst, src, mean, std, c_off=0):
+    """ToTensor()+Normalize() of transform.py:302-315 on the device: ``src`` uint8 [N,H,W,Cs] (HWC, as PIL/numpy hand it
+    over) is written as fp32 into channels [c_off, c_off+Cs) of ``dst`` [N,C,H,W].  mean/std: fp32 device tensors [Cs]."""
+    src = _req(src, "uint8 image batch", torch.uint8)
+    if src.dim() != 4:
+        raise TypeError("mcdseg: normalize_u8_ takes a uint8 [N,H,W,C] tensor")
+    if dst.dtype != torch.float32 or not dst.is_contiguous() or not dst.is_cuda:
+        raise TypeError("mcdseg: normalize_u8_ writes into a contiguous fp32 GPU tensor")
+    n, h, w, cs = src.shape
+    if tuple(dst.shape[0:1] + dst.shape[2:]) != (n, h, w):
+        raise ValueError("mcdseg: normalize_u8_ shape mismatch %s vs %s" % (tuple(src.shape), tuple(dst.shape)))
+    mean, std = _req(mean.float(), "mean"), _req(std.float(), "std")
+    check(lib().mcdseg_normalize_u8(_p(src), _p(dst), _p(mean), _p(std), n, h, w, cs, dst.shape[1], int(c_off), _stream()),
+          "normalize_u8")
+    return dst
+
+
+def relabel_u8(src, olabel, nlabel):
+    """ToLabel()+ReLabel(olabel, nlabel) (transform.py:21-48): uint8 label maps -> int64 with the background id remapped"""
+    src = _req(src, "uint8 label batch", torch.uint8)
+    out = torch.empty(src.shape, dtype=torch.int64, device=src.device)
+    check(lib().mcdseg_relabel_u8(_p(src), _p(out), src.numel(), int(olabel), int(nlabel), _stream()), "relabel_u8")
+    return out
+
+
+def confusion_hist_(hist, gt, pred):
+    """hist[n*gt + pred] += 1 for 0 <= gt < n (eval.py:21-23 fast_hist); ``hist`` int64 [n,n] on the GPU, accumulated."""
+    gt, pred = _req(gt.long(), "ground truth", torch.int64), _req(pred.long(), "prediction", torch.int64)
+    if gt.numel() != pred.numel():
+        raise ValueError("mcdseg: confusion_hist_ needs as many predictions as labels")
+    if hist.dtype != torch.int64 or not hist.is_cuda or not hist.is_contiguous() or hist.dim() != 2 or hist.shape[0] != hist.shape[1]:
+        raise TypeError("mcdseg: confusion_hist_ accumulates into a contiguous int64 [n,n] GPU tensor")
+    if gt.numel():
+        check(lib().mcdseg_confusion_hist(_p(gt), _p(pred), gt.numel(), hist.shape[0], _p(hist), _stream()), "confusion_hist")
+    return hist
+
+
 def _scale_(g, s):
     check(lib().mcdseg_scale_by_device_scalar(_p(g), _p(s), g.numel(), _stream()), "scale_by_device_scalar")
     return g

@@ -25,7 +25,7 @@ def main(argv=None):
         cli = args
         checkpoint = load_checkpoint(args.resume)
         args = checkpoint["args"]
-        for k in ("synthetic", "synthetic_len", "seed", "no_pretrained", "solver", "no_tflog"):
+        for k in ("synthetic", "synthetic_raw", "synthetic_len", "seed", "no_pretrained", "solver", "no_tflog"):
             if k not in vars(args):
                 setattr(args, k, getattr(cli, k))
         model = get_full_model(net=args.net, res=args.res, n_class=args.n_class, input_ch=args.input_ch)
@@ -65,8 +65,8 @@ def main(argv=None):
         epoch_loss = 0.0
         it = enumerate(train_loader)
         for ind, (images, labels) in (tqdm.tqdm(it) if run.is_main else it):
-            imgs = images.to(run.device, non_blocking=True)
-            lbls = labels.to(run.device, non_blocking=True)
+            imgs = run.images(images)
+            lbls = run.labels(labels)
             optimizer.zero_grad()
             preds = model(imgs)
             loss = criterion(preds, lbls)

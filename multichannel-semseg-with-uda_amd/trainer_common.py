@@ -20,6 +20,26 @@ class Run:
             os.environ["MCDSEG_PRETRAINED"] = "0"
         torch.manual_seed(getattr(args, "seed", 1234))
         self._log = None
+        self._pipe = None
+        self._args = args
+
+    def images(self, t):
+        """batch -> device; raw uint8 HWC batches (``--synthetic_raw``) go through the device input pipeline"""
+        if t.dtype == torch.uint8:
+            return self._pipeline().images(t)
+        return t.to(self.device, non_blocking=True)
+
+    def labels(self, t):
+        if t.dtype == torch.uint8:
+            return self._pipeline().labels(t)
+        return t.to(self.device, non_blocking=True)
+
+    def _pipeline(self):
+        if self._pipe is None:
+            from datasets import DeviceInputPipeline
+            self._pipe = DeviceInputPipeline(self._args.input_ch, self._args.n_class, self.device,
+                                             background_id=getattr(self._args, "background_id", 255))
+        return self._pipe
 
     @property
     def is_main(self):
@@ -66,14 +86,15 @@ class Run:
 
 def synthetic_spec(args, seed_offset, rank):
     shape = [int(x) for x in args.train_img_shape]
-    return dict(length=args.synthetic_len, img_shape=shape, n_class=args.n_class, seed=args.seed + seed_offset + 101 * rank)
+    return dict(length=args.synthetic_len, img_shape=shape, n_class=args.n_class, seed=args.seed + seed_offset + 101 * rank,
+                raw=getattr(args, "synthetic_raw", False), background_id=getattr(args, "background_id", 255))
 
 
 def make_loader(args, run, names_splits):
     """DataLoader over one dataset or a ConcatDataset of (source, target); per-rank shard by seed."""
     sets = []
     for i, (name, split) in enumerate(names_splits):
-        spec = synthetic_spec(args, 7 * i, run.rank) if args.synthetic else None
+        spec = synthetic_spec(args, 7 * i, run.rank) if (args.synthetic or getattr(args, "synthetic_raw", False)) else None
         sets.append(get_dataset(dataset_name=name, split=split, img_transform=None, label_transform=None, test=False,
                                 input_ch=args.input_ch, synthetic=spec))
     ds = sets[0] if len(sets) == 1 else ConcatDataset(*sets)

@@ -528,3 +528,75 @@ def test_conv_wgrad_presplit_operands(case, monkeypatch):
     e_loop, e_cb = _maxerr(dw_loop, gw_ref)[0], _maxerr(dw_cb, gw_ref)[0]
     assert e_cb <= max(2.0 * e_loop, 2e-6 * _maxerr(dw_loop, gw_ref)[1])
 
+
+
+# ------------------------------------------------------------------------------ input pipeline and evaluation kernels
+def _io_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "io_small.npz"))
+
+
+def test_normalize_u8_is_bit_exact():
+    """ToTensor+Normalize on the device = the oracle's fp32 arithmetic, bit for bit, including the two-source (RGB + HHA)
+    form and every byte value"""
+    dev = _dev()
+    from datasets import DeviceInputPipeline
+    from oracle import ref_io
+    rng = np.random.RandomState(6)
+    rgb = rng.randint(0, 256, size=(3, 21, 35, 3)).astype(np.uint8)
+    hha = rng.randint(0, 256, size=(3, 21, 35, 3)).astype(np.uint8)
+    rgb[0, :, :, 0].flat[:256] = np.arange(256, dtype=np.uint8)  # all byte values
+    pipe = DeviceInputPipeline(6, 41, dev)
+    got = pipe.images(torch.from_numpy(rgb), torch.from_numpy(hha))
+    ref = ref_io.normalize_u8(np.concatenate([rgb, hha], axis=3), ref_io.IMAGENET_MEAN6, ref_io.IMAGENET_STD6)
+    assert got.shape == (3, 6, 21, 35) and np.array_equal(got.cpu().numpy(), ref)
+    one = DeviceInputPipeline(1, 41, dev, normalize_way="none").images(torch.from_numpy(rgb[..., :1]))
+    assert np.array_equal(one.cpu().numpy(), ref_io.normalize_u8(rgb[..., :1], [0.0], [1.0]))
+    six = DeviceInputPipeline(6, 41, dev).images(torch.from_numpy(np.concatenate([rgb, hha], axis=3)))  # one 6-channel source
+    assert torch.equal(six, got)
+
+
+def test_relabel_u8_matches_reference_vector():
+    dev = _dev()
+    from mcdseg import ops
+    g = _io_golden()
+    got = ops.relabel_u8(torch.from_numpy(g["lbl_u8"]).to(dev), 255, 40)
+    assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), g["lbl_i64"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_confusion_hist_matches_reference_vector(tag):
+    """fast_hist on the device (LDS bins for n <= 64, global bins above) = the reference's bincount, exactly; the
+    call accumulates, and the summary numbers of the meter equal eval.py's"""
+    dev = _dev()
+    import eval as mc_eval
+    g = _io_golden()
+    n = int(g["n_" + tag])
+    gt, pred = torch.from_numpy(g["gt_" + tag]).to(dev), torch.from_numpy(g["pred_" + tag]).to(dev)
+    hist = mc_eval.fast_hist(gt, pred, n)
+    assert np.array_equal(hist.cpu().numpy(), g["hist_" + tag])
+    mc_eval.fast_hist(gt, pred, n, out=hist)
+    assert np.array_equal(hist.cpu().numpy(), 2 * g["hist_" + tag])
+    meter = mc_eval.ConfusionMeter(n, device=dev)
+    for i in range(gt.shape[0]):
+        meter.update(pred[i], gt[i])
+    s = meter.summary()
+    assert np.allclose(np.array(s["IoU"]) / 100, g["iu_" + tag], rtol=1e-12, equal_nan=True)
+    assert np.isclose(s["fwIoU"] / 100, float(g["fw_" + tag])) and np.isclose(s["pixAcc"] / 100, float(g["pa_" + tag]))
+    assert np.isclose(s["mAcc"] / 100, float(g["ma_" + tag]))
+
+
+def test_confusion_hist_full_size_checksum():
+    """BASELINE-size property: 16 x 480 x 640 label maps -- the matrix sums to the number of non-background pixels, its
+    row sums are the ground-truth class counts, its column sums the prediction counts over those pixels"""
+    dev = _dev()
+    import eval as mc_eval
+    g = torch.Generator().manual_seed(9)
+    gt = torch.randint(0, 41, (16, 480, 640), generator=g)
+    gt[gt == 40] = 255
+    pred = torch.randint(0, 40, (16, 480, 640), generator=g)
+    hist = mc_eval.fast_hist(gt.to(dev), pred.to(dev), 41).cpu()
+    keep = gt != 255
+    assert int(hist.sum()) == int(keep.sum())
+    assert torch.equal(hist.sum(1), torch.bincount(gt[keep], minlength=41))
+    assert torch.equal(hist.sum(0), torch.bincount(pred[keep], minlength=41))

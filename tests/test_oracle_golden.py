@@ -264,3 +264,58 @@ def test_multitask_cfg4(golden):
     assert int(enc.state_dict()["base.0.1.num_batches_tracked"]) == tr["nbt_enc"] == 8
     assert int(sd["semsegcls_dec1.cbr1.bn.num_batches_tracked"]) == tr["nbt_seg"] == 8
     assert int(sd["deprgr_dec.cbr1.bn.num_batches_tracked"]) == tr["nbt_dep"] == 4
+
+
+# ------------------------------------------------------------------------------ either side of the step
+def _io_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "io_small.npz"))
+
+
+def test_eval_metrics_and_label_transform_match_reference_vectors():
+    """oracle/ref_io.py against vectors produced by the reference's eval.py / transform.py (make_golden_io.py)"""
+    from oracle import ref_io
+    g = _io_golden()
+    for tag in "abc":
+        n = int(g["n_" + tag])
+        gt, pred = g["gt_" + tag].astype(np.int64).flatten(), g["pred_" + tag].astype(np.int64).flatten()
+        hist = ref_io.fast_hist(gt, pred, n)
+        assert np.array_equal(hist, g["hist_" + tag])
+        assert hist.sum() == int((gt < n).sum())                      # background (255) pixels are dropped
+        used = np.where(hist.sum(1) != 0)[0]
+        sub = hist[used][:, used].astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            assert np.allclose(ref_io.per_class_iu(sub), g["iu_" + tag], rtol=1e-12, equal_nan=True)
+            assert np.isclose(ref_io.calc_fw_iu(sub), float(g["fw_" + tag]), rtol=1e-12)
+            assert np.isclose(ref_io.calc_pixel_accuracy(sub), float(g["pa_" + tag]), rtol=1e-12)
+            assert np.isclose(ref_io.calc_mean_accuracy(sub), float(g["ma_" + tag]), rtol=1e-12)
+    assert np.array_equal(ref_io.relabel(g["lbl_u8"], 255, 40), g["lbl_i64"])
+
+
+def test_normalize_restatement_is_torch_totensor_normalize_arithmetic():
+    """torchvision is absent, so ToTensor()+Normalize() are pinned to their published arithmetic executed by torch itself:
+    byte -> float -> div(255), then sub_(mean).div_(std) per channel, all in fp32."""
+    from oracle import ref_io
+    rng = np.random.RandomState(5)
+    img = rng.randint(0, 256, size=(2, 9, 11, 6)).astype(np.uint8)
+    img[0, 0, 0] = [0, 255, 1, 254, 127, 128]
+    got = ref_io.normalize_u8(img, ref_io.IMAGENET_MEAN6, ref_io.IMAGENET_STD6)
+    t = torch.from_numpy(img).permute(0, 3, 1, 2).contiguous().float().div(255)
+    mean = torch.tensor(ref_io.IMAGENET_MEAN6, dtype=torch.float32).view(1, -1, 1, 1)
+    std = torch.tensor(ref_io.IMAGENET_STD6, dtype=torch.float32).view(1, -1, 1, 1)
+    t.sub_(mean).div_(std)
+    assert got.dtype == np.float32 and np.array_equal(got, t.numpy())
+
+
+def test_host_metrics_module_matches_reference_vectors():
+    """the product's eval.py (host formulas on the n x n matrix) against the same vectors"""
+    import eval as mc_eval
+    g = _io_golden()
+    for tag in "abc":
+        hist = g["hist_" + tag]
+        used = np.where(hist.sum(1) != 0)[0]
+        sub = hist[used][:, used]
+        assert np.allclose(mc_eval.per_class_iu(sub), g["iu_" + tag], rtol=1e-12, equal_nan=True)
+        assert np.isclose(mc_eval.calc_fw_iu(sub), float(g["fw_" + tag]), rtol=1e-12)
+        assert np.isclose(mc_eval.calc_pixel_accuracy(sub), float(g["pa_" + tag]), rtol=1e-12)
+        assert np.isclose(mc_eval.calc_mean_accuracy(sub), float(g["ma_" + tag]), rtol=1e-12)

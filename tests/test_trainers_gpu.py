@@ -120,3 +120,42 @@ def test_adapt_tester_label_maps_match_oracle(tmp_path):
         safe_total += got.size
     assert agree / safe_total > 0.995
     assert abs(ent - sum(ents) / 3) <= 1e-4 * abs(sum(ents) / 3)
+    # device-side evaluation written next to the label maps: same numbers as the oracle's fast_hist over the PNGs
+    import json
+    from oracle import ref_io
+    res = json.load(open(os.path.join(os.path.dirname(label_dir), "eval_result.json")))
+    hist = np.zeros((41, 41), dtype=np.int64)
+    for i in range(3):
+        _, lbl, name = ds[i]
+        gt = lbl.numpy().copy()
+        gt[gt == 40] = 255
+        pred = np.array(Image.open(os.path.join(label_dir, name)).resize((96, 64), Image.NEAREST)).astype(np.int64)
+        hist += ref_io.fast_hist(gt.flatten(), pred.flatten(), 41)
+    used = np.where(hist.sum(1) != 0)[0]
+    sub = hist[used][:, used].astype(np.float64)
+    assert res["used_class_ids"] == used.tolist()
+    assert abs(res["pixAcc"] - 100 * ref_io.calc_pixel_accuracy(sub)) < 1e-9
+    assert abs(res["mIoU"] - 100 * np.mean(ref_io.per_class_iu(sub))) < 1e-9
+
+
+def test_adapt_trainer_raw_uint8_input_pipeline(tmp_path):
+    """--synthetic_raw: uint8 HWC images and uint8 labels (background 255) go through the device-side
+    ToTensor/Normalize/ReLabel kernels; the step must equal feeding the oracle-preprocessed fp32 batch."""
+    _need_gpu()
+    import numpy as np
+    from datasets import DeviceInputPipeline, SyntheticRGBD
+    from oracle import ref_io
+    dev = torch.device("cuda:0")
+    ds = SyntheticRGBD(2, 6, [48, 32], 41, seed=11, raw=True)
+    img, lbl = ds[0]
+    assert img.dtype == torch.uint8 and tuple(img.shape) == (32, 48, 6) and lbl.dtype == torch.uint8 and int(lbl.max()) == 255
+    pipe = DeviceInputPipeline(6, 41, dev)
+    x = pipe.images(img[None])
+    y = pipe.labels(lbl[None])
+    assert np.array_equal(x.cpu().numpy(), ref_io.normalize_u8(img[None].numpy(), ref_io.IMAGENET_MEAN6, ref_io.IMAGENET_STD6))
+    assert np.array_equal(y.cpu().numpy(), ref_io.relabel(lbl[None].numpy(), 255, 40))
+    import adapt_trainer
+    out = str(tmp_path / "out")
+    args = [a for a in COMMON if a != "--synthetic"] + ["--synthetic_raw"]
+    assert adapt_trainer.main(["suncg", "nyu", "--base_outdir", out] + args) == 0
+    assert os.path.exists(os.path.join(out, "suncg-train2nyu-train_6ch", "pth", "MCD-normal-drn_d_38-1.pth.tar"))
