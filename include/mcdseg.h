@@ -183,6 +183,24 @@ int mcdseg_mse(const float* pred, const float* target, float* grad, float* loss,
                void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * MFNet late fusion beyond the plain sum (models/fusion.py:6-50) and its loss (loss.py:16-30)
+ *   gate_mix:    out = x1*s + x2*(1-s), s = sigmoid(g)   (GateFusion.forward :19-22; g = 1x1 conv of cat(x1,x2))
+ *                backward: dx1 = dy*s, dx2 = dy*(1-s), dg = dy*(x1-x2)*s*(1-s).  n = element count, multiple of 4.
+ *   softmax_ch:  softmax over C of NCHW (F.softmax of ScoreGateFusion :13-15); backward dx = y*(dy - sum_c dy*y). C <= 64.
+ *   prob_nll:    ProbCrossEntropyLoss2d: NLLLoss2d(weight)(log(p), labels).  loss[0] = weighted mean, loss[1] = weighted
+ *                sum, loss[2] = sum of weights; grad (may be NULL) = d loss[size_average ? 0 : 1] / dp, dense NCHW.
+ * ---------------------------------------------------------------------------------------------- */
+int mcdseg_gate_mix_fwd(const float* x1, const float* x2, const float* g, float* out, int64_t n, void* stream);
+int mcdseg_gate_mix_bwd(const float* dy, const float* x1, const float* x2, const float* g, float* dx1, float* dx2, float* dg,
+                        int64_t n, void* stream);
+int mcdseg_softmax_ch_fwd(const float* x, float* y, int32_t N, int32_t C, int32_t HW, void* stream);
+int mcdseg_softmax_ch_bwd(const float* dy, const float* y, float* dx, int32_t N, int32_t C, int32_t HW, void* stream);
+size_t mcdseg_prob_nll_workspace_bytes(int32_t N, int32_t HW);
+int mcdseg_prob_nll(const float* p, const int64_t* labels, const float* weight, int64_t ignore_index, int32_t size_average,
+                    float* grad, float* loss, int32_t N, int32_t C, int32_t HW, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Either side of the step: input transform and evaluation histogram
  *   normalize_u8:   ToTensor() + Normalize(mean,std) (transform.py:302-315): src uint8 [N,H,W,Cs] (HWC) ->
  *                   dst fp32 [N,C,H,W], channels [c_off, c_off+Cs): ((u/255) - mean[c]) / std[c], IEEE division.

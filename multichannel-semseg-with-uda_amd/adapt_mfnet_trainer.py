@@ -11,7 +11,7 @@ import tqdm
 
 from argmyparse import add_additional_params_to_args, get_da_mcd_training_parser
 from datasets import check_src_tgt_ok
-from loss import CrossEntropyLoss2d, get_prob_distance_criterion
+from loss import CrossEntropyLoss2d, ProbCrossEntropyLoss2d, get_prob_distance_criterion
 from models.model_util import fix_batchnorm_when_training, fix_dropout_when_training, get_models, get_optimizer
 from solvers.solver import MFNetMCDSolver
 from trainer_common import Run, make_loader
@@ -35,8 +35,6 @@ def main(argv=None):
     args = parser.parse_args(argv)
     args = add_additional_params_to_args(args)
     check_src_tgt_ok(args.src_dataset, args.tgt_dataset)
-    if "Gate" in args.method_detail:
-        raise NotImplementedError("GateFusion needs ProbCrossEntropyLoss2d (adapt_mfnet_trainer.py:149), outside the hot path")
     run = Run(args)
     detailed_method = args.method_detail
 
@@ -87,7 +85,8 @@ def main(argv=None):
         m.to(run.device)
     weight = weight.to(run.device)
     run.sync_replicas([g3, g1, f1, f2])
-    criterion = CrossEntropyLoss2d(weight)
+    # the gated fusions are paired with the probability-input criterion (adapt_mfnet_trainer.py:149)
+    criterion = CrossEntropyLoss2d(weight) if "Gate" not in detailed_method else ProbCrossEntropyLoss2d(weight)
     criterion_d = get_prob_distance_criterion(args.d_loss)
     for m in (g3, g1, f1, f2):
         m.train()

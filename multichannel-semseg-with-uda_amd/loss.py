@@ -1,6 +1,7 @@
 """Loss criteria of the MCD hot path on the fused HIP kernel (reference: loss.py).
 
   CrossEntropyLoss2d           loss.py:7-13    log_softmax(dim 1) + weighted NLL (mean over sum of weights)
+  ProbCrossEntropyLoss2d       loss.py:16-30   weighted NLL of log(p) for probability maps (gated MFNet fusions)
   Diff2d                       loss.py:93-100  mean |softmax(o1) - softmax(o2)|
   get_prob_distance_criterion  loss.py:192-210 ("diff" is the default ``--d_loss``, argmyparse.py:131)
 
@@ -38,6 +39,22 @@ class CrossEntropyLoss2d(nn.Module):
         if w is not None and w.device != inputs.device:
             w = w.to(inputs.device)
         return ops.cross_entropy2d(inputs, targets, w, self.ignore_index, self.size_average)
+
+
+class ProbCrossEntropyLoss2d(nn.Module):
+    """cross entropy between a probability map (0..1) and the labels (loss.py:16-30): the criterion the reference pairs
+    with the gated MFNet fusions (adapt_mfnet_trainer.py:149)"""
+
+    def __init__(self, weight=None, size_average=True):
+        super().__init__()
+        self.nll_loss = _ClassWeights(weight)
+        self.size_average = size_average
+
+    def forward(self, inputs, targets):
+        w = self.nll_loss.weight
+        if w is not None and w.device != inputs.device:
+            w = w.to(inputs.device)
+        return ops.prob_cross_entropy2d(inputs, targets, w, -100, self.size_average)
 
 
 class Diff2d(nn.Module):

@@ -66,6 +66,13 @@ _SIGNATURES = {
     "mcdseg_bilinear8_bwd": (c_int, [c_void_p, c_void_p] + [c_i32] * 4 + [c_void_p]),
     "mcdseg_mse_workspace_bytes": (c_size_t, [c_i64]),
     "mcdseg_mse": (c_int, [c_void_p] * 4 + [c_i64, c_void_p, c_size_t, c_void_p]),
+    "mcdseg_gate_mix_fwd": (c_int, [c_void_p] * 4 + [c_i64, c_void_p]),
+    "mcdseg_gate_mix_bwd": (c_int, [c_void_p] * 7 + [c_i64, c_void_p]),
+    "mcdseg_softmax_ch_fwd": (c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
+    "mcdseg_softmax_ch_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
+    "mcdseg_prob_nll_workspace_bytes": (c_size_t, [c_i32, c_i32]),
+    "mcdseg_prob_nll": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p,
+                                c_size_t, c_void_p]),
     "mcdseg_normalize_u8": (c_int, [c_void_p] * 4 + [c_i32] * 6 + [c_void_p]),
     "mcdseg_relabel_u8": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_void_p]),
     "mcdseg_confusion_hist": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p]),

@@ -654,6 +654,87 @@ def predict_labels(z1, z2=None, n_used=None):
     return labels, ent.reshape(())
 
 
+# ------------------------------------------------------------------------------------------------ MFNet gate fusion
+class _GateMix(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, g):
+        x1, x2, g = _req(x1, "x1"), _req(x2, "x2"), _req(g, "gate logits")
+        if not (x1.shape == x2.shape == g.shape) or x1.numel() % 4:
+            raise ValueError("mcdseg: gate_mix needs three tensors of one shape with a multiple of 4 elements")
+        out = torch.empty_like(x1)
+        check(lib().mcdseg_gate_mix_fwd(_p(x1), _p(x2), _p(g), _p(out), x1.numel(), _stream()), "gate_mix_fwd")
+        ctx.save_for_backward(x1, x2, g)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, g = ctx.saved_tensors
+        dy = _req(dy, "grad_output")
+        d1, d2, dg = torch.empty_like(x1), torch.empty_like(x1), torch.empty_like(x1)
+        check(lib().mcdseg_gate_mix_bwd(_p(dy), _p(x1), _p(x2), _p(g), _p(d1), _p(d2), _p(dg), x1.numel(), _stream()), "gate_mix_bwd")
+        return d1, d2, dg
+
+
+def gate_mix(x1, x2, gate_logits):
+    """x1*sigmoid(g) + x2*(1 - sigmoid(g)) (GateFusion.forward, models/fusion.py:19-22) in one pass, backward in one pass"""
+    return _GateMix.apply(x1, x2, gate_logits)
+
+
+class _SoftmaxCh(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, "logits")
+        n, c, h, w = x.shape
+        y = torch.empty_like(x)
+        check(lib().mcdseg_softmax_ch_fwd(_p(x), _p(y), n, c, h * w, _stream()), "softmax_ch_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _req(dy, "grad_output")
+        n, c, h, w = y.shape
+        dx = torch.empty_like(y)
+        check(lib().mcdseg_softmax_ch_bwd(_p(dy), _p(y), _p(dx), n, c, h * w, _stream()), "softmax_ch_bwd")
+        return dx
+
+
+def softmax_channels(x):
+    """F.softmax over dim 1 of an NCHW tensor (the ScoreGateFusion pre-step, models/fusion.py:13-15)"""
+    return _SoftmaxCh.apply(x)
+
+
+class _ProbNLL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, labels, weight, ignore_index, size_average):
+        L = lib()
+        p = _req(p, "probabilities")
+        labels = _req(labels, "labels", torch.int64)
+        weight = _req(weight, "class weights")
+        n, c, h, w = p.shape
+        if tuple(labels.shape) != (n, h, w):
+            raise ValueError("mcdseg: labels %s do not match probabilities %s" % (tuple(labels.shape), tuple(p.shape)))
+        loss = torch.empty(3, dtype=torch.float32, device=p.device)
+        grad = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(L.mcdseg_prob_nll_workspace_bytes(n, h * w) // 8 + 1, dtype=torch.float64, device=p.device)
+        check(L.mcdseg_prob_nll(_p(p), _p(labels), _p(weight), int(ignore_index), int(bool(size_average)), _p(grad), _p(loss), n, c,
+                                h * w, _p(ws), ctypes.c_size_t(ws.numel() * 8), _stream()), "prob_nll")
+        ctx.g = grad
+        return loss[0].clone() if size_average else loss[1].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g = ctx.g
+        ctx.g = None
+        return (g * grad_out if g is not None else None), None, None, None, None
+
+
+def prob_cross_entropy2d(p, labels, weight=None, ignore_index=-100, size_average=True):
+    """ProbCrossEntropyLoss2d (loss.py:16-30): NLLLoss2d(weight)(log(p), labels) with its gradient from the same call"""
+    return _ProbNLL.apply(p, labels, weight, ignore_index, size_average)
+
+
 def normalize_u8_(dst, src, mean, std, c_off=0):
     """ToTensor()+Normalize() of transform.py:302-315 on the device: ``src`` uint8 [N,H,W,Cs] (HWC, as PIL/numpy hand it
     over) is written as fp32 into channels [c_off, c_off+Cs) of ``dst`` [N,C,H,W].  mean/std: fp32 device tensors [Cs]."""

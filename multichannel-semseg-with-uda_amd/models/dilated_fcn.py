@@ -49,12 +49,23 @@ class Up8(nn.ConvTranspose2d):
         return ops.up8(x, self.weight)
 
 
+class Up8Pairs(nn.ConvTranspose2d):
+    """ConvTranspose2d(2C, C, 16, stride 8, padding 4, groups=C, bias=False) behind ``ConcatFusion``
+    (models/dilated_fcn.py:445-448): output channel g sums the up-sampled input channels 2g and 2g+1 of the stacked
+    tensor, each with its own 16x16 kernel -- the two-input form of the up-sampling kernel on the even / odd channels."""
+
+    def __init__(self, n_class):
+        super().__init__(2 * n_class, n_class, 16, stride=8, padding=4, output_padding=0, groups=n_class, bias=False)
+
+    def forward(self, x, output_size=None):
+        return ops.up8_dual(x[:, 0::2].contiguous(), self.weight[0::2].contiguous(), x[:, 1::2].contiguous(),
+                            self.weight[1::2].contiguous())
+
+
 def _up(cin, n_class, use_torch_up=False):
     if use_torch_up:
         raise NotImplementedError("use_torch_up (bilinear) is not on the MCD hot path")
-    if cin != n_class:
-        raise NotImplementedError("ConcatFusion up-sampler (2C -> C grouped transposed conv) is not on the MCD hot path")
-    return Up8(n_class)
+    return Up8(n_class) if cin == n_class else Up8Pairs(n_class)
 
 
 class DRNSeg(nn.Module):

@@ -54,6 +54,9 @@ class MCDSolver:
         self.opt_g, self.opt_f = optimizer_g, optimizer_f
         self.class_weight = getattr(criterion, "weight", None)
         self.ignore_index = getattr(criterion, "ignore_index", -100)
+        # the gated MFNet fusions emit probabilities and are trained with ProbCrossEntropyLoss2d (adapt_mfnet_trainer.py:149):
+        # that criterion runs as its own kernel per head; everything else takes the fused CE/CE kernel
+        self.prob_criterion = criterion if type(criterion).__name__ == "ProbCrossEntropyLoss2d" else None
         if type(criterion_d).__name__ != "Diff2d":
             raise NotImplementedError("the fused solver implements d_loss='diff' (loss.py:93-100)")
         self.num_k = num_k
@@ -70,6 +73,16 @@ class MCDSolver:
         return [self.g]
 
     def _ce(self, o1, o2, labels, want_grad=True):
+        if self.prob_criterion is not None:
+            vals, grads = [], []
+            for o in (o1, o2):
+                od = o.detach().requires_grad_(want_grad)
+                val = self.prob_criterion(od, labels)
+                if want_grad:
+                    val.backward()
+                vals.append(val.detach())
+                grads.append(od.grad)
+            return torch.stack(vals + [torch.zeros_like(vals[0])]), grads[0], grads[1]
         return ops.mcd_losses(o1, o2, labels, self.class_weight, self.ignore_index, ce_coef=1.0, want_grad=want_grad)
 
     def step(self, src_imgs, src_lbls, tgt_imgs):

@@ -33,6 +33,17 @@ class CrossEntropyLoss2d(nn.Module):
         return self.nll_loss(F.log_softmax(inputs, dim=1), targets)
 
 
+class ProbCrossEntropyLoss2d(nn.Module):
+    """loss.py:16-30: NLLLoss2d(weight, size_average)(log(inputs), targets) for probability maps (gated MFNet fusions)"""
+
+    def __init__(self, weight=None, size_average=True):
+        super().__init__()
+        self.nll_loss = nn.NLLLoss(weight, reduction="mean" if size_average else "sum")
+
+    def forward(self, inputs, targets):
+        return self.nll_loss(torch.log(inputs), targets)
+
+
 class Diff2d(nn.Module):
     def __init__(self, weight=None, size_average=True):
         super().__init__()

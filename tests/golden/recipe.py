@@ -57,3 +57,13 @@ def checksum(t):
 
 def state_checksums(module):
     return {k: checksum(v) for k, v in module.state_dict().items()}
+
+
+def fusion_inputs(seed, n_class):
+    """(x1, x2, grad_output, labels) of the fusion-classifier fixtures (make_golden_fusion.py)"""
+    rs = np.random.RandomState(seed)
+    x1 = torch.from_numpy(rs.standard_normal((2, n_class, 2, 4)).astype(np.float32))
+    x2 = torch.from_numpy(rs.standard_normal((2, n_class, 2, 4)).astype(np.float32))
+    gy = torch.from_numpy(rs.standard_normal((2, n_class, 16, 32)).astype(np.float32))
+    lbl = torch.from_numpy(rs.randint(0, n_class, size=(2, 16, 32)).astype(np.int64))
+    return x1, x2, gy, lbl

@@ -487,3 +487,50 @@ def test_rccl_path_world_size_one(golden):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+# ------------------------------------------------------------------------------ MFNet fusions other than the plain sum
+FUSION_VARIANTS = [("gate", "FusionDRNSegPixelClassifier", "MFNet-GateFusion", 300, 400),
+                   ("scoregate", "ScoreFusionDRNSegPixelClassifier", "MFNet-ScoreGateFusion", 301, 401),
+                   ("concat", "FusionDRNSegPixelClassifier", "MFNet-ConcatFusion", 302, 402),
+                   ("concatconv", "FusionDRNSegPixelClassifier", "MFNet-ConcatConvFusion", 303, 403)]
+
+
+@pytest.mark.parametrize("variant", FUSION_VARIANTS, ids=lambda v: v[0])
+def test_fusion_classifiers_match_reference_vectors(variant):
+    """HIP gate-mix / channel-softmax / paired up-sampler / 1x1 + 3x3 conv-with-bias kernels behind the reference's
+    fusion classifiers: outputs, input gradients and parameter gradients against the reference's fp64 vectors"""
+    import os
+    import numpy as np
+    from models import dilated_fcn
+    from recipe import fill_state_, fusion_inputs
+    dev = _dev()
+    tag, cls, ftype, wseed, xseed = variant
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fusion_small.npz"))
+    m = fill_state_(getattr(dilated_fcn, cls)(ftype, 41), wseed).to(dev)
+    assert sorted(m.state_dict().keys()) == list(g[tag + "_keys"])
+    x1, x2, gy, lbl = fusion_inputs(xseed, 41)
+    a, b = x1.to(dev).requires_grad_(), x2.to(dev).requires_grad_()
+    y = m(a, b)
+    names = [k for k, _ in m.named_parameters()]
+    grads = torch.autograd.grad(y, [a, b] + [p for _, p in m.named_parameters()], gy.to(dev))
+
+    def close(got, ref, rel, what):
+        err = float(np.abs(got.detach().cpu().numpy() - ref).max())
+        assert err <= rel * float(np.abs(ref).max()) + 1e-7, "%s/%s: err %.3e" % (tag, what, err)
+
+    close(y, g[tag + "_y"], 2e-5, "y")
+    close(grads[0], g[tag + "_dx1"], 2e-5, "dx1")
+    close(grads[1], g[tag + "_dx2"], 2e-5, "dx2")
+    for k, gv in zip(names, grads[2:]):
+        close(gv, g["%s_grad_%s" % (tag, k)], 1e-4, k)
+    if tag == "scoregate":
+        from loss import ProbCrossEntropyLoss2d
+        from oracle import ref_loss
+        w = ref_loss.class_weights(41).to(dev)
+        for sfx, sa in (("mean", True), ("sum", False)):
+            p = torch.from_numpy(g["scoregate_y"]).float().to(dev).requires_grad_()
+            val = ProbCrossEntropyLoss2d(w, sa)(p, torch.from_numpy(g["probce_lbl"]).to(dev))
+            (gp,) = torch.autograd.grad(val, [p])
+            assert abs(float(val) - float(g["probce_" + sfx])) <= 2e-6 * abs(float(g["probce_" + sfx]))
+            close(gp, g["probce_grad_" + sfx], 2e-6, "probce grad " + sfx)

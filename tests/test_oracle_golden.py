@@ -319,3 +319,45 @@ def test_host_metrics_module_matches_reference_vectors():
         assert np.isclose(mc_eval.calc_fw_iu(sub), float(g["fw_" + tag]), rtol=1e-12)
         assert np.isclose(mc_eval.calc_pixel_accuracy(sub), float(g["pa_" + tag]), rtol=1e-12)
         assert np.isclose(mc_eval.calc_mean_accuracy(sub), float(g["ma_" + tag]), rtol=1e-12)
+
+
+FUSION_VARIANTS = [("gate", "FusionDRNSegPixelClassifier", "MFNet-GateFusion", 300, 400),
+                   ("scoregate", "ScoreFusionDRNSegPixelClassifier", "MFNet-ScoreGateFusion", 301, 401),
+                   ("concat", "FusionDRNSegPixelClassifier", "MFNet-ConcatFusion", 302, 402),
+                   ("concatconv", "FusionDRNSegPixelClassifier", "MFNet-ConcatConvFusion", 303, 403)]
+
+
+def _fusion_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fusion_small.npz"))
+
+
+@pytest.mark.parametrize("variant", FUSION_VARIANTS, ids=lambda v: v[0])
+def test_fusion_classifiers_match_reference_vectors(variant):
+    """oracle fusion classifiers (gate / score-gate / concat / concat-conv) against the reference's fp64 outputs and
+    gradients; ProbCrossEntropyLoss2d on the score-gate probabilities"""
+    from recipe import fusion_inputs
+    tag, cls, ftype, wseed, xseed = variant
+    g = _fusion_golden()
+    m = fill_state_(getattr(ref_models, cls)(ftype, 41), wseed)
+    assert sorted(m.state_dict().keys()) == list(g[tag + "_keys"])
+    x1, x2, gy, lbl = fusion_inputs(xseed, 41)
+    a, b = x1.clone().requires_grad_(), x2.clone().requires_grad_()
+    y = m(a, b)
+    names = [k for k, _ in m.named_parameters()]
+    grads = torch.autograd.grad(y, [a, b] + [p for _, p in m.named_parameters()], gy)
+    tol = lambda ref: 2e-5 * float(np.abs(ref).max()) + 1e-7  # noqa: E731
+    assert np.abs(y.detach().numpy() - g[tag + "_y"]).max() <= tol(g[tag + "_y"])
+    assert np.abs(grads[0].numpy() - g[tag + "_dx1"]).max() <= tol(g[tag + "_dx1"])
+    assert np.abs(grads[1].numpy() - g[tag + "_dx2"]).max() <= tol(g[tag + "_dx2"])
+    for k, gv in zip(names, grads[2:]):
+        ref = g["%s_grad_%s" % (tag, k)]
+        assert np.abs(gv.numpy() - ref).max() <= 1e-4 * float(np.abs(ref).max()) + 1e-7, k
+    if tag == "scoregate":
+        w = ref_loss.class_weights(41)
+        p = torch.from_numpy(g["scoregate_y"]).requires_grad_()
+        for sfx, sa in (("mean", True), ("sum", False)):
+            val = ref_loss.ProbCrossEntropyLoss2d(w.double(), sa)(p, torch.from_numpy(g["probce_lbl"]))
+            (gp,) = torch.autograd.grad(val, [p])
+            assert abs(float(val) - float(g["probce_" + sfx])) <= 1e-12 * abs(float(val))
+            assert np.allclose(gp.numpy(), g["probce_grad_" + sfx], rtol=1e-12, atol=0)

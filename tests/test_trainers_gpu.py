@@ -159,3 +159,42 @@ def test_adapt_trainer_raw_uint8_input_pipeline(tmp_path):
     args = [a for a in COMMON if a != "--synthetic"] + ["--synthetic_raw"]
     assert adapt_trainer.main(["suncg", "nyu", "--base_outdir", out] + args) == 0
     assert os.path.exists(os.path.join(out, "suncg-train2nyu-train_6ch", "pth", "MCD-normal-drn_d_38-1.pth.tar"))
+
+
+def test_adapt_mfnet_trainer_score_gate_fusion_matches_oracle(tmp_path):
+    """MFNet-ScoreGateFusion with ProbCrossEntropyLoss2d (adapt_mfnet_trainer.py:149): one full three-step update on the
+    HIP path against the CPU oracle running the reference's statements from the same initial state."""
+    _need_gpu()
+    from loss import ProbCrossEntropyLoss2d, get_prob_distance_criterion
+    from models.model_util import get_models, get_optimizer
+    from oracle import ref_loss, ref_mcd, ref_models
+    from recipe import fill_state_, make_batch
+    from solvers.solver import MFNetMCDSolver
+    dev = torch.device("cuda:0")
+    os.environ["MCDSEG_PRETRAINED"] = "0"
+    method = "MFNet-ScoreGateFusion"
+    hip = get_models("drn_d_38", input_ch=6, n_class=41, method=method)
+    ora = ref_models.get_models("drn_d_38", 6, 41, method=method)
+    for i, (h, o) in enumerate(zip(hip, ora)):
+        fill_state_(o, 500 + i)
+        h.load_state_dict(o.state_dict())
+        h.to(dev).train(), o.train()
+    src, lbl, tgt = make_batch(77, 2, 6, 64, 96, 41)
+    w = ref_loss.class_weights(41)
+    o_og = torch.optim.SGD(list(ora[0].parameters()) + list(ora[1].parameters()), lr=1e-3, momentum=0.9, weight_decay=2e-5)
+    o_of = torch.optim.SGD(list(ora[2].parameters()) + list(ora[3].parameters()), lr=1e-3, momentum=0.9, weight_decay=2e-5)
+    oc, od = ref_mcd.mfnet_mcd_step(ora[0], ora[1], ora[2], ora[3], o_og, o_of, ref_loss.ProbCrossEntropyLoss2d(w), ref_loss.Diff2d(),
+                                    src, lbl, tgt, num_k=2)
+    h_og = get_optimizer(list(hip[0].parameters()) + list(hip[1].parameters()), "sgd", 1e-3, 0.9, 2e-5)
+    h_of = get_optimizer(list(hip[2].parameters()) + list(hip[3].parameters()), "sgd", 1e-3, 0.9, 2e-5)
+    solver = MFNetMCDSolver(hip[0], hip[1], hip[2], hip[3], h_og, h_of, ProbCrossEntropyLoss2d(w.to(dev)),
+                            get_prob_distance_criterion("diff"), num_k=2)
+    hc, hd = solver.step(src.to(dev), lbl.to(dev), tgt.to(dev))
+    assert abs(float(hc) - oc) <= 2e-4 * abs(oc), (float(hc), oc)
+    assert abs(float(hd) - od) <= 1e-2 * abs(od) + 1e-9, (float(hd), od)
+    for h, o in zip(hip[2:], ora[2:]):  # classifier parameters after the update (gate conv + both up-samplers)
+        for (k, a), (_, b) in zip(h.state_dict().items(), o.state_dict().items()):
+            assert float((a.cpu() - b).norm()) <= 3e-4 * float(b.norm()) + 1e-7, k
+    import adapt_mfnet_trainer
+    out = str(tmp_path / "out")
+    assert adapt_mfnet_trainer.main(["suncg", "nyu", "--base_outdir", out, "--method_detail", "MFNet-GateFusion"] + COMMON) == 0
