@@ -23,7 +23,9 @@ from mcdseg import ops
 from eval import ConfusionMeter
 
 
-def main(argv=None):
+def main(argv=None, mfnet=False):
+    """``mfnet=True`` is the two-encoder variant (adapt_mfnet_tester.py): checkpoints hold ``g_3ch_state_dict`` /
+    ``g_1ch_state_dict``, the classifier takes both feature maps and only F1 is evaluated (:102-105)."""
     args = get_da_mcd_testing_parser().parse_args(argv)
     args = add_additional_params_to_args(args)
     if not torch.cuda.is_available():
@@ -32,7 +34,7 @@ def main(argv=None):
     indir, infn = os.path.split(args.trained_checkpoint)
     trained_mode = indir.split(os.path.sep)[-2]
     args.mode = "%s---%s-%s" % (trained_mode, args.tgt_dataset, args.split)
-    model_name = infn.replace(".pth", "") + ("-use_f2" if args.use_f2 else "")
+    model_name = (infn.replace(".pth", "").replace(".tar", "") if mfnet else infn.replace(".pth", "")) + ("-use_f2" if args.use_f2 else "")
     if not os.path.exists(args.trained_checkpoint):
         raise OSError("%s does not exist!" % args.trained_checkpoint)
     checkpoint = load_checkpoint(args.trained_checkpoint)
@@ -52,13 +54,24 @@ def main(argv=None):
     loader = torch.utils.data.DataLoader(tgt_dataset, batch_size=args.batch_size, pin_memory=True)
 
     os.environ["MCDSEG_PRETRAINED"] = "0"  # weights come from the checkpoint
-    G, F1, F2 = get_models(net_name=train_args.net, res=train_args.res, input_ch=train_args.input_ch, n_class=train_args.n_class,
-                           method=getattr(train_args, "method", "MCD"), is_data_parallel=getattr(train_args, "is_data_parallel", False))
-    G.load_state_dict(checkpoint["g_state_dict"])
+    method = getattr(train_args, "method", "MCD")
+    if mfnet:  # the trainer stores the full "MFNet-<fusion>" name in method_detail (adapt_mfnet_trainer.py:29)
+        method = train_args.method_detail if "MFNet" in train_args.method_detail else method + "-" + train_args.method_detail
+    models = get_models(net_name=train_args.net, res=train_args.res, input_ch=train_args.input_ch, n_class=train_args.n_class,
+                        method=method, is_data_parallel=getattr(train_args, "is_data_parallel", False))
+    if mfnet:
+        G3, G1, F1, F2 = models
+        G3.load_state_dict(checkpoint["g_3ch_state_dict"])
+        G1.load_state_dict(checkpoint["g_1ch_state_dict"])
+        encoders = (G3, G1)
+    else:
+        G, F1, F2 = models
+        G.load_state_dict(checkpoint["g_state_dict"])
+        encoders = (G,)
     F1.load_state_dict(checkpoint["f1_state_dict"])
     if args.use_f2:
         F2.load_state_dict(checkpoint["f2_state_dict"])
-    for m in (G, F1, F2):
+    for m in encoders + (F1, F2):
         m.eval()
         m.to(dev)
     n_used = args.n_class if getattr(train_args, "add_bg_loss", False) else args.n_class - 1
@@ -71,9 +84,14 @@ def main(argv=None):
     meter = ConfusionMeter(train_args.n_class, background_id=255, device=dev)
     with torch.no_grad():
         for imgs, gts, paths in loader:
-            feature = G(imgs.to(dev, non_blocking=True))
-            out1 = F1(feature)
-            out2 = F2(feature) if args.use_f2 else None
+            imgs = imgs.to(dev, non_blocking=True)
+            if mfnet:
+                out1 = F1(encoders[0](imgs[:, :3, :, :]), encoders[1](imgs[:, 3:, :, :]))
+                out2 = None  # adapt_mfnet_tester.py:105 evaluates F1 alone, with or without --use_f2
+            else:
+                feature = encoders[0](imgs)
+                out1 = F1(feature)
+                out2 = F2(feature) if args.use_f2 else None
             labels, ent = ops.predict_labels(out1, out2, n_used)
             total_ent += float(ent)
             batches += 1

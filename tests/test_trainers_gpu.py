@@ -198,3 +198,41 @@ def test_adapt_mfnet_trainer_score_gate_fusion_matches_oracle(tmp_path):
     import adapt_mfnet_trainer
     out = str(tmp_path / "out")
     assert adapt_mfnet_trainer.main(["suncg", "nyu", "--base_outdir", out, "--method_detail", "MFNet-GateFusion"] + COMMON) == 0
+
+
+def test_adapt_mfnet_tester_label_maps_match_oracle(tmp_path):
+    """two-encoder tester (adapt_mfnet_tester.py:85-132): label PNGs and entropy against the CPU oracle on the same
+    checkpoint -- F1 alone is evaluated, on the RGB / HHA feature pair"""
+    _need_gpu()
+    import numpy as np
+    from PIL import Image
+    import adapt_mfnet_tester
+    import adapt_mfnet_trainer
+    import util
+    from datasets import SyntheticRGBD
+    from oracle import ref_models
+    out = str(tmp_path / "out")
+    assert adapt_mfnet_trainer.main(["suncg", "nyu", "--base_outdir", out, "--method_detail", "MFNet-ScoreAddFusion"] + COMMON) == 0
+    ck_fn = os.path.join(out, "suncg-train2nyu-train_6ch_MFNet", "pth", "MFNet-ScoreAddFusion-normal-drn_d_38-1.pth.tar")
+    label_dir, ent = adapt_mfnet_tester.main(["nyu", ck_fn, "--outdir", str(tmp_path / "test"), "--synthetic", "--synthetic_len", "2",
+                                              "--test_img_shape", "96", "64"])
+    ck = util.load_checkpoint(ck_fn)
+    g3, g1, f1, _ = ref_models.get_models("drn_d_38", 6, 41, method="MFNet-ScoreAddFusion")
+    g3.load_state_dict(ck["g_3ch_state_dict"]), g1.load_state_dict(ck["g_1ch_state_dict"]), f1.load_state_dict(ck["f1_state_dict"])
+    for m in (g3, g1, f1):
+        m.eval()
+    ds = SyntheticRGBD(2, 6, [96, 64], 41, seed=4321, test=True)
+    ents = []
+    for i in range(2):
+        img, _, name = ds[i]
+        with torch.no_grad():
+            o = f1(g3(img[None, :3]), g1(img[None, 3:]))
+        p = torch.softmax(o, dim=1)
+        ents.append(float(-(p * torch.log(p + 1e-6)).mean()))
+        top2 = o[0, :40].topk(2, dim=0).values
+        safe = ((top2[0] - top2[1]) > 2e-3).numpy()
+        got = np.array(Image.open(os.path.join(label_dir, name)))
+        ref = o[0, :40].argmax(0).numpy().astype(np.uint8)
+        assert got.shape == ref.shape == (64, 96)
+        assert (got == ref)[safe].all() and (got == ref).mean() > 0.995
+    assert abs(ent - sum(ents) / 2) <= 1e-4 * abs(sum(ents) / 2)
