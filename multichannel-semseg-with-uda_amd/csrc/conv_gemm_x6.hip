@@ -330,11 +330,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   // one K-step s (cur = s & 1): gathers of step s+2 go to the register set that step s just vacated, the weight slab of
   // step s+1 is DMA'd into the LDS buffer released by the previous barrier, MFMAs of step s, then step s+1's gathers
   // (loaded one step earlier) are split and written to LDS.
-  auto k_step = [&](int s, auto cur_c) {
+  auto k_step = [&](int s, auto cur_c, auto steady_c) {
     constexpr int CUR = decltype(cur_c)::value;
+    // STEADY: the caller guarantees s + 2 < nsteps, so nothing below is conditional.  That matters beyond the saved
+    // branches: the compiler's wait-count bookkeeping merges its state over every path through the loop body, and with
+    // the tail conditions inside it it concludes that older gathers may still be pending and drains vmcnt to 0 before
+    // issuing new ones.
+    constexpr bool STEADY = decltype(steady_c)::value;
     using SAME = std::integral_constant<int, CUR>;
     using OTHER = std::integral_constant<int, CUR ^ 1>;
-    if (A_DMA && s + 1 < nsteps) {
+    if (A_DMA && (STEADY || s + 1 < nsteps)) {
       ++l_dma_kstep;
       const int a_soff = (l_dma_kstep * 6 * p.Mp + tile_m * BM) * 16;
       unsigned char* adst = As + (CUR ^ 1) * A_BYTES + wave * 64 * 16;
@@ -347,17 +352,38 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
       (void)adst;
 #endif
     }
-    if (s + 2 < nsteps) {
+    // the counted wait at the end of the step relies on program order: weight DMA first, gathers after it
+    asm volatile("" ::: "memory");
+    if (STEADY || s + 2 < nsteps) {
       advance();
       load_regs(SAME{});
     }
     mfma_step(CUR);
-    if (s + 1 < nsteps) store_lds(CUR ^ 1, OTHER{});
-    __syncthreads();
+    if (STEADY || s + 1 < nsteps) store_lds(CUR ^ 1, OTHER{});
+    if constexpr (A_DMA) {
+      // __syncthreads() would drain every vector-memory operation (vmcnt(0)) because an LDS-DMA is pending, i.e. also
+      // the gathers issued for step s+2 -- the prefetch distance would collapse to one MFMA phase.  What the barrier
+      // has to guarantee is only: this wave's LDS writes have landed (lgkmcnt(0)) and the weight slab DMA'd for step s+1
+      // is complete -- it is OLDER than the gathers of step s+2, so a counted wait leaves exactly those in flight.
+      constexpr int AHEAD = (PRESPLIT ? 3 : 8) * B_ITEMS;
+      if (STEADY || s + 2 < nsteps)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(AHEAD) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      __syncthreads();
+    }
   };
-  for (int s = 0; s < nsteps; s += 2) {
-    k_step(s, S0{});
-    if (s + 1 < nsteps) k_step(s + 1, S1{});
+  using YES = std::integral_constant<bool, true>;
+  using NO = std::integral_constant<bool, false>;
+  int s = 0;
+  for (; s + 3 < nsteps; s += 2) {  // steady state: both steps of the pair still have two successors
+    k_step(s, S0{}, YES{});
+    k_step(s + 1, S1{}, YES{});
+  }
+  for (; s < nsteps; s += 2) {
+    k_step(s, S0{}, NO{});
+    if (s + 1 < nsteps) k_step(s + 1, S1{}, NO{});
   }
 
   // ---- epilogue (identical to conv_gemm.hip): acc[i][j][r] = D[row][col], row = (r&3) + 8*(r>>2) + 4*lh, col = l31

@@ -216,7 +216,7 @@ struct WgradCbParams {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad_x6_cb_kernel(WgradCbParams p) {
+__global__ __launch_bounds__(256, 3) void conv_wgrad_x6_cb_kernel(WgradCbParams p) {
   constexpr int BM = 128, BN = 128;
   constexpr int WM = 2, WN = 2, WAVES_N = 2;
   constexpr int PLANE = 130;               // 16-B units per k-octet plane (128 positions + 2 pad)
