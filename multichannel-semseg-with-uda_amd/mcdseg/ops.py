@@ -178,8 +178,11 @@ def _sub_desc(desc, n):
 
 
 def _batch_pieces(desc):
-    per_img = 4 * max((desc.Cin + 128) * desc.H * desc.W, (desc.Cout + 128) * desc.Ho * desc.Wo)
-    step = max(1, MAX_CONV_BYTES // per_img)
+    # the C side requires (N*C + 128) * H*W * 4 < 2 GiB per operand: the 128-channel tile of slack is per LAUNCH, not
+    # per image (charging it per image cut the full-resolution 16-channel layers in two and lost their pre-split operands)
+    step = desc.N
+    for c, hw in ((desc.Cin, desc.H * desc.W), (desc.Cout, desc.Ho * desc.Wo)):
+        step = min(step, max(1, (MAX_CONV_BYTES - 4 * 128 * hw) // (4 * c * hw)))
     if step >= desc.N:
         return [(0, desc.N)]
     return [(i, min(i + step, desc.N)) for i in range(0, desc.N, step)]

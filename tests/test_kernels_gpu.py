@@ -376,8 +376,8 @@ def test_conv_batch_split_for_large_operands(monkeypatch):
         return [t.detach().clone() for t in (y, x.grad, conv.weight.grad, bn.weight.grad, bn.bias.grad, bn.running_var)]
 
     whole = run()
-    per_img = 4 * (40 + 128) * 12 * 14
-    monkeypatch.setattr(ops, "MAX_CONV_BYTES", 2 * per_img)  # -> pieces of 2, 2, 1 images
+    hw = 12 * 14
+    monkeypatch.setattr(ops, "MAX_CONV_BYTES", 4 * 128 * hw + 2 * 4 * 40 * hw)  # tile slack + two images -> pieces of 2, 2, 1
     desc = ops.conv_desc(x.shape, conv.weight.shape, 1, 2, 2)
     assert ops._batch_pieces(desc) == [(0, 2), (2, 4), (4, 5)]
     split = run()
