@@ -77,7 +77,8 @@ int mcdseg_conv_x6_dgrad(const mcdseg_conv_desc* d, const float* dy, const void*
                          void* stream);
 /* same workspace as mcdseg_conv_wgrad; 128x128-tile layers run on the split path, thin layers on the f32 kernels.
  * x_cb / dy_cb (may be NULL; used only when BOTH are given): the pre-split companions of x and dy in the layout above --
- * the kernel then transposes 8x8 bf16 blocks in registers instead of splitting fp32 values.  x and dy stay mandatory. */
+ * the kernel then transposes 8x8 bf16 blocks in registers instead of splitting fp32 values.  x / dy may be NULL only when
+ * that path applies (both companions, channel counts divisible by 8, min(Cin,Cout) > 64 and not the thin-input plan). */
 int mcdseg_conv_x6_wgrad(const mcdseg_conv_desc* d, const float* x, const void* x_cb, const float* dy, const void* dy_cb,
                          float* dw, void* workspace, size_t workspace_bytes, void* stream);
 /* dw = x (*) dy ; split over pixels into slabs in `workspace`, then reduced in a fixed order. */
@@ -108,7 +109,8 @@ int mcdseg_bn_apply(const float* z, const float* mean, const float* rstd, const 
                     const float* residual, float* y, int32_t N, int32_t C, int32_t HW, int32_t relu, void* stream);
 /* Same as mcdseg_bn_apply / mcdseg_bn_bwd_apply, additionally emitting the exact 3-way bf16 split of the produced
  * tensor in the channel-blocked layout [piece 3][N][C/8][HW][8 bf16] (3*N*C*HW*2 bytes) consumed by the bf16x6
- * convolutions; C must be divisible by 8. */
+ * convolutions; C must be divisible by 8.  mcdseg_bn_bwd_apply_cb accepts dz == NULL (only the split companion is
+ * written) for layers whose input and weight gradients both read the companion. */
 int mcdseg_bn_apply_cb(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                        const float* residual, float* y, void* y_cb, int32_t N, int32_t C, int32_t HW, int32_t relu,
                        void* stream);

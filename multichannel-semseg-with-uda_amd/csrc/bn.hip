@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_kernel(const float* __res
     if (dres) dres[base + (size_t)e * HW] = gv;
     const float t = a * (gv - k1 - ((z[base + (size_t)e * HW] - mu) * rs) * k2);
     v[e] = t;
-    dz[base + (size_t)e * HW] = t;
+    if (dz) dz[base + (size_t)e * HW] = t;  // optional: the x6 dgrad and wgrad read only the split companion
   }
   split3_store(v, cb, (size_t)N * C * HW, (size_t)ng * HW + pix);
 }
@@ -458,7 +458,7 @@ extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float
 extern "C" int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
                                       const float* gamma, const float* dgamma, const float* dbeta, float* dz, float* dres,
                                       void* dz_cb, int32_t N, int32_t C, int32_t HW, int32_t relu, int32_t train, void* stream) {
-  MCD_REQUIRE(dy && z && mean && rstd && gamma && dz && dz_cb, "bn_bwd_apply_cb: null pointer");
+  MCD_REQUIRE(dy && z && mean && rstd && gamma && dz_cb, "bn_bwd_apply_cb: null pointer");
   MCD_REQUIRE(!relu || y, "bn_bwd_apply_cb: relu mask needs y");
   MCD_REQUIRE(!train || (dgamma && dbeta), "bn_bwd_apply_cb: train mode needs dgamma/dbeta");
   MCD_REQUIRE(N > 0 && C > 0 && HW > 0 && (C % 8) == 0, "bn_bwd_apply_cb: C must be a positive multiple of 8");

@@ -481,11 +481,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
 
 // ---- weight packing: w[Cout][Cin][T] (fp32) -> [chunk*T + tap][piece][half][Mp][8] bf16, chunk = 16 K-channels
 // MODE 0: m = cout, k = cin (forward); MODE 1: m = cin, k = cout (dgrad)
-__global__ void pack_weights_x6_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int Cout, int Cin, int T, int Mp,
-                                       int Kp, int mode) {
-  const int64_t total = (int64_t)(Kp / 16) * T * 2 * Mp * 8;  // one thread per (kstep, half, m, e): writes all 3 pieces
+// blockIdx.y selects the image, so both are produced by one launch (weights are re-packed after every optimizer step)
+__global__ void pack_weights_x6_kernel(const float* __restrict__ w, __bf16* __restrict__ out_fprop, __bf16* __restrict__ out_dgrad,
+                                       int Cout, int Cin, int T) {
+  const int mode = blockIdx.y;
+  __bf16* __restrict__ out = mode == 0 ? out_fprop : out_dgrad;
+  if (out == nullptr) return;
   const int M = mode == 0 ? Cout : Cin;
   const int K = mode == 0 ? Cin : Cout;
+  const int Mp = M <= 32 ? 32 : (M <= 64 ? 64 : ((M + 127) / 128) * 128);  // mcd_mp
+  const int Kp = ((K + 15) / 16) * 16;
+  const int64_t total = (int64_t)(Kp / 16) * T * 2 * Mp * 8;  // one thread per (kstep, half, m, e): writes all 3 pieces
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int e = (int)(i & 7);
     int64_t r = i >> 3;
@@ -562,17 +568,17 @@ extern "C" int mcdseg_conv_x6_pack_weights(const mcdseg_conv_desc* d, const floa
   MCD_REQUIRE(w != nullptr && (wp_fprop != nullptr || wp_dgrad != nullptr), "conv_x6_pack_weights: null pointer");
   const int T = d->KH * d->KW;
   hipStream_t st = (hipStream_t)stream;
+  int64_t most = 0;
   for (int mode = 0; mode < 2; ++mode) {
-    void* out = mode == 0 ? wp_fprop : wp_dgrad;
-    if (!out) continue;
     const int M = mode == 0 ? d->Cout : d->Cin, K = mode == 0 ? d->Cin : d->Cout;
-    const int Mp = mcd_mp(M), Kp = round_up(K, 16);
-    const int64_t total = (int64_t)(Kp / 16) * T * 2 * Mp * 8;
-    int64_t blocks = ceil_div64(total, 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pack_weights_x6_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, (__bf16*)out, d->Cout, d->Cin, T, Mp, Kp, mode);
-    MCD_LAUNCH_CHECK("conv_x6_pack_weights");
+    const int64_t total = (int64_t)(round_up(K, 16) / 16) * T * 2 * mcd_mp(M) * 8;
+    if ((mode == 0 ? wp_fprop : wp_dgrad) && total > most) most = total;
   }
+  int64_t blocks = ceil_div64(most, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pack_weights_x6_kernel, dim3((unsigned)blocks, 2), dim3(256), 0, st, w, (__bf16*)wp_fprop, (__bf16*)wp_dgrad,
+                     d->Cout, d->Cin, T);
+  MCD_LAUNCH_CHECK("conv_x6_pack_weights");
   return 0;
 }
 

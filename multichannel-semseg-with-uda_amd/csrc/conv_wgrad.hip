@@ -414,7 +414,9 @@ extern "C" size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d) {
 
 static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                       int x6, const void* x_cb, const void* dy_cb, void* stream) {
-  MCD_REQUIRE(d && x && dy && dw && workspace, "conv_wgrad: null pointer");
+  MCD_REQUIRE(d && dw && workspace, "conv_wgrad: null pointer");
+  const bool cb_path = x6 && x_cb && dy_cb && (d->Cin & 7) == 0 && (d->Cout & 7) == 0 && make_plan(d).cfg == 0;
+  MCD_REQUIRE(cb_path || (x && dy), "conv_wgrad: x and dy may be NULL only when the pre-split 128x128 plan applies");
   MCD_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0, "conv_wgrad: bad dims");
   MCD_REQUIRE(((int64_t)d->N * d->Cin + 128) * d->H * d->W * 4 < (1ll << 31) && ((int64_t)d->N * d->Cout + 128) * d->Ho * d->Wo * 4 < (1ll << 31),
               "conv_wgrad: activation tensor must stay below 2 GiB (32-bit buffer offsets); split the batch");
@@ -447,7 +449,7 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
     MCD_LAUNCH_CHECK("conv_wgrad_thin_reduce");
     return 0;
   }
-  if (pl.cfg == 0 && x6 && x_cb && dy_cb && (d->Cin & 7) == 0 && (d->Cout & 7) == 0) {
+  if (cb_path) {
     if (int rc = mcdseg_internal_wgrad_x6_cb_launch(d, x_cb, dy_cb, (float*)workspace, pl.co_p, pl.ci_p, pl.chunks_per_img, pl.splits, st))
       return rc;
   } else if (pl.cfg == 0 && x6) {

@@ -212,9 +212,14 @@ def _conv_fprop(desc, x, wf, bias, want_stats, mpf, x_cb=None):
     return y, part, rows
 
 
+def _sl(t, a, b):
+    return None if t is None else t[a:b]
+
+
 def _conv_dgrad(desc, dy, wd, dy_cb=None):
+    """``dy`` may be None when its pre-split companion is given and the batch is not cut (the kernel reads only ``dy_cb``)"""
     L = lib()
-    dx = torch.empty((desc.N, desc.Cin, desc.H, desc.W), dtype=torch.float32, device=dy.device)
+    dx = torch.empty((desc.N, desc.Cin, desc.H, desc.W), dtype=torch.float32, device=(dy if dy is not None else dy_cb).device)
     pieces = _batch_pieces(desc)
     if len(pieces) > 1:
         dy_cb = None
@@ -222,7 +227,7 @@ def _conv_dgrad(desc, dy, wd, dy_cb=None):
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
         with _timed(gemm_kernel_name(desc.Cin, desc.Cout, True, wd.dtype == torch.bfloat16, dy_cb is not None), conv_work(d)):
             if wd.dtype == torch.bfloat16:
-                check(L.mcdseg_conv_x6_dgrad(ctypes.byref(d), _p(dy[a:b]), _p(dy_cb), _p(wd), _p(dx[a:b]), _stream()), "conv_x6_dgrad")
+                check(L.mcdseg_conv_x6_dgrad(ctypes.byref(d), _p(_sl(dy, a, b)), _p(dy_cb), _p(wd), _p(dx[a:b]), _stream()), "conv_x6_dgrad")
             else:
                 check(L.mcdseg_conv_dgrad(ctypes.byref(d), _p(dy[a:b]), _p(wd), _p(dx[a:b]), _stream()), "conv_dgrad")
     return dx
@@ -253,7 +258,7 @@ def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None):
             wgrad_kernel_name(desc.Cout, desc.Cin, desc.KH * desc.KW)
         with _timed(name, conv_work(d)):
             if x6:
-                check(L.mcdseg_conv_x6_wgrad(ctypes.byref(d), _p(x[a:b]), _p(x_cb), _p(dy[a:b]), _p(dy_cb), _p(dw), _p(ws),
+                check(L.mcdseg_conv_x6_wgrad(ctypes.byref(d), _p(x[a:b]), _p(x_cb), _p(_sl(dy, a, b)), _p(dy_cb), _p(dw), _p(ws),
                                              ctypes.c_size_t(ws.numel() * 4), _stream()), "conv_x6_wgrad")
             else:
                 check(L.mcdseg_conv_wgrad(ctypes.byref(d), _p(x[a:b]), _p(dy[a:b]), _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4),
@@ -357,7 +362,7 @@ class _ConvBNAct(torch.autograd.Function):
         dy = _req(dy, "grad_output")
         n, c, hw = desc.N, desc.Cout, desc.Ho * desc.Wo
         dgamma, dbeta = _channel_reduce(dy, y if ctx.relu else None, z, mean, rstd, ctx.relu)
-        dz = torch.empty_like(z)
+        dz = None
         dres = None
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = torch.empty_like(z) if ctx.relu else dy
@@ -365,7 +370,18 @@ class _ConvBNAct(torch.autograd.Function):
         bwd_args = (_p(dy), _p(y) if ctx.relu else None, _p(z), _p(mean), _p(rstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dz),
                     _p(dres) if (dres is not None and ctx.relu) else None)
         want_cb = ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and ctx.x_cb is not None)
-        if want_cb and ctx.wd.dtype == torch.bfloat16 and _cb_wanted(c) and n * (c // 8) <= 65535:
+        use_cb = want_cb and ctx.wd.dtype == torch.bfloat16 and _cb_wanted(c) and n * (c // 8) <= 65535
+        # the fp32 dz is skipped when every consumer reads the split companion: dgrad (pre-split gather) and wgrad
+        # (pre-split 128x128 plan); a conv bias gradient or any fallback path still needs it
+        single = len(_batch_pieces(desc)) == 1
+        wgrad_cb = (CONV_MATH == "bf16x6" and ctx.x_cb is not None and min(desc.Cout, desc.Cin) > 64 and desc.Cin % 8 == 0
+                    and desc.Cout % 8 == 0 and not (desc.Cin <= 16 and desc.KH * desc.KW > 1))
+        skip_dz = (use_cb and single and not (ctx.has_bias and ctx.needs_input_grad[5])
+                   and (not ctx.needs_input_grad[1] or wgrad_cb))
+        if not skip_dz:
+            dz = torch.empty_like(z)
+        bwd_args = bwd_args[:8] + (_p(dz),) + bwd_args[9:]
+        if use_cb:
             dz_cb = _cb_alloc(n, c, hw, dy.device)
             check(L.mcdseg_bn_bwd_apply_cb(*bwd_args, _p(dz_cb), n, c, hw, int(ctx.relu), int(ctx.training), _stream()),
                   "bn_bwd_apply_cb")
