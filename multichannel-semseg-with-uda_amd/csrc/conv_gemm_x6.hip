@@ -42,6 +42,10 @@ struct ConvX6Params {
   int P;
   int src_bytes, wp_bytes, cb_bytes;
   int ablate;  // timing-only ablation bits (mcdseg_debug_ablate)
+  // stride-2 dgrad in parity classes: output pixels (y%2, x%2) = class receive only the taps of matching parity, so a
+  // tile holds pixels of ONE class and its K loop visits that class's taps only (1, 2, 2, 4 of 9 for a 3x3 kernel)
+  int sub;           // 1 when the class ordering is active
+  int cls_tile0[5];  // first tile of class c (c = 2*ry + rx), cls_tile0[4] = number of tiles
 };
 
 __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
@@ -82,7 +86,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   const int l31 = lane & 31, lh = lane >> 5;
 
   const int m_tiles = p.Mp / BM;
-  const int n_tiles = (p.P + BN - 1) / BN;
+  const bool SUB = DGRAD && p.sub != 0;
+  const int n_tiles = SUB ? p.cls_tile0[4] : (p.P + BN - 1) / BN;
   const int per_xcd = (n_tiles + 7) >> 3;
   const int xcd = blockIdx.x & 7;
   const int slot = blockIdx.x >> 3;
@@ -95,14 +100,33 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   const int bh0 = __builtin_amdgcn_readfirstlane(t / BN);  // k-half of item 0 (wave-uniform)
   const int HWd = p.Hd * p.Wd;
   const int HWs = p.Hs * p.Ws;
-  const int pix = tile_n * BN + bj;
-  const bool pv = pix < p.P;
-  int pn = 0, py = 0, px = 0;
+  // parity class of this tile (uniform): ry, rx, class grid Hc x Wc, first tile of the class
+  int cls = 0;
+  if (SUB) cls = (tile_n >= p.cls_tile0[1]) + (tile_n >= p.cls_tile0[2]) + (tile_n >= p.cls_tile0[3]);
+  const int ry = cls >> 1, rx = cls & 1;
+  const int Hc = SUB ? (p.Hd - ry + 1) >> 1 : p.Hd;
+  const int Wc = SUB ? (p.Wd - rx + 1) >> 1 : p.Wd;
+  const int HWc = Hc * Wc;
+  const int Pc = SUB ? p.N * HWc : p.P;
+  const int ltile = SUB ? tile_n - p.cls_tile0[cls] : tile_n;
+  const int pix = ltile * BN + bj;
+  const bool pv = pix < Pc;
+  int pn = 0, py = 0, px = 0, yc = 0, xc = 0;
   if (pv) {
-    pn = pix / HWd;
-    const int rem = pix - pn * HWd;
-    py = rem / p.Wd;
-    px = rem - py * p.Wd;
+    pn = pix / HWc;
+    const int rem = pix - pn * HWc;
+    yc = rem / Wc;
+    xc = rem - yc * Wc;
+    py = SUB ? 2 * yc + ry : yc;
+    px = SUB ? 2 * xc + rx : xc;
+  }
+  // taps of this class (all taps outside the class ordering)
+  unsigned cls_taps = 0;
+  if (SUB) {
+    for (int q = 0; q < p.KH * p.KW; ++q) {
+      const int qy = q / p.KW, qx = q - qy * p.KW;
+      if ((((ry + p.pad - qy * p.dil) | (rx + p.pad - qx * p.dil)) & 1) == 0) cls_taps |= 1u << q;
+    }
   }
   constexpr unsigned OOB = 0x80000000u;
   // PRESPLIT: the gathered operand was split into bf16 pieces by its producer (bn_apply_cb / bn_bwd_apply_cb); a pixel's
@@ -146,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   // own base plus a tap offset that is the SAME for every thread (scalar ALU), and whether the tap falls into the zero
   // padding is one bit of a per-thread mask computed once -- the K loop spends three VALU ops per step on addressing
   // instead of ~25 that would compete with the MFMA issue slots.  Strided dgrad keeps the general form.
-  const bool fast_taps = taps <= 32 && (!DGRAD || p.stride == 1);
+  const bool fast_taps = taps <= 32 && (!DGRAD || p.stride == 1 || SUB);
   unsigned valid_mask = 0;
   unsigned vbase = 0;
   if (fast_taps) {
@@ -158,18 +182,39 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
     }
     l_ky = 0;
     l_kx = 0;
-    vbase = DGRAD ? pix_base + (unsigned)(py * p.Ws + px) : pix_base + (unsigned)(py * p.stride * p.Ws + px * p.stride);
+    vbase = SUB ? pix_base + (unsigned)(yc * p.Ws + xc)
+                : (DGRAD ? pix_base + (unsigned)(py * p.Ws + px) : pix_base + (unsigned)(py * p.stride * p.Ws + px * p.stride));
   }
   auto fast_voff = [&]() {
-    const int rel = DGRAD ? (p.pad - l_ky * p.dil) * p.Ws + (p.pad - l_kx * p.dil)
-                          : (l_ky * p.dil - p.pad) * p.Ws + (l_kx * p.dil - p.pad);  // wave-uniform
+    // wave-uniform; in a parity class the source pixel is (yc + (ry + pad - ky*dil)/2, ...), the numerators being even
+    const int rel = SUB ? ((ry + p.pad - l_ky * p.dil) >> 1) * p.Ws + ((rx + p.pad - l_kx * p.dil) >> 1)
+                        : (DGRAD ? (p.pad - l_ky * p.dil) * p.Ws + (p.pad - l_kx * p.dil)
+                                 : (l_ky * p.dil - p.pad) * p.Ws + (l_kx * p.dil - p.pad));
     l_voff = ((valid_mask >> l_tap) & 1u) ? (vbase + (unsigned)rel) * UNIT : OOB;
   };
+  if (SUB && cls_taps != 0) {  // start at the class's first tap
+    l_tap = __builtin_ctz(cls_taps);
+    l_ky = l_tap / p.KW;
+    l_kx = l_tap - l_ky * p.KW;
+    l_kstep = l_tap;
+  }
   if (fast_taps)
     fast_voff();
   else
     tap_geom();
   auto advance = [&]() {
+    if (SUB) {  // next tap of the class, or its first tap in the next channel chunk
+      const unsigned rest = cls_taps & ~((2u << l_tap) - 1u);
+      if (rest) {
+        l_tap = __builtin_ctz(rest);
+      } else {
+        l_tap = __builtin_ctz(cls_taps);
+        l_c0 += 16;
+      }
+      l_ky = l_tap / p.KW;
+      l_kx = l_tap - l_ky * p.KW;
+      l_kstep = (l_c0 >> 4) * taps + l_tap;
+    } else {
     ++l_kstep;
     ++l_tap;
     ++l_kx;
@@ -182,6 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
       l_kx = 0;
       l_ky = 0;
       l_c0 += 16;
+    }
     }
     if (fast_taps)
       fast_voff();
@@ -289,17 +335,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nsteps = taps * (p.Kp / 16);
+  const int nsteps = (SUB ? __builtin_popcount(cls_taps) : taps) * (p.Kp / 16);  // 0 for a class no tap reaches: dx = 0 there
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   // loader state runs two steps ahead: regs set k&1 holds the gathers of step k
-  if (A_DMA) dma_weights(0);
-  load_regs(S0{});
-  store_lds(0, S0{});
-  int l_dma_kstep = 0;  // weight DMA runs one step ahead
-  if (nsteps > 1) {
-    advance();
-    load_regs(S1{});
+  int l_dma_kstep = l_kstep;  // weight DMA runs one step ahead
+  int dma_tap = l_tap, dma_c0 = 0;
+  if (nsteps > 0) {
+    if (A_DMA) dma_weights(0);
+    load_regs(S0{});
+    store_lds(0, S0{});
+    if (nsteps > 1) {
+      advance();
+      load_regs(S1{});
+    }
   }
   __syncthreads();
 
@@ -340,7 +389,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
     using SAME = std::integral_constant<int, CUR>;
     using OTHER = std::integral_constant<int, CUR ^ 1>;
     if (A_DMA && (STEADY || s + 1 < nsteps)) {
-      ++l_dma_kstep;
+      if (SUB) {
+        const unsigned rest = cls_taps & ~((2u << dma_tap) - 1u);
+        if (rest) {
+          dma_tap = __builtin_ctz(rest);
+        } else {
+          dma_tap = __builtin_ctz(cls_taps);
+          dma_c0 += 16;
+        }
+        l_dma_kstep = (dma_c0 >> 4) * taps + dma_tap;
+      } else {
+        ++l_dma_kstep;
+      }
       const int a_soff = (l_dma_kstep * 6 * p.Mp + tile_m * BM) * 16;
       unsigned char* adst = As + (CUR ^ 1) * A_BYTES + wave * 64 * 16;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -416,12 +476,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   size_t dbase[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
-    const int pp = p_wave + j * 32 + l31;
-    colv[j] = pp < p.P;
+    const int pp = ltile * BN + wn * (32 * WN) + j * 32 + l31;  // pixel index inside the (class) ordering
+    colv[j] = pp < Pc;
     int n = 0, rem = 0;
     if (colv[j]) {
-      n = pp / HWd;
-      rem = pp - n * HWd;
+      n = pp / HWc;
+      rem = pp - n * HWc;
+      if (SUB) {
+        const int cy = rem / Wc;
+        rem = (2 * cy + ry) * p.Wd + 2 * (rem - cy * Wc) + rx;
+      }
     }
     dbase[j] = (size_t)n * p.M * HWd + rem;
   }
@@ -532,12 +596,25 @@ int64_t x6_image_bytes(int M, int K, int T) { return (int64_t)(round_up(K, 16) /
 template <int WM, int WN, int WAVES_M, int WAVES_N, bool DGRAD>
 void launch_cfg(const ConvX6Params& p, hipStream_t st) {
   constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
-  const int n_tiles = ceil_div(p.P, BN);
+  ConvX6Params q = p;
+  q.sub = 0;
+  int n_tiles = ceil_div(p.P, BN);
+  if (DGRAD && p.stride == 2 && p.KH * p.KW <= 32) {  // parity classes: tiles never straddle a class
+    q.sub = 1;
+    int t0 = 0;
+    for (int c = 0; c < 4; ++c) {
+      q.cls_tile0[c] = t0;
+      const int hc = (p.Hd - (c >> 1) + 1) / 2, wc = (p.Wd - (c & 1) + 1) / 2;
+      t0 += ceil_div(p.N * hc * wc, BN);
+    }
+    q.cls_tile0[4] = t0;
+    n_tiles = t0;
+  }
   dim3 grid(8 * ceil_div(n_tiles, 8) * (p.Mp / BM));
   if (p.src_cb != nullptr)
-    hipLaunchKernelGGL((conv_gemm_x6_kernel<WM, WN, WAVES_M, WAVES_N, DGRAD, true>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_gemm_x6_kernel<WM, WN, WAVES_M, WAVES_N, DGRAD, true>), grid, dim3(256), 0, st, q);
   else
-    hipLaunchKernelGGL((conv_gemm_x6_kernel<WM, WN, WAVES_M, WAVES_N, DGRAD, false>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_gemm_x6_kernel<WM, WN, WAVES_M, WAVES_N, DGRAD, false>), grid, dim3(256), 0, st, q);
 }
 
 template <bool DGRAD>
