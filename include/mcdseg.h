@@ -64,6 +64,12 @@ int mcdseg_conv_dgrad(const mcdseg_conv_desc* d, const float* dy, const float* w
  * pipe with the six largest cross terms (dropped terms < 2^-24 of a product: fp32-grade results at 2.67x the f32
  * MFMA rate).  Weight images are bf16, layout [k-step][piece 3][k-half 2][Mp][8]; sizes from *_packed_bytes. */
 int mcdseg_conv_x6_packed_bytes(const mcdseg_conv_desc* d, int64_t* fprop_bytes, int64_t* dgrad_bytes);
+/* 1 when the forward of this geometry runs as the direct (LDS-tiled) convolution of the network stem (7x7, stride 1,
+ * pad 3, Cin <= 8, Cout <= 16; models/drn.py:126-131) -- the one case where the split path takes fewer than 16
+ * contraction channels.  mcdseg_conv_x6_stat_rows = rows of the BN partial-statistics buffer mcdseg_conv_x6_fprop
+ * writes (differs from mcdseg_conv_stat_rows for the direct kernel). */
+int32_t mcdseg_conv_x6_direct_ok(const mcdseg_conv_desc* d);
+int64_t mcdseg_conv_x6_stat_rows(const mcdseg_conv_desc* d);
 int mcdseg_conv_x6_pack_weights(const mcdseg_conv_desc* d, const float* w, void* wp_fprop, void* wp_dgrad, void* stream);
 /* x_cb / dy_cb (may be NULL): the gathered operand already split by its producer into the channel-blocked layout
  * [piece 3][N][C/8][H*W][8 bf16] (mcdseg_bn_apply_cb / mcdseg_bn_bwd_apply_cb); C must be divisible by 8.  With it the

@@ -631,11 +631,32 @@ void launch(const ConvX6Params& p, hipStream_t st) {
 }  // namespace
 
 int mcdseg_internal_ablate_bits();
+// direct convolution for the network stem (conv_stem_x6.hip)
+bool mcdseg_internal_stem_ok(const mcdseg_conv_desc* d);
+int64_t mcdseg_internal_stem_stat_rows(const mcdseg_conv_desc* d);
+int64_t mcdseg_internal_stem_image_bytes();
+int mcdseg_internal_stem_pack(const mcdseg_conv_desc* d, const float* w, void* out, hipStream_t st);
+int mcdseg_internal_stem_fprop(const mcdseg_conv_desc* d, const float* x, const void* wp, const float* bias, float* y, float* stats,
+                               const float* ep_scale, const float* ep_shift, const float* ep_res, int ep_relu, hipStream_t st);
+
+extern "C" int32_t mcdseg_conv_x6_direct_ok(const mcdseg_conv_desc* d) { return d != nullptr && mcdseg_internal_stem_ok(d) ? 1 : 0; }
+
+extern "C" int64_t mcdseg_conv_x6_stat_rows(const mcdseg_conv_desc* d) {
+  if (d == nullptr) return -22;
+  if (mcdseg_internal_stem_ok(d)) return mcdseg_internal_stem_stat_rows(d);
+  const int bm = mcd_bm(d->Cout);
+  const int64_t bn = bm == 128 ? 128 : 256;  // pixel tile and column waves of launch<>
+  const int64_t waves_n = bm == 128 ? 2 : 4;
+  return ceil_div64((int64_t)d->N * d->Ho * d->Wo, bn) * waves_n;
+}
 
 extern "C" int mcdseg_conv_x6_packed_bytes(const mcdseg_conv_desc* d, int64_t* fprop_bytes, int64_t* dgrad_bytes) {
   MCD_REQUIRE(d != nullptr, "conv_x6_packed_bytes: null descriptor");
   const int T = d->KH * d->KW;
-  if (fprop_bytes) *fprop_bytes = x6_image_bytes(d->Cout, d->Cin, T);
+  if (fprop_bytes) {
+    *fprop_bytes = x6_image_bytes(d->Cout, d->Cin, T);
+    if (mcdseg_internal_stem_ok(d) && *fprop_bytes < mcdseg_internal_stem_image_bytes()) *fprop_bytes = mcdseg_internal_stem_image_bytes();
+  }
   if (dgrad_bytes) *dgrad_bytes = x6_image_bytes(d->Cin, d->Cout, T);
   return 0;
 }
@@ -645,6 +666,11 @@ extern "C" int mcdseg_conv_x6_pack_weights(const mcdseg_conv_desc* d, const floa
   MCD_REQUIRE(w != nullptr && (wp_fprop != nullptr || wp_dgrad != nullptr), "conv_x6_pack_weights: null pointer");
   const int T = d->KH * d->KW;
   hipStream_t st = (hipStream_t)stream;
+  if (wp_fprop != nullptr && mcdseg_internal_stem_ok(d)) {  // the stem's forward image has its own layout (conv_stem_x6.hip)
+    if (int rc = mcdseg_internal_stem_pack(d, w, wp_fprop, st)) return rc;
+    wp_fprop = nullptr;
+    if (wp_dgrad == nullptr) return 0;
+  }
   int64_t most = 0;
   for (int mode = 0; mode < 2; ++mode) {
     const int M = mode == 0 ? d->Cout : d->Cin, K = mode == 0 ? d->Cin : d->Cout;
@@ -673,6 +699,10 @@ static int x6_fprop_impl(const mcdseg_conv_desc* d, const float* x, const void* 
                          float* stats, const float* ep_scale, const float* ep_shift, const float* ep_res, int ep_relu, void* stream) {
   if (int rc = x6_check(d, "conv_x6_fprop")) return rc;
   MCD_REQUIRE((x || x_cb) && wp && y, "conv_x6_fprop: null pointer");
+  if (mcdseg_internal_stem_ok(d)) {
+    MCD_REQUIRE(x != nullptr, "conv_x6_fprop: the stem kernel reads the fp32 input");
+    return mcdseg_internal_stem_fprop(d, x, wp, bias, y, stats, ep_scale, ep_shift, ep_res, ep_relu, (hipStream_t)stream);
+  }
   ConvX6Params p;
   if (int rc = x6_cb_bytes(d->N, d->Cin, d->H * d->W, x_cb, &p.cb_bytes)) return rc;
   p.src_cb = x_cb;

@@ -57,11 +57,13 @@ def conv_work(desc):
     return 2 * macs, byts
 
 
-def gemm_kernel_name(m, k, dgrad, x6=False, presplit=False):
+def gemm_kernel_name(m, k, dgrad, x6=False, presplit=False, direct=False):
     """Template instantiation conv_fprop / conv_dgrad dispatch to (same rule as csrc/common.h mcd_bm / mcd_bk); the
     string equals the kernel name rocprofv3 prints, so profiles/*_pmc_traffic.json can be keyed by it."""
     bm = 32 if m <= 32 else (64 if m <= 64 else 128)
     cfg = {128: "2, 2, 2, 2", 64: "2, 2, 1, 4", 32: "1, 2, 1, 4"}[bm]
+    if x6 and direct:
+        return "conv_stem_x6_kernel"
     if x6:
         return "conv_gemm_x6_kernel<%s, %s, %s>" % (cfg, "true" if dgrad else "false", "true" if presplit else "false")
     return "conv_gemm_kernel<%s, %d, %s>" % (cfg, 8 if k <= 8 else 16, "true" if dgrad else "false")
@@ -147,6 +149,8 @@ class PackedWeights:
             w = _req(weight.detach(), "conv weight")
             dev = w.device
             fx6, dx6 = _use_x6(desc.Cin, "fprop"), _use_x6(desc.Cout, "dgrad")
+            if CONV_MATH in ("bf16x6", "bf16x6-fprop") and L.mcdseg_conv_x6_direct_ok(ctypes.byref(desc)):
+                fx6 = True  # the stem: direct convolution on the split path although it contracts < 16 channels
             # f32 images (kept for whichever direction does not run on the split path)
             self.wf = None if fx6 else torch.empty(taps * kpf.value * mpf.value, dtype=torch.float32, device=dev)
             self.wd = None if dx6 else torch.empty(taps * kpd.value * mpd.value, dtype=torch.float32, device=dev)
@@ -197,13 +201,15 @@ def _conv_fprop(desc, x, wf, bias, want_stats, mpf, x_cb=None):
     descs = [desc if len(pieces) == 1 else _sub_desc(desc, b - a) for a, b in pieces]
     part, rows, row_off = None, 0, [0]
     if want_stats:
+        stat_rows = L.mcdseg_conv_x6_stat_rows if wf.dtype == torch.bfloat16 else L.mcdseg_conv_stat_rows
         for d in descs:
-            row_off.append(row_off[-1] + L.mcdseg_conv_stat_rows(ctypes.byref(d)))
+            row_off.append(row_off[-1] + stat_rows(ctypes.byref(d)))
         rows = row_off[-1]
         part = torch.empty(rows * 3 * mpf, dtype=torch.float32, device=x.device)
     for i, ((a, b), d) in enumerate(zip(pieces, descs)):
         pp = None if part is None else ctypes.c_void_p(part.data_ptr() + 4 * row_off[i] * 3 * mpf)
-        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, wf.dtype == torch.bfloat16, x_cb is not None), conv_work(d)):
+        direct = wf.dtype == torch.bfloat16 and bool(L.mcdseg_conv_x6_direct_ok(ctypes.byref(d)))
+        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, wf.dtype == torch.bfloat16, x_cb is not None, direct), conv_work(d)):
             if wf.dtype == torch.bfloat16:
                 check(L.mcdseg_conv_x6_fprop(ctypes.byref(d), _p(x[a:b]), _p(x_cb), _p(wf), _p(bias), _p(y[a:b]), pp, _stream()),
                       "conv_x6_fprop")

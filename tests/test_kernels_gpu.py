@@ -105,6 +105,11 @@ def test_conv_rejects_bad_geometry():
     (512, 512, 3, 1, 4, 8, 12, 2, True, True, True),
     (64, 64, 3, 1, 1, 12, 20, 2, True, True, False),   # eval-mode BN (fix_bn / inference)
     (40, 24, 3, 1, 1, 11, 13, 2, False, True, True),   # HW % 4 != 0 -> scalar paths
+    (6, 16, 7, 1, 1, 20, 28, 2, True, False, True),    # stem: direct (LDS-tiled) convolution, one ragged tile per image
+    (6, 16, 7, 1, 1, 19, 141, 2, True, False, True),   # stem: 3 x 3 tiles, ragged in both directions
+    (3, 16, 7, 1, 1, 17, 70, 1, True, False, True),    # MFNet RGB stem
+    (1, 16, 7, 1, 1, 9, 13, 2, True, False, True),     # MFNet single-channel stem
+    (6, 16, 7, 1, 1, 20, 28, 2, True, False, False),   # stem, eval-mode BN
 ], ids=lambda c: "x".join(map(str, c)))
 def test_conv_bn_act_fwd_bwd(cfg):
     dev = _dev()
@@ -600,3 +605,43 @@ def test_confusion_hist_full_size_checksum():
     assert int(hist.sum()) == int(keep.sum())
     assert torch.equal(hist.sum(1), torch.bincount(gt[keep], minlength=41))
     assert torch.equal(hist.sum(0), torch.bincount(pred[keep], minlength=41))
+
+
+def test_stem_direct_conv_matches_generic_kernels(monkeypatch):
+    """the stem's direct convolution (bf16x6) against fp64 and against the f32-MFMA implicit GEMM: plain, with bias, and the
+    folded-BN inference epilogue (scale, shift, ReLU)"""
+    dev = _dev()
+    from mcdseg import ops
+    from mcdseg._lib import lib
+    from models.drn import BatchNorm2d, Conv2d
+    import ctypes
+    g = torch.Generator().manual_seed(51)
+    x = torch.randn(2, 6, 23, 77, generator=g)
+    wt = torch.randn(16, 6, 7, 7, generator=g) * 0.08
+    bias = torch.randn(16, generator=g) * 0.1
+    desc = ops.conv_desc(x.shape, wt.shape, 1, 3, 1)
+    assert lib().mcdseg_conv_x6_direct_ok(ctypes.byref(desc)) == 1
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=3)
+    outs = {}
+    for math in ("f32", "bf16x6"):
+        monkeypatch.setattr(ops, "CONV_MATH", math)
+        wf, _, mpf = ops.PackedWeights().get(wt.to(dev), desc, need_dgrad=False)
+        assert (wf.dtype == torch.bfloat16) == (math == "bf16x6")
+        y, part, rows = ops._conv_fprop(desc, x.to(dev), wf, bias.to(dev), True, mpf)
+        _assert_close(y, ref, 2e-5, math + " stem fprop")
+        outs[math] = _maxerr(y, ref)[0]
+    assert outs["bf16x6"] <= max(2.0 * outs["f32"], 2e-6 * float(ref.abs().max()))
+    # inference: eval-mode BN folded into the epilogue
+    monkeypatch.setattr(ops, "CONV_MATH", "bf16x6")
+    conv, bn = Conv2d(6, 16, 7, padding=3, bias=False), BatchNorm2d(16)
+    with torch.no_grad():
+        conv.weight.copy_(wt)
+        bn.weight.copy_(1 + 0.2 * torch.randn(16, generator=g)), bn.bias.copy_(0.1 * torch.randn(16, generator=g))
+        bn.running_mean.copy_(0.1 * torch.randn(16, generator=g)), bn.running_var.copy_(0.5 + torch.rand(16, generator=g))
+    bn.eval()
+    o = F.relu(F.batch_norm(F.conv2d(x.double(), wt.double(), None, padding=3), bn.running_mean.double(), bn.running_var.double(),
+                            bn.weight.double(), bn.bias.double(), training=False, eps=1e-5))
+    conv.to(dev), bn.to(dev)
+    with torch.no_grad():
+        y = ops.conv_bn_act(x.to(dev), conv, bn, relu=True)
+    _assert_close(y, o, 3e-5, "stem inference")
