@@ -234,9 +234,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 3
 // Thin-input variant (Cin <= 16: 7x7 stem, layer1, layer2).  One wave per workgroup, a 32 (co) x 32 (columns) tile
 // whose columns are (tap_local, ci) pairs: 32/CINP taps share one MFMA tile instead of one tap per tile padded from
 // Cin to 32 columns -- 4x fewer MFMAs and dY re-reads for the 6-channel stem, 2x for 16 channels.
-template <int CINP>
+// ROWS16 (Cout <= 16, the stem and layer1): 16-row tile on v_mfma_f32_16x16x4_f32 instead of padding the output channels
+// to the 32 rows of v_mfma_f32_32x32x2_f32 -- the same FLOP rate per instruction, half the instructions.
+template <int CINP, bool ROWS16>
 __global__ __launch_bounds__(64) void conv_wgrad_thin_kernel(WgradParams p) {
-  constexpr int BKP = 32, LDP = BKP + 1, BM = 32, BN = 32;
+  constexpr int BKP = 32, LDP = BKP + 1, BM = ROWS16 ? 16 : 32, BN = 32;
+  constexpr int A_REGS = BM / 2;
   constexpr int TPT = 32 / CINP;  // taps per tile
   __shared__ float smem[2 * (BM + BN) * LDP];
   float* As = smem;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(64) void conv_wgrad_thin_kernel(WgradParams p) {
   const int t = threadIdx.x;
   const int l31 = t & 31, lh = t >> 5;
 
-  const int co_tiles = p.co_p / BM;
+  const int co_tiles = ROWS16 ? 1 : p.co_p / BM;  // the host plans 32-row tiles; 16 rows cover Cout <= 16 in one
   const int per_split = co_tiles * p.groups;
   const int xcd = blockIdx.x & 7;
   const int slot = blockIdx.x >> 3;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(64) void conv_wgrad_thin_kernel(WgradParams p) {
     tdx[q] = kx * p.dil - p.pad;
   }
 
-  float areg[16], breg[16];
+  float areg[A_REGS], breg[16];
   auto load_regs = [&](int r0) {
     const int r = r0 + sk;
     const bool rv = r < r_end;
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(64) void conv_wgrad_thin_kernel(WgradParams p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i)  // rows srg + 2i of dY
+    for (int i = 0; i < A_REGS; ++i)  // rows srg + 2i of dY
       areg[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dy_rs, a_voff, a_soff0 + 2 * i * HoWo * 4, 0));
 #pragma unroll
     for (int i = 0; i < 16; ++i) {  // column srg + 2i = (tap_local, ci): tap_local = 2i / CINP, ci = 2i % CINP + srg
@@ -313,14 +316,16 @@ __global__ __launch_bounds__(64) void conv_wgrad_thin_kernel(WgradParams p) {
     float* a = As + buf * BM * LDP;
     float* b = Bs + buf * BN * LDP;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[(srg + 2 * i) * LDP + sk] = areg[i];
+    for (int i = 0; i < A_REGS; ++i) a[(srg + 2 * i) * LDP + sk] = areg[i];
 #pragma unroll
     for (int i = 0; i < 16; ++i) b[(srg + 2 * i) * LDP + sk] = breg[i];
   };
 
-  f32x16 acc;
+  f32x16 acc;  // ROWS16: two 16x16 blocks (columns 0-15 and 16-31) in acc[0..3] and acc[4..7]
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  f32x4 acc_lo = {0.f, 0.f, 0.f, 0.f}, acc_hi = {0.f, 0.f, 0.f, 0.f};
+  const int l15 = t & 15, lq = t >> 4;
   const int nsteps = (r_end - r_begin + BKP - 1) / BKP;
   if (nsteps > 0) {
     load_regs(r_begin);
@@ -331,14 +336,35 @@ __global__ __launch_bounds__(64) void conv_wgrad_thin_kernel(WgradParams p) {
     const int cur = s & 1;
     const bool more = (s + 1) < nsteps;
     if (more) load_regs(r_begin + (s + 1) * BKP);
-    const float* a_base = As + cur * BM * LDP + l31 * LDP + lh;
-    const float* b_base = Bs + cur * BN * LDP + l31 * LDP + lh;
+    if constexpr (ROWS16) {
+      // 16x16x4: lane (row / column l & 15, k = l >> 4) holds one element of A and of B
+      const float* a_base = As + cur * BM * LDP + l15 * LDP + lq;
+      const float* b_base = Bs + cur * BN * LDP + l15 * LDP + lq;
 #pragma unroll
-    for (int kk = 0; kk < BKP; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_base[kk], b_base[kk], acc, 0, 0, 0);
+      for (int kk = 0; kk < BKP; kk += 4) {
+        const float av = a_base[kk];
+        acc_lo = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_base[kk], acc_lo, 0, 0, 0);
+        acc_hi = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_base[16 * LDP + kk], acc_hi, 0, 0, 0);
+      }
+    } else {
+      const float* a_base = As + cur * BM * LDP + l31 * LDP + lh;
+      const float* b_base = Bs + cur * BN * LDP + l31 * LDP + lh;
+#pragma unroll
+      for (int kk = 0; kk < BKP; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_base[kk], b_base[kk], acc, 0, 0, 0);
+    }
     if (more) store_lds(cur ^ 1);
     __syncthreads();
   }
   float* out = p.slab + ((size_t)split * p.groups + group) * p.co_p * 32;
+  if constexpr (ROWS16) {  // D[row 4*(l>>4) + r][column l & 15 (+16)]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * lq + r;
+      out[(size_t)row * 32 + l15] = acc_lo[r];
+      out[(size_t)row * 32 + 16 + l15] = acc_hi[r];
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = tile_co * BM + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -439,10 +465,15 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)T * d->Cout * d->Cin;
   if (pl.cfg == 3) {
-    if (pl.cinp == 8)
-      hipLaunchKernelGGL((conv_wgrad_thin_kernel<8>), grid, dim3(64), 0, st, p);
+    const bool rows16 = d->Cout <= 16 && pl.co_p == 32;
+    if (pl.cinp == 8 && rows16)
+      hipLaunchKernelGGL((conv_wgrad_thin_kernel<8, true>), grid, dim3(64), 0, st, p);
+    else if (pl.cinp == 8)
+      hipLaunchKernelGGL((conv_wgrad_thin_kernel<8, false>), grid, dim3(64), 0, st, p);
+    else if (rows16)
+      hipLaunchKernelGGL((conv_wgrad_thin_kernel<16, true>), grid, dim3(64), 0, st, p);
     else
-      hipLaunchKernelGGL((conv_wgrad_thin_kernel<16>), grid, dim3(64), 0, st, p);
+      hipLaunchKernelGGL((conv_wgrad_thin_kernel<16, false>), grid, dim3(64), 0, st, p);
     MCD_LAUNCH_CHECK("conv_wgrad_thin");
     hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3((unsigned)ceil_div64(total, 4)), dim3(256), 0, st, (const float*)workspace,
                        dw, d->Cout, d->Cin, T, pl.co_p, pl.groups, pl.cinp, pl.splits);

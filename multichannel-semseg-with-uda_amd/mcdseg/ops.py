@@ -71,7 +71,7 @@ def gemm_kernel_name(m, k, dgrad, x6=False, presplit=False, direct=False):
 
 def wgrad_kernel_name(cout, cin, taps=9):
     if cin <= 16 and taps > 1:
-        return "conv_wgrad_thin_kernel<%d>" % (8 if cin <= 8 else 16)
+        return "conv_wgrad_thin_kernel<%d, %s>" % (8 if cin <= 8 else 16, "true" if cout <= 16 else "false")
     lo = min(cout, cin)
     return "conv_wgrad_kernel<%s>" % ("2, 2, 2, 2, 16" if lo > 64 else ("1, 1, 2, 2, 32" if lo > 32 else "1, 1, 1, 1, 32"))
 
@@ -123,6 +123,9 @@ if CONV_MATH not in ("bf16x6", "f32", "mixed", "bf16x6-fprop", "bf16x6-dgrad"):
     raise ValueError("MCDSEG_CONV_MATH must be bf16x6, f32 or mixed, got %r" % CONV_MATH)
 
 
+STEM_DIRECT = os.environ.get("MCDSEG_STEM_DIRECT", "1") != "0"  # the stem's forward as the direct bf16x6 convolution
+
+
 def _use_x6(contraction_channels, direction="fprop"):
     if contraction_channels < 16:
         return False
@@ -149,7 +152,7 @@ class PackedWeights:
             w = _req(weight.detach(), "conv weight")
             dev = w.device
             fx6, dx6 = _use_x6(desc.Cin, "fprop"), _use_x6(desc.Cout, "dgrad")
-            if CONV_MATH in ("bf16x6", "bf16x6-fprop") and L.mcdseg_conv_x6_direct_ok(ctypes.byref(desc)):
+            if STEM_DIRECT and CONV_MATH in ("bf16x6", "bf16x6-fprop") and L.mcdseg_conv_x6_direct_ok(ctypes.byref(desc)):
                 fx6 = True  # the stem: direct convolution on the split path although it contracts < 16 channels
             # f32 images (kept for whichever direction does not run on the split path)
             self.wf = None if fx6 else torch.empty(taps * kpf.value * mpf.value, dtype=torch.float32, device=dev)
