@@ -24,6 +24,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the declarations below are exported */
+#pragma GCC visibility push(default)
 
 #define MCDSEG_VERSION 100
 
@@ -190,6 +192,11 @@ size_t mcdseg_mse_workspace_bytes(int64_t n);
 int mcdseg_mse(const float* pred, const float* target, float* grad, float* loss, int64_t n,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* Development hook (tools/ablate_conv.py, profiles/README.md): timing-only ablation of the f32 implicit-GEMM K loop --
+ * bit 0 skips the global loads, bit 1 the LDS stores, bit 2 the barriers.  Results are garbage while any bit is set;
+ * process-wide, not for production callers. */
+void mcdseg_debug_ablate(int bits);
+
 /* ------------------------------------------------------------------------------------------------
  * MFNet late fusion beyond the plain sum (models/fusion.py:6-50) and its loss (loss.py:16-30)
  *   gate_mix:    out = x1*s + x2*(1-s), s = sigmoid(g)   (GateFusion.forward :19-22; g = 1x1 conv of cat(x1,x2))
@@ -229,6 +236,7 @@ int mcdseg_confusion_hist(const int64_t* gt, const int64_t* pred, int64_t count,
 int mcdseg_sgd_momentum_flat(float* p, const float* g, float* v, int64_t n, float lr, float momentum,
                              float weight_decay, float grad_scale, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -41,7 +41,6 @@ struct ConvX6Params {
   int KH, KW, stride, pad, dil;
   int P;
   int src_bytes, wp_bytes, cb_bytes;
-  int ablate;  // timing-only ablation bits (mcdseg_debug_ablate)
   // stride-2 dgrad in parity classes: output pixels (y%2, x%2) = class receive only the taps of matching parity, so a
   // tile holds pixels of ONE class and its K loop visits that class's taps only (1, 2, 2, 4 of 9 for a 3x3 kernel)
   int sub;           // 1 when the class ordering is active
@@ -630,7 +629,6 @@ void launch(const ConvX6Params& p, hipStream_t st) {
 
 }  // namespace
 
-int mcdseg_internal_ablate_bits();
 // direct convolution for the network stem (conv_stem_x6.hip)
 bool mcdseg_internal_stem_ok(const mcdseg_conv_desc* d);
 int64_t mcdseg_internal_stem_stat_rows(const mcdseg_conv_desc* d);
@@ -719,7 +717,6 @@ static int x6_fprop_impl(const mcdseg_conv_desc* d, const float* x, const void* 
   const int64_t wb = x6_image_bytes(d->Cout, d->Cin, d->KH * d->KW);
   MCD_REQUIRE(wb < (1ll << 31), "conv_x6_fprop: packed weights exceed 2 GiB");
   p.wp_bytes = (int)wb;
-  p.ablate = mcdseg_internal_ablate_bits();
   launch<false>(p, (hipStream_t)stream);
   MCD_LAUNCH_CHECK("conv_x6_fprop");
   return 0;
@@ -757,7 +754,6 @@ extern "C" int mcdseg_conv_x6_dgrad(const mcdseg_conv_desc* d, const float* dy, 
   const int64_t wb = x6_image_bytes(d->Cin, d->Cout, d->KH * d->KW);
   MCD_REQUIRE(wb < (1ll << 31), "conv_x6_dgrad: packed weights exceed 2 GiB");
   p.wp_bytes = (int)wb;
-  p.ablate = mcdseg_internal_ablate_bits();
   launch<true>(p, (hipStream_t)stream);
   MCD_LAUNCH_CHECK("conv_x6_dgrad");
   return 0;

@@ -75,6 +75,7 @@ _SIGNATURES = {
     "mcdseg_prob_nll_workspace_bytes": (c_size_t, [c_i32, c_i32]),
     "mcdseg_prob_nll": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p,
                                 c_size_t, c_void_p]),
+    "mcdseg_debug_ablate": (None, [c_int]),
     "mcdseg_normalize_u8": (c_int, [c_void_p] * 4 + [c_i32] * 6 + [c_void_p]),
     "mcdseg_relabel_u8": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_void_p]),
     "mcdseg_confusion_hist": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p]),
@@ -98,7 +99,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC,
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-shared", "-I", INCLUDE, "-I", CSRC,
            "-o", LIB_PATH + ".tmp"] + srcs
     if verbose:
         print(" ".join(cmd))

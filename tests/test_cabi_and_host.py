@@ -27,6 +27,13 @@ def test_library_exports_every_header_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "libmcdseg.so does not export %s" % name
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
+    # ... and nothing else: every extern "C" symbol of the library is declared in the header
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    if nm.returncode == 0:
+        exported = set(re.findall(r"\b(mcdseg_[a-z0-9_]+)$", nm.stdout, re.M))
+        internal = {n for n in exported if n.startswith("mcdseg_internal_") or n == "mcdseg_set_error"}
+        assert exported - internal == declared, (exported - internal) ^ declared
     assert L.mcdseg_version() == 100
     assert isinstance(L.mcdseg_last_error(), bytes)
     # every source is written for gfx950 directly: no CUDA shims / dual paths
