@@ -294,7 +294,7 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None):
         return ((_conv_dgrad(desc, dy, wd, dy_cb) if need_dx else None),
                 (_conv_wgrad(desc, x, dy, x_cb, dy_cb) if need_dw else None))
     main = torch.cuda.current_stream()
-    side = _side_stream(dy.device)
+    side = _side_stream(x.device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
         dw = _conv_wgrad(desc, x, dy, x_cb, dy_cb)
