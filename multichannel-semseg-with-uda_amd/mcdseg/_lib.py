@@ -100,11 +100,11 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-shared", "-I", INCLUDE, "-I", CSRC,
-           "-o", LIB_PATH + ".tmp"] + srcs
+           "-o", LIB_PATH + ".tmp%d" % os.getpid()] + srcs  # private temp + atomic rename: concurrent builders cannot corrupt it
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    os.replace(LIB_PATH + ".tmp%d" % os.getpid(), LIB_PATH)
     return LIB_PATH
 
 
