@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Single-GPU step times of the other BASELINE configs on synthetic batches -- a development/measurement
+tool; bench.py (cfg2) is the judged benchmark.
+
+  cfg2  MCD early fusion          drn_d_38,  N=16, 6x480x640   (same as bench.py, for reference)
+  cfg3  MFNet-ScoreAddFusion      2x drn_d_38 encoders, N=16
+  cfg4  multitask (seg + HHA)     drn_d_38 RGB encoder + 3 decoders, N=8
+  cfg5* drn_d_105                 N as given (fp32 activations; the bf16-storage variant of cfg5 is not built)
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multichannel-semseg-with-uda_amd"))
+import torch  # noqa: E402
+
+os.environ["MCDSEG_PRETRAINED"] = "0"
+from loss import CrossEntropyLoss2d, Diff2d, get_prob_distance_criterion  # noqa: E402
+from models.model_util import get_models, get_multitask_models, get_optimizer  # noqa: E402
+from solvers.solver import MCDSolver, MFNetMCDSolver, MultiTaskMCDSolver  # noqa: E402
+
+NC = 41
+
+
+def batch(n, h, w, dev):
+    g = torch.Generator().manual_seed(1234)
+    return (torch.randn(n, 6, h, w, generator=g).to(dev), torch.randint(0, NC, (n, h, w), generator=g).to(dev),
+            torch.randn(n, 6, h, w, generator=g).to(dev))
+
+
+def opt(params):
+    return get_optimizer(params, "sgd", 1e-3, 0.9, 2e-5)
+
+
+def build(cfg, net, dev):
+    w = torch.ones(NC)
+    w[NC - 1] = 0
+    crit, crit_d = CrossEntropyLoss2d(w.to(dev)), get_prob_distance_criterion("diff")
+    torch.manual_seed(0)
+    if cfg in ("cfg2", "cfg5"):
+        g, f1, f2 = get_models(net, 6, NC, method="MCD")
+        for m in (g, f1, f2):
+            m.to(dev).train()
+        return MCDSolver(g, f1, f2, opt(g.parameters()), opt(list(f1.parameters()) + list(f2.parameters())), crit, crit_d, num_k=4)
+    if cfg == "cfg3":
+        g3, g1, f1, f2 = get_models(net, 6, NC, method="MFNet-ScoreAddFusion")
+        for m in (g3, g1, f1, f2):
+            m.to(dev).train()
+        return MFNetMCDSolver(g3, g1, f1, f2, opt(list(g3.parameters()) + list(g1.parameters())),
+                              opt(list(f1.parameters()) + list(f2.parameters())), crit, crit_d, num_k=4)
+    enc, dec = get_multitask_models(net, 6, NC, CrossEntropyLoss2d(w), Diff2d())
+    enc.to(dev).train(), dec.to(dev).train()
+    return MultiTaskMCDSolver(enc, dec, opt(enc.parameters()), opt(dec.parameters()), num_k=4)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg", default="cfg3,cfg4,cfg5")
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--n5", type=int, default=8, help="pairs per GPU for the drn_d_105 run")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    for cfg in args.cfg.split(","):
+        n = {"cfg2": 16, "cfg3": 16, "cfg4": 8, "cfg5": args.n5}[cfg]
+        net = "drn_d_105" if cfg == "cfg5" else "drn_d_38"
+        solver = build(cfg, net, dev)
+        s, l, t = batch(n, 480, 640, dev)
+        out = solver.step(s, l, t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = solver.step(s, l, t)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        print("%s %-10s N=%-2d 6x480x640: %.1f ms/step, %.2f pairs/s  (c_loss %.4f, d_loss %.6f)" % (
+            cfg, net, n, 1e3 * dt, n / dt, float(out[0]), float(out[1])), flush=True)
+        del solver, s, l, t
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
