@@ -83,53 +83,6 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
   if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
 }
 
-// Both stages in one launch for the common case of few partial rows (every 60x80 layer: 1200 rows): a block owns 32
-// channels, folds ALL rows (8 row groups, fixed order) and finalizes them -- no second kernel, no cross-block hand-off.
-__global__ __launch_bounds__(256) void bn_stats_fused_kernel(const float* __restrict__ part, int64_t rows, int C, int Mp,
-                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                             float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                             int64_t* nbt, float momentum, float eps) {
-  __shared__ double sh[3][8][33];
-  const int cx = threadIdx.x & 31;
-  const int g = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
-  double n = 0.0, s1 = 0.0, q = 0.0;
-  if (c < C) {
-    for (int64_t r = g; r < rows; r += 8) {
-      const float* row = part + (size_t)r * 3 * Mp;
-      const double cnt = (double)row[c];
-      const double mu = (double)row[Mp + c];
-      n += cnt;
-      s1 += cnt * mu;
-      q += (double)row[2 * (size_t)Mp + c] + cnt * mu * mu;
-    }
-  }
-  sh[0][g][cx] = n;
-  sh[1][g][cx] = s1;
-  sh[2][g][cx] = q;
-  __syncthreads();
-  if (g == 0 && c < C) {
-    n = s1 = q = 0.0;
-    for (int k = 0; k < 8; ++k) {
-      n += sh[0][k][cx];
-      s1 += sh[1][k][cx];
-      q += sh[2][k][cx];
-    }
-    const double mean = n > 0.0 ? s1 / n : 0.0;
-    double m2 = q - s1 * mean;
-    if (m2 < 0.0) m2 = 0.0;
-    const double var = n > 0.0 ? m2 / n : 0.0;
-    mean_out[c] = (float)mean;
-    rstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean != nullptr) {
-      const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
-      running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
-      running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
-    }
-  }
-  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
-}
-
 __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int C, float eps,
                                      float* __restrict__ mean, float* __restrict__ rstd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -447,12 +400,6 @@ extern "C" int mcdseg_bn_stats_finalize(const float* stat_partials, int64_t rows
   MCD_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "bn_stats_finalize: workspace must be 8-byte aligned");
   const int S = stats_slices(rows);
   hipStream_t st = (hipStream_t)stream;
-  if (rows <= 2048) {
-    hipLaunchKernelGGL(bn_stats_fused_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, st, stat_partials, rows, C, Mp, mean, rstd,
-                       running_mean, running_var, num_batches_tracked, momentum, eps);
-    MCD_LAUNCH_CHECK("bn_stats_fused");
-    return 0;
-  }
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ceil_div(C, 32), S), dim3(256), 0, st, stat_partials, rows, C, Mp,
                      (double*)workspace);
   MCD_LAUNCH_CHECK("bn_stats_partial");
