@@ -340,16 +340,44 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   // loader state runs two steps ahead: regs set k&1 holds the gathers of step k
   int l_dma_kstep = l_kstep;  // weight DMA runs one step ahead
   int dma_tap = l_tap, dma_c0 = 0;
-  if (nsteps > 0) {
-    if (A_DMA) dma_weights(0);
-    load_regs(S0{});
-    store_lds(0, S0{});
-    if (nsteps > 1) {
-      advance();
-      load_regs(S1{});
+  // B_DMA: the pre-split operand also goes global -> LDS by DMA.  Its LDS image [piece][half][pixel][16 B] is lane-linear
+  // per wave (64 consecutive pixels of one k-half), the gather address is per lane, and a padding pixel's out-of-range
+  // offset makes the DMA deposit zeros -- so the K loop issues six DMAs per thread and touches no vector register for
+  // staging: no ds_write, no register prefetch sets, no wait before the barrier other than vmcnt(0).
+  constexpr bool B_DMA = PRESPLIT && A_DMA && B_ITEMS == 1;
+  auto dma_b = [&](int buf) {
+    const int grp = (l_c0 >> 3) + bh0;
+    const int wave_px = __builtin_amdgcn_readfirstlane(bj - lane);
+    unsigned char* bdst = Bs + buf * B_BYTES + (bh0 * BN + wave_px) * 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+      const int soff = grp < C8 ? (grp * HWs + pc * piece_stride) * 16 : 0x7FFFFFFF;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (__attribute__((address_space(3))) void*)(bdst + pc * 2 * BN * 16), 16, l_voff, soff, 0, 0);
     }
+#else
+    (void)grp;
+    (void)bdst;
+#endif
+  };
+  if constexpr (B_DMA) {
+    if (nsteps > 0) {
+      dma_weights(0);
+      dma_b(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  } else {
+    if (nsteps > 0) {
+      if (A_DMA) dma_weights(0);
+      load_regs(S0{});
+      store_lds(0, S0{});
+      if (nsteps > 1) {
+        advance();
+        load_regs(S1{});
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   auto mfma_step = [&](int cur) {
     const unsigned char* a_base = As + cur * A_BYTES + (lh * BM + wm * (32 * WM) + l31) * 16;
@@ -435,14 +463,27 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   };
   using YES = std::integral_constant<bool, true>;
   using NO = std::integral_constant<bool, false>;
-  int s = 0;
-  for (; s + 3 < nsteps; s += 2) {  // steady state: both steps of the pair still have two successors
-    k_step(s, S0{}, YES{});
-    k_step(s + 1, S1{}, YES{});
-  }
-  for (; s < nsteps; s += 2) {
-    k_step(s, S0{}, NO{});
-    if (s + 1 < nsteps) k_step(s + 1, S1{}, NO{});
+  if constexpr (B_DMA) {
+    for (int s = 0; s < nsteps; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < nsteps) {  // both operands of step s+1 -> the buffer the barrier below step s-1 released
+        advance();
+        dma_weights(cur ^ 1);
+        dma_b(cur ^ 1);
+      }
+      mfma_step(cur);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  } else {
+    int s = 0;
+    for (; s + 3 < nsteps; s += 2) {  // steady state: both steps of the pair still have two successors
+      k_step(s, S0{}, YES{});
+      k_step(s + 1, S1{}, YES{});
+    }
+    for (; s < nsteps; s += 2) {
+      k_step(s, S0{}, NO{});
+      if (s + 1 < nsteps) k_step(s + 1, S1{}, NO{});
+    }
   }
 
   // ---- epilogue (identical to conv_gemm.hip): acc[i][j][r] = D[row][col], row = (r&3) + 8*(r>>2) + 4*lh, col = l31
@@ -619,7 +660,12 @@ void launch_cfg(const ConvX6Params& p, hipStream_t st) {
 template <bool DGRAD>
 void launch(const ConvX6Params& p, hipStream_t st) {
   const int bm = mcd_bm(p.M);
-  if (bm == 128)
+  // 256 x 128 tile (each wave 128 x 64): the gathered operand is fetched once per TWO row tiles and a K-step issues 18
+  // fragment reads per 48 MFMAs instead of 12 per 24 -- worth +5 % on the 512-channel layers, but only while the grid
+  // still holds two full rounds of the 512 workgroup slots this tile leaves (256-channel layers and small batches lose)
+  if (bm == 128 && p.src_cb != nullptr && (p.Mp % 256) == 0 && (int64_t)ceil_div(p.P, 128) * (p.Mp / 256) >= 1024)
+    launch_cfg<4, 2, 2, 2, DGRAD>(p, st);
+  else if (bm == 128)
     launch_cfg<2, 2, 2, 2, DGRAD>(p, st);
   else if (bm == 64)
     launch_cfg<2, 2, 1, 4, DGRAD>(p, st);

@@ -57,7 +57,7 @@ def conv_work(desc):
     return 2 * macs, byts
 
 
-def gemm_kernel_name(m, k, dgrad, x6=False, presplit=False, direct=False):
+def gemm_kernel_name(m, k, dgrad, x6=False, presplit=False, direct=False, pixels=0):
     """Template instantiation conv_fprop / conv_dgrad dispatch to (same rule as csrc/common.h mcd_bm / mcd_bk); the
     string equals the kernel name rocprofv3 prints, so profiles/*_pmc_traffic.json can be keyed by it."""
     bm = 32 if m <= 32 else (64 if m <= 64 else 128)
@@ -65,6 +65,9 @@ def gemm_kernel_name(m, k, dgrad, x6=False, presplit=False, direct=False):
     if x6 and direct:
         return "conv_stem_x6_kernel"
     if x6:
+        mp = -(-m // 128) * 128
+        if bm == 128 and presplit and mp % 256 == 0 and -(-pixels // 128) * (mp // 256) >= 1024:
+            cfg = "4, 2, 2, 2"  # the 256 x 128 tile (same rule as launch<> in csrc/conv_gemm_x6.hip)
         return "conv_gemm_x6_kernel<%s, %s, %s>" % (cfg, "true" if dgrad else "false", "true" if presplit else "false")
     return "conv_gemm_kernel<%s, %d, %s>" % (cfg, 8 if k <= 8 else 16, "true" if dgrad else "false")
 
@@ -212,7 +215,8 @@ def _conv_fprop(desc, x, wf, bias, want_stats, mpf, x_cb=None):
     for i, ((a, b), d) in enumerate(zip(pieces, descs)):
         pp = None if part is None else ctypes.c_void_p(part.data_ptr() + 4 * row_off[i] * 3 * mpf)
         direct = wf.dtype == torch.bfloat16 and bool(L.mcdseg_conv_x6_direct_ok(ctypes.byref(d)))
-        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, wf.dtype == torch.bfloat16, x_cb is not None, direct), conv_work(d)):
+        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, wf.dtype == torch.bfloat16, x_cb is not None, direct,
+                                     d.N * d.Ho * d.Wo), conv_work(d)):
             if wf.dtype == torch.bfloat16:
                 check(L.mcdseg_conv_x6_fprop(ctypes.byref(d), _p(x[a:b]), _p(x_cb), _p(wf), _p(bias), _p(y[a:b]), pp, _stream()),
                       "conv_x6_fprop")
@@ -234,7 +238,8 @@ def _conv_dgrad(desc, dy, wd, dy_cb=None):
         dy_cb = None
     for a, b in pieces:
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
-        with _timed(gemm_kernel_name(desc.Cin, desc.Cout, True, wd.dtype == torch.bfloat16, dy_cb is not None), conv_work(d)):
+        with _timed(gemm_kernel_name(desc.Cin, desc.Cout, True, wd.dtype == torch.bfloat16, dy_cb is not None, False,
+                                     d.N * d.H * d.W), conv_work(d)):
             if wd.dtype == torch.bfloat16:
                 check(L.mcdseg_conv_x6_dgrad(ctypes.byref(d), _p(_sl(dy, a, b)), _p(dy_cb), _p(wd), _p(dx[a:b]), _stream()), "conv_x6_dgrad")
             else:
@@ -422,7 +427,8 @@ def _conv_bn_act_inference(x, conv, bn, relu, residual):
     for a, b in _batch_pieces(desc):
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
         fn = L.mcdseg_conv_x6_fprop_affine if wf.dtype == torch.bfloat16 else L.mcdseg_conv_fprop_affine
-        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, wf.dtype == torch.bfloat16), conv_work(d)):
+        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, wf.dtype == torch.bfloat16, False,
+                                     wf.dtype == torch.bfloat16 and bool(L.mcdseg_conv_x6_direct_ok(ctypes.byref(d)))), conv_work(d)):
             args = (_p(scale), _p(shift), _p(residual[a:b]) if residual is not None else None, int(relu), _p(y[a:b]), _stream())
             if wf.dtype == torch.bfloat16:
                 check(fn(ctypes.byref(d), _p(x[a:b]), None, _p(wf), *args), "conv_x6_fprop_affine")
