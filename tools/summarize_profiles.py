@@ -4,6 +4,7 @@
     python tools/summarize_profiles.py r01c      # reads gpurun_out/r01c_{stats,fetch,write}, writes profiles/r01c_*
 
 * <tag>_kernel_stats.csv : rocprofv3 --kernel-trace --stats summary of `bench.py --steps 2 --warmup 1` (verbatim)
+* <tag>_pmc_sq.json      : per kernel MFMA-pipe busy fraction and wave-cycle breakdown from gpurun_out/<tag>_sq (SQ counters)
 * <tag>_pmc_traffic.json : per kernel (all launches of one MCD step): launches, mean FETCH_SIZE / WRITE_SIZE, and
                            HBM-side bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024.  The two counters come from
                            separate --pmc passes (TCC slot budget); FETCH_SIZE is doubled per the gfx950 note in
@@ -55,6 +56,31 @@ def main(tag):
         json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (two passes) -- python3 bench.py --steps 1 --warmup 0",
                    "units": "FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes = (2*FETCH + WRITE) * 1024 (gfx950 FETCH_SIZE halving)",
                    "kernels": table}, open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    q = glob.glob(os.path.join(src, tag + "_sq", "*", "*counter_collection.csv"))
+    if q:
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(q[0])):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        table = {}
+        for k, v in agg.items():
+            if not k.startswith(("conv_", "bn_", "softmax", "up8")) or "GRBM_GUI_ACTIVE" not in v:
+                continue
+            tot = {c: sum(x) for c, x in v.items()}
+            n = len(v["SQ_WAVE_CYCLES"])
+            cyc = tot["GRBM_GUI_ACTIVE"] / 8.0  # the counter sums the 8 XCDs
+            if cyc <= 0 or tot["SQ_WAVE_CYCLES"] <= 0:
+                continue
+            table[k] = {"launches_per_step": n, "kernel_cycles_per_launch": int(cyc / n),
+                        "mfma_pipe_busy_frac": round(tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), 3),
+                        "wave_cycles_parked_frac": round(tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"], 3),
+                        "wave_cycles_issue_stalled_frac": round(tot["SQ_WAIT_INST_ANY"] / tot["SQ_WAVE_CYCLES"], 3),
+                        "wave_cycles_issuing_frac": round(tot["SQ_ACTIVE_INST_ANY"] / tot["SQ_WAVE_CYCLES"], 3)}
+        json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
+                              "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 1 --warmup 0 --no_cpu_baseline",
+                   "notes": "kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs); mfma_pipe_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / "
+                            "(1024 SIMDs * kernel cycles), i.e. at the clock the kernel actually ran at; the wave-cycle fractions are of "
+                            "SQ_WAVE_CYCLES (parked = s_waitcnt / barrier, issue_stalled = waiting on a pipe, mostly the MFMA pipe)",
+                   "kernels": table}, open(os.path.join(out, tag + "_pmc_sq.json"), "w"), indent=1, sort_keys=True)
     b = os.path.join(src, tag + "_bench.json")
     if os.path.exists(b):
         shutil.copy(b, os.path.join(out, tag + "_bench_line.json"))
