@@ -8,19 +8,23 @@ one synthetic batch of N (source, target) RGB+HHA pairs per GPU, i.e. 7 generato
 elided).  ``value`` = pairs/s over the whole job, inputs resident in HBM.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8 --steps 5 --warmup 2          # starts the 8 ranks itself (before touching a GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant kernel (the 128x128-tile implicit-GEMM
-convolution) from HIP events recorded around its launches inside the timed region: algorithmic FLOPs
-of those launches / their summed duration, against the fp32 MFMA peak -- the pass is fp32-FLOP-bound,
-not HBM-bound; the HBM fractions of the whole step and of the streaming loss kernel are
-reported next to it.  ``cpu_baseline`` times the CPU oracle (plain PyTorch restatement of the reference)
-on a bounded sample of the same workload on the host cores.
+Rank 0 prints ONE JSON line.  Every kernel family of the step is bracketed by HIP events on the launch stream inside
+the timed region; ``roofline`` prices the kernel with the largest summed time (``dominant``): its algorithmic FLOPs or
+bytes per launch / its average launch duration, against the MFMA peak of the arithmetic it executes or the HBM peak.
+``roofline_forward`` is the same for the forward convolution carrying the most FLOPs.  The pass is matrix-rate bound,
+not HBM bound: ``step_accounting`` says so next to the raw HBM fraction the metric asks for.
+``cpu_baseline`` times the CPU oracle (plain PyTorch restatement of the reference) on a bounded sample of the same
+workload on the host cores (rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,31 +35,41 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 os.environ.setdefault("MCDSEG_PRETRAINED", "0")
 
-import torch  # noqa: E402
-
 PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector = fp32-input MFMA (MI355X_MICROARCH.md, chip-level table)
-PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md, chip-level table; the 5 PF figure is 2:1 sparse)
+PEAK_16BIT_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA (MI355X_MICROARCH.md, chip-level table; the 5 PF figure is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec
 # algorithmic work per image-pass (one image through G+F1+F2 forward+backward incl. loss), drn_d_38 6x480x640
 # (SURVEY.md section 8d / BASELINE.md section 3): 781.5 GFLOP, 1.94 GB
 GF_FWD_PER_IMG = 260.5
 GB_FWD_PER_IMG, GB_BWD_PER_IMG = 0.71, 1.23
 
-
-DTYPE_LABEL = {"f32": "f32", "bf16x6": "f32 (operands split 3-way into bf16, 6 cross terms on the bf16 MFMA pipe, fp32 accumulate)",
+# executed matrix FLOPs per algorithmic FLOP, the MFMA peak they are priced against, and what the arithmetic is
+MATH = {
+    "f32": (1.0, PEAK_FP32_TFLOPS, "v_mfma_f32_32x32x2_f32"),
+    "bf16x6": (6.0, PEAK_16BIT_TFLOPS, "fp32 operands as 3-way bf16 split, 6 cross terms on v_mfma_f32_32x32x16_bf16"),
+    "f16x3": (3.0, PEAK_16BIT_TFLOPS, "fp32 operands as scaled 2-way fp16 split, 3 cross terms on v_mfma_f32_32x32x16_f16"),
+}
+DTYPE_LABEL = {"f32": "f32",
+               "bf16x6": "f32 (operands split 3-way into bf16, 6 cross terms on the bf16 MFMA pipe, fp32 accumulate)",
+               "f16x3": "f32 (operands split 2-way into scaled fp16, 3 cross terms on the fp16 MFMA pipe, fp32 accumulate)",
                "mixed": "f32 (bf16x6 split for forward/dgrad, f32 MFMA for wgrad)"}
+TIMED_FAMILIES = {
+    "all": ["conv_", "bn_", "up8_", "softmax_ce_l1", "sgd_", "loss_", "wgrad_", "split_", "pack_"],
+    "conv": ["conv_gemm", "conv_stem", "conv_wgrad", "softmax_ce_l1"],
+    "none": [],
+}
 
 
 class LaunchTimer:
-    """Collects HIP-event pairs recorded around selected kernel launches (mcdseg.ops.LAUNCH_TIMER)."""
+    """Collects HIP-event pairs recorded around kernel launches (mcdseg.ops.LAUNCH_TIMER) on the launch stream."""
 
     def __init__(self, names):
-        self.names = set(names)
+        self.names = tuple(names)
         self.records = []
         self.enabled = False
 
     def wants(self, name):
-        return self.enabled and any(name.startswith(n) for n in self.names)
+        return self.enabled and name.startswith(self.names)
 
     def add(self, name, work, t0, t1):
         self.records.append((name, work, t0, t1))
@@ -74,6 +88,7 @@ class LaunchTimer:
 
 def synthetic_batch(n, ch, h, w, n_class, seed):
     """N(0,1) images (stand-in for ImageNet-normalised RGB+HHA), labels U{0..n_class-1}."""
+    import torch
     g = torch.Generator().manual_seed(seed)
     src = torch.randn(n, ch, h, w, generator=g)
     lbl = torch.randint(0, n_class, (n, h, w), generator=g, dtype=torch.int64)
@@ -82,6 +97,7 @@ def synthetic_batch(n, ch, h, w, n_class, seed):
 
 
 def build_hip(args, dev):
+    import torch
     from loss import CrossEntropyLoss2d, get_prob_distance_criterion
     from models.model_util import get_models, get_optimizer
     from solvers.solver import MCDSolver
@@ -97,25 +113,145 @@ def build_hip(args, dev):
     return solver, (g, f1, f2)
 
 
+def host_cpu():
+    """(model name, physical cores, logical cpus) of the host, from /proc/cpuinfo"""
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                phys.add((pid, v))
+    except OSError:
+        pass
+    return model, (len(phys) or (os.cpu_count() or 1)), (logical or (os.cpu_count() or 1))
+
+
 def cpu_baseline(args):
-    """The CPU oracle on the host cores: one full MCD step on ONE (src,tgt) pair of the bench geometry."""
+    """The CPU oracle on the host cores: full MCD steps on ``--cpu_pairs`` (src,tgt) pairs of the bench geometry --
+    one warm-up step, then up to ``--cpu_steps`` timed steps (median), bounded by ``--cpu_budget_s`` seconds of wall
+    clock (at least one timed step) so the default run stays within minutes."""
+    import torch
     from oracle import ref_loss, ref_mcd, ref_models
-    torch.manual_seed(0)
-    threads = torch.get_num_threads()
-    g, f1, f2 = ref_models.get_models(args.net, args.input_ch, args.n_class)
-    for m in (g, f1, f2):
-        m.train()
-    og = ref_models.get_optimizer(g.parameters(), "sgd", 1e-3, 0.9, 2e-5)
-    of = ref_models.get_optimizer(list(f1.parameters()) + list(f2.parameters()), "sgd", 1e-3, 0.9, 2e-5)
-    w = ref_loss.class_weights(args.n_class)
-    n = args.cpu_pairs
-    src, lbl, tgt = synthetic_batch(n, args.input_ch, args.height, args.width, args.n_class, 1234)
+    model, phys, logical = host_cpu()
+    threads = max(1, min(phys, logical))
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        torch.manual_seed(0)
+        g, f1, f2 = ref_models.get_models(args.net, args.input_ch, args.n_class)
+        for m in (g, f1, f2):
+            m.train()
+        og = ref_models.get_optimizer(g.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+        of = ref_models.get_optimizer(list(f1.parameters()) + list(f2.parameters()), "sgd", 1e-3, 0.9, 2e-5)
+        w = ref_loss.class_weights(args.n_class)
+        n = args.cpu_pairs
+        src, lbl, tgt = synthetic_batch(n, args.input_ch, args.height, args.width, args.n_class, 1234)
+        crit, critd = ref_loss.CrossEntropyLoss2d(w), ref_loss.Diff2d()
+        t_begin = time.perf_counter()
+        times = []
+        for i in range(1 + args.cpu_steps):
+            t0 = time.perf_counter()
+            ref_mcd.mcd_step(g, f1, f2, og, of, crit, critd, src, lbl, tgt)
+            dt = time.perf_counter() - t0
+            if i > 0:
+                times.append(dt)
+            elapsed = time.perf_counter() - t_begin
+            if i >= 1 and elapsed + dt > args.cpu_budget_s:
+                break
+    finally:
+        torch.set_num_threads(prev)
+    times.sort()
+    med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
+    return {"value": n / med, "unit": "img/s", "cores": threads, "kind": "port", "cpu_model": model, "physical_cores": phys,
+            "logical_cpus": logical, "timed_steps": len(times), "step_seconds": [round(t, 2) for t in times],
+            "sample": "CPU oracle, full MCD step (A+B+C, num_k=4; 7 fwd + 7 bwd passes) on %d pair(s) of %dx%dx%d: 1 warm-up + %d timed "
+                      "step(s), median %.1f s/step, %d threads on %s (%d physical cores)"
+                      % (n, args.input_ch, args.height, args.width, len(times), med, threads, model, phys)}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    """``python bench.py --gpus N`` without a launcher: start N ranks as CHILD processes through torch.distributed.run --
+    this process has not touched a GPU (and never does), it relays the children's output and exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args):
+    """Launcher / timing protocol without a GPU (MCDSEG_BENCH_DRY=1; tests/test_bench_launcher.py): gloo ranks, a stand-in step,
+    the same barriers, MAX over ranks and the one JSON line from rank 0."""
+    import torch
+    from mcdseg import dist as mdist
+    rank, world, _ = mdist.init_from_env(backend="gloo")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    mdist.barrier()
     t0 = time.perf_counter()
-    ref_mcd.mcd_step(g, f1, f2, og, of, ref_loss.CrossEntropyLoss2d(w), ref_loss.Diff2d(), src, lbl, tgt)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "img/s", "cores": threads, "kind": "port",
-            "sample": "1 full MCD step (A+B+C, num_k=4; 7 fwd + 7 bwd passes) of the CPU oracle on %d pair(s) of %dx%dx%d, "
-                      "%.1f s on %d threads, no warm-up" % (n, args.input_ch, args.height, args.width, dt, threads)}
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))
+    mdist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "value": args.batch * world * args.steps / float(el), "unit": "img/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * float(el) / args.steps,
+                          "scaling": "weak", "data": "none"}), flush=True)
+    mdist.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def kernel_roofline(name, k, math, traffic):
+    """roofline entry of one timed kernel family: MFMA-bound for the convolutions, HBM-bound for the streaming kernels"""
+    if name.startswith("conv_") and k["flops"] > 0:
+        if "x6" in name or "h3" in name or "stem" in name:
+            mult, peak, what = MATH.get(math, MATH["bf16x6"])
+            if "x6" in name:
+                mult, peak, what = MATH["bf16x6"]
+        else:
+            mult, peak, what = MATH["f32"]
+        tfl = k["flops"] / (k["ms"] * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "%s (%s)" % (name, what), "achieved": round(mult * tfl, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(mult * tfl / peak, 4), "traffic": traffic, "alg_tflops_fp32_equivalent": round(tfl, 2),
+                "executed_flops_per_alg_flop": mult, "alg_bytes_per_launch": k["bytes"] / k["launches"], "launches": k["launches"],
+                "avg_launch_ms": round(k["ms"] / k["launches"], 4), "alg_flops_per_launch": k["flops"] / k["launches"],
+                "share_of_timed_kernel_ms": k.get("share")}
+    gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "traffic": traffic, "alg_bytes_per_launch": k["bytes"] / k["launches"], "launches": k["launches"],
+            "avg_launch_ms": round(k["ms"] / k["launches"], 4), "share_of_timed_kernel_ms": k.get("share")}
+
+
+def pmc_traffic(name):
+    """HBM-side bytes per launch from the committed PMC passes (profiles/<round>_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE
+    collected in separate rocprofv3 --pmc runs of this same bench, FETCH_SIZE doubled per the gfx950 note); newest round first"""
+    import glob
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            return json.load(open(fn))["kernels"][name]["hbm_bytes_per_launch"]
+        except (KeyError, ValueError, OSError):
+            continue
+    return None
 
 
 def main():
@@ -129,14 +265,24 @@ def main():
     ap.add_argument("--net", default="drn_d_38")
     ap.add_argument("--input_ch", type=int, default=6)
     ap.add_argument("--n_class", type=int, default=41)
-    ap.add_argument("--cpu_pairs", type=int, default=1)
+    ap.add_argument("--cpu_pairs", type=int, default=2)
+    ap.add_argument("--cpu_steps", type=int, default=3, help="timed CPU-oracle steps after one warm-up (fewer if the budget runs out)")
+    ap.add_argument("--cpu_budget_s", type=float, default=150.0)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--timer", choices=sorted(TIMED_FAMILIES), default="all", help="kernel families bracketed by HIP events")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one.  Nothing above or below this line has initialised a GPU in this process.
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    if os.environ.get("MCDSEG_BENCH_DRY") == "1":
+        return dry_run(args)
+
+    import torch
     from mcdseg import dist as mdist
     from mcdseg import ops
     rank, world, local = mdist.init_from_env()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only implementation (no CPU fallback)")
@@ -146,7 +292,7 @@ def main():
     solver, models = build_hip(args, dev)
     src, lbl, tgt = (t.to(dev) for t in synthetic_batch(args.batch, args.input_ch, args.height, args.width, args.n_class,
                                                         1234 + rank))
-    timer = LaunchTimer(["conv_gemm_kernel", "conv_gemm_x6_kernel", "softmax_ce_l1_kernel"])
+    timer = LaunchTimer(TIMED_FAMILIES[args.timer])
     ops.LAUNCH_TIMER = timer
 
     for _ in range(args.warmup):
@@ -174,52 +320,42 @@ def main():
         pairs = args.batch * world * args.steps
         value = pairs / elapsed
         kern = timer.summary()
+        total_ms = sum(k["ms"] for k in kern.values()) or 1.0
         for k in kern.values():
             k["avg_ms"] = k["ms"] / max(k["launches"], 1)
             k["tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
             k["gbs"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
-        convs = {k: v for k, v in kern.items() if k.startswith("conv_gemm")}
-        # dominant kernel = the instantiation carrying the most algorithmic FLOPs of the step (the forward 128x128
-        # tile: 7 forward passes vs 5 backward); its launches run alone on the stream, so the event pairs are clean
-        dom_name = max(convs, key=lambda k: convs[k]["flops"]) if convs else None
-        roofline = None
-        traffic = None
+            k["share"] = round(k["ms"] / total_ms, 4)
         default_cfg = (args.net, args.batch, args.height, args.width, args.input_ch) == ("drn_d_38", 16, 480, 640, 6)
-        if dom_name and default_cfg:  # the PMC passes were taken on exactly this workload
-            # HBM-side bytes per launch from the committed PMC passes (profiles/<round>_pmc_traffic.json: FETCH_SIZE and
-            # WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same bench, FETCH_SIZE doubled per the gfx950 note)
-            import glob
-            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
-                try:
-                    traffic = json.load(open(fn))["kernels"][dom_name]["hbm_bytes_per_launch"]
-                    break
-                except (KeyError, ValueError, OSError):
-                    continue
-        if dom_name:
-            dom = convs[dom_name]
-            x6 = "x6" in dom_name
-            # bf16x6: every algorithmic fp32 MAC is executed as six bf16 MACs on v_mfma_f32_32x32x16_bf16, so the kernel is
-            # priced in EXECUTED bf16 FLOPs against the dense bf16 MFMA peak; the f32 kernel against the f32 MFMA peak
-            mult, peak = (6.0, PEAK_BF16_TFLOPS) if x6 else (1.0, PEAK_FP32_TFLOPS)
-            roofline = {"bound": "mfma",
-                        "kernel": dom_name + (" (implicit-GEMM conv, fp32 operands as 3-way bf16 split, 6 cross terms on "
-                                              "v_mfma_f32_32x32x16_bf16)" if x6 else " (implicit-GEMM conv on v_mfma_f32_32x32x2_f32)"),
-                        "achieved": round(mult * dom["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(mult * dom["tflops"] / peak, 4), "traffic": traffic,
-                        "alg_tflops_fp32_equivalent": round(dom["tflops"], 2),
-                        "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
-                        "launches": dom["launches"], "avg_launch_ms": round(dom["avg_ms"], 4),
-                        "alg_flops_per_launch": dom["flops"] / dom["launches"]}
+        # dominant kernel = the one with the largest summed duration inside the timed region; launches run alone on the
+        # stream, so the event pairs are clean
+        roofline = roofline_fwd = None
+        if kern:
+            dom = max(kern, key=lambda n: kern[n]["ms"])
+            roofline = kernel_roofline(dom, kern[dom], ops.CONV_MATH, pmc_traffic(dom) if default_cfg else None)
+            fwd = {n: v for n, v in kern.items() if n.startswith("conv_gemm") and ", false, " in n}
+            if fwd:
+                fn = max(fwd, key=lambda n: fwd[n]["flops"])
+                roofline_fwd = kernel_roofline(fn, fwd[fn], ops.CONV_MATH, pmc_traffic(fn) if default_cfg else None)
         # whole-step accounting on the algorithmic work of SURVEY.md 8d (drn_d_38 @ 6x480x640 only)
         step_acc = None
         if args.net == "drn_d_38" and (args.height, args.width, args.input_ch) == (480, 640, 6):
-            fwd, bwd = 7, 5  # passes actually executed per pair (step-B generator backward elided)
-            gf = GF_FWD_PER_IMG * (fwd + 2 * bwd)
-            gb = GB_FWD_PER_IMG * fwd + GB_BWD_PER_IMG * bwd
+            fwd_p, bwd_p = 7, 5  # passes actually executed per pair (step-B generator backward elided)
+            gf = GF_FWD_PER_IMG * (fwd_p + 2 * bwd_p)
+            gb = GB_FWD_PER_IMG * fwd_p + GB_BWD_PER_IMG * bwd_p
             t_pair = elapsed / (args.batch * args.steps)
+            mult, peak, _ = MATH.get(ops.CONV_MATH, MATH["bf16x6"])
+            t_mfma = gf * mult / (peak * 1e3)  # seconds per pair if every FLOP ran at the matrix peak of the arithmetic used
+            t_hbm = gb / PEAK_HBM_GBS
             step_acc = {"alg_gflop_per_pair": round(gf, 1), "alg_gb_per_pair": round(gb, 2),
                         "tflops": round(gf / t_pair / 1e3, 2), "frac_fp32_peak": round(gf / t_pair / 1e3 / PEAK_FP32_TFLOPS, 4),
+                        "frac_mfma_roof_of_conv_math": round(t_mfma / t_pair, 4),
                         "hbm_gbs": round(gb / t_pair, 1), "frac_hbm_peak": round(gb / t_pair / PEAK_HBM_GBS, 4),
+                        "frac_hbm_peak_ceiling": round(t_hbm / max(t_hbm, t_mfma), 4),
+                        "note": "the step is matrix-rate bound (SURVEY.md F7): even at the MFMA peak of its arithmetic the algorithmic "
+                                "bytes would use only frac_hbm_peak_ceiling of the 8 TB/s HBM peak, so the north-star's 40 %-of-HBM "
+                                "target is out of reach for fp32-grade results; per-kernel HBM fractions are under 'kernels'",
+                        "timed_kernel_ms_per_step": round(total_ms / args.steps, 2),
                         "ref_faithful_gflop_per_pair": round(GF_FWD_PER_IMG * 21, 1)}
         line = {
             "metric": "RGB-D img/s (6x480x640) MCD train step, drn_d_38", "value": round(value, 3), "unit": "img/s",
@@ -228,17 +364,19 @@ def main():
             "config": {"workload": "adapt_trainer MCD early-fusion %s %d-ch, bs=%d/GPU synthetic %dx%d, full A+B+C step (num_k=4)"
                                    % (args.net, args.input_ch, args.batch, args.height, args.width),
                        "pairs_per_gpu": args.batch, "global_pairs": args.batch * world, "parallelism": "dp%d" % world,
-                       "n_class": args.n_class, "conv_math": ops.CONV_MATH, "c_loss": c_loss, "d_loss": d_loss},
+                       "n_class": args.n_class, "conv_math": ops.CONV_MATH, "c_loss": c_loss, "d_loss": d_loss, "timer": args.timer},
             "roofline": roofline,
+            "roofline_forward": roofline_fwd,
             "step_accounting": step_acc,
-            "kernels": {k: {"launches": v["launches"], "ms_total": round(v["ms"], 2), "avg_ms": round(v["avg_ms"], 4),
-                            "tflops": round(v["tflops"], 2), "alg_gbs": round(v["gbs"], 1)} for k, v in kern.items()},
+            "kernels": {k: {"launches": v["launches"], "ms_total": round(v["ms"], 2), "avg_ms": round(v["avg_ms"], 4), "share": v["share"],
+                            "tflops": round(v["tflops"], 2), "alg_gbs": round(v["gbs"], 1)}
+                        for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     mdist.barrier()
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -119,6 +119,8 @@ int mcdseg_bn_apply(const float* z, const float* mean, const float* rstd, const 
  * tensor in the channel-blocked layout [piece 3][N][C/8][HW][8 bf16] (3*N*C*HW*2 bytes) consumed by the bf16x6
  * convolutions; C must be divisible by 8.  mcdseg_bn_bwd_apply_cb accepts dz == NULL (only the split companion is
  * written) for layers whose input and weight gradients both read the companion. */
+/* the split alone (fp32 NCHW -> companion) for operands no fused BN group produced */
+int mcdseg_split_cb(const float* x, void* x_cb, int32_t N, int32_t C, int32_t HW, void* stream);
 int mcdseg_bn_apply_cb(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                        const float* residual, float* y, void* y_cb, int32_t N, int32_t C, int32_t HW, int32_t relu,
                        void* stream);
@@ -191,11 +193,6 @@ int mcdseg_bilinear8_bwd(const float* dy, float* dx, int32_t N, int32_t C, int32
 size_t mcdseg_mse_workspace_bytes(int64_t n);
 int mcdseg_mse(const float* pred, const float* target, float* grad, float* loss, int64_t n,
                void* workspace, size_t workspace_bytes, void* stream);
-
-/* Development hook (tools/ablate_conv.py, profiles/README.md): timing-only ablation of the f32 implicit-GEMM K loop --
- * bit 0 skips the global loads, bit 1 the LDS stores, bit 2 the barriers.  Results are garbage while any bit is set;
- * process-wide, not for production callers. */
-void mcdseg_debug_ablate(int bits);
 
 /* ------------------------------------------------------------------------------------------------
  * MFNet late fusion beyond the plain sum (models/fusion.py:6-50) and its loss (loss.py:16-30)

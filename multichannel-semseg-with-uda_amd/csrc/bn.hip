@@ -373,6 +373,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_kernel(const float* __res
   split3_store(v, cb, (size_t)N * C * HW, (size_t)ng * HW + pix);
 }
 
+// the split alone, for operands no fused BN group produced (network inputs, gradients arriving from outside the encoder)
+__global__ __launch_bounds__(256) void split_cb_kernel(const float* __restrict__ x, __bf16* __restrict__ cb, int N, int C, int HW) {
+  const int C8 = C >> 3;
+  const int ng = blockIdx.y;
+  const int g = ng % C8;
+  const int n = ng / C8;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= HW) return;
+  const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = x[base + (size_t)e * HW];
+  split3_store(v, cb, (size_t)N * C * HW, (size_t)ng * HW + pix);
+}
+
 int plane_chunks(int HW, bool vec) {
   const int work = vec ? HW / 4 : HW;
   int chunks = ceil_div(work, 256 * 4);  // ~4 elements (float4s) per thread
@@ -452,6 +467,15 @@ extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float
   hipLaunchKernelGGL(bn_apply_cb_kernel, dim3(ceil_div(HW, 256), N * (C / 8)), dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma,
                      beta, residual, y, (__bf16*)y_cb, N, C, HW, relu);
   MCD_LAUNCH_CHECK("bn_apply_cb");
+  return 0;
+}
+
+extern "C" int mcdseg_split_cb(const float* x, void* x_cb, int32_t N, int32_t C, int32_t HW, void* stream) {
+  MCD_REQUIRE(x && x_cb, "split_cb: null pointer");
+  MCD_REQUIRE(N > 0 && C > 0 && HW > 0 && (C % 8) == 0, "split_cb: C must be a positive multiple of 8");
+  MCD_REQUIRE((int64_t)N * (C / 8) <= 65535, "split_cb: N*C/8 exceeds the grid limit");
+  hipLaunchKernelGGL(split_cb_kernel, dim3(ceil_div(HW, 256), N * (C / 8)), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)x_cb, N, C, HW);
+  MCD_LAUNCH_CHECK("split_cb");
   return 0;
 }
 

@@ -37,7 +37,6 @@ struct ConvGemmParams {
   int KH, KW, stride, pad, dil;
   int P;           // N*Hd*Wd
   int src_bytes, wp_bytes;  // buffer-descriptor ranges (< 2 GiB)
-  int ablate;      // timing-only ablation bits (mcdseg_debug_ablate): 1 no global loads, 2 no LDS stores, 4 no barriers
 };
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool DGRAD>
@@ -209,7 +208,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGemmParams p) {
     const bool more = (s + 1) < nsteps;
     if (more) {
       advance();
-      if (!(p.ablate & 1)) load_regs();
+      load_regs();
     }
     const float* a_base = As + cur * BK * BM + wm * (32 * WM) + l31;
     const float* b_base = Bs + cur * BK * BN + wn * (32 * WN) + l31;
@@ -237,8 +236,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][i], b[cb][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (more && !(p.ablate & 2)) store_lds(cur ^ 1);
-    if (!(p.ablate & 4)) __syncthreads();
+    if (more) store_lds(cur ^ 1);
+    __syncthreads();
   }
 
   // ---- epilogue.  acc[i][j][r] = D[row][col], row = (r&3) + 8*(r>>2) + 4*lh, col = l31 of the 32x32 tile
@@ -404,13 +403,7 @@ void launch(const ConvGemmParams& p, hipStream_t st) {
 int bn_for(int M) { return mcd_bm(M) == 128 ? 128 : 256; }
 int waves_n_for(int M) { return mcd_bm(M) == 128 ? 2 : 4; }
 
-int g_ablate = 0;
-
 }  // namespace
-
-// Timing-only ablation switch for kernel development (results are WRONG when non-zero).
-extern "C" void mcdseg_debug_ablate(int bits) { g_ablate = bits; }
-int mcdseg_internal_ablate_bits() { return g_ablate; }
 
 extern "C" int mcdseg_conv_packed_dims(const mcdseg_conv_desc* d, int32_t* Mp_f, int32_t* Kp_f, int32_t* Mp_d, int32_t* Kp_d) {
   MCD_REQUIRE(d != nullptr, "conv_packed_dims: null descriptor");
@@ -476,7 +469,6 @@ static int conv_fprop_impl(const mcdseg_conv_desc* d, const float* x, const floa
   p.P = d->N * d->Ho * d->Wo;
   p.src_bytes = (int)((int64_t)d->N * d->Cin * d->H * d->W * 4);
   p.wp_bytes = (int)((int64_t)d->KH * d->KW * p.Kp * p.Mp * 4);
-  p.ablate = g_ablate;
   launch<false>(p, (hipStream_t)stream);
   MCD_LAUNCH_CHECK("conv_fprop");
   return 0;
@@ -501,7 +493,6 @@ extern "C" int mcdseg_conv_dgrad(const mcdseg_conv_desc* d, const float* dy, con
   p.P = d->N * d->H * d->W;
   p.src_bytes = (int)((int64_t)d->N * d->Cout * d->Ho * d->Wo * 4);
   p.wp_bytes = (int)((int64_t)d->KH * d->KW * p.Kp * p.Mp * 4);
-  p.ablate = g_ablate;
   launch<true>(p, (hipStream_t)stream);
   MCD_LAUNCH_CHECK("conv_dgrad");
   return 0;

@@ -142,8 +142,12 @@ __global__ __launch_bounds__(256) void softmax_ce_l1_kernel(const float* __restr
   }
 }
 
+// has_ce: a cross-entropy term was requested.  With an all-background / all-ignored batch the normaliser W = sum w[y] is 0
+// and the reference's weighted mean is 0/0: nn.NLLLoss2d returns NaN and NaN gradients (loss.py:7-13).  The kernel does the
+// same -- value here, gradients through kce = ce_coef * w[y] / W in the main kernel -- so the failure is as visible as in
+// the reference instead of a healthy-looking 0 in the log while NaN gradients reach the optimizer.
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ part, int64_t nblk, float* __restrict__ losses,
-                                                            double inv_m) {
+                                                            double inv_m, int has_ce) {
   double s[3] = {0.0, 0.0, 0.0};
   for (int64_t i = threadIdx.x; i < nblk; i += 256) {
     s[0] += (double)part[i * 3 + 0];
@@ -161,8 +165,8 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     const double c1 = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
     const double c2 = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
     const double d = (sh[2][0] + sh[2][1]) + (sh[2][2] + sh[2][3]);
-    losses[0] = (W == 0.0 && c1 == 0.0) ? 0.f : (float)(c1 / W);
-    losses[1] = (W == 0.0 && c2 == 0.0) ? 0.f : (float)(c2 / W);
+    losses[0] = has_ce ? (float)(c1 / W) : 0.f;
+    losses[1] = has_ce ? (float)(c2 / W) : 0.f;
     losses[2] = (float)(d * inv_m);
   }
 }
@@ -323,7 +327,8 @@ extern "C" int mcdseg_softmax_ce_l1(const float* z1, const float* z2, const int6
     launch_loss<48>(two, grid, st, z1, z2, labels, class_weight, ignore_index, ce_coef, diff_coef, losses, g1, g2, part, C, HW, P,
                     (float)inv_m);
   MCD_LAUNCH_CHECK("softmax_ce_l1");
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nblk, losses, inv_m);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nblk, losses, inv_m,
+                     labels != nullptr ? 1 : 0);
   MCD_LAUNCH_CHECK("loss_finalize");
   return 0;
 }

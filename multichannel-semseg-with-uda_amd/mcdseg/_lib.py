@@ -41,6 +41,7 @@ _SIGNATURES = {
     "mcdseg_conv_x6_fprop": (c_int, [_P(ConvDesc)] + [c_void_p] * 7),
     "mcdseg_conv_x6_fprop_affine": (c_int, [_P(ConvDesc)] + [c_void_p] * 6 + [c_i32, c_void_p, c_void_p]),
     "mcdseg_conv_x6_dgrad": (c_int, [_P(ConvDesc)] + [c_void_p] * 5),
+    "mcdseg_split_cb": (c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
     "mcdseg_bn_apply_cb": (c_int, [c_void_p] * 8 + [c_i32] * 4 + [c_void_p]),
     "mcdseg_bn_bwd_apply_cb": (c_int, [c_void_p] * 11 + [c_i32] * 5 + [c_void_p]),
     "mcdseg_conv_x6_wgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -75,7 +76,6 @@ _SIGNATURES = {
     "mcdseg_prob_nll_workspace_bytes": (c_size_t, [c_i32, c_i32]),
     "mcdseg_prob_nll": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p,
                                 c_size_t, c_void_p]),
-    "mcdseg_debug_ablate": (None, [c_int]),
     "mcdseg_normalize_u8": (c_int, [c_void_p] * 4 + [c_i32] * 6 + [c_void_p]),
     "mcdseg_relabel_u8": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_void_p]),
     "mcdseg_confusion_hist": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p]),

@@ -257,6 +257,17 @@ def _cb_alloc(n, c, hw, device):
     return torch.empty(3 * n * c * hw, dtype=torch.bfloat16, device=device)
 
 
+def split_companion(x):
+    """pre-split companion of an fp32 NCHW tensor no fused BN group produced (None when the layout does not apply)"""
+    x = _req(x, "tensor to split")
+    n, c, h, w = x.shape
+    if not _cb_wanted(c) or n * (c // 8) > 65535:
+        return None
+    cb = _cb_alloc(n, c, h * w, x.device)
+    check(lib().mcdseg_split_cb(_p(x), _p(cb), n, c, h * w, _stream()), "split_cb")
+    return cb
+
+
 def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None):
     L = lib()
     total = None
@@ -317,8 +328,9 @@ def _channel_reduce(dy, y, z, mean, rstd, relu):
     ws = _ws(L.mcdseg_bn_bwd_workspace_bytes(n, c, hw), dy.device)
     dgamma = torch.empty(c, dtype=torch.float32, device=dy.device) if z is not None else None
     dbeta = torch.empty(c, dtype=torch.float32, device=dy.device)
-    check(L.mcdseg_bn_bwd_reduce(_p(dy), _p(y), _p(z), _p(mean), _p(rstd), _p(dgamma), _p(dbeta), n, c, hw, int(relu), _p(ws),
-                                 ctypes.c_size_t(ws.numel() * 4), _stream()), "bn_bwd_reduce")
+    with _timed("bn_bwd_reduce", (0, 4 * n * c * hw * (1 + (y is not None) + (z is not None)))):
+        check(L.mcdseg_bn_bwd_reduce(_p(dy), _p(y), _p(z), _p(mean), _p(rstd), _p(dgamma), _p(dbeta), n, c, hw, int(relu), _p(ws),
+                                     ctypes.c_size_t(ws.numel() * 4), _stream()), "bn_bwd_reduce")
     return dgamma, dbeta
 
 
@@ -340,23 +352,27 @@ class _ConvBNAct(torch.autograd.Function):
         if training:
             track = running_mean is not None
             ws = torch.empty(L.mcdseg_bn_stats_workspace_bytes(rows, c) // 8 + 1, dtype=torch.float64, device=x.device)
-            check(L.mcdseg_bn_stats_finalize(_p(part), rows, c, mpf, _p(mean), _p(rstd), _p(running_mean) if track else None,
-                                             _p(running_var) if track else None, _p(nbt) if track else None,
-                                             float(momentum), float(eps), _p(ws), ctypes.c_size_t(ws.numel() * 8), _stream()),
-                  "bn_stats_finalize")
+            with _timed("bn_stats_finalize", (0, 12 * rows * mpf)):
+                check(L.mcdseg_bn_stats_finalize(_p(part), rows, c, mpf, _p(mean), _p(rstd), _p(running_mean) if track else None,
+                                                 _p(running_var) if track else None, _p(nbt) if track else None,
+                                                 float(momentum), float(eps), _p(ws), ctypes.c_size_t(ws.numel() * 8), _stream()),
+                      "bn_stats_finalize")
         else:
             check(L.mcdseg_bn_eval_stats(_p(running_mean), _p(running_var), c, float(eps), _p(mean), _p(rstd), _stream()),
                   "bn_eval_stats")
         y = torch.empty_like(z)
         hw = desc.Ho * desc.Wo
         y_cb = None
+        elems = desc.N * c * hw
         if _cb_wanted(c) and desc.N * (c // 8) <= 65535:
             y_cb = _cb_alloc(desc.N, c, hw, x.device)
-            check(L.mcdseg_bn_apply_cb(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), _p(y), _p(y_cb), desc.N, c, hw,
-                                       int(relu), _stream()), "bn_apply_cb")
+            with _timed("bn_apply_cb", (0, elems * (8 + 6 + (4 if residual is not None else 0)))):
+                check(L.mcdseg_bn_apply_cb(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), _p(y), _p(y_cb), desc.N, c, hw,
+                                           int(relu), _stream()), "bn_apply_cb")
         else:
-            check(L.mcdseg_bn_apply(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), _p(y), desc.N, c, hw, int(relu),
-                                    _stream()), "bn_apply")
+            with _timed("bn_apply", (0, elems * (8 + (4 if residual is not None else 0)))):
+                check(L.mcdseg_bn_apply(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), _p(y), desc.N, c, hw, int(relu),
+                                        _stream()), "bn_apply")
         ctx.desc, ctx.wd, ctx.relu, ctx.training, ctx.has_res = desc, wd, relu, training, residual is not None
         ctx.has_bias = conv_bias is not None
         ctx.x_cb = x_cb  # wgrad reads the input's split companion too (an input of this node: safe to hold)
@@ -395,12 +411,15 @@ class _ConvBNAct(torch.autograd.Function):
         if not skip_dz:
             dz = torch.empty_like(z)
         bwd_args = bwd_args[:8] + (_p(dz),) + bwd_args[9:]
+        rd = 4 * n * c * hw * (2 + int(ctx.relu)) + 4 * n * c * hw * ((dz is not None) + (dres is not None and ctx.relu))
         if use_cb:
             dz_cb = _cb_alloc(n, c, hw, dy.device)
-            check(L.mcdseg_bn_bwd_apply_cb(*bwd_args, _p(dz_cb), n, c, hw, int(ctx.relu), int(ctx.training), _stream()),
-                  "bn_bwd_apply_cb")
+            with _timed("bn_bwd_apply_cb", (0, rd + 6 * n * c * hw)):
+                check(L.mcdseg_bn_bwd_apply_cb(*bwd_args, _p(dz_cb), n, c, hw, int(ctx.relu), int(ctx.training), _stream()),
+                      "bn_bwd_apply_cb")
         else:
-            check(L.mcdseg_bn_bwd_apply(*bwd_args, n, c, hw, int(ctx.relu), int(ctx.training), _stream()), "bn_bwd_apply")
+            with _timed("bn_bwd_apply", (0, rd)):
+                check(L.mcdseg_bn_bwd_apply(*bwd_args, n, c, hw, int(ctx.relu), int(ctx.training), _stream()), "bn_bwd_apply")
         dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz_cb, ctx.x_cb)
         dbias = None
         if ctx.has_bias and ctx.needs_input_grad[5]:
@@ -451,14 +470,24 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None):
                                bn.running_var if track else None, bn.num_batches_tracked if track else None, conv._packed, geom,
                                training, momentum, bn.eps, relu, _cb_of(x))
     if y_cb is not None:
-        y._mcd_cb = y_cb  # the pre-split companion travels with the tensor object to the next convolution
+        _attach_cb(y, y_cb)  # the pre-split companion travels with the tensor object to the next convolution
     return y
 
 
+def _attach_cb(y, y_cb):
+    # the companion is only valid for the values y holds NOW: remember the autograd version counter and the storage
+    y._mcd_cb = (y_cb, y._version, y.data_ptr())
+
+
 def _cb_of(x):
-    """pre-split companion attached by the producer of ``x`` (None if ``x`` did not come straight from a fused BN group)"""
-    cb = getattr(x, "_mcd_cb", None)
-    if cb is not None and (not x.is_contiguous() or cb.numel() != 3 * x.numel()):
+    """pre-split companion attached by the producer of ``x``: None if ``x`` did not come straight from a fused BN group,
+    or if anything wrote to ``x`` since (an in-place op of the caller -- ``x.add_()``, ``relu_()``, inplace dropout --
+    bumps ``x._version``; the consumer then splits the current values itself instead of reading a stale image)"""
+    rec = getattr(x, "_mcd_cb", None)
+    if rec is None:
+        return None
+    cb, version, ptr = rec
+    if x._version != version or x.data_ptr() != ptr or not x.is_contiguous() or cb.numel() != 3 * x.numel():
         return None
     return cb
 
@@ -494,7 +523,8 @@ def conv2d_bias(x, conv):
 # ------------------------------------------------------------------------------------------------ x8 up-sampler
 def _up8_bwd_input(dy, w, n, c, hi, wi):
     dx = torch.empty((n, c, hi, wi), dtype=torch.float32, device=dy.device)
-    check(lib().mcdseg_up8_bwd_input(_p(dy), _p(w), _p(dx), n, c, hi, wi, _stream()), "up8_bwd_input")
+    with _timed("up8_bwd_input", (0, 4 * n * c * hi * wi * 65)):
+        check(lib().mcdseg_up8_bwd_input(_p(dy), _p(w), _p(dx), n, c, hi, wi, _stream()), "up8_bwd_input")
     return dx
 
 
@@ -502,8 +532,9 @@ def _up8_bwd_weight(dy, x, n, c, hi, wi):
     L = lib()
     ws = _ws(L.mcdseg_up8_bwd_weight_workspace_bytes(n, c, hi, wi), dy.device)
     dw = torch.empty((c, 1, 16, 16), dtype=torch.float32, device=dy.device)
-    check(L.mcdseg_up8_bwd_weight(_p(dy), _p(x), _p(dw), n, c, hi, wi, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
-          "up8_bwd_weight")
+    with _timed("up8_bwd_weight", (0, 4 * n * c * hi * wi * 65)):
+        check(L.mcdseg_up8_bwd_weight(_p(dy), _p(x), _p(dw), n, c, hi, wi, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
+              "up8_bwd_weight")
     return dw
 
 
@@ -519,7 +550,8 @@ class _Up8(torch.autograd.Function):
         _check_up(x, w)
         n, c, hi, wi = x.shape
         y = torch.empty((n, c, 8 * hi, 8 * wi), dtype=torch.float32, device=x.device)
-        check(lib().mcdseg_up8_fwd(_p(x), _p(w), None, None, _p(y), n, c, hi, wi, _stream()), "up8_fwd")
+        with _timed("up8_fwd", (0, 4 * n * c * hi * wi * 65)):
+            check(lib().mcdseg_up8_fwd(_p(x), _p(w), None, None, _p(y), n, c, hi, wi, _stream()), "up8_fwd")
         ctx.save_for_backward(x, w)
         return y
 
@@ -544,7 +576,8 @@ class _Up8Dual(torch.autograd.Function):
             raise ValueError("mcdseg: up8_dual inputs differ in shape")
         n, c, hi, wi = x1.shape
         y = torch.empty((n, c, 8 * hi, 8 * wi), dtype=torch.float32, device=x1.device)
-        check(lib().mcdseg_up8_fwd(_p(x1), _p(w1), _p(x2), _p(w2), _p(y), n, c, hi, wi, _stream()), "up8_fwd")
+        with _timed("up8_fwd", (0, 4 * n * c * hi * wi * 66)):
+            check(lib().mcdseg_up8_fwd(_p(x1), _p(w1), _p(x2), _p(w2), _p(y), n, c, hi, wi, _stream()), "up8_fwd")
         ctx.save_for_backward(x1, w1, x2, w2)
         return y
 
@@ -857,6 +890,7 @@ def sgd_momentum_flat_(p, g, v, lr, momentum, weight_decay, grad_scale=1.0):
     for t, name in ((p, "params"), (g, "grads"), (v, "momentum")):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             raise RuntimeError("mcdseg: flat SGD needs contiguous fp32 GPU buffers (%s)" % name)
-    check(lib().mcdseg_sgd_momentum_flat(_p(p), _p(g), _p(v), p.numel(), float(lr), float(momentum), float(weight_decay),
-                                         float(grad_scale), _stream()), "sgd_momentum_flat")
+    with _timed("sgd_momentum_kernel", (0, 20 * p.numel())):
+        check(lib().mcdseg_sgd_momentum_flat(_p(p), _p(g), _p(v), p.numel(), float(lr), float(momentum), float(weight_decay),
+                                             float(grad_scale), _stream()), "sgd_momentum_flat")
     bump_weight_epoch()

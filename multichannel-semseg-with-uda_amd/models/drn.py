@@ -245,13 +245,17 @@ def replace_first_conv(model, input_ch, arch):
 
 
 def _load_pretrained(model, name):
-    """The reference downloads ImageNet weights (models/drn.py:8-18).  There is no network on the GPU box:
-    weights are taken from $MCDSEG_PRETRAINED_DIR/<name>-*.pth when present, else He-normal init stays."""
+    """The reference downloads ImageNet weights (models/drn.py:8-18).  There is no network on the GPU box: weights are
+    taken from $MCDSEG_PRETRAINED_DIR/<name>-*.pth.  Missing weights are an error -- a run that silently starts from
+    He-normal initialisation is not the reference's run -- unless MCDSEG_PRETRAINED=0 / --no_pretrained opts out."""
+    if os.environ.get("MCDSEG_PRETRAINED", "1") == "0":
+        return
     root = os.environ.get("MCDSEG_PRETRAINED_DIR", "")
     hits = sorted(glob.glob(os.path.join(root, name.replace("-", "_") + "-*.pth"))) if root else []
     if not hits:
-        warnings.warn("mcdseg: pretrained weights for %s not found (set MCDSEG_PRETRAINED_DIR); using random init" % name)
-        return
+        raise FileNotFoundError("mcdseg: pretrained weights for %s not found: put %s-*.pth under $MCDSEG_PRETRAINED_DIR, or set "
+                                "MCDSEG_PRETRAINED=0 (trainers: --no_pretrained) to train from He-normal initialisation"
+                                % (name, name.replace("-", "_")))
     sd = torch.load(hits[0], map_location="cpu")
     model.load_state_dict(sd, strict=False)
 

@@ -128,13 +128,41 @@ def test_factory_errors_and_quirks():
     assert loss.DiscrepancyLoss is loss.Diff2d
     assert isinstance(loss.get_prob_distance_criterion("diff"), loss.Diff2d)
     with pytest.raises(NotImplementedError):
-        loss.get_prob_distance_criterion("jsd")
+        loss.get_prob_distance_criterion("nope")
     g = model_util.get_models("drn_d_38", 6, 41)[0]
     w = g.base[0][0].weight.data
     assert torch.equal(w[:, 3:6], w[:, :3])  # models/drn.py:285-288
     g.train()
     model_util.fix_batchnorm_when_training(g)
     assert not g.base[5][0].bn1.training and g.base[5][0].training
+
+
+@pytest.mark.parametrize("name", ["jsd", "symkl", "nmlsymkl", "mysymkl", "spatial_jsd", "mis_symkl"])
+def test_non_default_distances_match_reference_vectors(golden, name):
+    """--d_loss other than 'diff' (loss.py:192-210 of the reference): plain-torch criteria, value and d/dlogits against
+    vectors produced by the reference's own classes (tests/golden/make_golden_dist.py)"""
+    import numpy as np
+    import loss
+    fx = golden.npz("dist_small.npz")
+    crit = loss.get_prob_distance_criterion(name, n_class=int(fx["n_class"]))
+    a = torch.from_numpy(fx["z1"]).requires_grad_()
+    b = torch.from_numpy(fx["z2"]).requires_grad_()
+    val = crit(a, b)
+    ga, gb = torch.autograd.grad(val, [a, b])
+    assert abs(float(val) - float(fx[name + "_val"])) <= 1e-12 * abs(float(fx[name + "_val"]))
+    assert np.abs(ga.numpy() - fx[name + "_g1"]).max() <= 1e-12 and np.abs(gb.numpy() - fx[name + "_g2"]).max() <= 1e-12
+
+
+def test_missing_pretrained_weights_are_an_error(monkeypatch, tmp_path):
+    """the reference's factories default to pretrained=True (a download, models/drn.py:8-18); without the weights on disk the
+    drop-in must not silently train from scratch"""
+    from models import drn
+    monkeypatch.setenv("MCDSEG_PRETRAINED", "1")
+    monkeypatch.setenv("MCDSEG_PRETRAINED_DIR", str(tmp_path))
+    with pytest.raises(FileNotFoundError, match="MCDSEG_PRETRAINED"):
+        drn.drn_d_22(pretrained=True)
+    monkeypatch.setenv("MCDSEG_PRETRAINED", "0")
+    drn.drn_d_22(pretrained=True)  # explicit opt-out: He-normal initialisation
 
 
 def test_checkpoint_layout_roundtrips_with_torch_modules(golden, tmp_path):

@@ -254,6 +254,19 @@ def test_loss_kernel_edge_cases(c, shape):
     assert np.abs(zt.grad.cpu().numpy() - g64).max() <= 2e-6 * np.abs(g64).max()
     assert float(zt.grad[0, :, 0, :2].abs().max()) == 0.0
     zt.grad = None
+    # all-background batch: W = sum w[y] = 0, the reference's weighted mean is 0/0 = nan with nan gradients (nn.NLLLoss2d)
+    cw0 = cw.copy()
+    cw0[1] = 0.0
+    y0 = np.full_like(y, 1)
+    y0[0, 0, :2] = -100
+    z0 = torch.from_numpy(z).to(dev).requires_grad_()
+    l0 = ops.cross_entropy2d(z0, torch.from_numpy(y0).to(dev), torch.from_numpy(cw0).to(dev))
+    l0.backward()
+    tz = torch.from_numpy(z).requires_grad_()
+    tl = F.nll_loss(F.log_softmax(tz, dim=1), torch.from_numpy(y0), torch.from_numpy(cw0))
+    tl.backward()
+    assert bool(torch.isnan(tl)) and bool(torch.isnan(l0))
+    assert torch.equal(torch.isnan(z0.grad).cpu(), torch.isnan(tz.grad))
     s = ops.cross_entropy2d(zt, torch.from_numpy(y).to(dev), torch.from_numpy(cw).to(dev), size_average=False)
     W = float(cw[y[y >= 0]].sum())
     assert abs(float(s) - l64 * W) <= 3e-6 * abs(l64 * W)
@@ -486,6 +499,127 @@ def test_presplit_operands_are_bitwise_equivalent(monkeypatch):
     a, b = run(True), run(False)
     for name, u, v in zip(["y1", "y2", "y3", "dx", "dw1", "dw2", "dw3"], a, b):
         assert torch.equal(u, v), "%s differs between pre-split and in-loop split (max %.3e)" % (name, float((u - v).abs().max()))
+
+
+def test_stale_presplit_companion_is_not_used(monkeypatch):
+    """An in-place write to an activation between two fused groups (the reference's statements run unchanged over the
+    drop-in modules may do that) must not leave the next convolution reading the old pre-split image."""
+    dev = _dev()
+    from mcdseg import ops
+    from models.drn import BatchNorm2d, Conv2d
+    g = torch.Generator().manual_seed(43)
+    c1, b1 = Conv2d(24, 64, 3, padding=1, bias=False).to(dev), BatchNorm2d(64).to(dev)
+    c2, b2 = Conv2d(64, 72, 3, padding=1, bias=False).to(dev), BatchNorm2d(72).to(dev)
+    x = torch.randn(2, 24, 12, 16, generator=g).to(dev)
+    mask = (torch.rand(2, 64, 12, 16, generator=g) > 0.5).float().to(dev)
+    gy = torch.randn(2, 72, 12, 16, generator=g).to(dev)
+
+    def run(presplit):
+        monkeypatch.setattr(ops, "PRESPLIT", presplit)
+        for p in list(c1.parameters()) + list(c2.parameters()):
+            p.grad = None
+        with torch.no_grad():
+            y1 = ops.conv_bn_act(x, c1, b1, relu=True)
+            had = ops._cb_of(y1) is not None
+            y1.mul_(mask)         # in-place: bumps y1._version
+            y1.add_(0.25)
+            assert ops._cb_of(y1) is None
+        y1 = y1.requires_grad_()
+        y2 = ops.conv_bn_act(y1, c2, b2, relu=True)
+        y2.backward(gy)
+        return had, [t.detach().clone() for t in (y2, y1.grad, c2.weight.grad)]
+
+    had, a = run(True)
+    assert had == (ops.CONV_MATH != "f32")
+    _, b = run(False)
+    for name, u, v in zip(["y2", "dy1", "dw2"], a, b):
+        assert torch.equal(u, v), "%s read a stale companion (max diff %.3e)" % (name, float((u - v).abs().max()))
+
+
+# the large pixel-tile instantiations only run at benchmark-size grids: (Cin, Cout, k, dil, N, H, W)
+BIG_TILE_CASES = [
+    (64, 512, 3, 4, 1, 256, 256),    # fprop 64 -> 512, dilation 4: P = 65 536 = 512 pixel tiles x 2 row tiles
+    (256, 512, 1, 1, 2, 181, 182),   # 1x1, ragged pixel count (65 884 is not a multiple of 128)
+    (512, 64, 3, 2, 1, 256, 257),    # dgrad towards 512 channels (M = Cin), ragged
+]
+
+
+@pytest.mark.parametrize("case", BIG_TILE_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_large_tile_kernels(case):
+    """The tiles chosen at BASELINE batch sizes (csrc launch rule: pre-split operand, 512 rows, >= 1024 tile slots) against
+    fp64, and bit-for-bit against the 128 x 128 kernel the same shape takes without a pre-split operand (same K order)."""
+    dev = _dev()
+    from mcdseg import ops
+    if ops.CONV_MATH == "f32":
+        pytest.skip("split-precision kernels only")
+    cin, cout, k, d, n, h, w = case
+    x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, 1, d, h, w, n, False), 29)
+    desc = ops.conv_desc(x.shape, wt.shape, 1, pad, d)
+    wf, wd, mpf = ops.PackedWeights().get(wt.to(dev), desc)
+    xg = x.to(dev)
+    gy = torch.randn(n, cout, desc.Ho, desc.Wo, generator=torch.Generator().manual_seed(30))
+    gyg = gy.to(dev)
+    x64, w64 = x.double().requires_grad_(), wt.double().requires_grad_()
+    ref = F.conv2d(x64, w64, None, 1, pad, d)
+    (gx_ref,) = torch.autograd.grad(ref, [x64], gy.double())
+    names = []
+
+    class _Names:
+        def wants(self, name):
+            names.append(name)
+            return False
+    prev, ops.LAUNCH_TIMER = ops.LAUNCH_TIMER, _Names()
+    try:
+        y_cb, part_cb, rows = ops._conv_fprop(desc, xg, wf, None, True, mpf, ops.split_companion(xg))
+        y, part, rows2 = ops._conv_fprop(desc, xg, wf, None, True, mpf)
+        dx_cb = ops._conv_dgrad(desc, None, wd, ops.split_companion(gyg))
+        dx = ops._conv_dgrad(desc, gyg, wd)
+    finally:
+        ops.LAUNCH_TIMER = prev
+    big = [nm for nm in names if "4, 2, 2, 2" in nm or "4, 4, 2, 2" in nm]
+    assert big, "no large-tile kernel ran: %s" % names
+    _assert_close(y_cb, ref, 2e-5, "fprop (large tile)")
+    _assert_close(dx_cb, gx_ref, 2e-5, "dgrad (large tile)")
+    assert torch.equal(y_cb, y) and torch.equal(dx_cb, dx), "large tile differs from the 128x128 kernel"
+    if rows == rows2:
+        assert torch.equal(part_cb, part), "fused BN partial statistics differ"
+    # the fused statistics reproduce the channel means / variances of the output
+    L = ops.lib()
+    import ctypes
+    mean = torch.empty(cout, device=dev)
+    rstd = torch.empty(cout, device=dev)
+    ws = torch.empty(L.mcdseg_bn_stats_workspace_bytes(rows, cout) // 8 + 1, dtype=torch.float64, device=dev)
+    ops.check(L.mcdseg_bn_stats_finalize(ops._p(part_cb), rows, cout, mpf, ops._p(mean), ops._p(rstd), None, None, None, 0.1, 1e-5,
+                                         ops._p(ws), ctypes.c_size_t(ws.numel() * 8), ops._stream()), "bn_stats_finalize")
+    r = ref.detach()
+    _assert_close(mean, r.mean((0, 2, 3)), 1e-5, "fused BN mean")
+    _assert_close(rstd, (r.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt(), 1e-5, "fused BN rstd")
+
+
+def test_conv_nonfinite_operands():
+    """Contract of the split-precision convolutions for non-finite data: an output that a NaN / inf operand reaches is
+    non-finite (an fp32 FMA chain would give +-inf where the split gives NaN: inf - inf in the remainder), every other output
+    is unaffected; denormal operands are harmless."""
+    dev = _dev()
+    from mcdseg import ops
+    x, wt, _, s, pad, d = _conv_inputs((64, 128, 3, 1, 1, 12, 16, 1, False), 37)
+    desc = ops.conv_desc(x.shape, wt.shape, 1, pad, d)
+    wf, wd, mpf = ops.PackedWeights().get(wt.to(dev), desc)
+    clean, _, _ = ops._conv_fprop(desc, x.to(dev), wf, None, False, mpf)
+    xb = x.clone()
+    xb[0, 5, 2, 3] = float("inf")
+    xb[0, 7, 9, 12] = float("nan")
+    xb[0, 9, 6, 1] = 1e-41  # denormal
+    for cb in (False, True):
+        xg = xb.to(dev)
+        y, _, _ = ops._conv_fprop(desc, xg, wf, None, False, mpf, ops.split_companion(xg) if cb else None)
+        bad = ~torch.isfinite(y)
+        touched = torch.zeros(1, 1, 12, 16, dtype=torch.bool)
+        touched[0, 0, 1:4, 2:5] = True
+        touched[0, 0, 8:11, 11:14] = True
+        assert bool((bad.cpu() == touched.expand_as(bad)).all()), "non-finite outputs are not exactly the reached ones"
+        ok = ~touched.expand_as(bad)
+        assert float((y.cpu()[ok] - clean.cpu()[ok]).abs().max()) <= 1e-6 * float(clean.abs().max())
 
 
 def _split_cb(t):

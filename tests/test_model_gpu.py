@@ -137,10 +137,42 @@ def test_backward_small_vs_reference(golden, which, math, k_noise, monkeypatch):
 
 
 def _check_state(mod, ref_cs, rtol):
+    """L2 norm AND plain sum of every tensor of the state against the reference's checksums (|sum(a) - sum(b)| <=
+    sqrt(n) * ||a - b||, so the sum is held to the same relative distance the norm is)"""
     got = state_checksums(mod)
     assert got.keys() == ref_cs.keys()
+    numel = {k: v.numel() for k, v in mod.state_dict().items()}
     bad = [(k, got[k][1], l2) for k, (s, l2) in ref_cs.items() if abs(got[k][1] - l2) > rtol * max(abs(l2), 1e-6)]
     assert not bad, bad[:5]
+    bad = [(k, got[k][0], s) for k, (s, l2) in ref_cs.items()
+           if abs(got[k][0] - s) > rtol * max(abs(l2), 1e-6) * max(numel[k], 1) ** 0.5]
+    assert not bad, bad[:5]
+
+
+def _pick(t):
+    return t if t.numel() <= 40000 else t.reshape(t.shape[0], -1)[:16, :288]
+
+
+def _check_deltas(golden, before, g, f1, f2):
+    """The UPDATE each tensor received (state after - state before) against the reference's, tests/golden/trace_deltas.npz:
+    a wrong-direction or missing update is a relative error of order 1 here, where it moves a norm of the state only to
+    second order.  Yardstick: the reference's own fp32-vs-fp64 spread on the same delta (1-5 % after two iterations)."""
+    fx = golden.npz("trace_deltas.npz")
+    after = dict(list(g.state_dict().items()) + [("f1." + k, v) for k, v in f1.state_dict().items()] +
+                 [("f2." + k, v) for k, v in f2.state_dict().items()])
+    seen = 0
+    for key in fx.files:
+        if not key.startswith("f64/"):
+            continue
+        kind, name = key[4:].split("/", 1)
+        r64, r32 = fx[key], fx["f32/" + key[4:]].astype(np.float64)
+        noise = np.linalg.norm(r32 - r64) / np.linalg.norm(r64)
+        cur = after[name].detach().double().cpu()
+        got = _pick(cur - before[name].double().cpu()).numpy() if kind == "delta" else cur.numpy()
+        rel = np.linalg.norm(got - r64) / np.linalg.norm(r64)
+        assert rel <= max(4.0 * noise, 1e-2 if kind == "delta" else 1e-4), "%s: rel L2 %.3e, reference fp32 noise %.3e" % (key, rel, noise)
+        seen += 1
+    assert seen >= 15
 
 
 def test_three_step_small_vs_reference(golden):
@@ -159,6 +191,8 @@ def test_three_step_small_vs_reference(golden):
     cw[NC - 1] = 0
     criterion = CrossEntropyLoss2d(cw.to(dev))
     criterion_d = get_prob_distance_criterion("diff")
+    before = {k: v.detach().clone() for k, v in list(g.state_dict().items()) + [("f1." + k, v) for k, v in f1.state_dict().items()] +
+              [("f2." + k, v) for k, v in f2.state_dict().items()]}
     for it in tr["iters"]:
         og.zero_grad(); of.zero_grad()
         out = g(s)
@@ -183,6 +217,7 @@ def test_three_step_small_vs_reference(golden):
         assert abs(c_loss - it["c_loss"]) <= 1e-4 * it["c_loss"], (c_loss, it)
         assert abs(d_loss - it["d_loss"]) <= 2e-3 * it["d_loss"], (d_loss, it)
     _check_state(g, tr["g"], 3e-4), _check_state(f1, tr["f1"], 3e-4), _check_state(f2, tr["f2"], 3e-4)
+    _check_deltas(golden, before, g, f1, f2)
     assert int(g.state_dict()["base.0.1.num_batches_tracked"]) == tr["nbt"] == 14
     sd = og.state_dict()
     assert sorted(sd.keys()) == tr["opt_g_state_keys"]
@@ -208,11 +243,14 @@ def test_solver_matches_drop_in_loop(golden):
     cw = torch.ones(NC)
     cw[NC - 1] = 0
     solver = MCDSolver(g, f1, f2, og, of, CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff"), num_k=4)
+    before = {k: v.detach().clone() for k, v in list(g.state_dict().items()) + [("f1." + k, v) for k, v in f1.state_dict().items()] +
+              [("f2." + k, v) for k, v in f2.state_dict().items()]}
     for it in tr["iters"]:
         c_loss, d_loss = solver.step(s, l, t)
         assert abs(float(c_loss) - it["c_loss"]) <= 1e-4 * it["c_loss"]
         assert abs(float(d_loss) - it["d_loss"]) <= 2e-3 * it["d_loss"]
     _check_state(g, tr["g"], 3e-4), _check_state(f1, tr["f1"], 3e-4), _check_state(f2, tr["f2"], 3e-4)
+    _check_deltas(golden, before, g, f1, f2)
     assert int(g.state_dict()["base.0.1.num_batches_tracked"]) == 14
 
 
@@ -326,6 +364,69 @@ def test_full_resolution_vs_oracle_and_properties():
         c1 = float(ops.cross_entropy2d(la + 3.0, lab, cw))
         assert abs(c0 - c1) <= 2e-5 * abs(c0)
     assert h.shape == (4, 16, 480, 640) and float(h.min()) >= 0.0
+
+
+def test_cfg2_full_batch_vs_oracle():
+    """BASELINE config 2 at its stated size -- 16 x 6 x 480 x 640, train-mode BatchNorm, with a tape -- so that the kernels the
+    benchmark times (the large-tile pre-split convolutions, selected only at this batch) are the ones compared: encoder
+    features and logits against the CPU oracle's N = 16 train-mode forward (<= 1e-3, north_star), then the cross-entropy
+    gradients of ``seg.weight`` and ``base.8.0.weight`` against the oracle's backward (adapt_trainer.py:163-185)."""
+    dev = _dev()
+    import os
+    from loss import CrossEntropyLoss2d
+    from mcdseg import ops
+    from oracle import ref_loss, ref_models
+    n = 16
+    desc = ops.conv_desc((n, 512, 60, 80), (512, 512, 3, 3), 1, 4, 4)
+    big = ops.gemm_kernel_name(512, 512, False, True, True, False, n * 60 * 80)
+    assert ops.CONV_MATH == "f32" or "2, 2, 2, 2" not in big, "N=16 must select the large tile, got %s" % big
+    g, f1, f2 = _mcd_models(dev)
+    og, of1, of2 = ref_models.get_models("drn_d_38", 6, NC)
+    fill_state_(og, 11), fill_state_(of1, 12), fill_state_(of2, 13)
+    og.train(), of1.train(), of2.train()
+    src, lbl, _ = make_batch(78, n, 6, 480, 640, NC)
+    cw = ref_loss.class_weights(NC)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(max(threads, os.cpu_count() or 1))
+    try:
+        ref_feat = og(src)
+        ref_logits = of1(ref_feat)
+        rcrit = ref_loss.CrossEntropyLoss2d(cw)
+        (rcrit(ref_logits, lbl) + rcrit(of2(ref_feat), lbl)).backward()
+    finally:
+        torch.set_num_threads(threads)
+    ref_gs = {k: dict(og.named_parameters())[k].grad.clone() for k in ("seg.weight", "base.8.0.weight")}
+    ref_feat, ref_logits = ref_feat.detach(), ref_logits.detach()[:, :, ::8, ::8].clone()
+    del og, of1, of2
+    names = []
+    timer_prev = ops.LAUNCH_TIMER
+
+    class _Names:
+        def wants(self, name):
+            names.append(name)
+            return False
+    ops.LAUNCH_TIMER = _Names()
+    try:
+        feat = g(src.to(dev))
+        logits = f1(feat)
+        crit = CrossEntropyLoss2d(cw.to(dev))
+        (crit(logits, lbl.to(dev)) + crit(f2(feat), lbl.to(dev))).backward()
+    finally:
+        ops.LAUNCH_TIMER = timer_prev
+    if ops.CONV_MATH != "f32":
+        assert big in names, "the forward pass did not run %s: %s" % (big, sorted(set(names)))
+        assert ops.gemm_kernel_name(512, 512, True, True, True, False, n * 60 * 80) in names, sorted(set(names))
+    err = float((feat.detach().cpu() - ref_feat).abs().max())
+    assert err <= 1e-3, "feat err %.3e" % err
+    lerr = float((logits.detach()[:, :, ::8, ::8].cpu() - ref_logits).abs().max())
+    assert lerr <= 1e-3, "logit err %.3e" % lerr
+    named = dict(g.named_parameters())
+    for k, rg in ref_gs.items():
+        # both sides are fp32 through 41 train-mode BatchNorms: the oracle's own fp32 noise on these gradients is 1-3 %
+        # of their scale (SURVEY.md section 7); direction and size must agree to that
+        got = named[k].grad.cpu()
+        rel = float((got - rg).norm() / rg.norm())
+        assert rel <= 5e-2, "%s: relative L2 difference %.3e" % (k, rel)
 
 
 def test_d105_bottleneck_vs_reference(golden):

@@ -150,11 +150,17 @@ def _check_state(mod, ref_cs, rtol=2e-4):
         assert abs(got[k][1] - l2) <= rtol * max(abs(l2), 1e-6), (k, got[k], (s, l2))
 
 
-def _mcd_trace(tr):
+def _flat_state(g, f1, f2):
+    return dict(list(g.state_dict().items()) + [("f1." + k, v) for k, v in f1.state_dict().items()] +
+                [("f2." + k, v) for k, v in f2.state_dict().items()])
+
+
+def _mcd_trace(tr, deltas=None):
     g, f1, f2 = ref_models.get_models("drn_d_38", 6, NC)
     for m, seed in ((g, 11), (f1, 12), (f2, 13)):
         fill_state_(m, seed)
         m.train()
+    before = {k: v.detach().clone() for k, v in _flat_state(g, f1, f2).items()}
     n, ch, h, w = tr["shape"]
     s, l, t = make_batch(tr["seed_batch"], n, ch, h, w, NC)
     og = ref_models.get_optimizer(g.parameters(), "sgd", 1e-3, 0.9, 2e-5)
@@ -167,10 +173,24 @@ def _mcd_trace(tr):
     _check_state(g, tr["g"]), _check_state(f1, tr["f1"]), _check_state(f2, tr["f2"])
     assert int(g.state_dict()["base.0.1.num_batches_tracked"]) == tr["nbt"] == 7 * len(tr["iters"])
     assert sorted(og.state_dict().keys()) == tr["opt_g_state_keys"]
+    if deltas is not None:
+        # the updates themselves (after - before) against the reference's, inside the reference's own fp32-vs-fp64 spread
+        after = _flat_state(g, f1, f2)
+        for key in deltas.files:
+            if not key.startswith("f64/"):
+                continue
+            kind, name = key[4:].split("/", 1)
+            r64, r32 = deltas[key], deltas["f32/" + key[4:]].astype(np.float64)
+            noise = np.linalg.norm(r32 - r64) / np.linalg.norm(r64)
+            cur = after[name].detach().double()
+            got = cur - before[name].double() if kind == "delta" else cur
+            got = (got if got.numel() <= 40000 else got.reshape(got.shape[0], -1)[:16, :288]).numpy()
+            rel = np.linalg.norm(got - r64) / np.linalg.norm(r64)
+            assert rel <= max(4.0 * noise, 1e-6), (key, rel, noise)
 
 
 def test_mcd_three_step_small(golden):
-    _mcd_trace(golden.json("traces.json")["mcd_small"])
+    _mcd_trace(golden.json("traces.json")["mcd_small"], golden.npz("trace_deltas.npz"))
 
 
 def test_mcd_three_step_240x320(golden):
