@@ -62,33 +62,49 @@ int mcdseg_conv_fprop_affine(const mcdseg_conv_desc* d, const float* x, const fl
                              const float* shift, const float* residual, int32_t relu, float* y, void* stream);
 /* dx = conv_transpose(dy, w)   (autograd of the same call sites) */
 int mcdseg_conv_dgrad(const mcdseg_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* stream);
-/* ---- "bf16x6" variants: same operators, fp32 operands split 3-way into bf16 and multiplied on the bf16 matrix
- * pipe with the six largest cross terms (dropped terms < 2^-24 of a product: fp32-grade results at 2.67x the f32
- * MFMA rate).  Weight images are bf16, layout [k-step][piece 3][k-half 2][Mp][8]; sizes from *_packed_bytes. */
-int mcdseg_conv_x6_packed_bytes(const mcdseg_conv_desc* d, int64_t* fprop_bytes, int64_t* dgrad_bytes);
+/* ---- split-precision variants: the same operators with the fp32 operands carried through the 16-bit matrix pipe as a
+ * sum of exact piece products (csrc/split.h).  `math` selects the arithmetic:
+ *   MCDSEG_MATH_F16X3   x = s (h1 + h2): two fp16 pieces and a power-of-two scale s per tensor, three cross terms on
+ *                       v_mfma_f32_32x32x16_f16 -- 5.3x the f32 MFMA rate, fp32-grade against the reference's fp64 gradients;
+ *   MCDSEG_MATH_BF16X6  x = a1 + a2 + a3: three bf16 pieces, the six largest cross terms on v_mfma_f32_32x32x16_bf16
+ *                       (2.67x the f32 MFMA rate; no scale needed).
+ * *_bound arguments (F16X3 only, NULL otherwise): one device float holding an UPPER BOUND of |tensor| -- written by the
+ * producer of the tensor (mcdseg_bn_stats_finalize, mcdseg_bn_bwd_reduce, mcdseg_conv_split_pack_weights) or measured
+ * with mcdseg_absmax; every kernel derives the scale 2^(ceil(log2 bound) - 15) from it, so no finite value overflows fp16.
+ * Weight images are 16-bit, layout [k-step][piece][k-half 2][Mp][8]; sizes from *_packed_bytes. */
+#define MCDSEG_MATH_F16X3 3
+#define MCDSEG_MATH_BF16X6 6
+int mcdseg_conv_split_packed_bytes(const mcdseg_conv_desc* d, int32_t math, int64_t* fprop_bytes, int64_t* dgrad_bytes);
 /* 1 when the forward of this geometry runs as the direct (LDS-tiled) convolution of the network stem (7x7, stride 1,
  * pad 3, Cin <= 8, Cout <= 16; models/drn.py:126-131) -- the one case where the split path takes fewer than 16
- * contraction channels.  mcdseg_conv_x6_stat_rows = rows of the BN partial-statistics buffer mcdseg_conv_x6_fprop
- * writes (differs from mcdseg_conv_stat_rows for the direct kernel). */
-int32_t mcdseg_conv_x6_direct_ok(const mcdseg_conv_desc* d);
-int64_t mcdseg_conv_x6_stat_rows(const mcdseg_conv_desc* d);
-int mcdseg_conv_x6_pack_weights(const mcdseg_conv_desc* d, const float* w, void* wp_fprop, void* wp_dgrad, void* stream);
+ * contraction channels (always in the bf16x6 arithmetic).  mcdseg_conv_split_stat_rows = rows of the BN partial-statistics
+ * buffer mcdseg_conv_split_fprop writes (differs from mcdseg_conv_stat_rows for the direct kernel). */
+int32_t mcdseg_conv_split_direct_ok(const mcdseg_conv_desc* d);
+int64_t mcdseg_conv_split_stat_rows(const mcdseg_conv_desc* d);
+/* bound[0] = max |x[i]| (exact, order-independent; non-finite data gives a non-finite bound) */
+int mcdseg_absmax(const float* x, int64_t n, float* bound, void* stream);
+/* w [Cout,Cin,KH,KW] -> fprop and/or dgrad image; F16X3 first measures w_bound = max |w| (device float, written here) */
+int mcdseg_conv_split_pack_weights(const mcdseg_conv_desc* d, int32_t math, const float* w, void* wp_fprop, void* wp_dgrad,
+                                   float* w_bound, void* stream);
 /* x_cb / dy_cb (may be NULL): the gathered operand already split by its producer into the channel-blocked layout
- * [piece 3][N][C/8][H*W][8 bf16] (mcdseg_bn_apply_cb / mcdseg_bn_bwd_apply_cb); C must be divisible by 8.  With it the
- * K loop does no conversion and loads 3 x 16 B per pixel and 8-channel group instead of 8 dwords. */
-int mcdseg_conv_x6_fprop(const mcdseg_conv_desc* d, const float* x, const void* x_cb, const void* wp_fprop,
-                         const float* bias, float* y, float* stat_partials, void* stream);
-int mcdseg_conv_x6_fprop_affine(const mcdseg_conv_desc* d, const float* x, const void* x_cb, const void* wp_fprop,
-                                const float* scale, const float* shift, const float* residual, int32_t relu, float* y,
-                                void* stream);
-int mcdseg_conv_x6_dgrad(const mcdseg_conv_desc* d, const float* dy, const void* dy_cb, const void* wp_dgrad, float* dx,
-                         void* stream);
+ * [piece][N][C/8][H*W][8 x 16 bit] (mcdseg_bn_apply_cb / mcdseg_bn_bwd_apply_cb / mcdseg_split_cb, same `math` and the same
+ * bound scalar); C must be divisible by 8.  With it the K loop does no conversion and moves 16 B per piece, pixel and
+ * 8-channel group straight into LDS instead of gathering 8 dwords and splitting them. */
+int mcdseg_conv_split_fprop(const mcdseg_conv_desc* d, int32_t math, const float* x, const void* x_cb, const float* x_bound,
+                            const void* wp_fprop, const float* w_bound, const float* bias, float* y, float* stat_partials,
+                            void* stream);
+int mcdseg_conv_split_fprop_affine(const mcdseg_conv_desc* d, int32_t math, const float* x, const void* x_cb, const float* x_bound,
+                                   const void* wp_fprop, const float* w_bound, const float* scale, const float* shift,
+                                   const float* residual, int32_t relu, float* y, void* stream);
+int mcdseg_conv_split_dgrad(const mcdseg_conv_desc* d, int32_t math, const float* dy, const void* dy_cb, const float* dy_bound,
+                            const void* wp_dgrad, const float* w_bound, float* dx, void* stream);
 /* same workspace as mcdseg_conv_wgrad; 128x128-tile layers run on the split path, thin layers on the f32 kernels.
  * x_cb / dy_cb (may be NULL; used only when BOTH are given): the pre-split companions of x and dy in the layout above --
- * the kernel then transposes 8x8 bf16 blocks in registers instead of splitting fp32 values.  x / dy may be NULL only when
- * that path applies (both companions, channel counts divisible by 8, min(Cin,Cout) > 64 and not the thin-input plan). */
-int mcdseg_conv_x6_wgrad(const mcdseg_conv_desc* d, const float* x, const void* x_cb, const float* dy, const void* dy_cb,
-                         float* dw, void* workspace, size_t workspace_bytes, void* stream);
+ * the kernel then transposes 8x8 blocks of 16-bit pieces in registers instead of splitting fp32 values.  x / dy may be NULL
+ * only when that path applies (both companions, channel counts divisible by 8, min(Cin,Cout) > 64, not the thin-input plan). */
+int mcdseg_conv_split_wgrad(const mcdseg_conv_desc* d, int32_t math, const float* x, const void* x_cb, const float* x_bound,
+                            const float* dy, const void* dy_cb, const float* dy_bound, float* dw, void* workspace,
+                            size_t workspace_bytes, void* stream);
 /* dw = x (*) dy ; split over pixels into slabs in `workspace`, then reduced in a fixed order. */
 size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d);
 int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw,
@@ -99,11 +115,16 @@ int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy
  * fused with ReLU and the residual add of BasicBlock/Bottleneck (models/drn.py:43-59, 80-100)
  * ---------------------------------------------------------------------------------------------- */
 /* Merge the conv epilogue partials -> mean[C], rstd[C]; update running_mean/var (unbiased var) and
- * ++num_batches_tracked when those pointers are non-NULL.  workspace: 8-byte aligned scratch. */
+ * ++num_batches_tracked when those pointers are non-NULL.  workspace: 8-byte aligned scratch.
+ * y_bound (may be NULL): receives an upper bound of |y| for the tensor mcdseg_bn_apply(_cb) is about to write from these
+ * statistics, y = act(gamma*xhat + beta (+ residual)): max_c(|gamma_c| sqrt(n-1) + |beta_c|) + res_bound[0], using
+ * Samuelson's inequality |xhat| <= sqrt(n-1) for a batch of n values normalised by their own mean and biased variance
+ * (gamma, beta required then; res_bound = bound scalar of the residual tensor or NULL). */
 size_t mcdseg_bn_stats_workspace_bytes(int64_t rows, int32_t C);
 int mcdseg_bn_stats_finalize(const float* stat_partials, int64_t rows, int32_t C, int32_t Mp,
                              float* mean, float* rstd, float* running_mean, float* running_var,
                              int64_t* num_batches_tracked, float momentum, float eps,
+                             const float* gamma, const float* beta, const float* res_bound, float* y_bound,
                              void* workspace, size_t workspace_bytes, void* stream);
 /* eval mode: mean = running_mean, rstd = 1/sqrt(running_var+eps) */
 int mcdseg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps,
@@ -115,24 +136,29 @@ int mcdseg_bn_eval_affine(const float* gamma, const float* beta, const float* ru
 /* y = act(gamma*(z-mean)*rstd + beta (+ residual)), act = ReLU if relu != 0 */
 int mcdseg_bn_apply(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                     const float* residual, float* y, int32_t N, int32_t C, int32_t HW, int32_t relu, void* stream);
-/* Same as mcdseg_bn_apply / mcdseg_bn_bwd_apply, additionally emitting the exact 3-way bf16 split of the produced
- * tensor in the channel-blocked layout [piece 3][N][C/8][HW][8 bf16] (3*N*C*HW*2 bytes) consumed by the bf16x6
- * convolutions; C must be divisible by 8.  mcdseg_bn_bwd_apply_cb accepts dz == NULL (only the split companion is
- * written) for layers whose input and weight gradients both read the companion. */
-/* the split alone (fp32 NCHW -> companion) for operands no fused BN group produced */
-int mcdseg_split_cb(const float* x, void* x_cb, int32_t N, int32_t C, int32_t HW, void* stream);
+/* Same as mcdseg_bn_apply / mcdseg_bn_bwd_apply, additionally emitting the split of the produced tensor (pieces of `math`,
+ * scale from the bound scalar for MCDSEG_MATH_F16X3; NULL for BF16X6) in the channel-blocked layout
+ * [piece][N][C/8][HW][8 x 16 bit] consumed by the split convolutions; C must be divisible by 8.  mcdseg_bn_bwd_apply_cb
+ * accepts dz == NULL (only the split companion is written) for layers whose input and weight gradients both read the
+ * companion.  mcdseg_split_cb is the split alone (fp32 NCHW -> companion) for operands no fused BN group produced. */
+int mcdseg_split_cb(const float* x, void* x_cb, const float* x_bound, int32_t math, int32_t N, int32_t C, int32_t HW, void* stream);
 int mcdseg_bn_apply_cb(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                       const float* residual, float* y, void* y_cb, int32_t N, int32_t C, int32_t HW, int32_t relu,
-                       void* stream);
+                       const float* residual, float* y, void* y_cb, const float* y_bound, int32_t math, int32_t N, int32_t C,
+                       int32_t HW, int32_t relu, void* stream);
 int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
                            const float* gamma, const float* dgamma, const float* dbeta, float* dz, float* dres,
-                           void* dz_cb, int32_t N, int32_t C, int32_t HW, int32_t relu, int32_t train, void* stream);
+                           void* dz_cb, const float* dz_bound, int32_t math, int32_t N, int32_t C, int32_t HW, int32_t relu,
+                           int32_t train, void* stream);
 /* Backward.  dy is the gradient w.r.t. y; y (the saved forward output) supplies the ReLU mask when
  * relu != 0.  reduce: dgamma[c] = sum dy_m*xhat, dbeta[c] = sum dy_m.  With z == NULL only dbeta is
- * produced (used for the conv bias gradient, models/dilated_fcn.py:227). */
+ * produced (used for the conv bias gradient, models/dilated_fcn.py:227).
+ * dz_bound (may be NULL; needs z and gamma): receives an upper bound of |dz| for the tensor mcdseg_bn_bwd_apply(_cb) will
+ * write: max_c |gamma_c rstd_c| (max|dy_m| + |dbeta_c|/n + sqrt(n-1) |dgamma_c|/n) in train mode, max_c |gamma_c rstd_c|
+ * max|dy_m| in eval mode (train selects). */
 size_t mcdseg_bn_bwd_workspace_bytes(int32_t N, int32_t C, int32_t HW);
 int mcdseg_bn_bwd_reduce(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
-                         float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, int32_t relu,
+                         float* dgamma, float* dbeta, const float* gamma, float* dz_bound, int32_t train,
+                         int32_t N, int32_t C, int32_t HW, int32_t relu,
                          void* workspace, size_t workspace_bytes, void* stream);
 /* dz = gamma*rstd*(dy_m - dbeta/n - xhat*dgamma/n) (train) or gamma*rstd*dy_m (eval);
  * dres (optional) = dy_m, the gradient of the residual branch. */

@@ -8,7 +8,7 @@
 // Reference semantics: nn.BatchNorm2d(eps=1e-5, momentum=0.1) in train mode normalises with the biased
 // batch variance and moves running_var with the unbiased one (models/drn.py:34,38,129,179,202);
 // ReLU is in place after the residual add (models/drn.py:48,55-57).
-#include "common.h"
+#include "split.h"
 
 namespace {
 
@@ -17,14 +17,18 @@ namespace {
 // partial rows into fp64 (sum n, sum n*mean, sum M2 + n*mean^2).  Stage 2: one thread per channel merges the
 // S slices: mean = S1/N, var = (Q - S1^2/N)/N -- in fp64 the subtraction costs ~1e-16 * mean^2/var, far below
 // fp32 resolution, while the fp32 data itself was centred per wave (shifted form) in the conv epilogue.
-int stats_slices(int64_t rows) {
-  int64_t s = rows / 64;
-  return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+int stats_slices(int64_t rows, int C) {
+  // enough blocks to fill the chip: ceil(C/32) channel blocks x S row slices ~ 1024, at least 8 rows per slice
+  const int cb = ceil_div(C, 32);
+  int64_t s = ceil_div64(1024, cb);
+  if (s > rows / 8) s = rows / 8;
+  return (int)(s < 1 ? 1 : (s > 512 ? 512 : s));
 }
 
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ part, int64_t rows, int C, int Mp,
-                                                               double* __restrict__ out) {
+                                                               double* __restrict__ out, float* __restrict__ y_bound) {
   __shared__ double sh[3][8][33];
+  if (y_bound != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *y_bound = 0.f;  // finalize takes an atomic max
   const int cx = threadIdx.x & 31;
   const int g = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
@@ -55,18 +59,40 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   }
 }
 
+// Stage 2: grid = C/32 blocks; thread (cx, g) folds slices g, g+8, ... of channel 32*blockIdx.x + cx, the 8 groups meet in
+// LDS.  Also forms the bound of the tensor bn_apply is about to write (see mcdseg.h): per-block maximum, then an integer
+// atomic max on the bit pattern (non-negative floats order like their bits; the scalar was zeroed by stage 1).
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ sl, int S, int C,
                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                                 float* __restrict__ running_mean,
                                                                 float* __restrict__ running_var, int64_t* nbt,
-                                                                float momentum, float eps) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+                                                                float momentum, float eps, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                const float* __restrict__ res_bound, float* __restrict__ y_bound) {
+  __shared__ double sh[3][8][33];
+  __shared__ float shb[32];
+  const int cx = threadIdx.x & 31;
+  const int g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  double n = 0.0, s1 = 0.0, q = 0.0;
   if (c < C) {
-    double n = 0.0, s1 = 0.0, q = 0.0;
-    for (int k = 0; k < S; ++k) {
+    for (int k = g; k < S; k += 8) {
       n += sl[((size_t)k * 3 + 0) * C + c];
       s1 += sl[((size_t)k * 3 + 1) * C + c];
       q += sl[((size_t)k * 3 + 2) * C + c];
+    }
+  }
+  sh[0][g][cx] = n;
+  sh[1][g][cx] = s1;
+  sh[2][g][cx] = q;
+  __syncthreads();
+  float bound = 0.f;
+  if (g == 0 && c < C) {
+    n = s1 = q = 0.0;
+    for (int k = 0; k < 8; ++k) {
+      n += sh[0][k][cx];
+      s1 += sh[1][k][cx];
+      q += sh[2][k][cx];
     }
     const double mean = n > 0.0 ? s1 / n : 0.0;
     double m2 = q - s1 * mean;
@@ -78,6 +104,22 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
       const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
       running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
       running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    }
+    if (y_bound != nullptr) bound = fabsf(gamma[c]) * (float)sqrt(n > 1.0 ? n - 1.0 : 1.0) * 1.0001f + fabsf(beta[c]);
+  }
+  if (y_bound != nullptr) {
+    if (g == 0) shb[cx] = bound;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = 0.f;
+      bool bad = false;
+      for (int k = 0; k < 32; ++k) {
+        bad = bad || !(shb[k] == shb[k]);
+        m = fmaxf(m, shb[k]);
+      }
+      m += res_bound ? *res_bound : 0.f;
+      if (bad || !(m == m)) m = __uint_as_float(0x7FC00000u);  // NaN parameters -> non-finite bound
+      atomicMax(reinterpret_cast<unsigned*>(y_bound), __float_as_uint(m) & 0x7FFFFFFFu);
     }
   }
   if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
@@ -173,12 +215,14 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                             const float* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ part, int N,
-                                                            int C, int HW, int relu, int cpp, int chunk) {
+                                                            int C, int HW, int relu, int cpp, int chunk,
+                                                            float* __restrict__ dz_bound) {
   const int c = blockIdx.x;
   const int S = gridDim.y;
+  if (dz_bound != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *dz_bound = 0.f;  // finalize: atomic max
   const float mu = z ? mean[c] : 0.f;
   const float rs = z ? rstd[c] : 0.f;
-  float s_dy = 0.f, s_dyx = 0.f;
+  float s_dy = 0.f, s_dyx = 0.f, m_g = 0.f;
   const int items = N * cpp;
   for (int item = blockIdx.y; item < items; item += S) {
     const int n = item / cpp;
@@ -199,6 +243,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
           g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
         }
         s_dy += (g.x + g.y) + (g.z + g.w);
+        m_g = fmaxf(m_g, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
         if (z) {
           const float4 v = z4[i];
           s_dyx += (g.x * ((v.x - mu) * rs) + g.y * ((v.y - mu) * rs)) + (g.z * ((v.z - mu) * rs) + g.w * ((v.w - mu) * rs));
@@ -209,35 +254,61 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         float g = dy[base + i];
         if (relu && !(y[base + i] > 0.f)) g = 0.f;
         s_dy += g;
+        m_g = fmaxf(m_g, fabsf(g));
         if (z) s_dyx += g * ((z[base + i] - mu) * rs);
       }
     }
   }
-  __shared__ float sh[2][4];
+  __shared__ float sh[3][4];
   s_dy = wave_sum(s_dy);
   s_dyx = wave_sum(s_dyx);
+  for (int o = 1; o < 64; o <<= 1) m_g = fmaxf(m_g, __shfl_xor(m_g, o));  // fmaxf drops NaN: a NaN gradient shows in the sums
   if ((threadIdx.x & 63) == 0) {
     sh[0][threadIdx.x >> 6] = s_dy;
     sh[1][threadIdx.x >> 6] = s_dyx;
+    sh[2][threadIdx.x >> 6] = m_g;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    part[((size_t)blockIdx.y * 2 + 0) * C + c] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
-    part[((size_t)blockIdx.y * 2 + 1) * C + c] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    part[((size_t)blockIdx.y * 3 + 0) * C + c] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    part[((size_t)blockIdx.y * 3 + 1) * C + c] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    part[((size_t)blockIdx.y * 3 + 2) * C + c] = fmaxf(fmaxf(sh[2][0], sh[2][1]), fmaxf(sh[2][2], sh[2][3]));
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int S, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
+// dgamma / dbeta from the S partial rows (fp64) and, when asked, the bound of the dz tensor bn_bwd_apply is about to write
+// (mcdseg.h): |dz| <= |gamma rstd| (max|g| + |dbeta|/n + sqrt(n-1) |dgamma|/n) since |xhat| <= sqrt(n-1).
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int S, int C, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, const float* __restrict__ gamma,
+                                                              const float* __restrict__ rstd, float n_total, int train,
+                                                              float* __restrict__ dz_bound) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0, b = 0.0;
-  for (int s = 0; s < S; ++s) {
-    a += (double)part[((size_t)s * 2 + 0) * C + c];
-    b += (double)part[((size_t)s * 2 + 1) * C + c];
+  float bound = 0.f;
+  if (c < C) {
+    double a = 0.0, b = 0.0;
+    float mg = 0.f;
+    for (int s = 0; s < S; ++s) {
+      a += (double)part[((size_t)s * 3 + 0) * C + c];
+      b += (double)part[((size_t)s * 3 + 1) * C + c];
+      mg = fmaxf(mg, part[((size_t)s * 3 + 2) * C + c]);
+    }
+    if (dbeta) dbeta[c] = (float)a;
+    if (dgamma) dgamma[c] = (float)b;
+    if (dz_bound != nullptr) {
+      const float ar = fabsf(gamma[c] * rstd[c]);
+      bound = train ? ar * (mg + fabsf((float)a) / n_total + sqrtf(n_total > 1.f ? n_total - 1.f : 1.f) * fabsf((float)b) / n_total) * 1.0001f
+                    : ar * mg;
+    }
   }
-  if (dbeta) dbeta[c] = (float)a;
-  if (dgamma) dgamma[c] = (float)b;
+  if (dz_bound != nullptr) {
+    const bool bad = !(bound == bound);
+    for (int o = 1; o < 64; o <<= 1) bound = fmaxf(bound, __shfl_xor(bound, o));
+    const unsigned long long anybad = __ballot(bad);
+    if ((threadIdx.x & 63) == 0) {
+      if (anybad) bound = __uint_as_float(0x7FC00000u);
+      atomicMax(reinterpret_cast<unsigned*>(dz_bound), __float_as_uint(bound) & 0x7FFFFFFFu);
+    }
+  }
 }
 
 template <bool VEC>
@@ -289,42 +360,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// "cb" variants: besides the fp32 tensor, emit its exact 3-way bf16 split in the channel-blocked layout
-//   cb[piece 3][N][C/8][HW][8 bf16]
-// which is what the bf16x6 convolution consumes as its gathered operand (one 16-B fragment per pixel and 8-channel
+// "cb" variants: besides the fp32 tensor, emit its split (policy P of split.h) in the channel-blocked layout
+//   cb[piece NP][N][C/8][HW][8 x 16 bit]
+// which is what the split convolutions consume as their gathered operand (one 16-B fragment per pixel and 8-channel
 // group, consecutive pixels contiguous).  Splitting here -- once, in an HBM-bound kernel whose VALU is idle -- instead
 // of inside the convolution's K loop (where every activation is re-split for each of the 9 taps and 4 M-tiles and the
 // conversion competes with MFMA issue slots) is worth ~1.3x on the convolution.  One thread = one pixel x 8 channels:
-// loads and fp32 stores are pixel-contiguous per channel, the three 16-B split stores are contiguous across lanes.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void split3_store(const float (&v)[8], __bf16* __restrict__ cb, size_t piece_stride, size_t idx16) {
-  bf16x8_t p1, p2, p3;
+// loads and fp32 stores are pixel-contiguous per channel, the 16-B split stores are contiguous across lanes.
+template <class P>
+__device__ __forceinline__ void split_store(const float (&v)[8], float inv_scale, typename P::elem* __restrict__ cb, size_t piece_stride,
+                                            size_t idx16) {
+  typename P::frag pieces[P::NP];
+  split_frag<P>(v, inv_scale, pieces);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 a = (__bf16)v[e];
-    const float r1 = v[e] - (float)a;
-    const __bf16 b = (__bf16)r1;
-    p1[e] = a;
-    p2[e] = b;
-    p3[e] = (__bf16)(r1 - (float)b);
-  }
-  *reinterpret_cast<bf16x8_t*>(cb + idx16 * 8) = p1;
-  *reinterpret_cast<bf16x8_t*>(cb + piece_stride + idx16 * 8) = p2;
-  *reinterpret_cast<bf16x8_t*>(cb + 2 * piece_stride + idx16 * 8) = p3;
+  for (int pc = 0; pc < P::NP; ++pc) *reinterpret_cast<typename P::frag*>(cb + pc * piece_stride + idx16 * 8) = pieces[pc];
 }
 
+template <class P>
 __global__ __launch_bounds__(256) void bn_apply_cb_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ res,
-                                                          float* __restrict__ y, __bf16* __restrict__ cb, int N, int C, int HW,
-                                                          int relu) {
+                                                          float* __restrict__ y, typename P::elem* __restrict__ cb,
+                                                          const float* __restrict__ y_bound, int N, int C, int HW, int relu) {
   const int C8 = C >> 3;
   const int ng = blockIdx.y;  // n * C8 + g
   const int g = ng % C8;
   const int n = ng / C8;
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= HW) return;
+  const float inv_scale = 1.f / operand_scale<P>(y_bound);
   const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
   float v[8];
 #pragma unroll
@@ -338,21 +402,24 @@ __global__ __launch_bounds__(256) void bn_apply_cb_kernel(const float* __restric
     v[e] = t;
     y[base + (size_t)e * HW] = t;
   }
-  split3_store(v, cb, (size_t)N * C * HW, (size_t)ng * HW + pix);
+  split_store<P>(v, inv_scale, cb, (size_t)N * C * HW, (size_t)ng * HW + pix);
 }
 
+template <class P>
 __global__ __launch_bounds__(256) void bn_bwd_apply_cb_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                               const float* __restrict__ z, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                               const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                               float* __restrict__ dz, float* __restrict__ dres,
-                                                              __bf16* __restrict__ cb, int N, int C, int HW, int relu, int train) {
+                                                              typename P::elem* __restrict__ cb, const float* __restrict__ dz_bound,
+                                                              int N, int C, int HW, int relu, int train) {
   const int C8 = C >> 3;
   const int ng = blockIdx.y;
   const int g = ng % C8;
   const int n = ng / C8;
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= HW) return;
+  const float inv_scale = 1.f / operand_scale<P>(dz_bound);
   const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
   const float inv_n = 1.f / ((float)N * (float)HW);
   float v[8];
@@ -368,24 +435,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_kernel(const float* __res
     if (dres) dres[base + (size_t)e * HW] = gv;
     const float t = a * (gv - k1 - ((z[base + (size_t)e * HW] - mu) * rs) * k2);
     v[e] = t;
-    if (dz) dz[base + (size_t)e * HW] = t;  // optional: the x6 dgrad and wgrad read only the split companion
+    if (dz) dz[base + (size_t)e * HW] = t;  // optional: the split dgrad and wgrad read only the companion
   }
-  split3_store(v, cb, (size_t)N * C * HW, (size_t)ng * HW + pix);
+  split_store<P>(v, inv_scale, cb, (size_t)N * C * HW, (size_t)ng * HW + pix);
 }
 
 // the split alone, for operands no fused BN group produced (network inputs, gradients arriving from outside the encoder)
-__global__ __launch_bounds__(256) void split_cb_kernel(const float* __restrict__ x, __bf16* __restrict__ cb, int N, int C, int HW) {
+template <class P>
+__global__ __launch_bounds__(256) void split_cb_kernel(const float* __restrict__ x, typename P::elem* __restrict__ cb,
+                                                       const float* __restrict__ x_bound, int N, int C, int HW) {
   const int C8 = C >> 3;
   const int ng = blockIdx.y;
   const int g = ng % C8;
   const int n = ng / C8;
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= HW) return;
+  const float inv_scale = 1.f / operand_scale<P>(x_bound);
   const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = x[base + (size_t)e * HW];
-  split3_store(v, cb, (size_t)N * C * HW, (size_t)ng * HW + pix);
+  split_store<P>(v, inv_scale, cb, (size_t)N * C * HW, (size_t)ng * HW + pix);
 }
 
 int plane_chunks(int HW, bool vec) {
@@ -402,24 +472,26 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 extern "C" size_t mcdseg_bn_stats_workspace_bytes(int64_t rows, int32_t C) {
   if (rows <= 0 || C <= 0) return 0;
-  return (size_t)stats_slices(rows) * 3 * C * sizeof(double);
+  return (size_t)stats_slices(rows, C) * 3 * C * sizeof(double);
 }
 
 extern "C" int mcdseg_bn_stats_finalize(const float* stat_partials, int64_t rows, int32_t C, int32_t Mp, float* mean, float* rstd,
                                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
-                                        float eps, void* workspace, size_t workspace_bytes, void* stream) {
+                                        float eps, const float* gamma, const float* beta, const float* res_bound, float* y_bound,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
   MCD_REQUIRE(stat_partials && mean && rstd && workspace, "bn_stats_finalize: null pointer");
   MCD_REQUIRE(rows > 0 && C > 0 && Mp >= C, "bn_stats_finalize: bad dims rows=%lld C=%d Mp=%d", (long long)rows, C, Mp);
   MCD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize: running stats must come in pairs");
+  MCD_REQUIRE(y_bound == nullptr || (gamma && beta), "bn_stats_finalize: the output bound needs gamma and beta");
   MCD_REQUIRE(workspace_bytes >= mcdseg_bn_stats_workspace_bytes(rows, C), "bn_stats_finalize: workspace too small");
   MCD_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "bn_stats_finalize: workspace must be 8-byte aligned");
-  const int S = stats_slices(rows);
+  const int S = stats_slices(rows, C);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ceil_div(C, 32), S), dim3(256), 0, st, stat_partials, rows, C, Mp,
-                     (double*)workspace);
+                     (double*)workspace, y_bound);
   MCD_LAUNCH_CHECK("bn_stats_partial");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const double*)workspace, S, C, mean,
-                     rstd, running_mean, running_var, num_batches_tracked, momentum, eps);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, st, (const double*)workspace, S, C, mean,
+                     rstd, running_mean, running_var, num_batches_tracked, momentum, eps, gamma, beta, res_bound, y_bound);
   MCD_LAUNCH_CHECK("bn_stats_finalize");
   return 0;
 }
@@ -458,37 +530,58 @@ extern "C" int mcdseg_bn_apply(const float* z, const float* mean, const float* r
   return 0;
 }
 
-extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                  const float* residual, float* y, void* y_cb, int32_t N, int32_t C, int32_t HW, int32_t relu,
-                                  void* stream) {
-  MCD_REQUIRE(z && mean && rstd && gamma && beta && y && y_cb, "bn_apply_cb: null pointer");
-  MCD_REQUIRE(N > 0 && C > 0 && HW > 0 && (C % 8) == 0, "bn_apply_cb: C must be a positive multiple of 8");
-  MCD_REQUIRE((int64_t)N * (C / 8) <= 65535, "bn_apply_cb: N*C/8 exceeds the grid limit");
-  hipLaunchKernelGGL(bn_apply_cb_kernel, dim3(ceil_div(HW, 256), N * (C / 8)), dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma,
-                     beta, residual, y, (__bf16*)y_cb, N, C, HW, relu);
-  MCD_LAUNCH_CHECK("bn_apply_cb");
+static int cb_check(const char* who, int32_t math, const float* bound, int32_t N, int32_t C, int32_t HW) {
+  MCD_REQUIRE(math == MCDSEG_MATH_BF16X6 || math == MCDSEG_MATH_F16X3, "%s: unknown math %d", who, math);
+  MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || bound != nullptr, "%s: the f16x3 split needs the bound scalar of the tensor", who);
+  MCD_REQUIRE(N > 0 && C > 0 && HW > 0 && (C % 8) == 0, "%s: C must be a positive multiple of 8", who);
+  MCD_REQUIRE((int64_t)N * (C / 8) <= 65535, "%s: N*C/8 exceeds the grid limit", who);
   return 0;
 }
 
-extern "C" int mcdseg_split_cb(const float* x, void* x_cb, int32_t N, int32_t C, int32_t HW, void* stream) {
+extern "C" int mcdseg_split_cb(const float* x, void* x_cb, const float* x_bound, int32_t math, int32_t N, int32_t C, int32_t HW,
+                               void* stream) {
   MCD_REQUIRE(x && x_cb, "split_cb: null pointer");
-  MCD_REQUIRE(N > 0 && C > 0 && HW > 0 && (C % 8) == 0, "split_cb: C must be a positive multiple of 8");
-  MCD_REQUIRE((int64_t)N * (C / 8) <= 65535, "split_cb: N*C/8 exceeds the grid limit");
-  hipLaunchKernelGGL(split_cb_kernel, dim3(ceil_div(HW, 256), N * (C / 8)), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)x_cb, N, C, HW);
+  if (int rc = cb_check("split_cb", math, x_bound, N, C, HW)) return rc;
+  const dim3 grid(ceil_div(HW, 256), N * (C / 8));
+  if (math == MCDSEG_MATH_F16X3)
+    hipLaunchKernelGGL(split_cb_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, x, (_Float16*)x_cb, x_bound, N, C, HW);
+  else
+    hipLaunchKernelGGL(split_cb_kernel<SplitBf16x6>, grid, dim3(256), 0, (hipStream_t)stream, x, (__bf16*)x_cb, x_bound, N, C, HW);
   MCD_LAUNCH_CHECK("split_cb");
+  return 0;
+}
+
+extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  const float* residual, float* y, void* y_cb, const float* y_bound, int32_t math, int32_t N,
+                                  int32_t C, int32_t HW, int32_t relu, void* stream) {
+  MCD_REQUIRE(z && mean && rstd && gamma && beta && y && y_cb, "bn_apply_cb: null pointer");
+  if (int rc = cb_check("bn_apply_cb", math, y_bound, N, C, HW)) return rc;
+  const dim3 grid(ceil_div(HW, 256), N * (C / 8));
+  if (math == MCDSEG_MATH_F16X3)
+    hipLaunchKernelGGL(bn_apply_cb_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual, y,
+                       (_Float16*)y_cb, y_bound, N, C, HW, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_cb_kernel<SplitBf16x6>, grid, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual, y,
+                       (__bf16*)y_cb, y_bound, N, C, HW, relu);
+  MCD_LAUNCH_CHECK("bn_apply_cb");
   return 0;
 }
 
 extern "C" int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
                                       const float* gamma, const float* dgamma, const float* dbeta, float* dz, float* dres,
-                                      void* dz_cb, int32_t N, int32_t C, int32_t HW, int32_t relu, int32_t train, void* stream) {
+                                      void* dz_cb, const float* dz_bound, int32_t math, int32_t N, int32_t C, int32_t HW,
+                                      int32_t relu, int32_t train, void* stream) {
   MCD_REQUIRE(dy && z && mean && rstd && gamma && dz_cb, "bn_bwd_apply_cb: null pointer");
   MCD_REQUIRE(!relu || y, "bn_bwd_apply_cb: relu mask needs y");
   MCD_REQUIRE(!train || (dgamma && dbeta), "bn_bwd_apply_cb: train mode needs dgamma/dbeta");
-  MCD_REQUIRE(N > 0 && C > 0 && HW > 0 && (C % 8) == 0, "bn_bwd_apply_cb: C must be a positive multiple of 8");
-  MCD_REQUIRE((int64_t)N * (C / 8) <= 65535, "bn_bwd_apply_cb: N*C/8 exceeds the grid limit");
-  hipLaunchKernelGGL(bn_bwd_apply_cb_kernel, dim3(ceil_div(HW, 256), N * (C / 8)), dim3(256), 0, (hipStream_t)stream, dy, y, z, mean,
-                     rstd, gamma, dgamma, dbeta, dz, dres, (__bf16*)dz_cb, N, C, HW, relu, train);
+  if (int rc = cb_check("bn_bwd_apply_cb", math, dz_bound, N, C, HW)) return rc;
+  const dim3 grid(ceil_div(HW, 256), N * (C / 8));
+  if (math == MCDSEG_MATH_F16X3)
+    hipLaunchKernelGGL(bn_bwd_apply_cb_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, z, mean, rstd, gamma, dgamma,
+                       dbeta, dz, dres, (_Float16*)dz_cb, dz_bound, N, C, HW, relu, train);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_cb_kernel<SplitBf16x6>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, z, mean, rstd, gamma, dgamma,
+                       dbeta, dz, dres, (__bf16*)dz_cb, dz_bound, N, C, HW, relu, train);
   MCD_LAUNCH_CHECK("bn_bwd_apply_cb");
   return 0;
 }
@@ -496,31 +589,32 @@ extern "C" int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const flo
 extern "C" size_t mcdseg_bn_bwd_workspace_bytes(int32_t N, int32_t C, int32_t HW) {
   if (N <= 0 || C <= 0 || HW <= 0) return 0;
   const BwdPlan pl = bwd_plan(N, C, HW);
-  return (size_t)pl.S * 2 * C * sizeof(float);
+  return (size_t)pl.S * 3 * C * sizeof(float);
 }
 
 extern "C" int mcdseg_bn_bwd_reduce(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
-                                    float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, int32_t relu, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+                                    float* dgamma, float* dbeta, const float* gamma, float* dz_bound, int32_t train, int32_t N,
+                                    int32_t C, int32_t HW, int32_t relu, void* workspace, size_t workspace_bytes, void* stream) {
   MCD_REQUIRE(dy && workspace && (dgamma || dbeta), "bn_bwd_reduce: null pointer");
   MCD_REQUIRE(!relu || y, "bn_bwd_reduce: relu mask needs y");
   MCD_REQUIRE(!z || (mean && rstd), "bn_bwd_reduce: z needs mean/rstd");
+  MCD_REQUIRE(dz_bound == nullptr || (z && gamma), "bn_bwd_reduce: the dz bound needs z, rstd and gamma");
   MCD_REQUIRE(N > 0 && C > 0 && HW > 0, "bn_bwd_reduce: bad dims");
   const BwdPlan pl = bwd_plan(N, C, HW);
-  MCD_REQUIRE(workspace_bytes >= (size_t)pl.S * 2 * C * sizeof(float), "bn_bwd_reduce: workspace too small");
+  MCD_REQUIRE(workspace_bytes >= (size_t)pl.S * 3 * C * sizeof(float), "bn_bwd_reduce: workspace too small");
   MCD_REQUIRE(pl.S <= 65535, "bn_bwd_reduce: too many splits");
   const bool vec = (HW % 4 == 0) && aligned16(dy) && (!y || aligned16(y)) && (!z || aligned16(z));
   dim3 grid(C, pl.S);
   hipStream_t st = (hipStream_t)stream;
   if (vec)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, (float*)workspace, N, C, HW, relu,
-                       pl.cpp, pl.chunk);
+                       pl.cpp, pl.chunk, dz_bound);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, (float*)workspace, N, C, HW,
-                       relu, pl.cpp, pl.chunk);
+                       relu, pl.cpp, pl.chunk, dz_bound);
   MCD_LAUNCH_CHECK("bn_bwd_reduce");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float*)workspace, pl.S, C,
-                     z ? dgamma : nullptr, dbeta);
+                     z ? dgamma : nullptr, dbeta, gamma, rstd, (float)N * (float)HW, train, dz_bound);
   MCD_LAUNCH_CHECK("bn_bwd_finalize");
   return 0;
 }

@@ -1,32 +1,30 @@
-// Implicit-GEMM convolution (forward and data-gradient) with fp32 operands carried through the bf16 matrix pipe
-// as a 3-way split ("bf16x6").
-//
-// Every fp32 value is split exactly into three bf16 pieces, a = a1 + a2 + a3 (8 + 8 + 8 significant bits), and a
-// product a*b is formed from the six largest cross terms a1b1, a1b2, a2b1, a2b2, a1b3, a3b1 -- each an exact
-// bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped terms are below 2^-24 of the
-// product, i.e. below fp32 rounding: measured against fp64 the result is as accurate as the f32-input MFMA chain
-// (tests/test_kernels_gpu.py::test_conv_x6_accuracy), but six 32-cycle K=16 MFMAs replace eight 64-cycle K=2
-// MFMAs: 2.67x the matrix rate.
+// Implicit-GEMM convolution (forward and data-gradient) with fp32 operands carried through the 16-bit matrix pipe as a
+// sum of exact piece products -- the split policies of split.h: SplitBf16x6 (three bf16 pieces, six cross terms) and
+// SplitF16x3 (two fp16 pieces and a per-tensor power-of-two scale, three cross terms; the default).
 //
 // Structure is that of conv_gemm.hip (buffer-load gathers, channel-chunk-outer / tap-inner K order, XCD-aware
 // tiles, double-buffered LDS, fused BatchNorm statistics); what differs is the operand path:
 //   * weights are pre-split on the host side of the ABI into the exact LDS image
-//     [k-step][piece 3][k-half 2][Mp][8 bf16], so a K-step's slab is six contiguous runs copied 16 B per lane;
+//     [k-step][piece NP][k-half 2][Mp][8 x 16 bit], so a K-step's slab is 2*NP contiguous runs copied 16 B per lane;
 //   * one thread gathers 8 consecutive channels of one pixel (8 coalesced dword loads, lanes = pixels), splits
-//     them with v_cvt_pk_bf16_f32 and writes three 16-B fragments [piece][k-half][pixel][8] -- exactly what one
-//     lane of the MFMA consumes, so fragment reads are ds_read_b128 over 512 contiguous bytes per half-wave.
+//     them and writes NP 16-B fragments [piece][k-half][pixel][8] -- exactly what one lane of the MFMA consumes, so
+//     fragment reads are ds_read_b128 over 512 contiguous bytes per half-wave; with a pre-split companion written by the
+//     operand's producer (bn.hip) the fragments come straight from memory;
+//   * SplitF16x3 multiplies the accumulators by scale(operand) * scale(weights) -- an exact power of two -- before the
+//     epilogue (bias, BatchNorm statistics, affine).
+#include <cstdlib>
 #include <type_traits>
 
-#include "common.h"
+#include "split.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-struct ConvX6Params {
+struct ConvSplitParams {
   const float* src;
-  const void* src_cb;  // optional pre-split operand: [piece 3][N][Cs/8][Hs*Ws][8 bf16] (PRESPLIT kernels)
-  const void* wp;  // bf16 image
+  const void* src_cb;  // optional pre-split operand: [piece NP][N][Cs/8][Hs*Ws][8 x 16 bit] (PRESPLIT kernels)
+  const void* wp;      // packed 16-bit weight image
+  const float* src_bound;  // SplitF16x3: device scalars, upper bounds of |src| and |w| (scale = mcd_scale_of_bound)
+  const float* w_bound;
   const float* bias;
   float* dst;
   float* stats;
@@ -47,35 +45,31 @@ struct ConvX6Params {
   int cls_tile0[5];  // first tile of class c (c = 2*ry + rx), cls_tile0[4] = number of tiles
 };
 
-__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 a = (__bf16)v[e];
-    const float r1 = v[e] - (float)a;  // exact
-    const __bf16 b = (__bf16)r1;
-    const float r2 = r1 - (float)b;    // exact
-    p1[e] = a;
-    p2[e] = b;
-    p3[e] = (__bf16)r2;
-  }
-}
-
-template <int WM, int WN, int WAVES_M, int WAVES_N, bool DGRAD, bool PRESPLIT>
-__global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
+template <class P, int WM, int WN, int WAVES_M, int WAVES_N, bool DGRAD, bool PRESPLIT>
+__global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams p) {
   constexpr int BM = 32 * WM * WAVES_M;
   constexpr int BN = 32 * WN * WAVES_N;
   constexpr int NT = 256;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   constexpr int B_ITEMS = BN * 2 / NT;             // (pixel, k-half) items per thread: 1 (BN=128) or 2 (BN=256)
-  constexpr int A_CHUNKS = 6 * BM;                 // 16-byte chunks of the weight slab per K-step
+  constexpr int NP = P::NP;                        // pieces per operand
+  constexpr int NQ = 2 * NP;                       // (piece, k-half) planes per K-step
+  typedef typename P::frag frag;
+  constexpr int A_CHUNKS = NQ * BM;                // 16-byte chunks of the weight slab per K-step
   constexpr int A_ITERS = (A_CHUNKS + NT - 1) / NT;
   constexpr bool A_EXACT = (A_CHUNKS % NT) == 0;
   constexpr bool A_DMA = A_EXACT;                  // weight slab by LDS-DMA when it tiles the workgroup exactly
-  constexpr int A_BYTES = 6 * BM * 16, B_BYTES = 6 * BN * 16;
+  constexpr int A_BYTES = NQ * BM * 16, B_BYTES = NQ * BN * 16;
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
-  unsigned char* As = smem;                  // [2][piece][half][BM][16 B]
-  unsigned char* Bs = smem + 2 * A_BYTES;    // [2][piece][half][BN][16 B]
+  // B_DMA: the pre-split operand also goes global -> LDS by DMA (see dma_b); that K loop keeps NSTAGE LDS stages: with three,
+  // the DMAs of step s+2 are in flight while step s multiplies -- a K-step of the three-term arithmetic is only ~400-800
+  // cycles, less than a round trip beyond the XCD's L2
+  constexpr bool B_DMA = PRESPLIT && A_DMA && B_ITEMS == 1;
+  constexpr int NSTAGE = (B_DMA && 3 * (A_BYTES + B_BYTES) <= 80 * 1024) ? 3 : 2;  // two workgroups per CU must still fit 160 KiB
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * (A_BYTES + B_BYTES)];
+  unsigned char* As = smem;                       // [NSTAGE][piece][half][BM][16 B]
+  unsigned char* Bs = smem + NSTAGE * A_BYTES;    // [NSTAGE][piece][half][BN][16 B]
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -128,14 +122,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
     }
   }
   constexpr unsigned OOB = 0x80000000u;
-  // PRESPLIT: the gathered operand was split into bf16 pieces by its producer (bn_apply_cb / bn_bwd_apply_cb); a pixel's
-  // 8-channel group is one 16-B fragment, so offsets count 16-B units and a K-step needs 3 x 16-B loads and no VALU.
+  // PRESPLIT: the gathered operand was split into 16-bit pieces by its producer (bn_apply_cb / bn_bwd_apply_cb); a pixel's
+  // 8-channel group is one 16-B fragment, so offsets count 16-B units and a K-step needs NP x 16-B loads and no VALU.
   constexpr unsigned UNIT = PRESPLIT ? 16u : 4u;
   const __amdgpu_buffer_rsrc_t src_rs = PRESPLIT ? __builtin_amdgcn_make_buffer_rsrc((void*)p.src_cb, 0, p.cb_bytes, 0x00020000)
                                                  : __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wp_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.wp_bytes, 0x00020000);
   const int C8 = p.Cs >> 3;
-  const int piece_stride = p.N * C8 * HWs;  // 16-B units between the three pieces
+  const int piece_stride = p.N * C8 * HWs;  // 16-B units between the pieces
+  const float inv_src_scale = 1.f / operand_scale<P>(p.src_bound);  // in-loop split only
   const unsigned pix_base = PRESPLIT ? (unsigned)pn * (unsigned)C8 * (unsigned)HWs : (unsigned)pn * (unsigned)p.Cs * (unsigned)HWs;
   const bool ragged = p.Kp != p.Cs;
   const int taps = p.KH * p.KW;
@@ -247,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   // cycles, less than a MALL/HBM round trip, so one step of prefetch distance leaves the first tap of every channel
   // chunk exposed)
   float breg[2][B_ITEMS][PRESPLIT ? 1 : 8];
-  f32x4 bsplit[2][B_ITEMS][PRESPLIT ? 3 : 1];
+  f32x4 bsplit[2][B_ITEMS][PRESPLIT ? NP : 1];
   f32x4 areg[2][A_ITERS];
   auto load_regs = [&](auto set_c) {
     constexpr int SET = decltype(set_c)::value;
@@ -257,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
       if constexpr (PRESPLIT) {
         const int grp = (l_c0 >> 3) + h;
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) {
+        for (int pc = 0; pc < NP; ++pc) {
           const int soff = grp < C8 ? (grp * HWs + pc * piece_stride) * 16 : 0x7FFFFFFF;
           const auto q = __builtin_amdgcn_raw_buffer_load_b128(src_rs, l_voff, soff, 0);
           bsplit[SET][it][pc][0] = __uint_as_float(q[0]);
@@ -274,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
         if constexpr (!PRESPLIT) breg[SET][it][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src_rs, l_voff, soff, 0));
       }
     }
-    const int a_soff = (l_kstep * 6 * p.Mp + tile_m * BM) * 16;
+    const int a_soff = (l_kstep * NQ * p.Mp + tile_m * BM) * 16;
     if (A_DMA) return;  // the weight slab goes global -> LDS directly (dma_weights)
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
@@ -288,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   // Pre-split weights are stored in exactly the LDS image order, so a K-step's slab is moved by LDS-DMA
   // (buffer_load_dwordx4 ... lds: wave-uniform LDS base + lane * 16 B): no VGPRs, no ds_write, no VALU.
   auto dma_weights = [&](int buf) {
-    const int a_soff = (l_kstep * 6 * p.Mp + tile_m * BM) * 16;
+    const int a_soff = (l_kstep * NQ * p.Mp + tile_m * BM) * 16;
     unsigned char* adst = As + buf * A_BYTES + wave * 64 * 16;
 #if defined(__HIP_DEVICE_COMPILE__)  // the LDS address space does not exist in the host pass of this translation unit
 #pragma unroll
@@ -307,14 +302,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
       const int h = (B_ITEMS == 1) ? bh0 : it;
       if constexpr (PRESPLIT) {
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<f32x4*>(bdst + ((pc * 2 + h) * BN + bj) * 16) = bsplit[SET][it][pc];
+        for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<f32x4*>(bdst + ((pc * 2 + h) * BN + bj) * 16) = bsplit[SET][it][pc];
         continue;
       }
-      bf16x8 p1, p2, p3;
-      if constexpr (!PRESPLIT) split3(breg[SET][it], p1, p2, p3);
-      *reinterpret_cast<bf16x8*>(bdst + ((0 * 2 + h) * BN + bj) * 16) = p1;
-      *reinterpret_cast<bf16x8*>(bdst + ((1 * 2 + h) * BN + bj) * 16) = p2;
-      *reinterpret_cast<bf16x8*>(bdst + ((2 * 2 + h) * BN + bj) * 16) = p3;
+      if constexpr (!PRESPLIT) {
+        frag pieces[NP];
+        split_frag<P>(breg[SET][it], inv_src_scale, pieces);
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<frag*>(bdst + ((pc * 2 + h) * BN + bj) * 16) = pieces[pc];
+      }
     }
     if (!A_DMA) {
       unsigned char* adst = As + buf * A_BYTES;
@@ -343,15 +339,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   // B_DMA: the pre-split operand also goes global -> LDS by DMA.  Its LDS image [piece][half][pixel][16 B] is lane-linear
   // per wave (64 consecutive pixels of one k-half), the gather address is per lane, and a padding pixel's out-of-range
   // offset makes the DMA deposit zeros -- so the K loop issues six DMAs per thread and touches no vector register for
-  // staging: no ds_write, no register prefetch sets, no wait before the barrier other than vmcnt(0).
-  constexpr bool B_DMA = PRESPLIT && A_DMA && B_ITEMS == 1;
+  // staging: no ds_write, no register prefetch sets.
   auto dma_b = [&](int buf) {
     const int grp = (l_c0 >> 3) + bh0;
     const int wave_px = __builtin_amdgcn_readfirstlane(bj - lane);
     unsigned char* bdst = Bs + buf * B_BYTES + (bh0 * BN + wave_px) * 16;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) {
+    for (int pc = 0; pc < NP; ++pc) {
       const int soff = grp < C8 ? (grp * HWs + pc * piece_stride) * 16 : 0x7FFFFFFF;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (__attribute__((address_space(3))) void*)(bdst + pc * 2 * BN * 16), 16, l_voff, soff, 0, 0);
     }
@@ -360,12 +355,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
     (void)bdst;
 #endif
   };
+  constexpr int DMA_PER_STEP = A_ITERS + NP;  // LDS-DMA instructions one thread issues per K-step (B_DMA loop)
   if constexpr (B_DMA) {
     if (nsteps > 0) {
       dma_weights(0);
       dma_b(0);
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (NSTAGE == 3 && nsteps > 1) {  // step 1 -> stage 1, left in flight behind step 0
+      advance();
+      dma_weights(1);
+      dma_b(1);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DMA_PER_STEP) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
   } else {
     if (nsteps > 0) {
       if (A_DMA) dma_weights(0);
@@ -382,26 +385,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   auto mfma_step = [&](int cur) {
     const unsigned char* a_base = As + cur * A_BYTES + (lh * BM + wm * (32 * WM) + l31) * 16;
     const unsigned char* b_base = Bs + cur * B_BYTES + (lh * BN + wn * (32 * WN) + l31) * 16;
-    bf16x8 a[3][WM], b[3][WN];
+    frag a[NP][WM], b[NP][WN];
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) {
+    for (int pc = 0; pc < NP; ++pc) {
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[pc][i] = *reinterpret_cast<const bf16x8*>(a_base + (pc * 2 * BM + i * 32) * 16);
+      for (int i = 0; i < WM; ++i) a[pc][i] = *reinterpret_cast<const frag*>(a_base + (pc * 2 * BM + i * 32) * 16);
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[pc][j] = *reinterpret_cast<const bf16x8*>(b_base + (pc * 2 * BN + j * 32) * 16);
+      for (int j = 0; j < WN; ++j) b[pc][j] = *reinterpret_cast<const frag*>(b_base + (pc * 2 * BN + j * 32) * 16);
     }
-    // six cross terms, smallest first
+    // the policy's cross terms, smallest first
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
-      }
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int tm = 0; tm < P::NTERMS; ++tm) acc[i][j] = P::mfma(a[P::TA[tm]][i], b[P::TB[tm]][j], acc[i][j]);
   };
   // one K-step s (cur = s & 1): gathers of step s+2 go to the register set that step s just vacated, the weight slab of
   // step s+1 is DMA'd into the LDS buffer released by the previous barrier, MFMAs of step s, then step s+1's gathers
@@ -428,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
       } else {
         ++l_dma_kstep;
       }
-      const int a_soff = (l_dma_kstep * 6 * p.Mp + tile_m * BM) * 16;
+      const int a_soff = (l_dma_kstep * NQ * p.Mp + tile_m * BM) * 16;
       unsigned char* adst = As + (CUR ^ 1) * A_BYTES + wave * 64 * 16;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -452,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
       // the gathers issued for step s+2 -- the prefetch distance would collapse to one MFMA phase.  What the barrier
       // has to guarantee is only: this wave's LDS writes have landed (lgkmcnt(0)) and the weight slab DMA'd for step s+1
       // is complete -- it is OLDER than the gathers of step s+2, so a counted wait leaves exactly those in flight.
-      constexpr int AHEAD = (PRESPLIT ? 3 : 8) * B_ITEMS;
+      constexpr int AHEAD = (PRESPLIT ? NP : 8) * B_ITEMS;
       if (STEADY || s + 2 < nsteps)
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(AHEAD) : "memory");
       else
@@ -463,7 +461,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   };
   using YES = std::integral_constant<bool, true>;
   using NO = std::integral_constant<bool, false>;
-  if constexpr (B_DMA) {
+  if constexpr (B_DMA && NSTAGE == 3) {
+    // stage of step s = s mod 3.  Entering iteration s: step s is complete in LDS (all waves), step s+1 is in flight.
+    int cur = 0, nxt2 = 2;
+    for (int s = 0; s < nsteps; ++s) {
+      const bool more2 = s + 2 < nsteps;
+      if (more2) {  // both operands of step s+2 -> the stage the barrier below step s-1 released
+        advance();
+        dma_weights(nxt2);
+        dma_b(nxt2);
+      }
+      mfma_step(cur);
+      // step s+1 must have landed before the next iteration; the DMAs of step s+2 (younger) stay in flight
+      if (more2)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DMA_PER_STEP) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      cur = cur == 2 ? 0 : cur + 1;
+      nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+    }
+  } else if constexpr (B_DMA) {
     for (int s = 0; s < nsteps; ++s) {
       const int cur = s & 1;
       if (s + 1 < nsteps) {  // both operands of step s+1 -> the buffer the barrier below step s-1 released
@@ -487,6 +504,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   }
 
   // ---- epilogue (identical to conv_gemm.hip): acc[i][j][r] = D[row][col], row = (r&3) + 8*(r>>2) + 4*lh, col = l31
+  if constexpr (P::SCALED) {
+    const float osc = mcd_scale_of_bound(*p.src_bound) * mcd_scale_of_bound(*p.w_bound);  // exact power of two
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= osc;
+  }
   const int m_wave = tile_m * BM + wm * (32 * WM);
   const int p_wave = tile_n * BN + wn * (32 * WN);
   if (!DGRAD && p.bias != nullptr) {
@@ -583,19 +609,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(ConvX6Params p) {
   }
 }
 
-// ---- weight packing: w[Cout][Cin][T] (fp32) -> [chunk*T + tap][piece][half][Mp][8] bf16, chunk = 16 K-channels
+// ---- weight packing: w[Cout][Cin][T] (fp32) -> [chunk*T + tap][piece][half][Mp][8] 16-bit pieces, chunk = 16 K-channels
 // MODE 0: m = cout, k = cin (forward); MODE 1: m = cin, k = cout (dgrad)
 // blockIdx.y selects the image, so both are produced by one launch (weights are re-packed after every optimizer step)
-__global__ void pack_weights_x6_kernel(const float* __restrict__ w, __bf16* __restrict__ out_fprop, __bf16* __restrict__ out_dgrad,
-                                       int Cout, int Cin, int T) {
+template <class P>
+__global__ void pack_weights_split_kernel(const float* __restrict__ w, typename P::elem* __restrict__ out_fprop,
+                                          typename P::elem* __restrict__ out_dgrad, const float* __restrict__ w_bound, int Cout, int Cin,
+                                          int T) {
+  constexpr int NP = P::NP;
   const int mode = blockIdx.y;
-  __bf16* __restrict__ out = mode == 0 ? out_fprop : out_dgrad;
+  typename P::elem* __restrict__ out = mode == 0 ? out_fprop : out_dgrad;
   if (out == nullptr) return;
+  const float inv_scale = 1.f / operand_scale<P>(w_bound);
   const int M = mode == 0 ? Cout : Cin;
   const int K = mode == 0 ? Cin : Cout;
   const int Mp = M <= 32 ? 32 : (M <= 64 ? 64 : ((M + 127) / 128) * 128);  // mcd_mp
   const int Kp = ((K + 15) / 16) * 16;
-  const int64_t total = (int64_t)(Kp / 16) * T * 2 * Mp * 8;  // one thread per (kstep, half, m, e): writes all 3 pieces
+  const int64_t total = (int64_t)(Kp / 16) * T * 2 * Mp * 8;  // one thread per (kstep, half, m, e): writes all pieces
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int e = (int)(i & 7);
     int64_t r = i >> 3;
@@ -608,19 +638,32 @@ __global__ void pack_weights_x6_kernel(const float* __restrict__ w, __bf16* __re
     const int k = chunk * 16 + 8 * h + e;
     float v = 0.f;
     if (m < M && k < K) v = mode == 0 ? w[((int64_t)m * Cin + k) * T + tap] : w[((int64_t)k * Cin + m) * T + tap];
-    const __bf16 a = (__bf16)v;
-    const float r1 = v - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const float r2 = r1 - (float)b;
-    const int64_t base = kstep * 6 * (int64_t)Mp * 8;
-    out[base + ((0 * 2 + h) * (int64_t)Mp + m) * 8 + e] = a;
-    out[base + ((1 * 2 + h) * (int64_t)Mp + m) * 8 + e] = b;
-    out[base + ((2 * 2 + h) * (int64_t)Mp + m) * 8 + e] = (__bf16)r2;
+    typename P::elem q[NP];
+    P::split(v, inv_scale, q);
+    const int64_t base = kstep * (2 * NP) * (int64_t)Mp * 8;
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) out[base + ((pc * 2 + h) * (int64_t)Mp + m) * 8 + e] = q[pc];
   }
 }
 
-int x6_check(const mcdseg_conv_desc* d, const char* who) {
+// bound[0] = max |x|: integer atomic max on the bit pattern of |x| -- order-preserving for non-negative floats, exact and
+// independent of the order of arrival; a NaN pattern compares above inf, so non-finite data yields a non-finite bound
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+  unsigned m = 0u;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned b = __float_as_uint(x[i]) & 0x7FFFFFFFu;
+    m = b > m ? b : m;
+  }
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_xor(m, o);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
+}
+
+int split_check(const mcdseg_conv_desc* d, int math, const char* who) {
   MCD_REQUIRE(d != nullptr, "%s: null descriptor", who);
+  MCD_REQUIRE(math == MCDSEG_MATH_BF16X6 || math == MCDSEG_MATH_F16X3, "%s: math must be MCDSEG_MATH_BF16X6 or MCDSEG_MATH_F16X3 (got %d)", who, math);
   MCD_REQUIRE(d->N > 0 && d->Cin > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "%s: non-positive dims", who);
   MCD_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0, "%s: bad kernel geometry", who);
   const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
@@ -631,12 +674,23 @@ int x6_check(const mcdseg_conv_desc* d, const char* who) {
   return 0;
 }
 
-int64_t x6_image_bytes(int M, int K, int T) { return (int64_t)(round_up(K, 16) / 16) * T * 6 * mcd_mp(M) * 16; }
+int64_t split_image_bytes(int math, int M, int K, int T) {
+  return (int64_t)(round_up(K, 16) / 16) * T * 2 * mcd_math_pieces(math) * mcd_mp(M) * 16;
+}
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, bool DGRAD>
-void launch_cfg(const ConvX6Params& p, hipStream_t st) {
+// development knob: number of tile slots from which the 256 x 128 tile is preferred (see launch<>)
+int big_tile_min_slots() {
+  static const int v = [] {
+    const char* e = getenv("MCDSEG_BIGTILE_MIN_SLOTS");
+    return e ? atoi(e) : 1024;
+  }();
+  return v;
+}
+
+template <class P, int WM, int WN, int WAVES_M, int WAVES_N, bool DGRAD>
+void launch_cfg(const ConvSplitParams& p, hipStream_t st) {
   constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
-  ConvX6Params q = p;
+  ConvSplitParams q = p;
   q.sub = 0;
   int n_tiles = ceil_div(p.P, BN);
   if (DGRAD && p.stride == 2 && p.KH * p.KW <= 32) {  // parity classes: tiles never straddle a class
@@ -652,30 +706,39 @@ void launch_cfg(const ConvX6Params& p, hipStream_t st) {
   }
   dim3 grid(8 * ceil_div(n_tiles, 8) * (p.Mp / BM));
   if (p.src_cb != nullptr)
-    hipLaunchKernelGGL((conv_gemm_x6_kernel<WM, WN, WAVES_M, WAVES_N, DGRAD, true>), grid, dim3(256), 0, st, q);
+    hipLaunchKernelGGL((conv_gemm_split_kernel<P, WM, WN, WAVES_M, WAVES_N, DGRAD, true>), grid, dim3(256), 0, st, q);
   else
-    hipLaunchKernelGGL((conv_gemm_x6_kernel<WM, WN, WAVES_M, WAVES_N, DGRAD, false>), grid, dim3(256), 0, st, q);
+    hipLaunchKernelGGL((conv_gemm_split_kernel<P, WM, WN, WAVES_M, WAVES_N, DGRAD, false>), grid, dim3(256), 0, st, q);
+}
+
+template <class P, bool DGRAD>
+void launch(const ConvSplitParams& p, hipStream_t st) {
+  const int bm = mcd_bm(p.M);
+  // 256 x 128 tile (each wave 128 x 64): the gathered operand is fetched once per TWO row tiles and a K-step issues fewer
+  // fragment reads per MFMA -- worth +5 % on the 512-channel layers, but only while the grid still holds two full rounds of
+  // the 512 workgroup slots this tile leaves (256-channel layers and small batches lose)
+  if (bm == 128 && p.src_cb != nullptr && (p.Mp % 256) == 0 && (int64_t)ceil_div(p.P, 128) * (p.Mp / 256) >= big_tile_min_slots())
+    launch_cfg<P, 4, 2, 2, 2, DGRAD>(p, st);
+  else if (bm == 128)
+    launch_cfg<P, 2, 2, 2, 2, DGRAD>(p, st);
+  else if (bm == 64)
+    launch_cfg<P, 2, 2, 1, 4, DGRAD>(p, st);
+  else
+    launch_cfg<P, 1, 2, 1, 4, DGRAD>(p, st);
 }
 
 template <bool DGRAD>
-void launch(const ConvX6Params& p, hipStream_t st) {
-  const int bm = mcd_bm(p.M);
-  // 256 x 128 tile (each wave 128 x 64): the gathered operand is fetched once per TWO row tiles and a K-step issues 18
-  // fragment reads per 48 MFMAs instead of 12 per 24 -- worth +5 % on the 512-channel layers, but only while the grid
-  // still holds two full rounds of the 512 workgroup slots this tile leaves (256-channel layers and small batches lose)
-  if (bm == 128 && p.src_cb != nullptr && (p.Mp % 256) == 0 && (int64_t)ceil_div(p.P, 128) * (p.Mp / 256) >= 1024)
-    launch_cfg<4, 2, 2, 2, DGRAD>(p, st);
-  else if (bm == 128)
-    launch_cfg<2, 2, 2, 2, DGRAD>(p, st);
-  else if (bm == 64)
-    launch_cfg<2, 2, 1, 4, DGRAD>(p, st);
+void launch_math(int math, const ConvSplitParams& p, hipStream_t st) {
+  if (math == MCDSEG_MATH_F16X3)
+    launch<SplitF16x3, DGRAD>(p, st);
   else
-    launch_cfg<1, 2, 1, 4, DGRAD>(p, st);
+    launch<SplitBf16x6, DGRAD>(p, st);
 }
 
 }  // namespace
 
-// direct convolution for the network stem (conv_stem_x6.hip)
+// direct convolution for the network stem (conv_stem_x6.hip; bf16x6 arithmetic whatever `math` says -- its operand is
+// the network input, which no producer pre-splits, and the layer is 0.5 % of the step)
 bool mcdseg_internal_stem_ok(const mcdseg_conv_desc* d);
 int64_t mcdseg_internal_stem_stat_rows(const mcdseg_conv_desc* d);
 int64_t mcdseg_internal_stem_image_bytes();
@@ -683,9 +746,9 @@ int mcdseg_internal_stem_pack(const mcdseg_conv_desc* d, const float* w, void* o
 int mcdseg_internal_stem_fprop(const mcdseg_conv_desc* d, const float* x, const void* wp, const float* bias, float* y, float* stats,
                                const float* ep_scale, const float* ep_shift, const float* ep_res, int ep_relu, hipStream_t st);
 
-extern "C" int32_t mcdseg_conv_x6_direct_ok(const mcdseg_conv_desc* d) { return d != nullptr && mcdseg_internal_stem_ok(d) ? 1 : 0; }
+extern "C" int32_t mcdseg_conv_split_direct_ok(const mcdseg_conv_desc* d) { return d != nullptr && mcdseg_internal_stem_ok(d) ? 1 : 0; }
 
-extern "C" int64_t mcdseg_conv_x6_stat_rows(const mcdseg_conv_desc* d) {
+extern "C" int64_t mcdseg_conv_split_stat_rows(const mcdseg_conv_desc* d) {
   if (d == nullptr) return -22;
   if (mcdseg_internal_stem_ok(d)) return mcdseg_internal_stem_stat_rows(d);
   const int bm = mcd_bm(d->Cout);
@@ -694,20 +757,34 @@ extern "C" int64_t mcdseg_conv_x6_stat_rows(const mcdseg_conv_desc* d) {
   return ceil_div64((int64_t)d->N * d->Ho * d->Wo, bn) * waves_n;
 }
 
-extern "C" int mcdseg_conv_x6_packed_bytes(const mcdseg_conv_desc* d, int64_t* fprop_bytes, int64_t* dgrad_bytes) {
-  MCD_REQUIRE(d != nullptr, "conv_x6_packed_bytes: null descriptor");
-  const int T = d->KH * d->KW;
-  if (fprop_bytes) {
-    *fprop_bytes = x6_image_bytes(d->Cout, d->Cin, T);
-    if (mcdseg_internal_stem_ok(d) && *fprop_bytes < mcdseg_internal_stem_image_bytes()) *fprop_bytes = mcdseg_internal_stem_image_bytes();
-  }
-  if (dgrad_bytes) *dgrad_bytes = x6_image_bytes(d->Cin, d->Cout, T);
+extern "C" int mcdseg_absmax(const float* x, int64_t n, float* bound, void* stream) {
+  MCD_REQUIRE(x && bound && n > 0, "absmax: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(bound, 0, sizeof(float), st);
+  int64_t blocks = ceil_div64(n, 256 * 8);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, (unsigned*)bound);
+  MCD_LAUNCH_CHECK("absmax");
   return 0;
 }
 
-extern "C" int mcdseg_conv_x6_pack_weights(const mcdseg_conv_desc* d, const float* w, void* wp_fprop, void* wp_dgrad, void* stream) {
-  if (int rc = x6_check(d, "conv_x6_pack_weights")) return rc;
-  MCD_REQUIRE(w != nullptr && (wp_fprop != nullptr || wp_dgrad != nullptr), "conv_x6_pack_weights: null pointer");
+extern "C" int mcdseg_conv_split_packed_bytes(const mcdseg_conv_desc* d, int32_t math, int64_t* fprop_bytes, int64_t* dgrad_bytes) {
+  MCD_REQUIRE(d != nullptr, "conv_split_packed_bytes: null descriptor");
+  MCD_REQUIRE(math == MCDSEG_MATH_BF16X6 || math == MCDSEG_MATH_F16X3, "conv_split_packed_bytes: unknown math %d", math);
+  const int T = d->KH * d->KW;
+  if (fprop_bytes) {
+    *fprop_bytes = split_image_bytes(math, d->Cout, d->Cin, T);
+    if (mcdseg_internal_stem_ok(d) && *fprop_bytes < mcdseg_internal_stem_image_bytes()) *fprop_bytes = mcdseg_internal_stem_image_bytes();
+  }
+  if (dgrad_bytes) *dgrad_bytes = split_image_bytes(math, d->Cin, d->Cout, T);
+  return 0;
+}
+
+extern "C" int mcdseg_conv_split_pack_weights(const mcdseg_conv_desc* d, int32_t math, const float* w, void* wp_fprop, void* wp_dgrad,
+                                              float* w_bound, void* stream) {
+  if (int rc = split_check(d, math, "conv_split_pack_weights")) return rc;
+  MCD_REQUIRE(w != nullptr && (wp_fprop != nullptr || wp_dgrad != nullptr), "conv_split_pack_weights: null pointer");
+  MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || w_bound != nullptr, "conv_split_pack_weights: the f16x3 images need the weight bound scalar");
   const int T = d->KH * d->KW;
   hipStream_t st = (hipStream_t)stream;
   if (wp_fprop != nullptr && mcdseg_internal_stem_ok(d)) {  // the stem's forward image has its own layout (conv_stem_x6.hip)
@@ -715,6 +792,8 @@ extern "C" int mcdseg_conv_x6_pack_weights(const mcdseg_conv_desc* d, const floa
     wp_fprop = nullptr;
     if (wp_dgrad == nullptr) return 0;
   }
+  if (math == MCDSEG_MATH_F16X3)
+    if (int rc = mcdseg_absmax(w, (int64_t)d->Cout * d->Cin * T, w_bound, stream)) return rc;
   int64_t most = 0;
   for (int mode = 0; mode < 2; ++mode) {
     const int M = mode == 0 ? d->Cout : d->Cin, K = mode == 0 ? d->Cin : d->Cout;
@@ -723,33 +802,40 @@ extern "C" int mcdseg_conv_x6_pack_weights(const mcdseg_conv_desc* d, const floa
   }
   int64_t blocks = ceil_div64(most, 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(pack_weights_x6_kernel, dim3((unsigned)blocks, 2), dim3(256), 0, st, w, (__bf16*)wp_fprop, (__bf16*)wp_dgrad,
-                     d->Cout, d->Cin, T);
-  MCD_LAUNCH_CHECK("conv_x6_pack_weights");
+  if (math == MCDSEG_MATH_F16X3)
+    hipLaunchKernelGGL(pack_weights_split_kernel<SplitF16x3>, dim3((unsigned)blocks, 2), dim3(256), 0, st, w, (_Float16*)wp_fprop,
+                       (_Float16*)wp_dgrad, (const float*)w_bound, d->Cout, d->Cin, T);
+  else
+    hipLaunchKernelGGL(pack_weights_split_kernel<SplitBf16x6>, dim3((unsigned)blocks, 2), dim3(256), 0, st, w, (__bf16*)wp_fprop,
+                       (__bf16*)wp_dgrad, (const float*)nullptr, d->Cout, d->Cin, T);
+  MCD_LAUNCH_CHECK("conv_split_pack_weights");
   return 0;
 }
 
-static int x6_cb_bytes(int N, int C, int HW, const void* cb, int* out) {
+static int split_cb_bytes(int math, int N, int C, int HW, const void* cb, int* out) {
   *out = 0;
   if (cb == nullptr) return 0;
-  MCD_REQUIRE((C % 8) == 0, "conv_x6: a pre-split operand needs a channel count divisible by 8 (got %d)", C);
-  const int64_t b = (int64_t)3 * N * C * HW * 2;
-  MCD_REQUIRE(b < (1ll << 31), "conv_x6: pre-split operand exceeds 2 GiB; split the batch");
+  MCD_REQUIRE((C % 8) == 0, "conv_split: a pre-split operand needs a channel count divisible by 8 (got %d)", C);
+  const int64_t b = (int64_t)mcd_math_pieces(math) * N * C * HW * 2;
+  MCD_REQUIRE(b < (1ll << 31), "conv_split: pre-split operand exceeds 2 GiB; split the batch");
   *out = (int)b;
   return 0;
 }
 
-static int x6_fprop_impl(const mcdseg_conv_desc* d, const float* x, const void* x_cb, const void* wp, const float* bias, float* y,
-                         float* stats, const float* ep_scale, const float* ep_shift, const float* ep_res, int ep_relu, void* stream) {
-  if (int rc = x6_check(d, "conv_x6_fprop")) return rc;
-  MCD_REQUIRE((x || x_cb) && wp && y, "conv_x6_fprop: null pointer");
+static int split_fprop_impl(const mcdseg_conv_desc* d, int math, const float* x, const void* x_cb, const float* x_bound, const void* wp,
+                            const float* w_bound, const float* bias, float* y, float* stats, const float* ep_scale,
+                            const float* ep_shift, const float* ep_res, int ep_relu, void* stream) {
+  if (int rc = split_check(d, math, "conv_split_fprop")) return rc;
+  MCD_REQUIRE((x || x_cb) && wp && y, "conv_split_fprop: null pointer");
   if (mcdseg_internal_stem_ok(d)) {
-    MCD_REQUIRE(x != nullptr, "conv_x6_fprop: the stem kernel reads the fp32 input");
+    MCD_REQUIRE(x != nullptr, "conv_split_fprop: the stem kernel reads the fp32 input");
     return mcdseg_internal_stem_fprop(d, x, wp, bias, y, stats, ep_scale, ep_shift, ep_res, ep_relu, (hipStream_t)stream);
   }
-  ConvX6Params p;
-  if (int rc = x6_cb_bytes(d->N, d->Cin, d->H * d->W, x_cb, &p.cb_bytes)) return rc;
+  MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || (x_bound && w_bound), "conv_split_fprop: f16x3 needs the operand and weight bound scalars");
+  ConvSplitParams p;
+  if (int rc = split_cb_bytes(math, d->N, d->Cin, d->H * d->W, x_cb, &p.cb_bytes)) return rc;
   p.src_cb = x_cb;
+  p.src_bound = x_bound; p.w_bound = w_bound;
   p.src = x; p.wp = wp; p.bias = bias; p.dst = y; p.stats = stats;
   p.ep_scale = ep_scale; p.ep_shift = ep_shift; p.ep_res = ep_res; p.ep_relu = ep_relu;
   p.N = d->N;
@@ -760,33 +846,36 @@ static int x6_fprop_impl(const mcdseg_conv_desc* d, const float* x, const void* 
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
   p.P = d->N * d->Ho * d->Wo;
   p.src_bytes = (int)((int64_t)d->N * d->Cin * d->H * d->W * 4);
-  const int64_t wb = x6_image_bytes(d->Cout, d->Cin, d->KH * d->KW);
-  MCD_REQUIRE(wb < (1ll << 31), "conv_x6_fprop: packed weights exceed 2 GiB");
+  const int64_t wb = split_image_bytes(math, d->Cout, d->Cin, d->KH * d->KW);
+  MCD_REQUIRE(wb < (1ll << 31), "conv_split_fprop: packed weights exceed 2 GiB");
   p.wp_bytes = (int)wb;
-  launch<false>(p, (hipStream_t)stream);
-  MCD_LAUNCH_CHECK("conv_x6_fprop");
+  launch_math<false>(math, p, (hipStream_t)stream);
+  MCD_LAUNCH_CHECK("conv_split_fprop");
   return 0;
 }
 
-extern "C" int mcdseg_conv_x6_fprop(const mcdseg_conv_desc* d, const float* x, const void* x_cb, const void* wp_fprop,
-                                    const float* bias, float* y, float* stat_partials, void* stream) {
-  return x6_fprop_impl(d, x, x_cb, wp_fprop, bias, y, stat_partials, nullptr, nullptr, nullptr, 0, stream);
+extern "C" int mcdseg_conv_split_fprop(const mcdseg_conv_desc* d, int32_t math, const float* x, const void* x_cb, const float* x_bound,
+                                       const void* wp_fprop, const float* w_bound, const float* bias, float* y, float* stat_partials,
+                                       void* stream) {
+  return split_fprop_impl(d, math, x, x_cb, x_bound, wp_fprop, w_bound, bias, y, stat_partials, nullptr, nullptr, nullptr, 0, stream);
 }
 
-extern "C" int mcdseg_conv_x6_fprop_affine(const mcdseg_conv_desc* d, const float* x, const void* x_cb, const void* wp_fprop,
-                                           const float* scale, const float* shift, const float* residual, int32_t relu, float* y,
-                                           void* stream) {
-  MCD_REQUIRE(scale && shift, "conv_x6_fprop_affine: null scale/shift");
-  return x6_fprop_impl(d, x, x_cb, wp_fprop, nullptr, y, nullptr, scale, shift, residual, relu, stream);
+extern "C" int mcdseg_conv_split_fprop_affine(const mcdseg_conv_desc* d, int32_t math, const float* x, const void* x_cb,
+                                              const float* x_bound, const void* wp_fprop, const float* w_bound, const float* scale,
+                                              const float* shift, const float* residual, int32_t relu, float* y, void* stream) {
+  MCD_REQUIRE(scale && shift, "conv_split_fprop_affine: null scale/shift");
+  return split_fprop_impl(d, math, x, x_cb, x_bound, wp_fprop, w_bound, nullptr, y, nullptr, scale, shift, residual, relu, stream);
 }
 
-extern "C" int mcdseg_conv_x6_dgrad(const mcdseg_conv_desc* d, const float* dy, const void* dy_cb, const void* wp_dgrad, float* dx,
-                                    void* stream) {
-  if (int rc = x6_check(d, "conv_x6_dgrad")) return rc;
-  MCD_REQUIRE((dy || dy_cb) && wp_dgrad && dx, "conv_x6_dgrad: null pointer");
-  ConvX6Params p;
-  if (int rc = x6_cb_bytes(d->N, d->Cout, d->Ho * d->Wo, dy_cb, &p.cb_bytes)) return rc;
+extern "C" int mcdseg_conv_split_dgrad(const mcdseg_conv_desc* d, int32_t math, const float* dy, const void* dy_cb, const float* dy_bound,
+                                       const void* wp_dgrad, const float* w_bound, float* dx, void* stream) {
+  if (int rc = split_check(d, math, "conv_split_dgrad")) return rc;
+  MCD_REQUIRE((dy || dy_cb) && wp_dgrad && dx, "conv_split_dgrad: null pointer");
+  MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || (dy_bound && w_bound), "conv_split_dgrad: f16x3 needs the operand and weight bound scalars");
+  ConvSplitParams p;
+  if (int rc = split_cb_bytes(math, d->N, d->Cout, d->Ho * d->Wo, dy_cb, &p.cb_bytes)) return rc;
   p.src_cb = dy_cb;
+  p.src_bound = dy_bound; p.w_bound = w_bound;
   p.src = dy; p.wp = wp_dgrad; p.bias = nullptr; p.dst = dx; p.stats = nullptr;
   p.ep_scale = nullptr; p.ep_shift = nullptr; p.ep_res = nullptr; p.ep_relu = 0;
   p.N = d->N;
@@ -797,10 +886,10 @@ extern "C" int mcdseg_conv_x6_dgrad(const mcdseg_conv_desc* d, const float* dy, 
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
   p.P = d->N * d->H * d->W;
   p.src_bytes = (int)((int64_t)d->N * d->Cout * d->Ho * d->Wo * 4);
-  const int64_t wb = x6_image_bytes(d->Cin, d->Cout, d->KH * d->KW);
-  MCD_REQUIRE(wb < (1ll << 31), "conv_x6_dgrad: packed weights exceed 2 GiB");
+  const int64_t wb = split_image_bytes(math, d->Cin, d->Cout, d->KH * d->KW);
+  MCD_REQUIRE(wb < (1ll << 31), "conv_split_dgrad: packed weights exceed 2 GiB");
   p.wp_bytes = (int)wb;
-  launch<true>(p, (hipStream_t)stream);
-  MCD_LAUNCH_CHECK("conv_x6_dgrad");
+  launch_math<true>(math, p, (hipStream_t)stream);
+  MCD_LAUNCH_CHECK("conv_split_dgrad");
   return 0;
 }

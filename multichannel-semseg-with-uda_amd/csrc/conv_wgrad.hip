@@ -9,7 +9,7 @@
 // (image x chunk); every workgroup writes its partial D tile to a slab and a second kernel sums the
 // slabs in a fixed order (fp64 accumulate) -- deterministic, no float atomics.
 #include <cstdlib>
-#include "common.h"
+#include "split.h"
 
 namespace {
 
@@ -404,8 +404,10 @@ __global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(const float* __r
   if (lane == 0) dw[((size_t)co * Cin + ci) * T + tap] = (float)s;
 }
 
+// x_bound / dy_bound (NULL unless the slabs come from the SplitF16x3 kernels): the slab sums are in scaled units and are
+// multiplied by scale(x) * scale(dy), an exact power of two
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int T, int co_p,
-                                    int ci_p, int splits) {
+                                    int ci_p, int splits, const float* __restrict__ x_bound, const float* __restrict__ dy_bound) {
   const int64_t total = (int64_t)T * Cout * Cin;
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -417,29 +419,33 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   const float* src = slab + ((size_t)tap * co_p + co) * ci_p + ci;
   double s = 0.0;
   for (int k = 0; k < splits; ++k) s += (double)src[(size_t)k * stride];
+  if (x_bound != nullptr) s *= (double)mcd_scale_of_bound(*x_bound) * (double)mcd_scale_of_bound(*dy_bound);
   dw[((size_t)co * Cin + ci) * T + tap] = (float)s;
 }
 
 }  // namespace
 
-int mcdseg_internal_wgrad_x6_launch(const mcdseg_conv_desc* d, const float* x, const float* dy, float* slab, int co_p, int ci_p,
-                                    int chunk, int chunks_per_img, int splits, hipStream_t st);
-int mcdseg_internal_wgrad_x6_cb_launch(const mcdseg_conv_desc* d, const void* x_cb, const void* dy_cb, float* slab, int co_p,
-                                       int ci_p, int chunks_per_img, int splits, hipStream_t st);
+int mcdseg_internal_wgrad_split_launch(const mcdseg_conv_desc* d, int math, const float* x, const float* x_bound, const float* dy,
+                                       const float* dy_bound, float* slab, int co_p, int ci_p, int chunk, int chunks_per_img, int splits,
+                                       hipStream_t st);
+int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, const void* x_cb, const void* dy_cb, float* slab,
+                                          int co_p, int ci_p, int chunks_per_img, int splits, hipStream_t st);
 
 static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
-                      int x6, const void* x_cb, const void* dy_cb, void* stream);
+                      int math, const void* x_cb, const float* x_bound, const void* dy_cb, const float* dy_bound, void* stream);
 
 extern "C" int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,
                                  size_t workspace_bytes, void* stream) {
-  return wgrad_impl(d, x, dy, dw, workspace, workspace_bytes, 0, nullptr, nullptr, stream);
+  return wgrad_impl(d, x, dy, dw, workspace, workspace_bytes, 0, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
-// bf16x6 arithmetic on the 128x128-tile plan (thin layers fall through to the f32 kernels); with BOTH pre-split
+// split arithmetic on the 128x128-tile plan (thin layers fall through to the f32 kernels); with BOTH pre-split
 // companions the 128x128 plan reads them instead of the fp32 tensors
-extern "C" int mcdseg_conv_x6_wgrad(const mcdseg_conv_desc* d, const float* x, const void* x_cb, const float* dy, const void* dy_cb,
-                                    float* dw, void* workspace, size_t workspace_bytes, void* stream) {
-  return wgrad_impl(d, x, dy, dw, workspace, workspace_bytes, 1, x_cb, dy_cb, stream);
+extern "C" int mcdseg_conv_split_wgrad(const mcdseg_conv_desc* d, int32_t math, const float* x, const void* x_cb, const float* x_bound,
+                                       const float* dy, const void* dy_cb, const float* dy_bound, float* dw, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  MCD_REQUIRE(math == MCDSEG_MATH_BF16X6 || math == MCDSEG_MATH_F16X3, "conv_split_wgrad: unknown math %d", math);
+  return wgrad_impl(d, x, dy, dw, workspace, workspace_bytes, math, x_cb, x_bound, dy_cb, dy_bound, stream);
 }
 
 extern "C" size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d) {
@@ -448,9 +454,11 @@ extern "C" size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d) {
 }
 
 static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
-                      int x6, const void* x_cb, const void* dy_cb, void* stream) {
+                      int math, const void* x_cb, const float* x_bound, const void* dy_cb, const float* dy_bound, void* stream) {
   MCD_REQUIRE(d && dw && workspace, "conv_wgrad: null pointer");
-  const bool cb_path = x6 && x_cb && dy_cb && (d->Cin & 7) == 0 && (d->Cout & 7) == 0 && make_plan(d).cfg == 0;
+  const bool cb_path = math && x_cb && dy_cb && (d->Cin & 7) == 0 && (d->Cout & 7) == 0 && make_plan(d).cfg == 0;
+  const bool split_plan = math && make_plan(d).cfg == 0;
+  MCD_REQUIRE(!(split_plan && math == MCDSEG_MATH_F16X3) || (x_bound && dy_bound), "conv_split_wgrad: f16x3 needs both bound scalars");
   MCD_REQUIRE(cb_path || (x && dy), "conv_wgrad: x and dy may be NULL only when the pre-split 128x128 plan applies");
   MCD_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0, "conv_wgrad: bad dims");
   MCD_REQUIRE(((int64_t)d->N * d->Cin + 128) * d->H * d->W * 4 < (1ll << 31) && ((int64_t)d->N * d->Cout + 128) * d->Ho * d->Wo * 4 < (1ll << 31),
@@ -489,11 +497,14 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
     MCD_LAUNCH_CHECK("conv_wgrad_thin_reduce");
     return 0;
   }
+  const bool scaled = split_plan && math == MCDSEG_MATH_F16X3;
   if (cb_path) {
-    if (int rc = mcdseg_internal_wgrad_x6_cb_launch(d, x_cb, dy_cb, (float*)workspace, pl.co_p, pl.ci_p, pl.chunks_per_img, pl.splits, st))
+    if (int rc = mcdseg_internal_wgrad_split_cb_launch(d, math, x_cb, dy_cb, (float*)workspace, pl.co_p, pl.ci_p, pl.chunks_per_img,
+                                                       pl.splits, st))
       return rc;
-  } else if (pl.cfg == 0 && x6) {
-    if (int rc = mcdseg_internal_wgrad_x6_launch(d, x, dy, (float*)workspace, pl.co_p, pl.ci_p, pl.chunk, pl.chunks_per_img, pl.splits, st))
+  } else if (pl.cfg == 0 && math) {
+    if (int rc = mcdseg_internal_wgrad_split_launch(d, math, x, x_bound, dy, dy_bound, (float*)workspace, pl.co_p, pl.ci_p, pl.chunk,
+                                                    pl.chunks_per_img, pl.splits, st))
       return rc;
   } else if (pl.cfg == 0)
     hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 2, 2, 16>), grid, dim3(256), 0, st, p);
@@ -503,7 +514,8 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
     hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 1, 32>), grid, dim3(64), 0, st, p);
   MCD_LAUNCH_CHECK("conv_wgrad");
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
-                     d->Cout, d->Cin, T, pl.co_p, pl.ci_p, pl.splits);
+                     d->Cout, d->Cin, T, pl.co_p, pl.ci_p, pl.splits, scaled ? x_bound : (const float*)nullptr,
+                     scaled ? dy_bound : (const float*)nullptr);
   MCD_LAUNCH_CHECK("conv_wgrad_reduce");
   return 0;
 }

@@ -1,21 +1,20 @@
-// Weight-gradient convolution on the bf16 matrix pipe with 3-way split fp32 operands ("bf16x6", see
-// conv_gemm_x6.hip for the arithmetic).  128 x 128 (co x ci) tiles only -- the layers that carry the FLOPs; thin
-// layers stay on the f32 kernels of conv_wgrad.hip.
+// Weight-gradient convolution on the 16-bit matrix pipe with split fp32 operands (policies of split.h; see
+// conv_gemm_split.hip for the arithmetic).  128 x 128 (co x ci) tiles only -- the layers that carry the FLOPs; thin
+// layers stay on the f32 kernels of conv_wgrad.hip.  The slabs hold the sums in SCALED units for SplitF16x3; the
+// fixed-order reduce of conv_wgrad.hip multiplies by scale(x) * scale(dy).
 //
 //   D[co][ci] (one tap) = sum_pix dY[co][pix] * X[ci][pix + shift(tap)]
 //
 // The contraction runs over pixels, 16 per K-step (one K=16 MFMA block).  A thread stages one pixel PAIR of four
 // dY rows and four X rows: lanes run along the pixels of a row, so global reads stay pixel-contiguous; each pair is
-// split into bf16 pieces and lands as one 32-bit word in the fragment image [piece][k-half][row][8 bf16], which the
+// split into 16-bit pieces and lands as one 32-bit word in the fragment image [piece][k-half][row][8 x 16 bit], which the
 // MFMA lanes read back as ds_read_b128 over 512 contiguous bytes per half-wave.  Slabs + fixed-order fp64 reduce
 // as in conv_wgrad.hip (same plan, same workspace).
-#include "common.h"
+#include "split.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-struct WgradX6Params {
+struct WgradSplitParams {
   const float* x;
   const float* dy;
   float* slab;
@@ -24,22 +23,28 @@ struct WgradX6Params {
   int co_p, ci_p;
   int chunk, chunks_per_img, splits;
   int x_bytes, dy_bytes;
+  const float* x_bound;   // SplitF16x3: bound scalars of the two operands
+  const float* dy_bound;
 };
 
-__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& w1, unsigned& w2, unsigned& w3) {
-  const __bf16 a0 = (__bf16)v0, a1 = (__bf16)v1;
-  const float r0 = v0 - (float)a0, r1 = v1 - (float)a1;
-  const __bf16 b0 = (__bf16)r0, b1 = (__bf16)r1;
-  const __bf16 c0 = (__bf16)(r0 - (float)b0), c1 = (__bf16)(r1 - (float)b1);
-  w1 = (unsigned)__builtin_bit_cast(unsigned short, a0) | ((unsigned)__builtin_bit_cast(unsigned short, a1) << 16);
-  w2 = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
-  w3 = (unsigned)__builtin_bit_cast(unsigned short, c0) | ((unsigned)__builtin_bit_cast(unsigned short, c1) << 16);
+// a pixel pair of one row -> NP words, word pc = (piece pc of v0) | (piece pc of v1) << 16
+template <class P>
+__device__ __forceinline__ void split_pair(float v0, float v1, float inv_scale, unsigned (&w)[P::NP]) {
+  typename P::elem q0[P::NP], q1[P::NP];
+  P::split(v0, inv_scale, q0);
+  P::split(v1, inv_scale, q1);
+#pragma unroll
+  for (int pc = 0; pc < P::NP; ++pc)
+    w[pc] = (unsigned)__builtin_bit_cast(unsigned short, q0[pc]) | ((unsigned)__builtin_bit_cast(unsigned short, q1[pc]) << 16);
 }
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(WgradX6Params p) {
+template <class P>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradSplitParams p) {
   constexpr int BM = 128, BN = 128, BKP = 16, NT = 256;
   constexpr int WM = 2, WN = 2, WAVES_N = 2;
-  constexpr int A_BYTES = 6 * BM * 16, B_BYTES = 6 * BN * 16;  // [piece 3][k-half 2][row][16 B]
+  constexpr int NP = P::NP;
+  typedef typename P::frag frag;
+  constexpr int A_BYTES = 2 * NP * BM * 16, B_BYTES = 2 * NP * BN * 16;  // [piece NP][k-half 2][row][16 B]
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
   unsigned char* As = smem;
   unsigned char* Bs = smem + 2 * A_BYTES;
@@ -84,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(WgradX6Params p) 
   const unsigned b_row = (unsigned)row0 * (unsigned)HW;
   const int lds_word = ((q >> 2) * BM + row0) * 16 + (q & 3) * 4;  // + piece*2*BM*16 + 32*i*16
 
+  const float inv_a = 1.f / operand_scale<P>(p.dy_bound), inv_b = 1.f / operand_scale<P>(p.x_bound);
   float areg[4][2], breg[4][2];
   auto load_regs = [&](int r0) {
     unsigned a_voff[2], b_voff[2];
@@ -114,15 +120,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(WgradX6Params p) 
     unsigned char* b = Bs + buf * B_BYTES + lds_word;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      unsigned w1, w2, w3;
-      split_pair(areg[i][0], areg[i][1], w1, w2, w3);
-      *reinterpret_cast<unsigned*>(a + (0 * 2 * BM + 32 * i) * 16) = w1;
-      *reinterpret_cast<unsigned*>(a + (1 * 2 * BM + 32 * i) * 16) = w2;
-      *reinterpret_cast<unsigned*>(a + (2 * 2 * BM + 32 * i) * 16) = w3;
-      split_pair(breg[i][0], breg[i][1], w1, w2, w3);
-      *reinterpret_cast<unsigned*>(b + (0 * 2 * BN + 32 * i) * 16) = w1;
-      *reinterpret_cast<unsigned*>(b + (1 * 2 * BN + 32 * i) * 16) = w2;
-      *reinterpret_cast<unsigned*>(b + (2 * 2 * BN + 32 * i) * 16) = w3;
+      unsigned w[NP];
+      split_pair<P>(areg[i][0], areg[i][1], inv_a, w);
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<unsigned*>(a + (pc * 2 * BM + 32 * i) * 16) = w[pc];
+      split_pair<P>(breg[i][0], breg[i][1], inv_b, w);
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<unsigned*>(b + (pc * 2 * BN + 32 * i) * 16) = w[pc];
     }
   };
 
@@ -146,25 +150,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(WgradX6Params p) 
     if (more) load_regs(r_begin + (s + 1) * BKP);
     const unsigned char* a_base = As + cur * A_BYTES + (lh * BM + wm * 64 + l31) * 16;
     const unsigned char* b_base = Bs + cur * B_BYTES + (lh * BN + wn * 64 + l31) * 16;
-    bf16x8 a[3][WM], b[3][WN];
+    frag a[NP][WM], b[NP][WN];
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) {
+    for (int pc = 0; pc < NP; ++pc) {
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[pc][i] = *reinterpret_cast<const bf16x8*>(a_base + (pc * 2 * BM + i * 32) * 16);
+      for (int i = 0; i < WM; ++i) a[pc][i] = *reinterpret_cast<const frag*>(a_base + (pc * 2 * BM + i * 32) * 16);
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[pc][j] = *reinterpret_cast<const bf16x8*>(b_base + (pc * 2 * BN + j * 32) * 16);
+      for (int j = 0; j < WN; ++j) b[pc][j] = *reinterpret_cast<const frag*>(b_base + (pc * 2 * BN + j * 32) * 16);
     }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
-      }
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int tm = 0; tm < P::NTERMS; ++tm) acc[i][j] = P::mfma(a[P::TA[tm]][i], b[P::TB[tm]][j], acc[i][j]);
     if (more) store_lds(cur ^ 1);
     __syncthreads();
   }
@@ -185,8 +184,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(WgradX6Params p) 
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Pre-split variant: both operands arrive in the channel-blocked bf16x3 layout their producers wrote
-// ([piece 3][N][C/8][H*W][8 bf16]: mcdseg_bn_bwd_apply_cb for dY, mcdseg_bn_apply_cb for X).  One 16-B load is
+// Pre-split variant: both operands arrive in the channel-blocked layout their producers wrote
+// ([piece NP][N][C/8][H*W][8 x 16 bit]: mcdseg_bn_bwd_apply_cb for dY, mcdseg_bn_apply_cb for X).  One 16-B load is
 // 8 channels of one pixel; the MFMA wants 8 pixels of one channel per lane, so a thread loads the same 8-channel
 // group at 8 pixels and transposes the 8x8 block of 16-bit values in registers (32 v_perm_b32) -- 0.5 VALU per value
 // instead of ~11 for splitting an fp32 value, and no conversion at all.
@@ -198,11 +197,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(WgradX6Params p) 
 // wave-uniform: a wave stages one (operand, piece), the tile and tap offsets go into the SGPR offset, rows that fall
 // into the padding get an out-of-range SGPR offset, columns an out-of-range VGPR offset (hardware returns 0).
 //
-// LDS image per operand [piece 3][k-octet 4][position 128][16 B] with position = c*16 + cg for channel cg*8 + c of
+// LDS image per operand [piece NP][k-octet 4][position 128][16 B] with position = c*16 + cg for channel cg*8 + c of
 // the tile: transposed rows are written 16 B per lane with consecutive cg (conflict-free) and MFMA lane i reads
 // position blockbase + i (conflict-free); the position -> channel permutation is undone when the slab is stored.
 // Octet planes are padded by 32 B so the four quad lanes (four planes) of a write hit different banks.
-// One LDS stage (48.75 KB), two workgroups per CU: one transposes/writes while the other multiplies.
+// One LDS stage (16.25 KB per piece pair: 48.75 KB for three pieces, 32.5 KB for two), three workgroups per CU: one
+// transposes/writes while the others multiply.  Staging units = (operand, piece): with two pieces each of the four waves
+// owns exactly one; with three, the two piece-2 units alternate between the wave pairs from step to step.
 struct WgradCbParams {
   const void* x_cb;
   const void* dy_cb;
@@ -216,12 +217,17 @@ struct WgradCbParams {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256, 3) void conv_wgrad_x6_cb_kernel(WgradCbParams p) {
+template <class P>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_split_cb_kernel(WgradCbParams p) {
   constexpr int BM = 128, BN = 128;
   constexpr int WM = 2, WN = 2, WAVES_N = 2;
+  constexpr int NP = P::NP;
+  constexpr bool EXTRA = NP == 3;          // a third piece: its two staging units alternate between the wave pairs
+  static_assert(NP == 2 || NP == 3, "two or three pieces");
+  typedef typename P::frag frag;
   constexpr int PLANE = 130;               // 16-B units per k-octet plane (128 positions + 2 pad)
   constexpr int PIECE = 4 * PLANE;         // four octets per super-step
-  constexpr int OP_BYTES = 3 * PIECE * 16; // one operand
+  constexpr int OP_BYTES = NP * PIECE * 16; // one operand
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * OP_BYTES];
 
   const int t = threadIdx.x;
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_x6_cb_kernel(WgradCbParams 
 
   // ---- staging role of this wave: operand (0 = dY rows, 1 = X rows) and piece are wave-uniform
   const int opnd = wave & 1;
-  const int pieceA = wave >> 1;  // first unit: piece 0 or 1; the piece-2 unit alternates between the wave pairs
+  const int pieceA = wave >> 1;  // this wave's unit: piece 0 or 1 (a third piece alternates between the wave pairs)
   const int ps = lane & 3;
   const int cg = lane >> 2;
   // source geometry of the staged operand: X is gathered through the conv geometry, dY is its own output grid
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_x6_cb_kernel(WgradCbParams 
   const int sbase = (n * sC8 + ctile * 16) * sHW;  // 16-B units
   const int lane_x = ps * sS;
 
-  u32x4 R[2][8];
+  u32x4 R[EXTRA ? 2 : 1][8];
   auto issue_loads = [&](int tt, int piece, u32x4 (&dst)[8]) {
     const int ty = tt / p.tiles_x;
     const int tx = tt - ty * p.tiles_x;
@@ -320,43 +326,41 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_x6_cb_kernel(WgradCbParams 
   const int nsteps = t_end - t_begin;
   if (nsteps > 0) {
     issue_loads(t_begin, pieceA, R[0]);
-    if ((wave >> 1) == 0) issue_loads(t_begin, 2, R[1]);
+    if constexpr (EXTRA)
+      if ((wave >> 1) == 0) issue_loads(t_begin, 2, R[EXTRA ? 1 : 0]);
   }
   for (int s = 0; s < nsteps; ++s) {
-    const bool extra = (wave >> 1) == (s & 1);  // this wave pair also stages piece 2 of the step
-    if (s > 0) __syncthreads();                 // all fragment reads of the previous step are done
+    const bool extra = EXTRA && (wave >> 1) == (s & 1);  // this wave pair also stages piece 2 of the step
+    if (s > 0) __syncthreads();                          // all fragment reads of the previous step are done
     transpose_store(pieceA, R[0]);
-    if (extra) transpose_store(2, R[1]);
+    if constexpr (EXTRA)
+      if (extra) transpose_store(2, R[EXTRA ? 1 : 0]);
     if (s + 1 < nsteps) {
       issue_loads(t_begin + s + 1, pieceA, R[0]);
-      if ((wave >> 1) == ((s + 1) & 1)) issue_loads(t_begin + s + 1, 2, R[1]);
+      if constexpr (EXTRA)
+        if ((wave >> 1) == ((s + 1) & 1)) issue_loads(t_begin + s + 1, 2, R[EXTRA ? 1 : 0]);
     }
     __syncthreads();
     const unsigned char* a_base = smem + (lh * PLANE + wm * 64 + l31) * 16;
     const unsigned char* b_base = smem + OP_BYTES + (lh * PLANE + wn * 64 + l31) * 16;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 a[3][WM], b[3][WN];
+      frag a[NP][WM], b[NP][WN];
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) {
+      for (int pc = 0; pc < NP; ++pc) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
-          a[pc][i] = *reinterpret_cast<const bf16x8*>(a_base + (pc * PIECE + 2 * kk * PLANE + i * 32) * 16);
+          a[pc][i] = *reinterpret_cast<const frag*>(a_base + (pc * PIECE + 2 * kk * PLANE + i * 32) * 16);
 #pragma unroll
         for (int j = 0; j < WN; ++j)
-          b[pc][j] = *reinterpret_cast<const bf16x8*>(b_base + (pc * PIECE + 2 * kk * PLANE + j * 32) * 16);
+          b[pc][j] = *reinterpret_cast<const frag*>(b_base + (pc * PIECE + 2 * kk * PLANE + j * 32) * 16);
       }
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int tm = 0; tm < P::NTERMS; ++tm) acc[i][j] = P::mfma(a[P::TA[tm]][i], b[P::TB[tm]][j], acc[i][j]);
     }
   }
 
@@ -379,11 +383,13 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_x6_cb_kernel(WgradCbParams 
 
 }  // namespace
 
-// launched by mcdseg_conv_wgrad (conv_wgrad.hip) when the 128x128 plan applies and bf16x6 math is requested
-int mcdseg_internal_wgrad_x6_launch(const mcdseg_conv_desc* d, const float* x, const float* dy, float* slab, int co_p, int ci_p,
-                                    int chunk, int chunks_per_img, int splits, hipStream_t st) {
-  WgradX6Params p;
+// launched by wgrad_impl (conv_wgrad.hip) when the 128x128 plan applies and a split arithmetic is requested
+int mcdseg_internal_wgrad_split_launch(const mcdseg_conv_desc* d, int math, const float* x, const float* x_bound, const float* dy,
+                                       const float* dy_bound, float* slab, int co_p, int ci_p, int chunk, int chunks_per_img, int splits,
+                                       hipStream_t st) {
+  WgradSplitParams p;
   p.x = x; p.dy = dy; p.slab = slab;
+  p.x_bound = x_bound; p.dy_bound = dy_bound;
   p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.Ho = d->Ho; p.Wo = d->Wo;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
   p.co_p = co_p; p.ci_p = ci_p; p.chunk = chunk; p.chunks_per_img = chunks_per_img; p.splits = splits;
@@ -392,18 +398,21 @@ int mcdseg_internal_wgrad_x6_launch(const mcdseg_conv_desc* d, const float* x, c
   const int64_t per_split = (int64_t)(co_p / 128) * (ci_p / 128) * d->KH * d->KW;
   const int64_t nwg = 8 * ceil_div64(splits, 8) * per_split;
   if (nwg >= (1ll << 31)) {
-    mcdseg_set_error("conv_wgrad_x6: grid too large");
+    mcdseg_set_error("conv_wgrad_split: grid too large");
     return -22;
   }
-  hipLaunchKernelGGL(conv_wgrad_x6_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
-  MCD_LAUNCH_CHECK("conv_wgrad_x6");
+  if (math == MCDSEG_MATH_F16X3)
+    hipLaunchKernelGGL(conv_wgrad_split_kernel<SplitF16x3>, dim3((unsigned)nwg), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(conv_wgrad_split_kernel<SplitBf16x6>, dim3((unsigned)nwg), dim3(256), 0, st, p);
+  MCD_LAUNCH_CHECK("conv_wgrad_split");
   return 0;
 }
 
-// pre-split operands (see conv_wgrad_x6_cb_kernel); chunks_per_img / splits come from the shared plan, the pixel range
+// pre-split operands (see conv_wgrad_split_cb_kernel); chunks_per_img / splits come from the shared plan, the pixel range
 // of a chunk is expressed in 8x4 output tiles
-int mcdseg_internal_wgrad_x6_cb_launch(const mcdseg_conv_desc* d, const void* x_cb, const void* dy_cb, float* slab, int co_p,
-                                       int ci_p, int chunks_per_img, int splits, hipStream_t st) {
+int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, const void* x_cb, const void* dy_cb, float* slab,
+                                          int co_p, int ci_p, int chunks_per_img, int splits, hipStream_t st) {
   WgradCbParams p;
   p.x_cb = x_cb; p.dy_cb = dy_cb; p.slab = slab;
   p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.Ho = d->Ho; p.Wo = d->Wo;
@@ -412,9 +421,10 @@ int mcdseg_internal_wgrad_x6_cb_launch(const mcdseg_conv_desc* d, const void* x_
   p.tiles_x = ceil_div(d->Wo, 8);
   p.tiles_y = ceil_div(d->Ho, 4);
   p.tiles_per_chunk = ceil_div(p.tiles_x * p.tiles_y, chunks_per_img);
-  const int64_t xb = (int64_t)3 * d->N * d->Cin * d->H * d->W * 2, yb = (int64_t)3 * d->N * d->Cout * d->Ho * d->Wo * 2;
+  const int64_t np = mcd_math_pieces(math);
+  const int64_t xb = np * d->N * d->Cin * d->H * d->W * 2, yb = np * d->N * d->Cout * d->Ho * d->Wo * 2;
   if ((d->Cin & 7) || (d->Cout & 7) || xb + 4096 >= (1ll << 31) || yb + 4096 >= (1ll << 31) || d->pad > 128) {
-    mcdseg_set_error("conv_wgrad_x6: pre-split operands need channel counts divisible by 8 and < 2 GiB per operand");
+    mcdseg_set_error("conv_wgrad_split: pre-split operands need channel counts divisible by 8 and < 2 GiB per operand");
     return -22;
   }
   p.x_cb_bytes = (int)xb;
@@ -422,10 +432,13 @@ int mcdseg_internal_wgrad_x6_cb_launch(const mcdseg_conv_desc* d, const void* x_
   const int64_t per_split = (int64_t)(co_p / 128) * (ci_p / 128) * d->KH * d->KW;
   const int64_t nwg = 8 * ceil_div64(splits, 8) * per_split;
   if (nwg >= (1ll << 31)) {
-    mcdseg_set_error("conv_wgrad_x6: grid too large");
+    mcdseg_set_error("conv_wgrad_split: grid too large");
     return -22;
   }
-  hipLaunchKernelGGL(conv_wgrad_x6_cb_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
-  MCD_LAUNCH_CHECK("conv_wgrad_x6_cb");
+  if (math == MCDSEG_MATH_F16X3)
+    hipLaunchKernelGGL(conv_wgrad_split_cb_kernel<SplitF16x3>, dim3((unsigned)nwg), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(conv_wgrad_split_cb_kernel<SplitBf16x6>, dim3((unsigned)nwg), dim3(256), 0, st, p);
+  MCD_LAUNCH_CHECK("conv_wgrad_split_cb");
   return 0;
 }

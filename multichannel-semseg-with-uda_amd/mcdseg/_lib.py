@@ -29,32 +29,33 @@ _SIGNATURES = {
     "mcdseg_conv_packed_dims": (c_int, [_P(ConvDesc), _P(c_i32), _P(c_i32), _P(c_i32), _P(c_i32)]),
     "mcdseg_conv_pack_weights": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcdseg_conv_stat_rows": (c_i64, [_P(ConvDesc)]),
-    "mcdseg_conv_x6_stat_rows": (c_i64, [_P(ConvDesc)]),
-    "mcdseg_conv_x6_direct_ok": (c_i32, [_P(ConvDesc)]),
+    "mcdseg_conv_split_stat_rows": (c_i64, [_P(ConvDesc)]),
+    "mcdseg_conv_split_direct_ok": (c_i32, [_P(ConvDesc)]),
     "mcdseg_conv_fprop": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcdseg_conv_fprop_affine": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p]),
     "mcdseg_bn_eval_affine": (c_int, [c_void_p] * 5 + [c_i32, c_float, c_void_p, c_void_p, c_void_p]),
     "mcdseg_predict_workspace_bytes": (c_size_t, [c_i32, c_i32]),
     "mcdseg_predict_labels": (c_int, [c_void_p] * 4 + [c_i32] * 4 + [c_void_p, c_size_t, c_void_p]),
-    "mcdseg_conv_x6_packed_bytes": (c_int, [_P(ConvDesc), _P(c_i64), _P(c_i64)]),
-    "mcdseg_conv_x6_pack_weights": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
-    "mcdseg_conv_x6_fprop": (c_int, [_P(ConvDesc)] + [c_void_p] * 7),
-    "mcdseg_conv_x6_fprop_affine": (c_int, [_P(ConvDesc)] + [c_void_p] * 6 + [c_i32, c_void_p, c_void_p]),
-    "mcdseg_conv_x6_dgrad": (c_int, [_P(ConvDesc)] + [c_void_p] * 5),
-    "mcdseg_split_cb": (c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
-    "mcdseg_bn_apply_cb": (c_int, [c_void_p] * 8 + [c_i32] * 4 + [c_void_p]),
-    "mcdseg_bn_bwd_apply_cb": (c_int, [c_void_p] * 11 + [c_i32] * 5 + [c_void_p]),
-    "mcdseg_conv_x6_wgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mcdseg_absmax": (c_int, [c_void_p, c_i64, c_void_p, c_void_p]),
+    "mcdseg_conv_split_packed_bytes": (c_int, [_P(ConvDesc), c_i32, _P(c_i64), _P(c_i64)]),
+    "mcdseg_conv_split_pack_weights": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 5),
+    "mcdseg_conv_split_fprop": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 9),
+    "mcdseg_conv_split_fprop_affine": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 8 + [c_i32, c_void_p, c_void_p]),
+    "mcdseg_conv_split_dgrad": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 7),
+    "mcdseg_split_cb": (c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p]),
+    "mcdseg_bn_apply_cb": (c_int, [c_void_p] * 9 + [c_i32] * 5 + [c_void_p]),
+    "mcdseg_bn_bwd_apply_cb": (c_int, [c_void_p] * 12 + [c_i32] * 6 + [c_void_p]),
+    "mcdseg_conv_split_wgrad": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "mcdseg_conv_dgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcdseg_conv_wgrad_workspace_bytes": (c_size_t, [_P(ConvDesc)]),
     "mcdseg_conv_wgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mcdseg_bn_stats_workspace_bytes": (c_size_t, [c_i64, c_i32]),
     "mcdseg_bn_stats_finalize": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                         c_float, c_float, c_void_p, c_size_t, c_void_p]),
+                                         c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mcdseg_bn_eval_stats": (c_int, [c_void_p, c_void_p, c_i32, c_float, c_void_p, c_void_p, c_void_p]),
     "mcdseg_bn_apply": (c_int, [c_void_p] * 7 + [c_i32] * 4 + [c_void_p]),
     "mcdseg_bn_bwd_workspace_bytes": (c_size_t, [c_i32, c_i32, c_i32]),
-    "mcdseg_bn_bwd_reduce": (c_int, [c_void_p] * 7 + [c_i32] * 4 + [c_void_p, c_size_t, c_void_p]),
+    "mcdseg_bn_bwd_reduce": (c_int, [c_void_p] * 9 + [c_i32] * 5 + [c_void_p, c_size_t, c_void_p]),
     "mcdseg_bn_bwd_apply": (c_int, [c_void_p] * 10 + [c_i32] * 5 + [c_void_p]),
     "mcdseg_up8_fwd": (c_int, [c_void_p] * 5 + [c_i32] * 4 + [c_void_p]),
     "mcdseg_up8_bwd_input": (c_int, [c_void_p] * 3 + [c_i32] * 4 + [c_void_p]),

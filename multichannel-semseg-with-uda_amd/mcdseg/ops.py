@@ -57,18 +57,22 @@ def conv_work(desc):
     return 2 * macs, byts
 
 
-def gemm_kernel_name(m, k, dgrad, x6=False, presplit=False, direct=False, pixels=0):
+POLICY = {"f16x3": "SplitF16x3", "bf16x6": "SplitBf16x6"}
+
+
+def gemm_kernel_name(m, k, dgrad, split=False, presplit=False, direct=False, pixels=0, math=None):
     """Template instantiation conv_fprop / conv_dgrad dispatch to (same rule as csrc/common.h mcd_bm / mcd_bk); the
     string equals the kernel name rocprofv3 prints, so profiles/*_pmc_traffic.json can be keyed by it."""
     bm = 32 if m <= 32 else (64 if m <= 64 else 128)
     cfg = {128: "2, 2, 2, 2", 64: "2, 2, 1, 4", 32: "1, 2, 1, 4"}[bm]
-    if x6 and direct:
+    if split and direct:
         return "conv_stem_x6_kernel"
-    if x6:
+    if split:
         mp = -(-m // 128) * 128
-        if bm == 128 and presplit and mp % 256 == 0 and -(-pixels // 128) * (mp // 256) >= 1024:
-            cfg = "4, 2, 2, 2"  # the 256 x 128 tile (same rule as launch<> in csrc/conv_gemm_x6.hip)
-        return "conv_gemm_x6_kernel<%s, %s, %s>" % (cfg, "true" if dgrad else "false", "true" if presplit else "false")
+        if bm == 128 and presplit and mp % 256 == 0 and -(-pixels // 128) * (mp // 256) >= BIGTILE_MIN_SLOTS:
+            cfg = "4, 2, 2, 2"  # the 256 x 128 tile (same rule as launch<> in csrc/conv_gemm_split.hip)
+        return "conv_gemm_split_kernel<%s, %s, %s, %s>" % (POLICY[math or CONV_MATH], cfg, "true" if dgrad else "false",
+                                                           "true" if presplit else "false")
     return "conv_gemm_kernel<%s, %d, %s>" % (cfg, 8 if k <= 8 else 16, "true" if dgrad else "false")
 
 
@@ -112,38 +116,70 @@ def conv_desc(x_shape, w_shape, stride, pad, dil):
     return ConvDesc(n, cin, h, w, cout, kh, kw, stride, pad, dil, ho, wo)
 
 
-# Matrix-pipe arithmetic of the convolutions (MCDSEG_CONV_MATH):
-#   "bf16x6" (default)  fp32 operands split exactly into three bf16 pieces, the six largest cross terms on
-#                       v_mfma_f32_32x32x16_bf16 -- fp32-grade (measured <= 2x the rounding noise of an fp32 FMA chain,
-#                       tests/test_kernels_gpu.py::test_conv_x6_accuracy) at 2.67x the f32 matrix rate;
-#   "f32"               v_mfma_f32_32x32x2_f32, the exact k-ordered fp32 FMA chain;
-#   "mixed"             bf16x6 for forward / data-gradient, f32 for the weight gradients.
-CONV_MATH = os.environ.get("MCDSEG_CONV_MATH", "bf16x6")
-# producers (BN apply / BN backward apply) also emit the 3-way bf16 split of what they write, so the convolution that
-# gathers it does not re-split every activation inside its K loop (MCDSEG_PRESPLIT=0 turns this off)
+# Matrix-pipe arithmetic of the convolutions (MCDSEG_CONV_MATH), csrc/split.h:
+#   "f16x3" (default)   fp32 operands as s * (h1 + h2): two fp16 pieces and a power-of-two scale per tensor, three cross terms
+#                       on v_mfma_f32_32x32x16_f16 -- fp32-grade against the reference's fp64 gradients (same noise-floor
+#                       test as the other modes) at 5.3x the f32 matrix rate;
+#   "bf16x6"            three bf16 pieces, the six largest cross terms on v_mfma_f32_32x32x16_bf16 (2.67x the f32 rate);
+#   "f32"               v_mfma_f32_32x32x2_f32, the exact k-ordered fp32 FMA chain.
+CONV_MATH = os.environ.get("MCDSEG_CONV_MATH", "f16x3")
+# producers (BN apply / BN backward apply) also emit the split of what they write, so the convolution that gathers it
+# does not re-split every activation inside its K loop (MCDSEG_PRESPLIT=0 turns this off)
 PRESPLIT = os.environ.get("MCDSEG_PRESPLIT", "1") != "0"
-if CONV_MATH not in ("bf16x6", "f32", "mixed", "bf16x6-fprop", "bf16x6-dgrad"):
-    raise ValueError("MCDSEG_CONV_MATH must be bf16x6, f32 or mixed, got %r" % CONV_MATH)
+if CONV_MATH not in ("f16x3", "bf16x6", "f32"):
+    raise ValueError("MCDSEG_CONV_MATH must be f16x3, bf16x6 or f32, got %r" % CONV_MATH)
+MATH_ID = {"f16x3": 3, "bf16x6": 6}   # MCDSEG_MATH_F16X3 / MCDSEG_MATH_BF16X6 of include/mcdseg.h
+PIECES = {"f16x3": 2, "bf16x6": 3}
+BIGTILE_MIN_SLOTS = int(os.environ.get("MCDSEG_BIGTILE_MIN_SLOTS", "1024"))  # launch<> rule of csrc/conv_gemm_split.hip
 
 
-STEM_DIRECT = os.environ.get("MCDSEG_STEM_DIRECT", "1") != "0"  # the stem's forward as the direct bf16x6 convolution
+STEM_DIRECT = os.environ.get("MCDSEG_STEM_DIRECT", "1") != "0"  # the stem's forward as the direct (bf16x6) convolution
 
 
-def _use_x6(contraction_channels, direction="fprop"):
-    if contraction_channels < 16:
-        return False
-    if CONV_MATH in ("bf16x6", "mixed"):
-        return True
-    return CONV_MATH == "bf16x6-" + direction  # "bf16x6-fprop" / "bf16x6-dgrad": one direction only (experiments)
+def _use_split(contraction_channels):
+    return contraction_channels >= 16 and CONV_MATH in MATH_ID
+
+
+def _scaled():
+    """the active arithmetic needs per-tensor bound scalars (f16x3)"""
+    return CONV_MATH == "f16x3"
+
+
+def absmax(x):
+    """device scalar max |x| -- the bound of a tensor whose producer did not supply one"""
+    x = _req(x, "tensor")
+    b = torch.empty(1, dtype=torch.float32, device=x.device)
+    check(lib().mcdseg_absmax(_p(x), x.numel(), _p(b), _stream()), "absmax")
+    return b
+
+
+def _bound_or_measure(x, bound):
+    """bound scalar of ``x`` for the scaled arithmetic: the producer's if known, else measured (cached on the tensor)"""
+    if not _scaled():
+        return None
+    if bound is not None:
+        return bound
+    rec = getattr(x, "_mcd_bound", None)
+    if rec is not None and rec[1] == x._version and rec[2] == x.data_ptr():
+        return rec[0]
+    b = absmax(x)
+    try:
+        x._mcd_bound = (b, x._version, x.data_ptr())
+    except AttributeError:
+        pass
+    return b
 
 
 class PackedWeights:
-    """GEMM images of one conv kernel, refreshed when the parameter changes."""
+    """GEMM images of one conv kernel, refreshed when the parameter changes.  ``wf`` / ``wd``: forward / data-gradient image
+    (fp32 for the f32 kernels, 16-bit pieces for the split kernels); ``w_bound``: device scalar max |w| (f16x3)."""
 
     def __init__(self):
         self.key = None
         self.wf = None
         self.wd = None
+        self.w_bound = None
+        self.mpf = 0
 
     def get(self, weight, desc, need_dgrad=True):
         key = (weight.data_ptr(), weight._version, WEIGHT_EPOCH, weight.device, CONV_MATH)
@@ -154,26 +190,36 @@ class PackedWeights:
             taps = desc.KH * desc.KW
             w = _req(weight.detach(), "conv weight")
             dev = w.device
-            fx6, dx6 = _use_x6(desc.Cin, "fprop"), _use_x6(desc.Cout, "dgrad")
-            if STEM_DIRECT and CONV_MATH in ("bf16x6", "bf16x6-fprop") and L.mcdseg_conv_x6_direct_ok(ctypes.byref(desc)):
-                fx6 = True  # the stem: direct convolution on the split path although it contracts < 16 channels
+            fsp, dsp = _use_split(desc.Cin), _use_split(desc.Cout)
+            if STEM_DIRECT and CONV_MATH in MATH_ID and L.mcdseg_conv_split_direct_ok(ctypes.byref(desc)):
+                fsp = True  # the stem: direct convolution on the split path although it contracts < 16 channels
             # f32 images (kept for whichever direction does not run on the split path)
-            self.wf = None if fx6 else torch.empty(taps * kpf.value * mpf.value, dtype=torch.float32, device=dev)
-            self.wd = None if dx6 else torch.empty(taps * kpd.value * mpd.value, dtype=torch.float32, device=dev)
+            self.wf = None if fsp else torch.empty(taps * kpf.value * mpf.value, dtype=torch.float32, device=dev)
+            self.wd = None if dsp else torch.empty(taps * kpd.value * mpd.value, dtype=torch.float32, device=dev)
             if self.wf is not None or self.wd is not None:
                 check(L.mcdseg_conv_pack_weights(ctypes.byref(desc), _p(w), _p(self.wf), _p(self.wd), _stream()), "conv_pack_weights")
-            if fx6 or dx6:
+            if fsp or dsp:
+                mid = MATH_ID[CONV_MATH]
                 fb, db = ctypes.c_int64(), ctypes.c_int64()
-                check(L.mcdseg_conv_x6_packed_bytes(ctypes.byref(desc), fb, db), "conv_x6_packed_bytes")
-                if fx6:
-                    self.wf = torch.empty(fb.value // 2, dtype=torch.bfloat16, device=dev)
-                if dx6:
-                    self.wd = torch.empty(db.value // 2, dtype=torch.bfloat16, device=dev)
-                check(L.mcdseg_conv_x6_pack_weights(ctypes.byref(desc), _p(w), _p(self.wf) if fx6 else None,
-                                                    _p(self.wd) if dx6 else None, _stream()), "conv_x6_pack_weights")
+                check(L.mcdseg_conv_split_packed_bytes(ctypes.byref(desc), mid, fb, db), "conv_split_packed_bytes")
+                if fsp:
+                    self.wf = torch.empty(fb.value // 2, dtype=torch.int16, device=dev)
+                if dsp:
+                    self.wd = torch.empty(db.value // 2, dtype=torch.int16, device=dev)
+                if _scaled() and self.w_bound is None:
+                    self.w_bound = torch.empty(1, dtype=torch.float32, device=dev)
+                with _timed("pack_weights_split_kernel", (0, 4 * w.numel() + (fb.value if fsp else 0) + (db.value if dsp else 0))):
+                    check(L.mcdseg_conv_split_pack_weights(ctypes.byref(desc), mid, _p(w), _p(self.wf) if fsp else None,
+                                                           _p(self.wd) if dsp else None, _p(self.w_bound) if _scaled() else None,
+                                                           _stream()), "conv_split_pack_weights")
             self.mpf = mpf.value
             self.key = key
         return self.wf, self.wd, self.mpf
+
+
+def _is_split(w_image):
+    """packed image of the split kernels (16-bit pieces) rather than of the f32 kernels"""
+    return w_image.dtype == torch.int16
 
 
 # ------------------------------------------------------------------------------------------------ raw launchers
@@ -198,28 +244,30 @@ def _batch_pieces(desc):
     return [(i, min(i + step, desc.N)) for i in range(0, desc.N, step)]
 
 
-def _conv_fprop(desc, x, wf, bias, want_stats, mpf, x_cb=None):
+def _conv_fprop(desc, x, wf, bias, want_stats, mpf, x_cb=None, x_bound=None, w_bound=None):
     L = lib()
     y = torch.empty((desc.N, desc.Cout, desc.Ho, desc.Wo), dtype=torch.float32, device=x.device)
     pieces = _batch_pieces(desc)
     if len(pieces) > 1:
         x_cb = None  # the piece-major split layout cannot be sliced along N
     descs = [desc if len(pieces) == 1 else _sub_desc(desc, b - a) for a, b in pieces]
+    split = _is_split(wf)
     part, rows, row_off = None, 0, [0]
     if want_stats:
-        stat_rows = L.mcdseg_conv_x6_stat_rows if wf.dtype == torch.bfloat16 else L.mcdseg_conv_stat_rows
+        stat_rows = L.mcdseg_conv_split_stat_rows if split else L.mcdseg_conv_stat_rows
         for d in descs:
             row_off.append(row_off[-1] + stat_rows(ctypes.byref(d)))
         rows = row_off[-1]
         part = torch.empty(rows * 3 * mpf, dtype=torch.float32, device=x.device)
+    direct = split and bool(L.mcdseg_conv_split_direct_ok(ctypes.byref(desc)))
+    if split and not direct:
+        x_bound = _bound_or_measure(x, x_bound)
     for i, ((a, b), d) in enumerate(zip(pieces, descs)):
         pp = None if part is None else ctypes.c_void_p(part.data_ptr() + 4 * row_off[i] * 3 * mpf)
-        direct = wf.dtype == torch.bfloat16 and bool(L.mcdseg_conv_x6_direct_ok(ctypes.byref(d)))
-        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, wf.dtype == torch.bfloat16, x_cb is not None, direct,
-                                     d.N * d.Ho * d.Wo), conv_work(d)):
-            if wf.dtype == torch.bfloat16:
-                check(L.mcdseg_conv_x6_fprop(ctypes.byref(d), _p(x[a:b]), _p(x_cb), _p(wf), _p(bias), _p(y[a:b]), pp, _stream()),
-                      "conv_x6_fprop")
+        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, split, x_cb is not None, direct, d.N * d.Ho * d.Wo), conv_work(d)):
+            if split:
+                check(L.mcdseg_conv_split_fprop(ctypes.byref(d), MATH_ID[CONV_MATH], _p(x[a:b]), _p(x_cb), _p(x_bound), _p(wf), _p(w_bound),
+                                                _p(bias), _p(y[a:b]), pp, _stream()), "conv_split_fprop")
             else:
                 check(L.mcdseg_conv_fprop(ctypes.byref(d), _p(x[a:b]), _p(wf), _p(bias), _p(y[a:b]), pp, _stream()), "conv_fprop")
     return y, part, rows
@@ -229,62 +277,75 @@ def _sl(t, a, b):
     return None if t is None else t[a:b]
 
 
-def _conv_dgrad(desc, dy, wd, dy_cb=None):
+def _conv_dgrad(desc, dy, wd, dy_cb=None, dy_bound=None, w_bound=None):
     """``dy`` may be None when its pre-split companion is given and the batch is not cut (the kernel reads only ``dy_cb``)"""
     L = lib()
     dx = torch.empty((desc.N, desc.Cin, desc.H, desc.W), dtype=torch.float32, device=(dy if dy is not None else dy_cb).device)
     pieces = _batch_pieces(desc)
     if len(pieces) > 1:
         dy_cb = None
+    split = _is_split(wd)
+    if split and dy is not None:
+        dy_bound = _bound_or_measure(dy, dy_bound)
     for a, b in pieces:
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
-        with _timed(gemm_kernel_name(desc.Cin, desc.Cout, True, wd.dtype == torch.bfloat16, dy_cb is not None, False,
-                                     d.N * d.H * d.W), conv_work(d)):
-            if wd.dtype == torch.bfloat16:
-                check(L.mcdseg_conv_x6_dgrad(ctypes.byref(d), _p(_sl(dy, a, b)), _p(dy_cb), _p(wd), _p(dx[a:b]), _stream()), "conv_x6_dgrad")
+        with _timed(gemm_kernel_name(desc.Cin, desc.Cout, True, split, dy_cb is not None, False, d.N * d.H * d.W), conv_work(d)):
+            if split:
+                check(L.mcdseg_conv_split_dgrad(ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(dy, a, b)), _p(dy_cb), _p(dy_bound), _p(wd),
+                                                _p(w_bound), _p(dx[a:b]), _stream()), "conv_split_dgrad")
             else:
                 check(L.mcdseg_conv_dgrad(ctypes.byref(d), _p(dy[a:b]), _p(wd), _p(dx[a:b]), _stream()), "conv_dgrad")
     return dx
 
 
 def _cb_wanted(channels):
-    """Emit the pre-split (channel-blocked bf16x3) companion of a tensor with this many channels?  Only when the conv
-    that gathers it runs on the split path (contraction >= 16 channels) and the layout applies (multiple of 8)."""
-    return PRESPLIT and _use_x6(channels) and channels % 8 == 0
+    """Emit the pre-split (channel-blocked) companion of a tensor with this many channels?  Only when the conv that gathers
+    it runs on the split path (contraction >= 16 channels) and the layout applies (multiple of 8)."""
+    return PRESPLIT and _use_split(channels) and channels % 8 == 0
 
 
 def _cb_alloc(n, c, hw, device):
-    return torch.empty(3 * n * c * hw, dtype=torch.bfloat16, device=device)
+    return torch.empty(PIECES[CONV_MATH] * n * c * hw, dtype=torch.int16, device=device)
 
 
-def split_companion(x):
-    """pre-split companion of an fp32 NCHW tensor no fused BN group produced (None when the layout does not apply)"""
+def split_companion(x, bound=None):
+    """pre-split companion of an fp32 NCHW tensor no fused BN group produced: (companion, bound scalar) -- (None, None) when
+    the layout does not apply"""
     x = _req(x, "tensor to split")
     n, c, h, w = x.shape
     if not _cb_wanted(c) or n * (c // 8) > 65535:
-        return None
+        return None, None
+    bound = _bound_or_measure(x, bound)
     cb = _cb_alloc(n, c, h * w, x.device)
-    check(lib().mcdseg_split_cb(_p(x), _p(cb), n, c, h * w, _stream()), "split_cb")
-    return cb
+    check(lib().mcdseg_split_cb(_p(x), _p(cb), _p(bound), MATH_ID[CONV_MATH], n, c, h * w, _stream()), "split_cb")
+    return cb, bound
 
 
-def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None):
+def _wgrad_split_plan(desc):
+    """the 128x128 split-arithmetic plan of csrc/conv_wgrad.hip applies (else the f32 kernels run)"""
+    return CONV_MATH in MATH_ID and min(desc.Cout, desc.Cin) > 64 and not (desc.Cin <= 16 and desc.KH * desc.KW > 1)
+
+
+def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None, x_bound=None, dy_bound=None):
     L = lib()
     total = None
     pieces = _batch_pieces(desc)
     if len(pieces) > 1 or x_cb is None or dy_cb is None:
         x_cb = dy_cb = None  # the piece-major split layout cannot be sliced along N; both companions or none
+    split = _wgrad_split_plan(desc)
+    if split and x_cb is None:
+        x_bound, dy_bound = _bound_or_measure(x, x_bound), _bound_or_measure(dy, dy_bound)
     for a, b in pieces:
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
-        ws = _ws(L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(d)), x.device)
-        dw = torch.empty((desc.Cout, desc.Cin, desc.KH, desc.KW), dtype=torch.float32, device=x.device)
-        x6 = CONV_MATH == "bf16x6" and min(desc.Cout, desc.Cin) > 64 and not (desc.Cin <= 16 and desc.KH * desc.KW > 1)
-        name = ("conv_wgrad_x6_cb_kernel" if x_cb is not None else "conv_wgrad_x6_kernel") if x6 else \
+        ws = _ws(L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(d)), (x if x is not None else x_cb).device)
+        dw = torch.empty((desc.Cout, desc.Cin, desc.KH, desc.KW), dtype=torch.float32, device=ws.device)
+        name = ("conv_wgrad_split_cb_kernel<%s>" if x_cb is not None else "conv_wgrad_split_kernel<%s>") % POLICY[CONV_MATH] if split else \
             wgrad_kernel_name(desc.Cout, desc.Cin, desc.KH * desc.KW)
         with _timed(name, conv_work(d)):
-            if x6:
-                check(L.mcdseg_conv_x6_wgrad(ctypes.byref(d), _p(x[a:b]), _p(x_cb), _p(_sl(dy, a, b)), _p(dy_cb), _p(dw), _p(ws),
-                                             ctypes.c_size_t(ws.numel() * 4), _stream()), "conv_x6_wgrad")
+            if split:
+                check(L.mcdseg_conv_split_wgrad(ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(x, a, b)), _p(x_cb), _p(x_bound),
+                                                _p(_sl(dy, a, b)), _p(dy_cb), _p(dy_bound), _p(dw), _p(ws),
+                                                ctypes.c_size_t(ws.numel() * 4), _stream()), "conv_split_wgrad")
             else:
                 check(L.mcdseg_conv_wgrad(ctypes.byref(d), _p(x[a:b]), _p(dy[a:b]), _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4),
                                           _stream()), "conv_wgrad")
@@ -305,129 +366,151 @@ def _side_stream(device):
     return _SIDE[key]
 
 
-def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None):
+def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_bound=None, x_bound=None, w_bound=None):
     if not (need_dx and need_dw and OVERLAP_WGRAD):
-        return ((_conv_dgrad(desc, dy, wd, dy_cb) if need_dx else None),
-                (_conv_wgrad(desc, x, dy, x_cb, dy_cb) if need_dw else None))
+        return ((_conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound) if need_dx else None),
+                (_conv_wgrad(desc, x, dy, x_cb, dy_cb, x_bound, dy_bound) if need_dw else None))
     main = torch.cuda.current_stream()
     side = _side_stream(x.device)
+    if _scaled() and dy is not None:
+        dy_bound = _bound_or_measure(dy, dy_bound)  # measured once, on the main stream, for both consumers
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        dw = _conv_wgrad(desc, x, dy, x_cb, dy_cb)
-    dx = _conv_dgrad(desc, dy, wd, dy_cb)
+        dw = _conv_wgrad(desc, x, dy, x_cb, dy_cb, x_bound, dy_bound)
+    dx = _conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound)
     main.wait_stream(side)
     dw.record_stream(main)
     return dx, dw
 
 
-def _channel_reduce(dy, y, z, mean, rstd, relu):
-    """(dgamma, dbeta) of a BN (z given) or just the per-channel sum of dy (z None)."""
+def _channel_reduce(dy, y, z, mean, rstd, relu, gamma=None, want_bound=False, train=True):
+    """(dgamma, dbeta) of a BN (z given) or just the per-channel sum of dy (z None); with ``want_bound`` also the device
+    scalar bounding |dz| of the tensor bn_bwd_apply will write from these sums (include/mcdseg.h)"""
     L = lib()
     n, c = dy.shape[0], dy.shape[1]
     hw = dy.shape[2] * dy.shape[3]
     ws = _ws(L.mcdseg_bn_bwd_workspace_bytes(n, c, hw), dy.device)
     dgamma = torch.empty(c, dtype=torch.float32, device=dy.device) if z is not None else None
     dbeta = torch.empty(c, dtype=torch.float32, device=dy.device)
+    bound = torch.empty(1, dtype=torch.float32, device=dy.device) if want_bound else None
     with _timed("bn_bwd_reduce", (0, 4 * n * c * hw * (1 + (y is not None) + (z is not None)))):
-        check(L.mcdseg_bn_bwd_reduce(_p(dy), _p(y), _p(z), _p(mean), _p(rstd), _p(dgamma), _p(dbeta), n, c, hw, int(relu), _p(ws),
-                                     ctypes.c_size_t(ws.numel() * 4), _stream()), "bn_bwd_reduce")
-    return dgamma, dbeta
+        check(L.mcdseg_bn_bwd_reduce(_p(dy), _p(y), _p(z), _p(mean), _p(rstd), _p(dgamma), _p(dbeta), _p(gamma) if want_bound else None,
+                                     _p(bound), int(train), n, c, hw, int(relu), _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
+              "bn_bwd_reduce")
+    return dgamma, dbeta, bound
 
 
 # ------------------------------------------------------------------------------------------------ conv + BN + act
 class _ConvBNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, conv_bias, running_mean, running_var, nbt, packed, geom, training,
-                momentum, eps, relu, x_cb):
+                momentum, eps, relu, x_cb, x_bound, res_bound):
         L = lib()
         x = _req(x, "conv input")
         residual = _req(residual, "residual")
         stride, pad, dil = geom
         desc = conv_desc(x.shape, weight.shape, stride, pad, dil)
         wf, wd, mpf = packed.get(weight, desc)
-        z, part, rows = _conv_fprop(desc, x, wf, _req(conv_bias, "conv bias"), training, mpf, x_cb)
+        w_bound = packed.w_bound
+        if _is_split(wf) and _scaled():
+            x_bound = _bound_or_measure(x, x_bound)
+        z, part, rows = _conv_fprop(desc, x, wf, _req(conv_bias, "conv bias"), training, mpf, x_cb, x_bound, w_bound)
         c = desc.Cout
+        hw = desc.Ho * desc.Wo
         mean = torch.empty(c, dtype=torch.float32, device=x.device)
         rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        # the pre-split companion of y: the scaled arithmetic needs |y|'s bound BEFORE y is written -- train-mode statistics
+        # give one (Samuelson), eval-mode running statistics do not (the consumer then measures y)
+        want_cb = _cb_wanted(c) and desc.N * (c // 8) <= 65535 and (training or not _scaled())
+        y_bound = None
+        if training and _scaled() and _use_split(c):  # with or without a companion: consumers that split y themselves use it too
+            y_bound = torch.empty(1, dtype=torch.float32, device=x.device)
+            if residual is not None:
+                res_bound = _bound_or_measure(residual, res_bound)
         if training:
             track = running_mean is not None
             ws = torch.empty(L.mcdseg_bn_stats_workspace_bytes(rows, c) // 8 + 1, dtype=torch.float64, device=x.device)
             with _timed("bn_stats_finalize", (0, 12 * rows * mpf)):
                 check(L.mcdseg_bn_stats_finalize(_p(part), rows, c, mpf, _p(mean), _p(rstd), _p(running_mean) if track else None,
                                                  _p(running_var) if track else None, _p(nbt) if track else None,
-                                                 float(momentum), float(eps), _p(ws), ctypes.c_size_t(ws.numel() * 8), _stream()),
+                                                 float(momentum), float(eps), _p(gamma) if y_bound is not None else None,
+                                                 _p(beta) if y_bound is not None else None,
+                                                 _p(res_bound) if (y_bound is not None and residual is not None) else None, _p(y_bound),
+                                                 _p(ws), ctypes.c_size_t(ws.numel() * 8), _stream()),
                       "bn_stats_finalize")
         else:
             check(L.mcdseg_bn_eval_stats(_p(running_mean), _p(running_var), c, float(eps), _p(mean), _p(rstd), _stream()),
                   "bn_eval_stats")
         y = torch.empty_like(z)
-        hw = desc.Ho * desc.Wo
         y_cb = None
         elems = desc.N * c * hw
-        if _cb_wanted(c) and desc.N * (c // 8) <= 65535:
+        if want_cb:
             y_cb = _cb_alloc(desc.N, c, hw, x.device)
-            with _timed("bn_apply_cb", (0, elems * (8 + 6 + (4 if residual is not None else 0)))):
-                check(L.mcdseg_bn_apply_cb(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), _p(y), _p(y_cb), desc.N, c, hw,
-                                           int(relu), _stream()), "bn_apply_cb")
+            with _timed("bn_apply_cb", (0, elems * (8 + 2 * PIECES[CONV_MATH] + (4 if residual is not None else 0)))):
+                check(L.mcdseg_bn_apply_cb(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), _p(y), _p(y_cb), _p(y_bound),
+                                           MATH_ID[CONV_MATH], desc.N, c, hw, int(relu), _stream()), "bn_apply_cb")
         else:
             with _timed("bn_apply", (0, elems * (8 + (4 if residual is not None else 0)))):
                 check(L.mcdseg_bn_apply(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), _p(y), desc.N, c, hw, int(relu),
                                         _stream()), "bn_apply")
         ctx.desc, ctx.wd, ctx.relu, ctx.training, ctx.has_res = desc, wd, relu, training, residual is not None
+        ctx.w_bound = w_bound
         ctx.has_bias = conv_bias is not None
-        ctx.x_cb = x_cb  # wgrad reads the input's split companion too (an input of this node: safe to hold)
+        ctx.x_cb, ctx.x_bound = x_cb, x_bound  # wgrad reads the input's split companion too (an input of this node: safe to hold)
         ctx.save_for_backward(x, z, y, mean, rstd, gamma)
-        ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the non-differentiable split companion
-        if y_cb is not None:
-            ctx.mark_non_differentiable(y_cb)
-        return y, y_cb
+        ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the non-differentiable companions
+        for t in (y_cb, y_bound):
+            if t is not None:
+                ctx.mark_non_differentiable(t)
+        return y, y_cb, y_bound
 
     @staticmethod
-    def backward(ctx, dy, _dcb=None):
+    def backward(ctx, dy, _dcb=None, _dbound=None):
         L = lib()
         if dy is None:
-            return (None,) * 16
+            return (None,) * 18
         x, z, y, mean, rstd, gamma = ctx.saved_tensors
         desc = ctx.desc
         dy = _req(dy, "grad_output")
         n, c, hw = desc.N, desc.Cout, desc.Ho * desc.Wo
-        dgamma, dbeta = _channel_reduce(dy, y if ctx.relu else None, z, mean, rstd, ctx.relu)
+        split_d = _is_split(ctx.wd)
+        want_cb = ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and ctx.x_cb is not None)
+        use_cb = want_cb and split_d and _cb_wanted(c) and n * (c // 8) <= 65535
+        dgamma, dbeta, dz_bound = _channel_reduce(dy, y if ctx.relu else None, z, mean, rstd, ctx.relu, gamma,
+                                                  want_bound=_scaled() and (split_d or _wgrad_split_plan(desc)), train=ctx.training)
         dz = None
         dres = None
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = torch.empty_like(z) if ctx.relu else dy
         dz_cb = None
-        bwd_args = (_p(dy), _p(y) if ctx.relu else None, _p(z), _p(mean), _p(rstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dz),
-                    _p(dres) if (dres is not None and ctx.relu) else None)
-        want_cb = ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and ctx.x_cb is not None)
-        use_cb = want_cb and ctx.wd.dtype == torch.bfloat16 and _cb_wanted(c) and n * (c // 8) <= 65535
         # the fp32 dz is skipped when every consumer reads the split companion: dgrad (pre-split gather) and wgrad
         # (pre-split 128x128 plan); a conv bias gradient or any fallback path still needs it
         single = len(_batch_pieces(desc)) == 1
-        wgrad_cb = (CONV_MATH == "bf16x6" and ctx.x_cb is not None and min(desc.Cout, desc.Cin) > 64 and desc.Cin % 8 == 0
-                    and desc.Cout % 8 == 0 and not (desc.Cin <= 16 and desc.KH * desc.KW > 1))
+        wgrad_cb = (ctx.x_cb is not None and _wgrad_split_plan(desc) and desc.Cin % 8 == 0 and desc.Cout % 8 == 0)
         skip_dz = (use_cb and single and not (ctx.has_bias and ctx.needs_input_grad[5])
                    and (not ctx.needs_input_grad[1] or wgrad_cb))
         if not skip_dz:
             dz = torch.empty_like(z)
-        bwd_args = bwd_args[:8] + (_p(dz),) + bwd_args[9:]
+        bwd_args = (_p(dy), _p(y) if ctx.relu else None, _p(z), _p(mean), _p(rstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dz),
+                    _p(dres) if (dres is not None and ctx.relu) else None)
         rd = 4 * n * c * hw * (2 + int(ctx.relu)) + 4 * n * c * hw * ((dz is not None) + (dres is not None and ctx.relu))
         if use_cb:
             dz_cb = _cb_alloc(n, c, hw, dy.device)
-            with _timed("bn_bwd_apply_cb", (0, rd + 6 * n * c * hw)):
-                check(L.mcdseg_bn_bwd_apply_cb(*bwd_args, _p(dz_cb), n, c, hw, int(ctx.relu), int(ctx.training), _stream()),
-                      "bn_bwd_apply_cb")
+            with _timed("bn_bwd_apply_cb", (0, rd + 2 * PIECES[CONV_MATH] * n * c * hw)):
+                check(L.mcdseg_bn_bwd_apply_cb(*bwd_args, _p(dz_cb), _p(dz_bound), MATH_ID[CONV_MATH], n, c, hw, int(ctx.relu),
+                                               int(ctx.training), _stream()), "bn_bwd_apply_cb")
         else:
             with _timed("bn_bwd_apply", (0, rd)):
                 check(L.mcdseg_bn_bwd_apply(*bwd_args, n, c, hw, int(ctx.relu), int(ctx.training), _stream()), "bn_bwd_apply")
-        dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz_cb, ctx.x_cb)
+        dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz_cb, ctx.x_cb, dz_bound,
+                                ctx.x_bound, ctx.w_bound)
         dbias = None
         if ctx.has_bias and ctx.needs_input_grad[5]:
             # a bias in front of train-mode BN has zero gradient up to rounding (BN removes the channel mean);
             # it is still formed, as autograd does in the reference (CBR, models/dilated_fcn.py:632-644)
-            _, dbias = _channel_reduce(dz, None, None, None, None, False)
+            _, dbias, _ = _channel_reduce(dz, None, None, None, None, False)
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres, dbias,
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def _conv_bn_act_inference(x, conv, bn, relu, residual):
@@ -443,16 +526,18 @@ def _conv_bn_act_inference(x, conv, bn, relu, residual):
     check(L.mcdseg_bn_eval_affine(_p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), _p(conv.bias), c,
                                   float(bn.eps), _p(scale), _p(shift), _stream()), "bn_eval_affine")
     y = torch.empty((desc.N, c, desc.Ho, desc.Wo), dtype=torch.float32, device=x.device)
+    split = _is_split(wf)
+    direct = split and bool(L.mcdseg_conv_split_direct_ok(ctypes.byref(desc)))
+    x_bound = _bound_or_measure(x, None) if (split and not direct) else None
     for a, b in _batch_pieces(desc):
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
-        fn = L.mcdseg_conv_x6_fprop_affine if wf.dtype == torch.bfloat16 else L.mcdseg_conv_fprop_affine
-        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, wf.dtype == torch.bfloat16, False,
-                                     wf.dtype == torch.bfloat16 and bool(L.mcdseg_conv_x6_direct_ok(ctypes.byref(d)))), conv_work(d)):
+        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, split, False, direct), conv_work(d)):
             args = (_p(scale), _p(shift), _p(residual[a:b]) if residual is not None else None, int(relu), _p(y[a:b]), _stream())
-            if wf.dtype == torch.bfloat16:
-                check(fn(ctypes.byref(d), _p(x[a:b]), None, _p(wf), *args), "conv_x6_fprop_affine")
+            if split:
+                check(L.mcdseg_conv_split_fprop_affine(ctypes.byref(d), MATH_ID[CONV_MATH], _p(x[a:b]), None, _p(x_bound), _p(wf),
+                                                       _p(conv._packed.w_bound), *args), "conv_split_fprop_affine")
             else:
-                check(fn(ctypes.byref(d), _p(x[a:b]), _p(wf), *args), "conv_fprop_affine")
+                check(L.mcdseg_conv_fprop_affine(ctypes.byref(d), _p(x[a:b]), _p(wf), *args), "conv_fprop_affine")
     return y
 
 
@@ -466,41 +551,48 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None):
     if not training and not track:
         raise NotImplementedError("mcdseg: eval-mode BatchNorm needs running statistics")
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    y, y_cb = _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, residual, conv.bias, bn.running_mean if track else None,
-                               bn.running_var if track else None, bn.num_batches_tracked if track else None, conv._packed, geom,
-                               training, momentum, bn.eps, relu, _cb_of(x))
-    if y_cb is not None:
-        _attach_cb(y, y_cb)  # the pre-split companion travels with the tensor object to the next convolution
+    x_cb, x_bound = _cb_of(x)
+    res_bound = _cb_of(residual)[1] if residual is not None else None
+    y, y_cb, y_bound = _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, residual, conv.bias, bn.running_mean if track else None,
+                                        bn.running_var if track else None, bn.num_batches_tracked if track else None, conv._packed,
+                                        geom, training, momentum, bn.eps, relu, x_cb, x_bound, res_bound)
+    if y_cb is not None or y_bound is not None:
+        _attach_cb(y, y_cb, y_bound)  # the pre-split companion (and the bound) travel with the tensor object to the next convolution
     return y
 
 
-def _attach_cb(y, y_cb):
-    # the companion is only valid for the values y holds NOW: remember the autograd version counter and the storage
-    y._mcd_cb = (y_cb, y._version, y.data_ptr())
+def _attach_cb(y, y_cb, y_bound=None):
+    # the companion (and the bound) is only valid for the values y holds NOW: remember the autograd version counter and the storage
+    y._mcd_cb = (y_cb, y_bound, y._version, y.data_ptr())
 
 
 def _cb_of(x):
-    """pre-split companion attached by the producer of ``x``: None if ``x`` did not come straight from a fused BN group,
-    or if anything wrote to ``x`` since (an in-place op of the caller -- ``x.add_()``, ``relu_()``, inplace dropout --
-    bumps ``x._version``; the consumer then splits the current values itself instead of reading a stale image)"""
+    """(pre-split companion, bound scalar) attached by the producer of ``x``: (None, None) if ``x`` did not come straight from a
+    fused BN group, or if anything wrote to ``x`` since (an in-place op of the caller -- ``x.add_()``, ``relu_()``, inplace
+    dropout -- bumps ``x._version``; the consumer then splits the current values itself instead of reading a stale image)"""
     rec = getattr(x, "_mcd_cb", None)
     if rec is None:
-        return None
-    cb, version, ptr = rec
-    if x._version != version or x.data_ptr() != ptr or not x.is_contiguous() or cb.numel() != 3 * x.numel():
-        return None
-    return cb
+        return None, None
+    cb, bound, version, ptr = rec
+    if x._version != version or x.data_ptr() != ptr or not x.is_contiguous():
+        return None, None
+    if cb is not None and cb.numel() != PIECES.get(CONV_MATH, 0) * x.numel():
+        cb = None
+    return cb, (bound if _scaled() else None)
 
 
 # ------------------------------------------------------------------------------------------------ conv (+bias)
 class _Conv2dBias(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, geom, x_cb):
+    def forward(ctx, x, weight, bias, packed, geom, x_cb, x_bound):
         x = _req(x, "conv input")
         desc = conv_desc(x.shape, weight.shape, *geom)
         wf, wd, mpf = packed.get(weight, desc)
-        y, _, _ = _conv_fprop(desc, x, wf, _req(bias, "conv bias"), False, mpf, x_cb)
-        ctx.desc, ctx.wd, ctx.has_bias = desc, wd, bias is not None
+        if _is_split(wf) and _scaled():
+            x_bound = _bound_or_measure(x, x_bound)
+        y, _, _ = _conv_fprop(desc, x, wf, _req(bias, "conv bias"), False, mpf, x_cb, x_bound, packed.w_bound)
+        ctx.desc, ctx.wd, ctx.has_bias, ctx.w_bound = desc, wd, bias is not None, packed.w_bound
+        ctx.x_bound = x_bound
         ctx.save_for_backward(x)
         return y
 
@@ -508,16 +600,18 @@ class _Conv2dBias(torch.autograd.Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         dy = _req(dy, "grad_output")
-        dx, dw = _conv_backward(ctx.desc, x, dy, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dx, dw = _conv_backward(ctx.desc, x, dy, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], None, None, None, ctx.x_bound,
+                                ctx.w_bound)
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            _, db = _channel_reduce(dy, None, None, None, None, False)
-        return dx, dw, db, None, None, None
+            _, db, _ = _channel_reduce(dy, None, None, None, None, False)
+        return dx, dw, db, None, None, None, None
 
 
 def conv2d_bias(x, conv):
     geom = (conv.stride[0], conv.padding[0], conv.dilation[0])
-    return _Conv2dBias.apply(x, conv.weight, conv.bias, conv._packed, geom, _cb_of(x))
+    x_cb, x_bound = _cb_of(x)
+    return _Conv2dBias.apply(x, conv.weight, conv.bias, conv._packed, geom, x_cb, x_bound)
 
 
 # ------------------------------------------------------------------------------------------------ x8 up-sampler

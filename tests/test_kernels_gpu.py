@@ -68,14 +68,14 @@ def test_conv_fprop_dgrad_wgrad(case):
     packed = ops.PackedWeights()
     xg, wg = x.to(dev), wt.to(dev)
     wf, wd, mpf = packed.get(wg, desc)
-    y, _, _ = ops._conv_fprop(desc, xg, wf, b.to(dev) if b is not None else None, False, mpf)
+    y, _, _ = ops._conv_fprop(desc, xg, wf, b.to(dev) if b is not None else None, False, mpf, w_bound=packed.w_bound)
     x64 = x.double().requires_grad_()
     w64 = wt.double().requires_grad_()
     ref = F.conv2d(x64, w64, b.double() if b is not None else None, stride=s, padding=pad, dilation=d)
     _assert_close(y, ref, 2e-5, "fprop")
     gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(8))
     gx_ref, gw_ref = torch.autograd.grad(ref, [x64, w64], gy.double())
-    dx = ops._conv_dgrad(desc, gy.to(dev), wd)
+    dx = ops._conv_dgrad(desc, gy.to(dev), wd, w_bound=packed.w_bound)
     _assert_close(dx, gx_ref, 2e-5, "dgrad")
     dw = ops._conv_wgrad(desc, xg, gy.to(dev))
     _assert_close(dw, gw_ref, 2e-5, "wgrad")
@@ -439,9 +439,9 @@ def test_folded_bn_inference_and_predict_tail():
 
 
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if min(c[0], c[1]) >= 16], ids=lambda c: "x".join(map(str, c[:5])))
-def test_conv_x6_accuracy(case, monkeypatch):
-    """bf16x6 split-precision path: against fp64 it must be as accurate as the exact-fp32 MFMA path (within 2x of
-    its error, and within the same 2e-5-of-scale bound)."""
+def test_conv_split_accuracy(case, monkeypatch):
+    """split-precision paths (f16x3: two scaled fp16 pieces, three cross terms; bf16x6: three bf16 pieces, six terms): against
+    fp64 they must be as accurate as the exact-fp32 MFMA path (within 2x of its error, and within the same 2e-5-of-scale bound)."""
     dev = _dev()
     from mcdseg import ops
     x, wt, b, s, pad, d = _conv_inputs(case, 17)
@@ -452,29 +452,66 @@ def test_conv_x6_accuracy(case, monkeypatch):
     gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(18))
     gx_ref, gw_ref = torch.autograd.grad(ref, [x64, w64], gy.double())
     errs = {}
-    for math in ("f32", "bf16x6"):
+    for math in ("f32", "bf16x6", "f16x3"):
         monkeypatch.setattr(ops, "CONV_MATH", math)
-        wf, wd, mpf = ops.PackedWeights().get(wg, desc)
-        assert (wf.dtype == torch.bfloat16) == (math == "bf16x6")
-        y, part, rows = ops._conv_fprop(desc, xg, wf, b.to(dev) if b is not None else None, True, mpf)
-        dx = ops._conv_dgrad(desc, gy.to(dev), wd)
+        pk = ops.PackedWeights()
+        wf, wd, mpf = pk.get(wg, desc)
+        assert ops._is_split(wf) == (math != "f32")
+        y, part, rows = ops._conv_fprop(desc, xg, wf, b.to(dev) if b is not None else None, True, mpf, w_bound=pk.w_bound)
+        dx = ops._conv_dgrad(desc, gy.to(dev), wd, w_bound=pk.w_bound)
         dw = ops._conv_wgrad(desc, xg, gy.to(dev))
         errs[math] = (_maxerr(y, ref), _maxerr(dx, gx_ref), _maxerr(dw, gw_ref))
         _assert_close(y, ref, 2e-5, math + " fprop")
         _assert_close(dx, gx_ref, 2e-5, math + " dgrad")
         _assert_close(dw, gw_ref, 2e-5, math + " wgrad")
-    for k in (0, 1, 2):
-        e32, e6 = errs["f32"][k][0], errs["bf16x6"][k][0]
-        assert e6 <= max(2.0 * e32, 2e-6 * errs["f32"][k][1]), "bf16x6 err %.3e vs f32-MFMA err %.3e" % (e6, e32)
+    for math in ("bf16x6", "f16x3"):
+        for k in (0, 1, 2):
+            e32, es = errs["f32"][k][0], errs[math][k][0]
+            assert es <= max(2.0 * e32, 2e-6 * errs["f32"][k][1]), "%s err %.3e vs f32-MFMA err %.3e" % (math, es, e32)
 
 
-def test_presplit_operands_are_bitwise_equivalent(monkeypatch):
-    """Splitting an activation into bf16 pieces in its producer (bn_apply_cb / bn_bwd_apply_cb) or inside the consuming
-    convolution's K loop is the same arithmetic: results must be bit-identical, forward and backward."""
+def test_f16x3_scaling_covers_the_fp32_range(monkeypatch):
+    """The per-tensor power-of-two scale makes the fp16 pieces independent of the operand's magnitude: tensors scaled by
+    2^-40 ... 2^+40 give the correspondingly scaled result to the same relative accuracy (no overflow to inf, no flush to 0),
+    and a tensor with a 2^20 dynamic range keeps its small entries' contribution."""
+    dev = _dev()
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "CONV_MATH", "f16x3")
+    x, wt, _, s, pad, d = _conv_inputs((64, 128, 3, 1, 1, 12, 16, 2, False), 19)
+    desc = ops.conv_desc(x.shape, wt.shape, 1, pad, d)
+    ref = F.conv2d(x.double(), wt.double(), None, 1, pad, d)
+    for ex, ew in ((0, 0), (40, -30), (-40, 20), (60, 60), (-50, -50)):
+        xs, ws = x * 2.0 ** ex, wt * 2.0 ** ew
+        pk = ops.PackedWeights()
+        wf, wd, mpf = pk.get(ws.to(dev), desc)
+        y, _, _ = ops._conv_fprop(desc, xs.to(dev), wf, None, False, mpf, w_bound=pk.w_bound)
+        _assert_close(y.double().cpu() * 2.0 ** (-ex - ew), ref, 2e-5, "fprop at 2^%d x 2^%d" % (ex, ew))
+        cb, bound = ops.split_companion(xs.to(dev))
+        y2, _, _ = ops._conv_fprop(desc, xs.to(dev), wf, None, False, mpf, cb, bound, pk.w_bound)
+        assert torch.equal(y, y2)
+    # wide dynamic range inside one tensor: channel 0 carries values 2^20 larger than the rest; outputs that only see the small
+    # channels through zero weights on channel 0 must keep their accuracy
+    xw = x.clone()
+    xw[:, 0] *= 2.0 ** 20
+    w0 = wt.clone()
+    w0[:64, 0] = 0.0  # the first 64 output channels ignore the large input channel
+    pk = ops.PackedWeights()
+    wf, wd, mpf = pk.get(w0.to(dev), desc)
+    y, _, _ = ops._conv_fprop(desc, xw.to(dev), wf, None, False, mpf, w_bound=pk.w_bound)
+    refw = F.conv2d(xw.double(), w0.double(), None, 1, pad, d)
+    _assert_close(y[:, :64], refw[:, :64], 2e-4, "small-magnitude channels beside a 2^20 larger one")
+    _assert_close(y[:, 64:], refw[:, 64:], 2e-5, "large-magnitude channels")
+
+
+@pytest.mark.parametrize("math", ["f16x3", "bf16x6"])
+def test_presplit_operands_are_bitwise_equivalent(math, monkeypatch):
+    """Splitting an activation into 16-bit pieces in its producer (bn_apply_cb / bn_bwd_apply_cb) or inside the consuming
+    convolution's K loop is the same arithmetic: results must be bit-identical, forward and backward.  (f16x3: both paths must
+    then use the same scale -- the in-loop path is handed the producer's bound.)"""
     dev = _dev()
     from mcdseg import ops
     from models.drn import BatchNorm2d, Conv2d
-    monkeypatch.setattr(ops, "CONV_MATH", "bf16x6")
+    monkeypatch.setattr(ops, "CONV_MATH", math)
     g = torch.Generator().manual_seed(41)
     c1, b1 = Conv2d(24, 40, 3, padding=1, bias=False).to(dev), BatchNorm2d(40).to(dev)     # 40 = 2.5 x 16: ragged last chunk
     c2, b2 = Conv2d(40, 64, 3, padding=2, dilation=2, bias=False).to(dev), BatchNorm2d(64).to(dev)
@@ -490,7 +527,7 @@ def test_presplit_operands_are_bitwise_equivalent(monkeypatch):
         for p in list(c1.parameters()) + list(c2.parameters()) + list(c3.parameters()):
             p.grad = None
         y1 = ops.conv_bn_act(xs, c1, b1, relu=True)
-        assert (getattr(y1, "_mcd_cb", None) is not None) == presplit
+        assert (ops._cb_of(y1)[0] is not None) == presplit
         y2 = ops.conv_bn_act(y1, c2, b2, relu=True, residual=None)
         y3 = ops.conv_bn_act(y2, c3, b3, relu=False)
         y3.backward(gy)
@@ -520,10 +557,10 @@ def test_stale_presplit_companion_is_not_used(monkeypatch):
             p.grad = None
         with torch.no_grad():
             y1 = ops.conv_bn_act(x, c1, b1, relu=True)
-            had = ops._cb_of(y1) is not None
+            had = ops._cb_of(y1)[0] is not None
             y1.mul_(mask)         # in-place: bumps y1._version
             y1.add_(0.25)
-            assert ops._cb_of(y1) is None
+            assert ops._cb_of(y1) == (None, None)
         y1 = y1.requires_grad_()
         y2 = ops.conv_bn_act(y1, c2, b2, relu=True)
         y2.backward(gy)
@@ -555,7 +592,8 @@ def test_conv_large_tile_kernels(case):
     cin, cout, k, d, n, h, w = case
     x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, 1, d, h, w, n, False), 29)
     desc = ops.conv_desc(x.shape, wt.shape, 1, pad, d)
-    wf, wd, mpf = ops.PackedWeights().get(wt.to(dev), desc)
+    pk = ops.PackedWeights()
+    wf, wd, mpf = pk.get(wt.to(dev), desc)
     xg = x.to(dev)
     gy = torch.randn(n, cout, desc.Ho, desc.Wo, generator=torch.Generator().manual_seed(30))
     gyg = gy.to(dev)
@@ -570,10 +608,12 @@ def test_conv_large_tile_kernels(case):
             return False
     prev, ops.LAUNCH_TIMER = ops.LAUNCH_TIMER, _Names()
     try:
-        y_cb, part_cb, rows = ops._conv_fprop(desc, xg, wf, None, True, mpf, ops.split_companion(xg))
-        y, part, rows2 = ops._conv_fprop(desc, xg, wf, None, True, mpf)
-        dx_cb = ops._conv_dgrad(desc, None, wd, ops.split_companion(gyg))
-        dx = ops._conv_dgrad(desc, gyg, wd)
+        x_cb, x_bound = ops.split_companion(xg)
+        gy_cb, gy_bound = ops.split_companion(gyg)
+        y_cb, part_cb, rows = ops._conv_fprop(desc, xg, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)
+        y, part, rows2 = ops._conv_fprop(desc, xg, wf, None, True, mpf, None, x_bound, pk.w_bound)
+        dx_cb = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound)
+        dx = ops._conv_dgrad(desc, gyg, wd, None, gy_bound, pk.w_bound)
     finally:
         ops.LAUNCH_TIMER = prev
     big = [nm for nm in names if "4, 2, 2, 2" in nm or "4, 4, 2, 2" in nm]
@@ -589,10 +629,15 @@ def test_conv_large_tile_kernels(case):
     mean = torch.empty(cout, device=dev)
     rstd = torch.empty(cout, device=dev)
     ws = torch.empty(L.mcdseg_bn_stats_workspace_bytes(rows, cout) // 8 + 1, dtype=torch.float64, device=dev)
+    gam, bet, yb = torch.full((cout,), 1.5, device=dev), torch.full((cout,), -0.25, device=dev), torch.empty(1, device=dev)
     ops.check(L.mcdseg_bn_stats_finalize(ops._p(part_cb), rows, cout, mpf, ops._p(mean), ops._p(rstd), None, None, None, 0.1, 1e-5,
-                                         ops._p(ws), ctypes.c_size_t(ws.numel() * 8), ops._stream()), "bn_stats_finalize")
+                                         ops._p(gam), ops._p(bet), None, ops._p(yb), ops._p(ws), ctypes.c_size_t(ws.numel() * 8),
+                                         ops._stream()), "bn_stats_finalize")
+    npix = n * desc.Ho * desc.Wo  # Samuelson bound of the BN output: |gamma| sqrt(n-1) + |beta|
+    assert abs(float(yb) - (1.5 * (npix - 1) ** 0.5 + 0.25)) <= 1e-3 * float(yb)
     r = ref.detach()
-    _assert_close(mean, r.mean((0, 2, 3)), 1e-5, "fused BN mean")
+    merr = float((mean.double().cpu() - r.mean((0, 2, 3))).abs().max())
+    assert merr <= 1e-5 * float(r.std()), "fused BN mean off by %.3e (output std %.3e)" % (merr, float(r.std()))
     _assert_close(rstd, (r.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt(), 1e-5, "fused BN rstd")
 
 
@@ -604,33 +649,24 @@ def test_conv_nonfinite_operands():
     from mcdseg import ops
     x, wt, _, s, pad, d = _conv_inputs((64, 128, 3, 1, 1, 12, 16, 1, False), 37)
     desc = ops.conv_desc(x.shape, wt.shape, 1, pad, d)
-    wf, wd, mpf = ops.PackedWeights().get(wt.to(dev), desc)
-    clean, _, _ = ops._conv_fprop(desc, x.to(dev), wf, None, False, mpf)
+    pk = ops.PackedWeights()
+    wf, wd, mpf = pk.get(wt.to(dev), desc)
+    clean, _, _ = ops._conv_fprop(desc, x.to(dev), wf, None, False, mpf, w_bound=pk.w_bound)
     xb = x.clone()
     xb[0, 5, 2, 3] = float("inf")
     xb[0, 7, 9, 12] = float("nan")
     xb[0, 9, 6, 1] = 1e-41  # denormal
     for cb in (False, True):
         xg = xb.to(dev)
-        y, _, _ = ops._conv_fprop(desc, xg, wf, None, False, mpf, ops.split_companion(xg) if cb else None)
+        x_cb, x_bound = ops.split_companion(xg) if cb else (None, None)
+        y, _, _ = ops._conv_fprop(desc, xg, wf, None, False, mpf, x_cb, x_bound, pk.w_bound)
         bad = ~torch.isfinite(y)
         touched = torch.zeros(1, 1, 12, 16, dtype=torch.bool)
         touched[0, 0, 1:4, 2:5] = True
         touched[0, 0, 8:11, 11:14] = True
         assert bool((bad.cpu() == touched.expand_as(bad)).all()), "non-finite outputs are not exactly the reached ones"
         ok = ~touched.expand_as(bad)
-        assert float((y.cpu()[ok] - clean.cpu()[ok]).abs().max()) <= 1e-6 * float(clean.abs().max())
-
-
-def _split_cb(t):
-    """fp32 NCHW -> the channel-blocked bf16x3 companion [piece 3][N][C/8][H*W][8] (what bn_apply_cb writes)"""
-    n, c, h, w = t.shape
-    p1 = t.bfloat16()
-    r = t - p1.float()
-    p2 = r.bfloat16()
-    p3 = (r - p2.float()).bfloat16()
-    cb = torch.stack([p1, p2, p3]).reshape(3, n, c // 8, 8, h * w).permute(0, 1, 2, 4, 3).contiguous()
-    return cb.reshape(-1)
+        assert float((y.cpu()[ok] - clean.cpu()[ok]).abs().max()) <= 2e-5 * float(clean.abs().max())
 
 
 # (Cin, Cout, k, stride, dil, H, W, N): 128x128-plan layers only (min(C) > 64, C % 8 == 0)
@@ -645,13 +681,13 @@ WGRAD_CB_CASES = [
 ]
 
 
-@pytest.mark.gpu
+@pytest.mark.parametrize("math", ["f16x3", "bf16x6"])
 @pytest.mark.parametrize("case", WGRAD_CB_CASES, ids=lambda c: "x".join(map(str, c[:7])))
-def test_conv_wgrad_presplit_operands(case, monkeypatch):
+def test_conv_wgrad_presplit_operands(case, math, monkeypatch):
     """weight gradient from the pre-split companions (8x8 register transposes) = the in-loop split kernel = fp64"""
     dev = _dev()
     from mcdseg import ops
-    monkeypatch.setattr(ops, "CONV_MATH", "bf16x6")
+    monkeypatch.setattr(ops, "CONV_MATH", math)
     cin, cout, k, s, d, h, w, n = case
     x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, s, d, h, w, n, False), 23)
     desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
@@ -660,13 +696,15 @@ def test_conv_wgrad_presplit_operands(case, monkeypatch):
     gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(24))
     (gw_ref,) = torch.autograd.grad(ref, [w64], gy.double())
     xg, gyg = x.to(dev), gy.to(dev)
-    dw_loop = ops._conv_wgrad(desc, xg, gyg)
-    dw_cb = ops._conv_wgrad(desc, xg, gyg, _split_cb(xg), _split_cb(gyg))
+    x_cb, x_bound = ops.split_companion(xg)
+    gy_cb, gy_bound = ops.split_companion(gyg)
+    assert x_cb is not None and gy_cb is not None
+    dw_loop = ops._conv_wgrad(desc, xg, gyg, None, None, x_bound, gy_bound)
+    dw_cb = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
     _assert_close(dw_loop, gw_ref, 2e-5, "wgrad (in-loop split)")
     _assert_close(dw_cb, gw_ref, 2e-5, "wgrad (pre-split operands)")
     e_loop, e_cb = _maxerr(dw_loop, gw_ref)[0], _maxerr(dw_cb, gw_ref)[0]
     assert e_cb <= max(2.0 * e_loop, 2e-6 * _maxerr(dw_loop, gw_ref)[1])
-
 
 
 # ------------------------------------------------------------------------------ input pipeline and evaluation kernels
@@ -754,19 +792,19 @@ def test_stem_direct_conv_matches_generic_kernels(monkeypatch):
     wt = torch.randn(16, 6, 7, 7, generator=g) * 0.08
     bias = torch.randn(16, generator=g) * 0.1
     desc = ops.conv_desc(x.shape, wt.shape, 1, 3, 1)
-    assert lib().mcdseg_conv_x6_direct_ok(ctypes.byref(desc)) == 1
+    assert lib().mcdseg_conv_split_direct_ok(ctypes.byref(desc)) == 1
     ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=3)
     outs = {}
-    for math in ("f32", "bf16x6"):
+    for math in ("f32", "bf16x6", "f16x3"):  # the direct kernel keeps the bf16x6 arithmetic under either split mode
         monkeypatch.setattr(ops, "CONV_MATH", math)
         wf, _, mpf = ops.PackedWeights().get(wt.to(dev), desc, need_dgrad=False)
-        assert (wf.dtype == torch.bfloat16) == (math == "bf16x6")
+        assert ops._is_split(wf) == (math != "f32")
         y, part, rows = ops._conv_fprop(desc, x.to(dev), wf, bias.to(dev), True, mpf)
         _assert_close(y, ref, 2e-5, math + " stem fprop")
         outs[math] = _maxerr(y, ref)[0]
-    assert outs["bf16x6"] <= max(2.0 * outs["f32"], 2e-6 * float(ref.abs().max()))
+    assert outs["bf16x6"] <= max(2.0 * outs["f32"], 2e-6 * float(ref.abs().max())) and outs["f16x3"] == outs["bf16x6"]
     # inference: eval-mode BN folded into the epilogue
-    monkeypatch.setattr(ops, "CONV_MATH", "bf16x6")
+    monkeypatch.setattr(ops, "CONV_MATH", "f16x3")
     conv, bn = Conv2d(6, 16, 7, padding=3, bias=False), BatchNorm2d(16)
     with torch.no_grad():
         conv.weight.copy_(wt)

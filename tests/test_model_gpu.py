@@ -80,7 +80,7 @@ def test_forward_small_vs_reference(golden, mode):
         assert int(sd["base.8.1.num_batches_tracked"]) == 1
 
 
-@pytest.mark.parametrize("math,k_noise", [("f32", 4.0), ("bf16x6", 8.0)])
+@pytest.mark.parametrize("math,k_noise", [("f32", 4.0), ("bf16x6", 8.0), ("f16x3", 8.0)])
 @pytest.mark.parametrize("which", ["ce", "diff"])
 def test_backward_small_vs_reference(golden, which, math, k_noise, monkeypatch):
     """Gradients against the reference's fp64 gradients: |g - g64| <= max(1e-3 * max(scale, 1e-3), k * |g32_ref - g64|).
@@ -88,7 +88,8 @@ def test_backward_small_vs_reference(golden, which, math, k_noise, monkeypatch):
     so the yardstick is the reference's fp32-vs-fp64 deviation.  Measured worst ratios: exact f32 MFMA chain 1.7 (CE) /
     2.2 (discrepancy); bf16x6 split path 1.8 / 4.2 -- its matrix-pipe accumulation carries about twice the rounding
     noise of an FMA chain (unchanged when all nine cross terms are kept), all of it far below the 1e-3 of north_star
-    (absolute errors here are <= 3e-6).  k = 4 for the f32 path, 8 for the split path."""
+    (absolute errors here are <= 3e-6); the default f16x3 split (two scaled fp16 pieces, three cross terms) measures 1.2 / 4.9
+    in the CPU emulation of tools/split_numerics.py.  k = 4 for the f32 path, 8 for the split paths."""
     dev = _dev()
     from loss import CrossEntropyLoss2d, Diff2d
     from mcdseg import ops
@@ -379,7 +380,7 @@ def test_cfg2_full_batch_vs_oracle():
     n = 16
     desc = ops.conv_desc((n, 512, 60, 80), (512, 512, 3, 3), 1, 4, 4)
     big = ops.gemm_kernel_name(512, 512, False, True, True, False, n * 60 * 80)
-    assert ops.CONV_MATH == "f32" or "2, 2, 2, 2" not in big, "N=16 must select the large tile, got %s" % big
+    assert ops.CONV_MATH == "f32" or ", 2, 2, 2, 2," not in big, "N=16 must select the large tile, got %s" % big
     g, f1, f2 = _mcd_models(dev)
     og, of1, of2 = ref_models.get_models("drn_d_38", 6, NC)
     fill_state_(og, 11), fill_state_(of1, 12), fill_state_(of2, 13)

@@ -45,22 +45,12 @@ def timeit(fn, reps):
     return t0.elapsed_time(t1) / reps
 
 
-def split_cb(t):
-    """fp32 NCHW -> [piece 3][N][C/8][H*W][8] bf16 (the layout bn_apply_cb / bn_bwd_apply_cb write)"""
-    n, c, h, w = t.shape
-    p1 = t.bfloat16()
-    r = t - p1.float()
-    p2 = r.bfloat16()
-    p3 = (r - p2.float()).bfloat16()
-    return torch.stack([p1, p2, p3]).reshape(3, n, c // 8, 8, h * w).permute(0, 1, 2, 4, 3).contiguous().reshape(-1)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
-    ap.add_argument("--math", default=None, help="f32 | bf16x6")
+    ap.add_argument("--math", default=None, help="f32 | bf16x6 | f16x3")
     args = ap.parse_args()
     if args.math:
         ops.CONV_MATH = args.math
@@ -79,15 +69,18 @@ def main():
         wf, wd, mpf = pk.get(wt, desc)
         gy = torch.randn(n, cout, desc.Ho, desc.Wo, device=dev)
         gf = 2.0 * n * desc.Ho * desc.Wo * cout * cin * k * k / 1e9
-        tf = timeit(lambda: ops._conv_fprop(desc, x, wf, None, True, mpf), args.reps)
-        td = timeit(lambda: ops._conv_dgrad(desc, gy, wd), args.reps)
-        tw = timeit(lambda: ops._conv_wgrad(desc, x, gy), args.reps)
+        xb = ops._bound_or_measure(x, None)
+        gb = ops._bound_or_measure(gy, None)
+        wb = pk.w_bound
+        tf = timeit(lambda: ops._conv_fprop(desc, x, wf, None, True, mpf, None, xb, wb), args.reps)
+        td = timeit(lambda: ops._conv_dgrad(desc, gy, wd, None, gb, wb), args.reps)
+        tw = timeit(lambda: ops._conv_wgrad(desc, x, gy, None, None, xb, gb), args.reps)
         extra = ""
-        if ops.CONV_MATH == "bf16x6" and min(cin, cout) > 64 and cin % 8 == 0 and cout % 8 == 0:
-            x_cb, gy_cb = split_cb(x), split_cb(gy)
-            tf2 = timeit(lambda: ops._conv_fprop(desc, x, wf, None, True, mpf, x_cb), args.reps)
-            td2 = timeit(lambda: ops._conv_dgrad(desc, gy, wd, gy_cb), args.reps)
-            tw2 = timeit(lambda: ops._conv_wgrad(desc, x, gy, x_cb, gy_cb), args.reps)
+        if ops.CONV_MATH in ops.MATH_ID and min(cin, cout) >= 16 and cin % 8 == 0 and cout % 8 == 0:
+            (x_cb, _), (gy_cb, _) = ops.split_companion(x, xb), ops.split_companion(gy, gb)
+            tf2 = timeit(lambda: ops._conv_fprop(desc, x, wf, None, True, mpf, x_cb, xb, wb), args.reps)
+            td2 = timeit(lambda: ops._conv_dgrad(desc, gy, wd, gy_cb, gb, wb), args.reps)
+            tw2 = timeit(lambda: ops._conv_wgrad(desc, x, gy, x_cb, gy_cb, xb, gb), args.reps)
             extra = " | pre-split: fprop %.3f ms %.1f TF, dgrad %.3f ms %.1f TF, wgrad %.3f ms %.1f TF" % (
                 tf2, gf / tf2, td2, gf / td2, tw2, gf / tw2)
         tot["fprop"] += tf * cnt
