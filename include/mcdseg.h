@@ -86,6 +86,12 @@ int mcdseg_absmax(const float* x, int64_t n, float* bound, void* stream);
 /* w [Cout,Cin,KH,KW] -> fprop and/or dgrad image; F16X3 first measures w_bound = max |w| (device float, written here) */
 int mcdseg_conv_split_pack_weights(const mcdseg_conv_desc* d, int32_t math, const float* w, void* wp_fprop, void* wp_dgrad,
                                    float* w_bound, void* stream);
+/* The same for n convolutions in two launches (every image of a model after an optimizer step).  Device tables: ptrs[4*e ..] =
+ * {w, wp_fprop or 0, wp_dgrad or 0, &bounds[e]} as 64-bit addresses, dims[4*e ..] = {Cout, Cin, KH*KW, 0}; bounds: n device
+ * floats, written here (F16X3; may be NULL for BF16X6, the table's bound addresses are then ignored).  The stem's direct-kernel
+ * forward image is not produced by this call (pass 0 for it and use mcdseg_conv_split_pack_weights). */
+int mcdseg_conv_split_pack_weights_multi(const int64_t* ptrs, const int32_t* dims, int32_t n, int32_t math, float* bounds,
+                                         void* stream);
 /* x_cb / dy_cb (may be NULL): the gathered operand already split by its producer into the channel-blocked layout
  * [piece][N][C/8][H*W][8 x 16 bit] (mcdseg_bn_apply_cb / mcdseg_bn_bwd_apply_cb / mcdseg_split_cb, same `math` and the same
  * bound scalar); C must be divisible by 8.  With it the K loop does no conversion and moves 16 B per piece, pixel and

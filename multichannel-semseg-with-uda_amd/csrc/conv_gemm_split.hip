@@ -382,24 +382,36 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
     __syncthreads();
   }
 
-  auto mfma_step = [&](int cur) {
+  frag fa[NP][WM], fb[NP][WN];
+  auto read_frags = [&](int cur) {
     const unsigned char* a_base = As + cur * A_BYTES + (lh * BM + wm * (32 * WM) + l31) * 16;
     const unsigned char* b_base = Bs + cur * B_BYTES + (lh * BN + wn * (32 * WN) + l31) * 16;
-    frag a[NP][WM], b[NP][WN];
 #pragma unroll
     for (int pc = 0; pc < NP; ++pc) {
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[pc][i] = *reinterpret_cast<const frag*>(a_base + (pc * 2 * BM + i * 32) * 16);
+      for (int i = 0; i < WM; ++i) fa[pc][i] = *reinterpret_cast<const frag*>(a_base + (pc * 2 * BM + i * 32) * 16);
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[pc][j] = *reinterpret_cast<const frag*>(b_base + (pc * 2 * BN + j * 32) * 16);
+      for (int j = 0; j < WN; ++j) fb[pc][j] = *reinterpret_cast<const frag*>(b_base + (pc * 2 * BN + j * 32) * 16);
     }
+  };
+  auto mfma_frags = [&]() {
+#if defined(MCD_SETPRIO)
+    __builtin_amdgcn_s_setprio(1);
+#endif
     // the policy's cross terms, smallest first
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int tm = 0; tm < P::NTERMS; ++tm) acc[i][j] = P::mfma(a[P::TA[tm]][i], b[P::TB[tm]][j], acc[i][j]);
+        for (int tm = 0; tm < P::NTERMS; ++tm) acc[i][j] = P::mfma(fa[P::TA[tm]][i], fb[P::TB[tm]][j], acc[i][j]);
+#if defined(MCD_SETPRIO)
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  };
+  auto mfma_step = [&](int cur) {
+    read_frags(cur);
+    mfma_frags();
   };
   // one K-step s (cur = s & 1): gathers of step s+2 go to the register set that step s just vacated, the weight slab of
   // step s+1 is DMA'd into the LDS buffer released by the previous barrier, MFMAs of step s, then step s+1's gathers
@@ -466,12 +478,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
     int cur = 0, nxt2 = 2;
     for (int s = 0; s < nsteps; ++s) {
       const bool more2 = s + 2 < nsteps;
+      // fragment reads go out first -- right behind the barrier -- and the loader's scalar bookkeeping and DMA issue
+      // run while they are in flight; the matrix instructions follow
+#if defined(MCD_ABLATE) && (MCD_ABLATE & 4)
+      if (s == 0)
+#endif
+      read_frags(cur);
+      __builtin_amdgcn_sched_barrier(0);
       if (more2) {  // both operands of step s+2 -> the stage the barrier below step s-1 released
         advance();
+#if !defined(MCD_ABLATE) || !(MCD_ABLATE & 1)  // MCD_ABLATE: timing-only variant builds (tools/build_variant.py), never shipped
         dma_weights(nxt2);
+#endif
+#if !defined(MCD_ABLATE) || !(MCD_ABLATE & 2)
         dma_b(nxt2);
+#endif
       }
-      mfma_step(cur);
+      __builtin_amdgcn_sched_barrier(0);
+#if !defined(MCD_ABLATE) || !(MCD_ABLATE & 8)
+      mfma_frags();
+#endif
       // step s+1 must have landed before the next iteration; the DMAs of step s+2 (younger) stay in flight
       if (more2)
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DMA_PER_STEP) : "memory");
@@ -661,6 +687,59 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
 }
 
+// ---- all convolutions of a model in two launches (one optimizer step re-packs every image): entry e of the device tables is
+// ptrs[e] = {w, out_fprop, out_dgrad, bound}, dims[e] = {Cout, Cin, T, 0}; blockIdx.y = entry (absmax) or 2 * entry + mode (pack)
+__global__ __launch_bounds__(256) void absmax_multi_kernel(const int64_t* __restrict__ ptrs, const int32_t* __restrict__ dims) {
+  const int e = blockIdx.y;
+  const float* __restrict__ x = reinterpret_cast<const float*>(ptrs[4 * e + 0]);
+  unsigned* __restrict__ out = reinterpret_cast<unsigned*>(ptrs[4 * e + 3]);
+  const int64_t n = (int64_t)dims[4 * e + 0] * dims[4 * e + 1] * dims[4 * e + 2];
+  unsigned m = 0u;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned b = __float_as_uint(x[i]) & 0x7FFFFFFFu;
+    m = b > m ? b : m;
+  }
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_xor(m, o);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* __restrict__ ptrs, const int32_t* __restrict__ dims) {
+  constexpr int NP = P::NP;
+  const int e = blockIdx.y >> 1, mode = blockIdx.y & 1;
+  const float* __restrict__ w = reinterpret_cast<const float*>(ptrs[4 * e + 0]);
+  typename P::elem* __restrict__ out = reinterpret_cast<typename P::elem*>(ptrs[4 * e + 1 + mode]);
+  if (out == nullptr) return;
+  const float inv_scale = 1.f / operand_scale<P>(reinterpret_cast<const float*>(ptrs[4 * e + 3]));
+  const int Cout = dims[4 * e + 0], Cin = dims[4 * e + 1], T = dims[4 * e + 2];
+  const int M = mode == 0 ? Cout : Cin;
+  const int K = mode == 0 ? Cin : Cout;
+  const int Mp = M <= 32 ? 32 : (M <= 64 ? 64 : ((M + 127) / 128) * 128);  // mcd_mp
+  const int Kp = ((K + 15) / 16) * 16;
+  const int64_t total = (int64_t)(Kp / 16) * T * 2 * Mp * 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int el = (int)(i & 7);
+    int64_t r = i >> 3;
+    const int m = (int)(r % Mp);
+    r /= Mp;
+    const int h = (int)(r & 1);
+    const int64_t kstep = r >> 1;
+    const int tap = (int)(kstep % T);
+    const int chunk = (int)(kstep / T);
+    const int k = chunk * 16 + 8 * h + el;
+    float v = 0.f;
+    if (m < M && k < K) v = mode == 0 ? w[((int64_t)m * Cin + k) * T + tap] : w[((int64_t)k * Cin + m) * T + tap];
+    typename P::elem q[NP];
+    P::split(v, inv_scale, q);
+    const int64_t base = kstep * (2 * NP) * (int64_t)Mp * 8;
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) out[base + ((pc * 2 + h) * (int64_t)Mp + m) * 8 + el] = q[pc];
+  }
+}
+
 int split_check(const mcdseg_conv_desc* d, int math, const char* who) {
   MCD_REQUIRE(d != nullptr, "%s: null descriptor", who);
   MCD_REQUIRE(math == MCDSEG_MATH_BF16X6 || math == MCDSEG_MATH_F16X3, "%s: math must be MCDSEG_MATH_BF16X6 or MCDSEG_MATH_F16X3 (got %d)", who, math);
@@ -809,6 +888,24 @@ extern "C" int mcdseg_conv_split_pack_weights(const mcdseg_conv_desc* d, int32_t
     hipLaunchKernelGGL(pack_weights_split_kernel<SplitBf16x6>, dim3((unsigned)blocks, 2), dim3(256), 0, st, w, (__bf16*)wp_fprop,
                        (__bf16*)wp_dgrad, (const float*)nullptr, d->Cout, d->Cin, T);
   MCD_LAUNCH_CHECK("conv_split_pack_weights");
+  return 0;
+}
+
+extern "C" int mcdseg_conv_split_pack_weights_multi(const int64_t* ptrs, const int32_t* dims, int32_t n, int32_t math, float* bounds,
+                                                    void* stream) {
+  MCD_REQUIRE(ptrs && dims && n > 0 && n <= 32767, "conv_split_pack_weights_multi: bad table");
+  MCD_REQUIRE(math == MCDSEG_MATH_BF16X6 || math == MCDSEG_MATH_F16X3, "conv_split_pack_weights_multi: unknown math %d", math);
+  MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || bounds != nullptr, "conv_split_pack_weights_multi: f16x3 needs the bounds array");
+  hipStream_t st = (hipStream_t)stream;
+  if (math == MCDSEG_MATH_F16X3) {
+    (void)hipMemsetAsync(bounds, 0, sizeof(float) * (size_t)n, st);
+    hipLaunchKernelGGL(absmax_multi_kernel, dim3(16, (unsigned)n), dim3(256), 0, st, ptrs, dims);
+    MCD_LAUNCH_CHECK("absmax_multi");
+    hipLaunchKernelGGL(pack_weights_multi_kernel<SplitF16x3>, dim3(48, 2u * (unsigned)n), dim3(256), 0, st, ptrs, dims);
+  } else {
+    hipLaunchKernelGGL(pack_weights_multi_kernel<SplitBf16x6>, dim3(48, 2u * (unsigned)n), dim3(256), 0, st, ptrs, dims);
+  }
+  MCD_LAUNCH_CHECK("conv_split_pack_weights_multi");
   return 0;
 }
 

@@ -10,6 +10,7 @@
 // split into 16-bit pieces and lands as one 32-bit word in the fragment image [piece][k-half][row][8 x 16 bit], which the
 // MFMA lanes read back as ds_read_b128 over 512 contiguous bytes per half-wave.  Slabs + fixed-order fp64 reduce
 // as in conv_wgrad.hip (same plan, same workspace).
+#include <cstdlib>
 #include "split.h"
 
 namespace {
@@ -381,6 +382,233 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_split_cb_kernel(WgradCbPara
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pre-split operands, all-DMA variant (two-piece policies): the register transposition above is replaced by gfx950's
+// transposing LDS read.  The operands stay in LDS exactly as they sit in memory -- 16-B units of 8 channels x 1 pixel --
+// deposited by LDS-DMA (buffer_load ... lds: no staging registers, no v_perm, no ds_write), and the MFMA fragments (8 pixels
+// of one channel per lane) are formed by ds_read_b64_tr_b16: per 16-lane group it reads a block of 4 rows (pixels) x 16
+// columns (channels) and hands lane i column i -- the transpose is free.
+//
+// Stage = one 8 x R pixel tile of the output image = 2R quads of 4 consecutive pixels (quad j: row j % R, column half j / R);
+// one DMA instruction moves one quad of 128 channels of one (operand, piece): lane = (channel group cg = lane >> 2, pixel
+// ps = lane & 3), i.e. 16 runs of 64 contiguous bytes, and lands lane-linear as [cg 16][pixel 4][16 B] = 1 KB.  Everything
+// about a DMA except the lane part is wave-uniform (tile, tap shift, padding rows via an out-of-range SGPR offset, padding
+// columns / ragged channel groups via an out-of-range VGPR offset: the DMA deposits zeros).  MFMA lane (row l31, k-half lh)
+// takes quads 4 kk + 2 lh and 4 kk + 2 lh + 1 of k-block kk; which pixel sits in which k slot is irrelevant as long as dY and
+// X agree.  Transposed-read addresses of a 32-lane half cover 256 contiguous bytes: conflict-free.
+//
+//   <WM = 2, R = 4, NSTAGE = 2>   128 (co) x 128 (ci) tile, 32-pixel stages of 32 KB, two stages
+//   <WM = 4, R = 2, NSTAGE = 3>   256 (co) x 128 (ci) tile (each wave 128 x 64), 16-pixel stages of 24 KB, three stages: the
+//                                 DMAs of tile s+2 fly while tile s multiplies -- the structure of the forward kernel's
+//                                 256 x 128 configuration, for the layers with Cout a multiple of 256
+template <class P, int WM, int R, int NSTAGE>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr_kernel(WgradCbParams p) {
+  static_assert(P::NP == 2, "two-piece policies");
+  constexpr int WN = 2, WAVES_N = 2;
+  constexpr int BM = 64 * WM, BN = 128;
+  constexpr int NP = P::NP;
+  constexpr int NQD = 2 * R;                 // quads per stage
+  constexpr int KK = NQD / 4;                // K = 16 blocks per stage
+  constexpr int AB = BM / 128;               // 128-channel blocks of the dY tile
+  typedef typename P::frag frag;
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  constexpr int QUAD = 1024;                 // bytes one DMA instruction deposits: [cg 16][pixel 4][16 B]
+  constexpr int A_UNIT = NQD * AB * QUAD;    // one piece of the dY tile: [quad][cg 16 AB][pixel 4][16 B]
+  constexpr int B_UNIT = NQD * QUAD;
+  constexpr int STAGE = NP * (A_UNIT + B_UNIT);
+  static_assert(NSTAGE * STAGE <= 80 * 1024, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int ci_tiles = p.ci_p / BN;
+  const int co_tiles = p.co_p / BM;
+  const int T_ = p.KH * p.KW;
+  const int per_split = co_tiles * ci_tiles * T_;
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int split = (slot / per_split) * 8 + xcd;
+  if (split >= p.splits) return;
+  int rem = slot % per_split;
+  const int tap = rem % T_;
+  rem /= T_;
+  const int tile_ci = rem % ci_tiles;
+  const int tile_co = rem / ci_tiles;
+  const int n = split / p.chunks_per_img;
+  const int chunk_id = split - n * p.chunks_per_img;
+  const int ky = tap / p.KW;
+  const int kx = tap - ky * p.KW;
+  const int ntiles = p.tiles_x * p.tiles_y;
+  const int t_begin = chunk_id * p.tiles_per_chunk;
+  int t_end = t_begin + p.tiles_per_chunk;
+  if (t_end > ntiles) t_end = ntiles;
+
+  // ---- DMA role of this wave: (operand, piece), wave-uniform (operand 0 = dY rows, 1 = X rows)
+  const int opnd = wave >> 1;
+  const int piece = wave & 1;
+  const int ps = lane & 3;
+  const int cg = lane >> 2;
+  const int sH = opnd ? p.H : p.Ho;
+  const int sW = opnd ? p.W : p.Wo;
+  const int sS = opnd ? p.stride : 1;
+  const int shy = opnd ? ky * p.dil - p.pad : 0;
+  const int shx = opnd ? kx * p.dil - p.pad : 0;
+  const int sC8 = (opnd ? p.Cin : p.Cout) >> 3;
+  const int cg0 = opnd ? tile_ci * 16 : tile_co * (16 * AB);  // first channel group of the tile
+  const int nblk = opnd ? 1 : AB;                              // 128-channel blocks this wave moves per quad
+  const int sHW = sH * sW;
+  const int pstride = p.N * sC8 * sHW;  // 16-B units between pieces
+  // the descriptor starts `bias` bytes below the tensor so that the SGPR offset (tile + tap shift) is never negative
+  const int bias = p.pad * 16 + 16;
+  const char* sptr = (const char*)(opnd ? p.x_cb : p.dy_cb) - bias;
+  const int sbytes = (opnd ? p.x_cb_bytes : p.dy_cb_bytes) + bias;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sptr, 0, sbytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned vconst[AB];
+#pragma unroll
+  for (int b = 0; b < AB; ++b) vconst[b] = (cg0 + 16 * b + cg) < sC8 ? (unsigned)((16 * b + cg) * sHW + ps * sS) * 16u : OOB;
+  const int sbase = (n * sC8 + cg0) * sHW + piece * pstride;  // 16-B units
+  const int lane_x = ps * sS;
+  unsigned char* const unit_lds = smem + (opnd ? NP * A_UNIT + piece * B_UNIT : piece * A_UNIT);
+
+  auto issue_dma = [&](int tt, int stage) {
+    const int ty = tt / p.tiles_x;
+    const int tx = tt - ty * p.tiles_x;
+    bool colok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ux = (tx * 8 + 4 * h) * sS + shx;  // uniform
+      colok[h] = (unsigned)(ux + lane_x) < (unsigned)sW;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int j = 0; j < NQD; ++j) {  // quad j: row j % R of the tile, column half j / R
+      const int h = j / R;
+      const int iy = (ty * R + (j % R)) * sS + shy;
+      const int ux = (tx * 8 + 4 * h) * sS + shx;
+      const int soff = ((unsigned)iy < (unsigned)sH) ? (sbase + iy * sW + ux) * 16 + bias : 0x7FFFFFFF;
+#pragma unroll
+      for (int b = 0; b < AB; ++b)
+        if (b < nblk)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              rs, (__attribute__((address_space(3))) void*)(unit_lds + stage * STAGE + (j * (opnd ? 1 : AB) + b) * QUAD), 16,
+              colok[h] ? vconst[b] : OOB, soff, 0, 0);
+    }
+#else
+    (void)colok;
+    (void)stage;
+#endif
+  };
+  // number of DMA instructions this wave issues per stage (wave-uniform): the counted wait below leaves one stage in flight
+  const int dma_per_stage = NQD * nblk;
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposed-read address of this lane inside a (piece, quad) image, for the 32-row block i of the wave's rows:
+  // 16-lane group g = lane >> 4 covers rows 16 (g & 1) .. +15; lane 4q + pp of the group supplies pixel q, channels 4 pp .. 4 pp + 3
+  const int gl = lane & 15;
+  const int tq = gl >> 2, tpp = gl & 3;
+  const int trow = ((((lane >> 4) & 1) * 2 + (tpp >> 1)) * 4 + tq) * 16 + 8 * (tpp & 1);
+  const int a_lane = (wm * 4 * WM) * 64 + trow;  // the wave's first channel group: 4 WM groups per wave
+  const int b_lane = (wn * 4 * WN) * 64 + trow;
+
+  auto tr_read = [&](const unsigned char* addr) -> s16x4 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(addr));
+#else
+    (void)addr;
+    return s16x4{};
+#endif
+  };
+  auto load_frag = [&](const unsigned char* unit, int quad_bytes, int quad0, int lane_off, int i) -> frag {
+    const s16x4 lo = tr_read(unit + quad0 * quad_bytes + lane_off + i * 256);
+    const s16x4 hi = tr_read(unit + (quad0 + 1) * quad_bytes + lane_off + i * 256);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(frag, v);
+  };
+  frag fa[NP][WM], fb[NP][WN];
+  auto read_frags = [&](const unsigned char* st, int kk) {
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) fa[pc][i] = load_frag(st + pc * A_UNIT, AB * QUAD, 4 * kk + 2 * lh, a_lane, i);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) fb[pc][j] = load_frag(st + NP * A_UNIT + pc * B_UNIT, QUAD, 4 * kk + 2 * lh, b_lane, j);
+    }
+  };
+  auto mfma_frags = [&]() {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int tm = 0; tm < P::NTERMS; ++tm) acc[i][j] = P::mfma(fa[P::TA[tm]][i], fb[P::TB[tm]][j], acc[i][j]);
+  };
+  // wait until at most `left` of this wave's DMAs are outstanding (left is wave-uniform: 0, NQD or NQD * AB), then barrier
+  auto wait_barrier = [&](int left) {
+    if (left == 0)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (left == NQD)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NQD) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NQD * AB) : "memory");
+  };
+
+  const int nsteps = t_end - t_begin;
+  if (nsteps > 0) issue_dma(t_begin, 0);
+  if (NSTAGE == 3 && nsteps > 1) {
+    issue_dma(t_begin + 1, 1);
+    wait_barrier(dma_per_stage);
+  } else {
+    wait_barrier(0);
+  }
+  int cur = 0, nxt = NSTAGE - 1;
+  for (int s = 0; s < nsteps; ++s) {
+    const unsigned char* st = smem + cur * STAGE;
+    const bool more = s + (NSTAGE - 1) < nsteps;
+    // k-block 0 fragments first (right behind the barrier), then the DMAs of the tile NSTAGE-1 ahead, then the matrix instructions
+    read_frags(st, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) issue_dma(t_begin + s + (NSTAGE - 1), nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_frags();
+#pragma unroll
+    for (int kk = 1; kk < KK; ++kk) {
+      read_frags(st, kk);
+      mfma_frags();
+    }
+    // NSTAGE = 3: tile s+1 must have landed, the DMAs of tile s+2 (younger) stay in flight; NSTAGE = 2: everything
+    wait_barrier((NSTAGE == 3 && more) ? dma_per_stage : 0);
+    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+  }
+
+  float* out = p.slab + ((size_t)split * T_ + tap) * p.co_p * p.ci_p;
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tile_co * BM + wm * (32 * WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int col = tile_ci * BN + wn * 64 + j * 32 + l31;
+        out[(size_t)row * p.ci_p + col] = acc[i][j][r];
+      }
+    }
+}
+
 }  // namespace
 
 // launched by wgrad_impl (conv_wgrad.hip) when the 128x128 plan applies and a split arithmetic is requested
@@ -418,8 +646,22 @@ int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, c
   p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.Ho = d->Ho; p.Wo = d->Wo;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
   p.co_p = co_p; p.ci_p = ci_p; p.chunks_per_img = chunks_per_img; p.splits = splits;
+  static const bool use_tr = [] {
+    const char* e = getenv("MCDSEG_WGRAD_TR");  // development knob: 0 = register-transposing kernel for the two-piece policy too
+    return e == nullptr || atoi(e) != 0;
+  }();
+  static const bool use_big = [] {
+    const char* e = getenv("MCDSEG_WGRAD_BIG");  // development knob: 0 = 128 x 128 tiles only
+    return e == nullptr || atoi(e) != 0;
+  }();
+  // 256 x 128 tiles (16-pixel stages) for the layers whose padded Cout is a multiple of 256 -- the plan was made for 128-row
+  // tiles, so the number of workgroups halves; taken only while that still fills the chip twice over
+  const bool tr = math == MCDSEG_MATH_F16X3 && use_tr;
+  const bool big = tr && use_big && (co_p % 256) == 0 &&
+                   (int64_t)(co_p / 256) * (ci_p / 128) * d->KH * d->KW * splits >= 1024;
+  const int rows = big ? 2 : 4;  // pixel rows of a stage tile
   p.tiles_x = ceil_div(d->Wo, 8);
-  p.tiles_y = ceil_div(d->Ho, 4);
+  p.tiles_y = ceil_div(d->Ho, rows);
   p.tiles_per_chunk = ceil_div(p.tiles_x * p.tiles_y, chunks_per_img);
   const int64_t np = mcd_math_pieces(math);
   const int64_t xb = np * d->N * d->Cin * d->H * d->W * 2, yb = np * d->N * d->Cout * d->Ho * d->Wo * 2;
@@ -429,13 +671,17 @@ int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, c
   }
   p.x_cb_bytes = (int)xb;
   p.dy_cb_bytes = (int)yb;
-  const int64_t per_split = (int64_t)(co_p / 128) * (ci_p / 128) * d->KH * d->KW;
+  const int64_t per_split = (int64_t)(co_p / (big ? 256 : 128)) * (ci_p / 128) * d->KH * d->KW;
   const int64_t nwg = 8 * ceil_div64(splits, 8) * per_split;
   if (nwg >= (1ll << 31)) {
     mcdseg_set_error("conv_wgrad_split: grid too large");
     return -22;
   }
-  if (math == MCDSEG_MATH_F16X3)
+  if (big)
+    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x3, 4, 2, 3>), dim3((unsigned)nwg), dim3(256), 0, st, p);
+  else if (tr)
+    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x3, 2, 4, 2>), dim3((unsigned)nwg), dim3(256), 0, st, p);
+  else if (math == MCDSEG_MATH_F16X3)
     hipLaunchKernelGGL(conv_wgrad_split_cb_kernel<SplitF16x3>, dim3((unsigned)nwg), dim3(256), 0, st, p);
   else
     hipLaunchKernelGGL(conv_wgrad_split_cb_kernel<SplitBf16x6>, dim3((unsigned)nwg), dim3(256), 0, st, p);

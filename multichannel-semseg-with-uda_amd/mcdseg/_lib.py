@@ -10,7 +10,8 @@ PKG = os.path.dirname(HERE)
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(REPO, "include")
-LIB_PATH = os.path.join(HERE, "libmcdseg.so")
+# MCDSEG_LIB: load another build of the library (kernel development: A/B variants built with tools/build_variant.py)
+LIB_PATH = os.environ.get("MCDSEG_LIB") or os.path.join(HERE, "libmcdseg.so")
 
 c_void_p, c_int, c_i32, c_i64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64,
                                                     ctypes.c_float, ctypes.c_size_t)
@@ -39,6 +40,7 @@ _SIGNATURES = {
     "mcdseg_absmax": (c_int, [c_void_p, c_i64, c_void_p, c_void_p]),
     "mcdseg_conv_split_packed_bytes": (c_int, [_P(ConvDesc), c_i32, _P(c_i64), _P(c_i64)]),
     "mcdseg_conv_split_pack_weights": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 5),
+    "mcdseg_conv_split_pack_weights_multi": (c_int, [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p]),
     "mcdseg_conv_split_fprop": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 9),
     "mcdseg_conv_split_fprop_affine": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 8 + [c_i32, c_void_p, c_void_p]),
     "mcdseg_conv_split_dgrad": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 7),

@@ -13,6 +13,7 @@ mirror the ATen call sites of the reference's hot path:
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -170,9 +171,17 @@ def _bound_or_measure(x, bound):
     return b
 
 
+_PACK_REGISTRY = weakref.WeakSet()   # every PackedWeights alive
+_PACK_TABLES = {}                    # (device, math) -> cached device tables of the last group pack
+GROUP_PACK = os.environ.get("MCDSEG_GROUP_PACK", "1") != "0"
+
+
 class PackedWeights:
     """GEMM images of one conv kernel, refreshed when the parameter changes.  ``wf`` / ``wd``: forward / data-gradient image
-    (fp32 for the f32 kernels, 16-bit pieces for the split kernels); ``w_bound``: device scalar max |w| (f16x3)."""
+    (fp32 for the f32 kernels, 16-bit pieces for the split kernels); ``w_bound``: device scalar max |w| (f16x3).
+
+    An optimizer step invalidates every image of the model at once, so the first stale ``get`` of a forward pass re-packs ALL
+    known convolutions of that device in two launches (``mcdseg_conv_split_pack_weights_multi``) instead of ~3 per conv."""
 
     def __init__(self):
         self.key = None
@@ -180,41 +189,100 @@ class PackedWeights:
         self.wd = None
         self.w_bound = None
         self.mpf = 0
+        self._weight = None   # weakref to the parameter, for group packs
+        self._dims = None     # (Cout, Cin, taps, direct-stem?, math)
+        _PACK_REGISTRY.add(self)
+
+    @staticmethod
+    def _key_of(weight):
+        return (weight.data_ptr(), weight._version, WEIGHT_EPOCH, weight.device, CONV_MATH)
 
     def get(self, weight, desc, need_dgrad=True):
-        key = (weight.data_ptr(), weight._version, WEIGHT_EPOCH, weight.device, CONV_MATH)
+        key = self._key_of(weight)
         if key != self.key or (need_dgrad and self.wd is None):
-            L = lib()
-            mpf, kpf, mpd, kpd = (ctypes.c_int32() for _ in range(4))
-            check(L.mcdseg_conv_packed_dims(ctypes.byref(desc), mpf, kpf, mpd, kpd), "conv_packed_dims")
-            taps = desc.KH * desc.KW
-            w = _req(weight.detach(), "conv weight")
-            dev = w.device
-            fsp, dsp = _use_split(desc.Cin), _use_split(desc.Cout)
-            if STEM_DIRECT and CONV_MATH in MATH_ID and L.mcdseg_conv_split_direct_ok(ctypes.byref(desc)):
-                fsp = True  # the stem: direct convolution on the split path although it contracts < 16 channels
-            # f32 images (kept for whichever direction does not run on the split path)
-            self.wf = None if fsp else torch.empty(taps * kpf.value * mpf.value, dtype=torch.float32, device=dev)
-            self.wd = None if dsp else torch.empty(taps * kpd.value * mpd.value, dtype=torch.float32, device=dev)
-            if self.wf is not None or self.wd is not None:
-                check(L.mcdseg_conv_pack_weights(ctypes.byref(desc), _p(w), _p(self.wf), _p(self.wd), _stream()), "conv_pack_weights")
-            if fsp or dsp:
-                mid = MATH_ID[CONV_MATH]
-                fb, db = ctypes.c_int64(), ctypes.c_int64()
-                check(L.mcdseg_conv_split_packed_bytes(ctypes.byref(desc), mid, fb, db), "conv_split_packed_bytes")
-                if fsp:
-                    self.wf = torch.empty(fb.value // 2, dtype=torch.int16, device=dev)
-                if dsp:
-                    self.wd = torch.empty(db.value // 2, dtype=torch.int16, device=dev)
-                if _scaled() and self.w_bound is None:
-                    self.w_bound = torch.empty(1, dtype=torch.float32, device=dev)
-                with _timed("pack_weights_split_kernel", (0, 4 * w.numel() + (fb.value if fsp else 0) + (db.value if dsp else 0))):
-                    check(L.mcdseg_conv_split_pack_weights(ctypes.byref(desc), mid, _p(w), _p(self.wf) if fsp else None,
-                                                           _p(self.wd) if dsp else None, _p(self.w_bound) if _scaled() else None,
-                                                           _stream()), "conv_split_pack_weights")
-            self.mpf = mpf.value
-            self.key = key
+            if GROUP_PACK and self._dims is not None and self.wd is not None and self._dims[4] == CONV_MATH:
+                _pack_group(weight.device)
+            if self._key_of(weight) != self.key or (need_dgrad and self.wd is None):
+                self._pack_single(weight, desc)
         return self.wf, self.wd, self.mpf
+
+    def _pack_single(self, weight, desc):
+        L = lib()
+        mpf, kpf, mpd, kpd = (ctypes.c_int32() for _ in range(4))
+        check(L.mcdseg_conv_packed_dims(ctypes.byref(desc), mpf, kpf, mpd, kpd), "conv_packed_dims")
+        taps = desc.KH * desc.KW
+        w = _req(weight.detach(), "conv weight")
+        dev = w.device
+        fsp, dsp = _use_split(desc.Cin), _use_split(desc.Cout)
+        direct = STEM_DIRECT and CONV_MATH in MATH_ID and bool(L.mcdseg_conv_split_direct_ok(ctypes.byref(desc)))
+        if direct:
+            fsp = True  # the stem: direct convolution on the split path although it contracts < 16 channels
+        # f32 images (kept for whichever direction does not run on the split path)
+        self.wf = None if fsp else torch.empty(taps * kpf.value * mpf.value, dtype=torch.float32, device=dev)
+        self.wd = None if dsp else torch.empty(taps * kpd.value * mpd.value, dtype=torch.float32, device=dev)
+        if self.wf is not None or self.wd is not None:
+            check(L.mcdseg_conv_pack_weights(ctypes.byref(desc), _p(w), _p(self.wf), _p(self.wd), _stream()), "conv_pack_weights")
+        self._dims = None
+        if fsp or dsp:
+            mid = MATH_ID[CONV_MATH]
+            fb, db = ctypes.c_int64(), ctypes.c_int64()
+            check(L.mcdseg_conv_split_packed_bytes(ctypes.byref(desc), mid, fb, db), "conv_split_packed_bytes")
+            if fsp:
+                self.wf = torch.empty(fb.value // 2, dtype=torch.int16, device=dev)
+            if dsp:
+                self.wd = torch.empty(db.value // 2, dtype=torch.int16, device=dev)
+            if _scaled() and self.w_bound is None:
+                self.w_bound = torch.empty(1, dtype=torch.float32, device=dev)
+            with _timed("pack_weights_split_kernel", (0, 4 * w.numel() + (fb.value if fsp else 0) + (db.value if dsp else 0))):
+                check(L.mcdseg_conv_split_pack_weights(ctypes.byref(desc), mid, _p(w), _p(self.wf) if fsp else None,
+                                                       _p(self.wd) if dsp else None, _p(self.w_bound) if _scaled() else None,
+                                                       _stream()), "conv_split_pack_weights")
+            if fsp and dsp:  # both images on the split path: eligible for the group pack from now on
+                self._weight = weakref.ref(weight)
+                self._dims = (desc.Cout, desc.Cin, taps, direct, CONV_MATH)
+        self.mpf = mpf.value
+        self.key = self._key_of(weight)
+
+
+def _pack_group(device):
+    """re-pack every known split-path convolution on ``device`` whose image is stale: one table-driven absmax launch and one
+    table-driven pack launch (plus the stem's own forward image)"""
+    L = lib()
+    members = []
+    for pw in list(_PACK_REGISTRY):
+        w = pw._weight() if pw._weight is not None else None
+        if w is None or pw._dims is None or pw._dims[4] != CONV_MATH or w.device != device or pw.wd is None or pw.wf is None:
+            continue
+        members.append((pw, w))
+    if len(members) < 2:
+        return
+    members.sort(key=lambda m: m[1].data_ptr())
+    sig = tuple((w.data_ptr(), pw.wf.data_ptr(), pw.wd.data_ptr()) + pw._dims for pw, w in members)
+    tab = _PACK_TABLES.get((device, CONV_MATH))
+    if tab is None or tab["sig"] != sig:
+        n = len(members)
+        bounds = torch.zeros(n, dtype=torch.float32, device=device)
+        ptrs, dims = [], []
+        for i, (pw, w) in enumerate(members):
+            ptrs += [w.data_ptr(), 0 if pw._dims[3] else pw.wf.data_ptr(), pw.wd.data_ptr(), bounds.data_ptr() + 4 * i]
+            dims += [pw._dims[0], pw._dims[1], pw._dims[2], 0]
+        tab = dict(sig=sig, bounds=bounds, ptrs=torch.tensor(ptrs, dtype=torch.int64).to(device),
+                   dims=torch.tensor(dims, dtype=torch.int32).to(device))
+        _PACK_TABLES[(device, CONV_MATH)] = tab
+    if _scaled():
+        for i, (pw, _) in enumerate(members):
+            pw.w_bound = tab["bounds"][i:i + 1]
+    n = len(members)
+    nbytes = sum(4 * w.numel() + 2 * pw.wf.numel() + 2 * pw.wd.numel() for pw, w in members)
+    with _timed("pack_weights_multi_kernel", (0, nbytes)):
+        check(L.mcdseg_conv_split_pack_weights_multi(_p(tab["ptrs"]), _p(tab["dims"]), n, MATH_ID[CONV_MATH],
+                                                     _p(tab["bounds"]) if _scaled() else None, _stream()), "conv_split_pack_weights_multi")
+    for pw, w in members:
+        if pw._dims[3]:  # the stem's direct-kernel forward image has its own layout
+            d = ConvDesc(1, pw._dims[1], 8, 8, pw._dims[0], 7, 7, 1, 3, 1, 8, 8)
+            check(L.mcdseg_conv_split_pack_weights(ctypes.byref(d), MATH_ID[CONV_MATH], _p(w.detach()), _p(pw.wf), None,
+                                                   _p(pw.w_bound) if _scaled() else None, _stream()), "conv_split_pack_weights")
+        pw.key = PackedWeights._key_of(w)
 
 
 def _is_split(w_image):

@@ -651,6 +651,7 @@ def test_conv_nonfinite_operands():
     desc = ops.conv_desc(x.shape, wt.shape, 1, pad, d)
     pk = ops.PackedWeights()
     wf, wd, mpf = pk.get(wt.to(dev), desc)
+    x[0, 9, 6, 1] = 0.0  # the position that will hold the denormal
     clean, _, _ = ops._conv_fprop(desc, x.to(dev), wf, None, False, mpf, w_bound=pk.w_bound)
     xb = x.clone()
     xb[0, 5, 2, 3] = float("inf")

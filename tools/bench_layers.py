@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--math", default=None, help="f32 | bf16x6 | f16x3")
+    ap.add_argument("--hw", type=int, nargs=2, default=None, help="override the feature-map size of every selected layer (tile-count experiments)")
     args = ap.parse_args()
     if args.math:
         ops.CONV_MATH = args.math
@@ -62,6 +63,8 @@ def main():
         if args.only and args.only not in name:
             continue
         pad = d * (k // 2)
+        if args.hw:
+            h, w = args.hw
         x = torch.randn(n, cin, h, w, device=dev)
         wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
         desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
