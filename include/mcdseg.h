@@ -146,24 +146,29 @@ int mcdseg_bn_apply(const float* z, const float* mean, const float* rstd, const 
  * scale from the bound scalar for MCDSEG_MATH_F16X3; NULL for BF16X6) in the channel-blocked layout
  * [piece][N][C/8][HW][8 x 16 bit] consumed by the split convolutions; C must be divisible by 8.  mcdseg_bn_bwd_apply_cb
  * accepts dz == NULL (only the split companion is written) for layers whose input and weight gradients both read the
- * companion.  mcdseg_split_cb is the split alone (fp32 NCHW -> companion) for operands no fused BN group produced. */
+ * companion.  mcdseg_split_cb is the split alone (fp32 NCHW -> companion) for operands no fused BN group produced,
+ * mcdseg_unsplit_cb its inverse (value = scale * sum of the pieces: exact for BF16X6, the 22 leading bits for F16X3).
+ * Compact activation storage (the fp32 activation is never written; what travels is the companion): mcdseg_bn_apply_cb accepts
+ * y == NULL and the residual as a companion (res_cb, res_bound) instead of fp32; the backward kernels accept y == NULL with y_cb,
+ * reading the ReLU mask from the companion's leading piece. */
 int mcdseg_split_cb(const float* x, void* x_cb, const float* x_bound, int32_t math, int32_t N, int32_t C, int32_t HW, void* stream);
+int mcdseg_unsplit_cb(const void* x_cb, const float* x_bound, int32_t math, int32_t N, int32_t C, int32_t HW, float* x, void* stream);
 int mcdseg_bn_apply_cb(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                       const float* residual, float* y, void* y_cb, const float* y_bound, int32_t math, int32_t N, int32_t C,
-                       int32_t HW, int32_t relu, void* stream);
-int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
+                       const float* residual, const void* res_cb, const float* res_bound, float* y, void* y_cb,
+                       const float* y_bound, int32_t math, int32_t N, int32_t C, int32_t HW, int32_t relu, void* stream);
+int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const void* y_cb, const float* z, const float* mean, const float* rstd,
                            const float* gamma, const float* dgamma, const float* dbeta, float* dz, float* dres,
                            void* dz_cb, const float* dz_bound, int32_t math, int32_t N, int32_t C, int32_t HW, int32_t relu,
                            int32_t train, void* stream);
-/* Backward.  dy is the gradient w.r.t. y; y (the saved forward output) supplies the ReLU mask when
- * relu != 0.  reduce: dgamma[c] = sum dy_m*xhat, dbeta[c] = sum dy_m.  With z == NULL only dbeta is
- * produced (used for the conv bias gradient, models/dilated_fcn.py:227).
+/* Backward.  dy is the gradient w.r.t. y; y (the saved forward output) -- or, when y == NULL, its companion y_cb of
+ * arithmetic `math` -- supplies the ReLU mask when relu != 0.  reduce: dgamma[c] = sum dy_m*xhat, dbeta[c] = sum dy_m.
+ * With z == NULL only dbeta is produced (used for the conv bias gradient, models/dilated_fcn.py:227).
  * dz_bound (may be NULL; needs z and gamma): receives an upper bound of |dz| for the tensor mcdseg_bn_bwd_apply(_cb) will
  * write: max_c |gamma_c rstd_c| (max|dy_m| + |dbeta_c|/n + sqrt(n-1) |dgamma_c|/n) in train mode, max_c |gamma_c rstd_c|
  * max|dy_m| in eval mode (train selects). */
 size_t mcdseg_bn_bwd_workspace_bytes(int32_t N, int32_t C, int32_t HW);
-int mcdseg_bn_bwd_reduce(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
-                         float* dgamma, float* dbeta, const float* gamma, float* dz_bound, int32_t train,
+int mcdseg_bn_bwd_reduce(const float* dy, const float* y, const void* y_cb, int32_t math, const float* z, const float* mean,
+                         const float* rstd, float* dgamma, float* dbeta, const float* gamma, float* dz_bound, int32_t train,
                          int32_t N, int32_t C, int32_t HW, int32_t relu,
                          void* workspace, size_t workspace_bytes, void* stream);
 /* dz = gamma*rstd*(dy_m - dbeta/n - xhat*dgamma/n) (train) or gamma*rstd*dy_m (eval);

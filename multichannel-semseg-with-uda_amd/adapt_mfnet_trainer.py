@@ -87,7 +87,7 @@ def main(argv=None):
     run.sync_replicas([g3, g1, f1, f2])
     # the gated fusions are paired with the probability-input criterion (adapt_mfnet_trainer.py:149)
     criterion = CrossEntropyLoss2d(weight) if "Gate" not in detailed_method else ProbCrossEntropyLoss2d(weight)
-    criterion_d = get_prob_distance_criterion(args.d_loss)
+    criterion_d = get_prob_distance_criterion(args.d_loss, n_class=args.n_class)  # symkl needs the row length (the reference passes none and fails there)
     for m in (g3, g1, f1, f2):
         m.train()
     if args.no_dropout:

@@ -39,7 +39,7 @@ def main(argv=None):
 
     def criteria(a):
         w = get_class_weight_from_file(n_class=a.n_class, weight_filename=a.loss_weights_file, add_bg_loss=a.add_bg_loss)
-        return CrossEntropyLoss2d(w), get_prob_distance_criterion(a.d_loss)
+        return CrossEntropyLoss2d(w), get_prob_distance_criterion(a.d_loss, n_class=a.n_class)
 
     resume_flg = bool(args.resume)
     start_epoch = 0

@@ -119,7 +119,7 @@ def main(argv=None):
     run.sync_replicas([model_g, model_f1, model_f2])
 
     criterion = CrossEntropyLoss2d(weight)
-    criterion_d = get_prob_distance_criterion(args.d_loss)
+    criterion_d = get_prob_distance_criterion(args.d_loss, n_class=args.n_class)  # symkl needs the row length (the reference passes none and fails there)
     for m in (model_g, model_f1, model_f2):
         m.train()
     if args.no_dropout:

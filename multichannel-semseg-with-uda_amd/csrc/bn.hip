@@ -282,32 +282,29 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               float* __restrict__ dbeta, const float* __restrict__ gamma,
                                                               const float* __restrict__ rstd, float n_total, int train,
                                                               float* __restrict__ dz_bound) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  float bound = 0.f;
-  if (c < C) {
-    double a = 0.0, b = 0.0;
-    float mg = 0.f;
-    for (int s = 0; s < S; ++s) {
-      a += (double)part[((size_t)s * 3 + 0) * C + c];
-      b += (double)part[((size_t)s * 3 + 1) * C + c];
-      mg = fmaxf(mg, part[((size_t)s * 3 + 2) * C + c]);
-    }
-    if (dbeta) dbeta[c] = (float)a;
-    if (dgamma) dgamma[c] = (float)b;
-    if (dz_bound != nullptr) {
-      const float ar = fabsf(gamma[c] * rstd[c]);
-      bound = train ? ar * (mg + fabsf((float)a) / n_total + sqrtf(n_total > 1.f ? n_total - 1.f : 1.f) * fabsf((float)b) / n_total) * 1.0001f
-                    : ar * mg;
-    }
+  // one wave per channel: lanes stride over the S partial rows (hundreds for the full-resolution layers), fixed-order fp64 sums
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= C) return;  // wave-uniform
+  double a = 0.0, b = 0.0;
+  float mg = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    a += (double)part[((size_t)s * 3 + 0) * C + c];
+    b += (double)part[((size_t)s * 3 + 1) * C + c];
+    mg = fmaxf(mg, part[((size_t)s * 3 + 2) * C + c]);
   }
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  for (int o = 1; o < 64; o <<= 1) mg = fmaxf(mg, __shfl_xor(mg, o));
+  if (lane != 0) return;
+  if (dbeta) dbeta[c] = (float)a;
+  if (dgamma) dgamma[c] = (float)b;
   if (dz_bound != nullptr) {
-    const bool bad = !(bound == bound);
-    for (int o = 1; o < 64; o <<= 1) bound = fmaxf(bound, __shfl_xor(bound, o));
-    const unsigned long long anybad = __ballot(bad);
-    if ((threadIdx.x & 63) == 0) {
-      if (anybad) bound = __uint_as_float(0x7FC00000u);
-      atomicMax(reinterpret_cast<unsigned*>(dz_bound), __float_as_uint(bound) & 0x7FFFFFFFu);
-    }
+    const float ar = fabsf(gamma[c] * rstd[c]);
+    float bound = train ? ar * (mg + fabsf((float)a) / n_total + sqrtf(n_total > 1.f ? n_total - 1.f : 1.f) * fabsf((float)b) / n_total) * 1.0001f
+                        : ar * mg;
+    if (!(bound == bound)) bound = __uint_as_float(0x7FC00000u);  // NaN statistics -> non-finite bound
+    atomicMax(reinterpret_cast<unsigned*>(dz_bound), __float_as_uint(bound) & 0x7FFFFFFFu);
   }
 }
 
@@ -376,12 +373,42 @@ __device__ __forceinline__ void split_store(const float (&v)[8], float inv_scale
   for (int pc = 0; pc < P::NP; ++pc) *reinterpret_cast<typename P::frag*>(cb + pc * piece_stride + idx16 * 8) = pieces[pc];
 }
 
+// the inverse: 8 channels of one pixel back from the companion, value = scale * (sum of the pieces) -- exact for the bf16
+// split, the 22 leading bits for the fp16 one
+template <class P>
+__device__ __forceinline__ void join_load(const typename P::elem* __restrict__ cb, float scale, size_t piece_stride, size_t idx16,
+                                          float (&v)[8]) {
+  typename P::frag pieces[P::NP];
+#pragma unroll
+  for (int pc = 0; pc < P::NP; ++pc) pieces[pc] = *reinterpret_cast<const typename P::frag*>(cb + pc * piece_stride + idx16 * 8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float t = 0.f;
+#pragma unroll
+    for (int pc = P::NP - 1; pc >= 0; --pc) t += (float)pieces[pc][e];  // smallest piece first: exact
+    v[e] = t * scale;
+  }
+}
+
+// ReLU mask of 8 channels of one pixel from the leading piece of the activation's companion (y > 0 <=> its leading piece > 0,
+// except for 0 < y < 2^-25 of the scale, which the piece rounds to zero)
+template <class P>
+__device__ __forceinline__ unsigned mask_load(const typename P::elem* __restrict__ cb, size_t idx16) {
+  const typename P::frag lead = *reinterpret_cast<const typename P::frag*>(cb + idx16 * 8);
+  unsigned m = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m |= ((float)lead[e] > 0.f ? 1u : 0u) << e;
+  return m;
+}
+
 template <class P>
 __global__ __launch_bounds__(256) void bn_apply_cb_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ res,
-                                                          float* __restrict__ y, typename P::elem* __restrict__ cb,
-                                                          const float* __restrict__ y_bound, int N, int C, int HW, int relu) {
+                                                          const typename P::elem* __restrict__ res_cb,
+                                                          const float* __restrict__ res_bound, float* __restrict__ y,
+                                                          typename P::elem* __restrict__ cb, const float* __restrict__ y_bound, int N,
+                                                          int C, int HW, int relu) {
   const int C8 = C >> 3;
   const int ng = blockIdx.y;  // n * C8 + g
   const int g = ng % C8;
@@ -390,6 +417,8 @@ __global__ __launch_bounds__(256) void bn_apply_cb_kernel(const float* __restric
   if (pix >= HW) return;
   const float inv_scale = 1.f / operand_scale<P>(y_bound);
   const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
+  float r[8];
+  if (res_cb != nullptr) join_load<P>(res_cb, operand_scale<P>(res_bound), (size_t)N * C * HW, (size_t)ng * HW + pix, r);
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -398,9 +427,10 @@ __global__ __launch_bounds__(256) void bn_apply_cb_kernel(const float* __restric
     const float b = beta[c] - mean[c] * a;
     float t = fmaf(z[base + (size_t)e * HW], a, b);
     if (res) t += res[base + (size_t)e * HW];
+    if (res_cb != nullptr) t += r[e];
     if (relu) t = fmaxf(t, 0.f);
     v[e] = t;
-    y[base + (size_t)e * HW] = t;
+    if (y != nullptr) y[base + (size_t)e * HW] = t;  // compact activation storage: the companion is the activation
   }
   split_store<P>(v, inv_scale, cb, (size_t)N * C * HW, (size_t)ng * HW + pix);
 }
@@ -412,7 +442,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_kernel(const float* __res
                                                               const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                               float* __restrict__ dz, float* __restrict__ dres,
                                                               typename P::elem* __restrict__ cb, const float* __restrict__ dz_bound,
-                                                              int N, int C, int HW, int relu, int train) {
+                                                              const typename P::elem* __restrict__ y_cb, int N, int C, int HW, int relu,
+                                                              int train) {
   const int C8 = C >> 3;
   const int ng = blockIdx.y;
   const int g = ng % C8;
@@ -422,6 +453,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_kernel(const float* __res
   const float inv_scale = 1.f / operand_scale<P>(dz_bound);
   const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
   const float inv_n = 1.f / ((float)N * (float)HW);
+  const unsigned ymask = (relu && y == nullptr) ? mask_load<P>(y_cb, (size_t)ng * HW + pix) : 0xFFu;
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -431,13 +463,91 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_kernel(const float* __res
     const float k1 = train ? dbeta[c] * inv_n : 0.f;
     const float k2 = train ? dgamma[c] * inv_n : 0.f;
     float gv = dy[base + (size_t)e * HW];
-    if (relu && !(y[base + (size_t)e * HW] > 0.f)) gv = 0.f;
+    if (relu && (y != nullptr ? !(y[base + (size_t)e * HW] > 0.f) : !((ymask >> e) & 1u))) gv = 0.f;
     if (dres) dres[base + (size_t)e * HW] = gv;
     const float t = a * (gv - k1 - ((z[base + (size_t)e * HW] - mu) * rs) * k2);
     v[e] = t;
     if (dz) dz[base + (size_t)e * HW] = t;  // optional: the split dgrad and wgrad read only the companion
   }
   split_store<P>(v, inv_scale, cb, (size_t)N * C * HW, (size_t)ng * HW + pix);
+}
+
+// backward reduce with the ReLU mask read from the activation's companion (compact activation storage: no fp32 y exists).
+// One thread = one pixel x 8 channels, as the apply kernels; grid (slices, N * C/8): a block strides over the pixels of its
+// (image, channel group) and writes one partial row per channel: part[(n * slices + slice) * 3 + {0,1,2}][C]
+template <class P>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_cb_kernel(const float* __restrict__ dy, const typename P::elem* __restrict__ y_cb,
+                                                               const float* __restrict__ z, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, float* __restrict__ part, int N, int C,
+                                                               int HW, int relu, float* __restrict__ dz_bound) {
+  const int C8 = C >> 3;
+  const int ng = blockIdx.y;
+  const int g = ng % C8;
+  const int n = ng / C8;
+  if (dz_bound != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *dz_bound = 0.f;  // finalize: atomic max
+  float mu[8], rs[8], s_dy[8], s_dyx[8], m_g[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mu[e] = mean[8 * g + e];
+    rs[e] = rstd[8 * g + e];
+    s_dy[e] = s_dyx[e] = m_g[e] = 0.f;
+  }
+  for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < HW; pix += gridDim.x * blockDim.x) {
+    const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
+    const unsigned ymask = relu ? mask_load<P>(y_cb, (size_t)ng * HW + pix) : 0xFFu;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float gv = dy[base + (size_t)e * HW];
+      if (!((ymask >> e) & 1u)) gv = 0.f;
+      s_dy[e] += gv;
+      m_g[e] = fmaxf(m_g[e], fabsf(gv));
+      s_dyx[e] += gv * ((z[base + (size_t)e * HW] - mu[e]) * rs[e]);
+    }
+  }
+  __shared__ float sh[3][8][4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float a = wave_sum(s_dy[e]), b = wave_sum(s_dyx[e]);
+    float m = m_g[e];
+    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) {
+      sh[0][e][threadIdx.x >> 6] = a;
+      sh[1][e][threadIdx.x >> 6] = b;
+      sh[2][e][threadIdx.x >> 6] = m;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 24) {
+    const int k = threadIdx.x >> 3, e = threadIdx.x & 7;
+    const float v = k == 2 ? fmaxf(fmaxf(sh[2][e][0], sh[2][e][1]), fmaxf(sh[2][e][2], sh[2][e][3]))
+                           : (sh[k][e][0] + sh[k][e][1]) + (sh[k][e][2] + sh[k][e][3]);
+    part[((size_t)(n * gridDim.x + blockIdx.x) * 3 + k) * C + 8 * g + e] = v;
+  }
+}
+
+int bwd_cb_slices(int N, int C, int HW) {
+  // ~2048 blocks, at least 256 pixels per block
+  int s = (int)ceil_div64(2048, (int64_t)N * (C / 8));
+  const int most = ceil_div(HW, 256);
+  if (s > most) s = most;
+  return s < 1 ? 1 : s;
+}
+
+// companion -> fp32 NCHW (an activation kept only as its companion, for a consumer outside the split kernels)
+template <class P>
+__global__ __launch_bounds__(256) void unsplit_cb_kernel(const typename P::elem* __restrict__ cb, const float* __restrict__ bound,
+                                                         float* __restrict__ x, int N, int C, int HW) {
+  const int C8 = C >> 3;
+  const int ng = blockIdx.y;
+  const int g = ng % C8;
+  const int n = ng / C8;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= HW) return;
+  float v[8];
+  join_load<P>(cb, operand_scale<P>(bound), (size_t)N * C * HW, (size_t)ng * HW + pix, v);
+  const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[base + (size_t)e * HW] = v[e];
 }
 
 // the split alone, for operands no fused BN group produced (network inputs, gradients arriving from outside the encoder)
@@ -552,36 +662,51 @@ extern "C" int mcdseg_split_cb(const float* x, void* x_cb, const float* x_bound,
 }
 
 extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                  const float* residual, float* y, void* y_cb, const float* y_bound, int32_t math, int32_t N,
-                                  int32_t C, int32_t HW, int32_t relu, void* stream) {
-  MCD_REQUIRE(z && mean && rstd && gamma && beta && y && y_cb, "bn_apply_cb: null pointer");
+                                  const float* residual, const void* res_cb, const float* res_bound, float* y, void* y_cb,
+                                  const float* y_bound, int32_t math, int32_t N, int32_t C, int32_t HW, int32_t relu, void* stream) {
+  MCD_REQUIRE(z && mean && rstd && gamma && beta && y_cb, "bn_apply_cb: null pointer");
+  MCD_REQUIRE(!(residual && res_cb), "bn_apply_cb: the residual comes either as fp32 or as its companion, not both");
+  MCD_REQUIRE(res_cb == nullptr || math != MCDSEG_MATH_F16X3 || res_bound != nullptr, "bn_apply_cb: the residual companion needs its bound");
   if (int rc = cb_check("bn_apply_cb", math, y_bound, N, C, HW)) return rc;
   const dim3 grid(ceil_div(HW, 256), N * (C / 8));
   if (math == MCDSEG_MATH_F16X3)
-    hipLaunchKernelGGL(bn_apply_cb_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual, y,
-                       (_Float16*)y_cb, y_bound, N, C, HW, relu);
+    hipLaunchKernelGGL(bn_apply_cb_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
+                       (const _Float16*)res_cb, res_bound, y, (_Float16*)y_cb, y_bound, N, C, HW, relu);
   else
-    hipLaunchKernelGGL(bn_apply_cb_kernel<SplitBf16x6>, grid, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual, y,
-                       (__bf16*)y_cb, y_bound, N, C, HW, relu);
+    hipLaunchKernelGGL(bn_apply_cb_kernel<SplitBf16x6>, grid, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
+                       (const __bf16*)res_cb, res_bound, y, (__bf16*)y_cb, y_bound, N, C, HW, relu);
   MCD_LAUNCH_CHECK("bn_apply_cb");
   return 0;
 }
 
-extern "C" int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
-                                      const float* gamma, const float* dgamma, const float* dbeta, float* dz, float* dres,
-                                      void* dz_cb, const float* dz_bound, int32_t math, int32_t N, int32_t C, int32_t HW,
+extern "C" int mcdseg_unsplit_cb(const void* x_cb, const float* x_bound, int32_t math, int32_t N, int32_t C, int32_t HW, float* x,
+                                 void* stream) {
+  MCD_REQUIRE(x_cb && x, "unsplit_cb: null pointer");
+  if (int rc = cb_check("unsplit_cb", math, x_bound, N, C, HW)) return rc;
+  const dim3 grid(ceil_div(HW, 256), N * (C / 8));
+  if (math == MCDSEG_MATH_F16X3)
+    hipLaunchKernelGGL(unsplit_cb_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x_cb, x_bound, x, N, C, HW);
+  else
+    hipLaunchKernelGGL(unsplit_cb_kernel<SplitBf16x6>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)x_cb, x_bound, x, N, C, HW);
+  MCD_LAUNCH_CHECK("unsplit_cb");
+  return 0;
+}
+
+extern "C" int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const void* y_cb, const float* z, const float* mean,
+                                      const float* rstd, const float* gamma, const float* dgamma, const float* dbeta, float* dz,
+                                      float* dres, void* dz_cb, const float* dz_bound, int32_t math, int32_t N, int32_t C, int32_t HW,
                                       int32_t relu, int32_t train, void* stream) {
   MCD_REQUIRE(dy && z && mean && rstd && gamma && dz_cb, "bn_bwd_apply_cb: null pointer");
-  MCD_REQUIRE(!relu || y, "bn_bwd_apply_cb: relu mask needs y");
+  MCD_REQUIRE(!relu || y || y_cb, "bn_bwd_apply_cb: relu mask needs y or its companion");
   MCD_REQUIRE(!train || (dgamma && dbeta), "bn_bwd_apply_cb: train mode needs dgamma/dbeta");
   if (int rc = cb_check("bn_bwd_apply_cb", math, dz_bound, N, C, HW)) return rc;
   const dim3 grid(ceil_div(HW, 256), N * (C / 8));
   if (math == MCDSEG_MATH_F16X3)
     hipLaunchKernelGGL(bn_bwd_apply_cb_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, z, mean, rstd, gamma, dgamma,
-                       dbeta, dz, dres, (_Float16*)dz_cb, dz_bound, N, C, HW, relu, train);
+                       dbeta, dz, dres, (_Float16*)dz_cb, dz_bound, (const _Float16*)y_cb, N, C, HW, relu, train);
   else
     hipLaunchKernelGGL(bn_bwd_apply_cb_kernel<SplitBf16x6>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, z, mean, rstd, gamma, dgamma,
-                       dbeta, dz, dres, (__bf16*)dz_cb, dz_bound, N, C, HW, relu, train);
+                       dbeta, dz, dres, (__bf16*)dz_cb, dz_bound, (const __bf16*)y_cb, N, C, HW, relu, train);
   MCD_LAUNCH_CHECK("bn_bwd_apply_cb");
   return 0;
 }
@@ -589,31 +714,53 @@ extern "C" int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const flo
 extern "C" size_t mcdseg_bn_bwd_workspace_bytes(int32_t N, int32_t C, int32_t HW) {
   if (N <= 0 || C <= 0 || HW <= 0) return 0;
   const BwdPlan pl = bwd_plan(N, C, HW);
-  return (size_t)pl.S * 3 * C * sizeof(float);
+  size_t rows = (size_t)pl.S;
+  if ((C % 8) == 0) {  // the companion-mask form of the reduce has its own slicing
+    const size_t r2 = (size_t)N * bwd_cb_slices(N, C, HW);
+    if (r2 > rows) rows = r2;
+  }
+  return rows * 3 * C * sizeof(float);
 }
 
-extern "C" int mcdseg_bn_bwd_reduce(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
-                                    float* dgamma, float* dbeta, const float* gamma, float* dz_bound, int32_t train, int32_t N,
-                                    int32_t C, int32_t HW, int32_t relu, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int mcdseg_bn_bwd_reduce(const float* dy, const float* y, const void* y_cb, int32_t math, const float* z, const float* mean,
+                                    const float* rstd, float* dgamma, float* dbeta, const float* gamma, float* dz_bound, int32_t train,
+                                    int32_t N, int32_t C, int32_t HW, int32_t relu, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
   MCD_REQUIRE(dy && workspace && (dgamma || dbeta), "bn_bwd_reduce: null pointer");
-  MCD_REQUIRE(!relu || y, "bn_bwd_reduce: relu mask needs y");
+  MCD_REQUIRE(!relu || y || y_cb, "bn_bwd_reduce: relu mask needs y or its companion");
   MCD_REQUIRE(!z || (mean && rstd), "bn_bwd_reduce: z needs mean/rstd");
   MCD_REQUIRE(dz_bound == nullptr || (z && gamma), "bn_bwd_reduce: the dz bound needs z, rstd and gamma");
   MCD_REQUIRE(N > 0 && C > 0 && HW > 0, "bn_bwd_reduce: bad dims");
-  const BwdPlan pl = bwd_plan(N, C, HW);
-  MCD_REQUIRE(workspace_bytes >= (size_t)pl.S * 3 * C * sizeof(float), "bn_bwd_reduce: workspace too small");
-  MCD_REQUIRE(pl.S <= 65535, "bn_bwd_reduce: too many splits");
-  const bool vec = (HW % 4 == 0) && aligned16(dy) && (!y || aligned16(y)) && (!z || aligned16(z));
-  dim3 grid(C, pl.S);
+  MCD_REQUIRE(workspace_bytes >= mcdseg_bn_bwd_workspace_bytes(N, C, HW), "bn_bwd_reduce: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  if (vec)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, (float*)workspace, N, C, HW, relu,
-                       pl.cpp, pl.chunk, dz_bound);
-  else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, (float*)workspace, N, C, HW,
-                       relu, pl.cpp, pl.chunk, dz_bound);
+  int S;
+  if (relu && y == nullptr) {  // mask from the companion: pixel x 8-channel threads
+    MCD_REQUIRE(z != nullptr, "bn_bwd_reduce: the companion-mask form is the BatchNorm form (needs z)");
+    if (int rc = cb_check("bn_bwd_reduce", math, math == MCDSEG_MATH_F16X3 ? rstd : nullptr, N, C, HW)) return rc;  // layout rules only
+    const int sl = bwd_cb_slices(N, C, HW);
+    S = N * sl;
+    const dim3 grid(sl, N * (C / 8));
+    if (math == MCDSEG_MATH_F16X3)
+      hipLaunchKernelGGL(bn_bwd_reduce_cb_kernel<SplitF16x3>, grid, dim3(256), 0, st, dy, (const _Float16*)y_cb, z, mean, rstd,
+                         (float*)workspace, N, C, HW, relu, dz_bound);
+    else
+      hipLaunchKernelGGL(bn_bwd_reduce_cb_kernel<SplitBf16x6>, grid, dim3(256), 0, st, dy, (const __bf16*)y_cb, z, mean, rstd,
+                         (float*)workspace, N, C, HW, relu, dz_bound);
+  } else {
+    const BwdPlan pl = bwd_plan(N, C, HW);
+    MCD_REQUIRE(pl.S <= 65535, "bn_bwd_reduce: too many splits");
+    S = pl.S;
+    const bool vec = (HW % 4 == 0) && aligned16(dy) && (!y || aligned16(y)) && (!z || aligned16(z));
+    dim3 grid(C, pl.S);
+    if (vec)
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, (float*)workspace, N, C, HW, relu,
+                         pl.cpp, pl.chunk, dz_bound);
+    else
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, (float*)workspace, N, C, HW,
+                         relu, pl.cpp, pl.chunk, dz_bound);
+  }
   MCD_LAUNCH_CHECK("bn_bwd_reduce");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float*)workspace, pl.S, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, S, C,
                      z ? dgamma : nullptr, dbeta, gamma, rstd, (float)N * (float)HW, train, dz_bound);
   MCD_LAUNCH_CHECK("bn_bwd_finalize");
   return 0;

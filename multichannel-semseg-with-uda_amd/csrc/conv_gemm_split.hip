@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* 
   }
 }
 
-int split_check(const mcdseg_conv_desc* d, int math, const char* who) {
+int split_check(const mcdseg_conv_desc* d, int math, const char* who, bool operands = true) {
   MCD_REQUIRE(d != nullptr, "%s: null descriptor", who);
   MCD_REQUIRE(math == MCDSEG_MATH_BF16X6 || math == MCDSEG_MATH_F16X3, "%s: math must be MCDSEG_MATH_BF16X6 or MCDSEG_MATH_F16X3 (got %d)", who, math);
   MCD_REQUIRE(d->N > 0 && d->Cin > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "%s: non-positive dims", who);
@@ -748,7 +748,7 @@ int split_check(const mcdseg_conv_desc* d, int math, const char* who) {
   const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
   const int wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
   MCD_REQUIRE(ho == d->Ho && wo == d->Wo, "%s: Ho/Wo (%d,%d) do not match geometry (%d,%d)", who, d->Ho, d->Wo, ho, wo);
-  MCD_REQUIRE((int64_t)d->N * d->Cin * d->H * d->W * 4 < (1ll << 31) && (int64_t)d->N * d->Cout * d->Ho * d->Wo * 4 < (1ll << 31),
+  MCD_REQUIRE(!operands || ((int64_t)d->N * d->Cin * d->H * d->W * 4 < (1ll << 31) && (int64_t)d->N * d->Cout * d->Ho * d->Wo * 4 < (1ll << 31)),
               "%s: activation tensor must stay below 2 GiB (32-bit buffer offsets); split the batch", who);
   return 0;
 }
@@ -861,7 +861,7 @@ extern "C" int mcdseg_conv_split_packed_bytes(const mcdseg_conv_desc* d, int32_t
 
 extern "C" int mcdseg_conv_split_pack_weights(const mcdseg_conv_desc* d, int32_t math, const float* w, void* wp_fprop, void* wp_dgrad,
                                               float* w_bound, void* stream) {
-  if (int rc = split_check(d, math, "conv_split_pack_weights")) return rc;
+  if (int rc = split_check(d, math, "conv_split_pack_weights", false)) return rc;  // weights only: any batch size
   MCD_REQUIRE(w != nullptr && (wp_fprop != nullptr || wp_dgrad != nullptr), "conv_split_pack_weights: null pointer");
   MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || w_bound != nullptr, "conv_split_pack_weights: the f16x3 images need the weight bound scalar");
   const int T = d->KH * d->KW;

@@ -45,8 +45,9 @@ _SIGNATURES = {
     "mcdseg_conv_split_fprop_affine": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 8 + [c_i32, c_void_p, c_void_p]),
     "mcdseg_conv_split_dgrad": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 7),
     "mcdseg_split_cb": (c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p]),
-    "mcdseg_bn_apply_cb": (c_int, [c_void_p] * 9 + [c_i32] * 5 + [c_void_p]),
-    "mcdseg_bn_bwd_apply_cb": (c_int, [c_void_p] * 12 + [c_i32] * 6 + [c_void_p]),
+    "mcdseg_unsplit_cb": (c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
+    "mcdseg_bn_apply_cb": (c_int, [c_void_p] * 11 + [c_i32] * 5 + [c_void_p]),
+    "mcdseg_bn_bwd_apply_cb": (c_int, [c_void_p] * 13 + [c_i32] * 6 + [c_void_p]),
     "mcdseg_conv_split_wgrad": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "mcdseg_conv_dgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcdseg_conv_wgrad_workspace_bytes": (c_size_t, [_P(ConvDesc)]),
@@ -57,7 +58,7 @@ _SIGNATURES = {
     "mcdseg_bn_eval_stats": (c_int, [c_void_p, c_void_p, c_i32, c_float, c_void_p, c_void_p, c_void_p]),
     "mcdseg_bn_apply": (c_int, [c_void_p] * 7 + [c_i32] * 4 + [c_void_p]),
     "mcdseg_bn_bwd_workspace_bytes": (c_size_t, [c_i32, c_i32, c_i32]),
-    "mcdseg_bn_bwd_reduce": (c_int, [c_void_p] * 9 + [c_i32] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "mcdseg_bn_bwd_reduce": (c_int, [c_void_p] * 3 + [c_i32] + [c_void_p] * 7 + [c_i32] * 5 + [c_void_p, c_size_t, c_void_p]),
     "mcdseg_bn_bwd_apply": (c_int, [c_void_p] * 10 + [c_i32] * 5 + [c_void_p]),
     "mcdseg_up8_fwd": (c_int, [c_void_p] * 5 + [c_i32] * 4 + [c_void_p]),
     "mcdseg_up8_bwd_input": (c_int, [c_void_p] * 3 + [c_i32] * 4 + [c_void_p]),

@@ -136,6 +136,56 @@ BIGTILE_MIN_SLOTS = int(os.environ.get("MCDSEG_BIGTILE_MIN_SLOTS", "1024"))  # l
 
 STEM_DIRECT = os.environ.get("MCDSEG_STEM_DIRECT", "1") != "0"  # the stem's forward as the direct (bf16x6) convolution
 
+# Activation storage inside a DRN trunk (MCDSEG_ACT_STORAGE):
+#   "fp32" (default)  every fused group writes its fp32 output y next to the pre-split companion;
+#   "compact"         between the layers of a trunk only the companion is written (4 B/element with f16x3: the 22 leading bits
+#                     of y) -- residual adds and ReLU masks read it, no fp32 y exists.  8 instead of 12 B/element are kept for
+#                     backward, which is what lets BASELINE config 5 (drn_d_105, 32 x 720 x 1280 per GPU) fit 288 GB, and the
+#                     BatchNorm passes move a third fewer bytes.  The trunk's last layer, and everything outside a trunk, stays fp32.
+ACT_STORAGE = os.environ.get("MCDSEG_ACT_STORAGE", "fp32")
+if ACT_STORAGE not in ("fp32", "compact"):
+    raise ValueError("MCDSEG_ACT_STORAGE must be fp32 or compact, got %r" % ACT_STORAGE)
+_TRUNK_DEPTH = 0
+
+
+class trunk_internal:
+    """context of the layers INSIDE a trunk whose outputs only other fused groups consume (models/dilated_fcn.py Trunk)"""
+
+    def __enter__(self):
+        global _TRUNK_DEPTH
+        _TRUNK_DEPTH += 1
+
+    def __exit__(self, *exc):
+        global _TRUNK_DEPTH
+        _TRUNK_DEPTH -= 1
+
+
+def _compact_now():
+    return ACT_STORAGE == "compact" and _TRUNK_DEPTH > 0 and _scaled()
+
+
+def _virtual(shape, device):
+    """stand-in for an activation that exists only as its companion: right shape / device / dtype, 4 bytes of storage"""
+    return torch.empty(1, dtype=torch.float32, device=device).expand(shape)
+
+
+def is_virtual(t):
+    return t is not None and getattr(t, "_mcd_virtual", False)
+
+
+def materialize(x, cb=None, bound=None):
+    """fp32 tensor of an activation kept as its companion (value = scale * sum of pieces); ``x`` itself when it is real"""
+    if cb is None:
+        if not is_virtual(x):
+            return x
+        cb, bound = _cb_of(x)
+    if cb is None:
+        raise RuntimeError("mcdseg: a compact activation lost its companion (was it modified in place?)")
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=cb.device)
+    check(lib().mcdseg_unsplit_cb(_p(cb), _p(bound), MATH_ID[CONV_MATH], n, c, h * w, _p(out), _stream()), "unsplit_cb")
+    return out
+
 
 def _use_split(contraction_channels):
     return contraction_channels >= 16 and CONV_MATH in MATH_ID
@@ -451,7 +501,7 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_
     return dx, dw
 
 
-def _channel_reduce(dy, y, z, mean, rstd, relu, gamma=None, want_bound=False, train=True):
+def _channel_reduce(dy, y, z, mean, rstd, relu, gamma=None, want_bound=False, train=True, y_cb=None):
     """(dgamma, dbeta) of a BN (z given) or just the per-channel sum of dy (z None); with ``want_bound`` also the device
     scalar bounding |dz| of the tensor bn_bwd_apply will write from these sums (include/mcdseg.h)"""
     L = lib()
@@ -462,9 +512,9 @@ def _channel_reduce(dy, y, z, mean, rstd, relu, gamma=None, want_bound=False, tr
     dbeta = torch.empty(c, dtype=torch.float32, device=dy.device)
     bound = torch.empty(1, dtype=torch.float32, device=dy.device) if want_bound else None
     with _timed("bn_bwd_reduce", (0, 4 * n * c * hw * (1 + (y is not None) + (z is not None)))):
-        check(L.mcdseg_bn_bwd_reduce(_p(dy), _p(y), _p(z), _p(mean), _p(rstd), _p(dgamma), _p(dbeta), _p(gamma) if want_bound else None,
-                                     _p(bound), int(train), n, c, hw, int(relu), _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
-              "bn_bwd_reduce")
+        check(L.mcdseg_bn_bwd_reduce(_p(dy), _p(y), _p(y_cb) if y is None else None, MATH_ID.get(CONV_MATH, 0), _p(z), _p(mean), _p(rstd),
+                                     _p(dgamma), _p(dbeta), _p(gamma) if want_bound else None, _p(bound), int(train), n, c, hw,
+                                     int(relu), _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()), "bn_bwd_reduce")
     return dgamma, dbeta, bound
 
 
@@ -472,60 +522,73 @@ def _channel_reduce(dy, y, z, mean, rstd, relu, gamma=None, want_bound=False, tr
 class _ConvBNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, conv_bias, running_mean, running_var, nbt, packed, geom, training,
-                momentum, eps, relu, x_cb, x_bound, res_bound):
+                momentum, eps, relu, x_cb, x_bound, res_bound, aux):
+        """aux: dict(x_virtual, res_virtual, res_cb, compact) -- compact activation storage (see ACT_STORAGE)"""
         L = lib()
-        x = _req(x, "conv input")
-        residual = _req(residual, "residual")
         stride, pad, dil = geom
         desc = conv_desc(x.shape, weight.shape, stride, pad, dil)
         wf, wd, mpf = packed.get(weight, desc)
         w_bound = packed.w_bound
+        x_virtual = aux["x_virtual"]
+        if x_virtual and not (_is_split(wf) and x_cb is not None and len(_batch_pieces(desc)) == 1):
+            x, x_virtual = materialize(x, x_cb, x_bound), False  # this consumer reads fp32
+        if not x_virtual:
+            x = _req(x, "conv input")
         if _is_split(wf) and _scaled():
             x_bound = _bound_or_measure(x, x_bound)
         z, part, rows = _conv_fprop(desc, x, wf, _req(conv_bias, "conv bias"), training, mpf, x_cb, x_bound, w_bound)
         c = desc.Cout
         hw = desc.Ho * desc.Wo
-        mean = torch.empty(c, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        mean = torch.empty(c, dtype=torch.float32, device=z.device)
+        rstd = torch.empty(c, dtype=torch.float32, device=z.device)
         # the pre-split companion of y: the scaled arithmetic needs |y|'s bound BEFORE y is written -- train-mode statistics
         # give one (Samuelson), eval-mode running statistics do not (the consumer then measures y)
         want_cb = _cb_wanted(c) and desc.N * (c // 8) <= 65535 and (training or not _scaled())
+        compact = aux["compact"] and want_cb and training
+        res_cb = aux["res_cb"] if aux["res_virtual"] else None
+        if aux["res_virtual"] and not want_cb:
+            residual, res_cb = materialize(residual, aux["res_cb"], res_bound), None  # plain bn_apply reads fp32
+        elif not aux["res_virtual"]:
+            residual = _req(residual, "residual")
+        has_res = residual is not None
         y_bound = None
         if training and _scaled() and _use_split(c):  # with or without a companion: consumers that split y themselves use it too
-            y_bound = torch.empty(1, dtype=torch.float32, device=x.device)
-            if residual is not None:
+            y_bound = torch.empty(1, dtype=torch.float32, device=z.device)
+            if has_res:
                 res_bound = _bound_or_measure(residual, res_bound)
         if training:
             track = running_mean is not None
-            ws = torch.empty(L.mcdseg_bn_stats_workspace_bytes(rows, c) // 8 + 1, dtype=torch.float64, device=x.device)
+            ws = torch.empty(L.mcdseg_bn_stats_workspace_bytes(rows, c) // 8 + 1, dtype=torch.float64, device=z.device)
             with _timed("bn_stats_finalize", (0, 12 * rows * mpf)):
                 check(L.mcdseg_bn_stats_finalize(_p(part), rows, c, mpf, _p(mean), _p(rstd), _p(running_mean) if track else None,
                                                  _p(running_var) if track else None, _p(nbt) if track else None,
                                                  float(momentum), float(eps), _p(gamma) if y_bound is not None else None,
                                                  _p(beta) if y_bound is not None else None,
-                                                 _p(res_bound) if (y_bound is not None and residual is not None) else None, _p(y_bound),
+                                                 _p(res_bound) if (y_bound is not None and has_res) else None, _p(y_bound),
                                                  _p(ws), ctypes.c_size_t(ws.numel() * 8), _stream()),
                       "bn_stats_finalize")
         else:
             check(L.mcdseg_bn_eval_stats(_p(running_mean), _p(running_var), c, float(eps), _p(mean), _p(rstd), _stream()),
                   "bn_eval_stats")
-        y = torch.empty_like(z)
+        y = _virtual(z.shape, z.device) if compact else torch.empty_like(z)
         y_cb = None
         elems = desc.N * c * hw
         if want_cb:
-            y_cb = _cb_alloc(desc.N, c, hw, x.device)
-            with _timed("bn_apply_cb", (0, elems * (8 + 2 * PIECES[CONV_MATH] + (4 if residual is not None else 0)))):
-                check(L.mcdseg_bn_apply_cb(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), _p(y), _p(y_cb), _p(y_bound),
-                                           MATH_ID[CONV_MATH], desc.N, c, hw, int(relu), _stream()), "bn_apply_cb")
+            y_cb = _cb_alloc(desc.N, c, hw, z.device)
+            with _timed("bn_apply_cb", (0, elems * (4 + (0 if compact else 4) + 2 * PIECES[CONV_MATH] + (4 if has_res else 0)))):
+                check(L.mcdseg_bn_apply_cb(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual) if res_cb is None else None,
+                                           _p(res_cb), _p(res_bound) if res_cb is not None else None, None if compact else _p(y),
+                                           _p(y_cb), _p(y_bound), MATH_ID[CONV_MATH], desc.N, c, hw, int(relu), _stream()), "bn_apply_cb")
         else:
-            with _timed("bn_apply", (0, elems * (8 + (4 if residual is not None else 0)))):
+            with _timed("bn_apply", (0, elems * (8 + (4 if has_res else 0)))):
                 check(L.mcdseg_bn_apply(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), _p(y), desc.N, c, hw, int(relu),
                                         _stream()), "bn_apply")
-        ctx.desc, ctx.wd, ctx.relu, ctx.training, ctx.has_res = desc, wd, relu, training, residual is not None
+        ctx.desc, ctx.wd, ctx.relu, ctx.training, ctx.has_res = desc, wd, relu, training, has_res
         ctx.w_bound = w_bound
         ctx.has_bias = conv_bias is not None
         ctx.x_cb, ctx.x_bound = x_cb, x_bound  # wgrad reads the input's split companion too (an input of this node: safe to hold)
-        ctx.save_for_backward(x, z, y, mean, rstd, gamma)
+        ctx.x_virtual, ctx.compact = x_virtual, compact
+        ctx.save_for_backward(x, z, y, mean, rstd, gamma, y_cb if compact else None, y_bound if compact else None)
         ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the non-differentiable companions
         for t in (y_cb, y_bound):
             if t is not None:
@@ -536,16 +599,20 @@ class _ConvBNAct(torch.autograd.Function):
     def backward(ctx, dy, _dcb=None, _dbound=None):
         L = lib()
         if dy is None:
-            return (None,) * 18
-        x, z, y, mean, rstd, gamma = ctx.saved_tensors
+            return (None,) * 19
+        x, z, y, mean, rstd, gamma, y_cb, y_bound = ctx.saved_tensors
         desc = ctx.desc
         dy = _req(dy, "grad_output")
         n, c, hw = desc.N, desc.Cout, desc.Ho * desc.Wo
         split_d = _is_split(ctx.wd)
         want_cb = ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and ctx.x_cb is not None)
         use_cb = want_cb and split_d and _cb_wanted(c) and n * (c // 8) <= 65535
-        dgamma, dbeta, dz_bound = _channel_reduce(dy, y if ctx.relu else None, z, mean, rstd, ctx.relu, gamma,
-                                                  want_bound=_scaled() and (split_d or _wgrad_split_plan(desc)), train=ctx.training)
+        if ctx.compact and not use_cb:  # the plain backward kernels read the fp32 activation for the ReLU mask
+            y, y_cb = materialize(y, y_cb, y_bound), None
+        y_mask = (y if y_cb is None else None) if ctx.relu else None
+        dgamma, dbeta, dz_bound = _channel_reduce(dy, y_mask, z, mean, rstd, ctx.relu, gamma,
+                                                  want_bound=_scaled() and (split_d or _wgrad_split_plan(desc)), train=ctx.training,
+                                                  y_cb=y_cb if ctx.relu else None)
         dz = None
         dres = None
         if ctx.has_res and ctx.needs_input_grad[4]:
@@ -559,17 +626,22 @@ class _ConvBNAct(torch.autograd.Function):
                    and (not ctx.needs_input_grad[1] or wgrad_cb))
         if not skip_dz:
             dz = torch.empty_like(z)
-        bwd_args = (_p(dy), _p(y) if ctx.relu else None, _p(z), _p(mean), _p(rstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dz),
-                    _p(dres) if (dres is not None and ctx.relu) else None)
         rd = 4 * n * c * hw * (2 + int(ctx.relu)) + 4 * n * c * hw * ((dz is not None) + (dres is not None and ctx.relu))
         if use_cb:
             dz_cb = _cb_alloc(n, c, hw, dy.device)
             with _timed("bn_bwd_apply_cb", (0, rd + 2 * PIECES[CONV_MATH] * n * c * hw)):
-                check(L.mcdseg_bn_bwd_apply_cb(*bwd_args, _p(dz_cb), _p(dz_bound), MATH_ID[CONV_MATH], n, c, hw, int(ctx.relu),
-                                               int(ctx.training), _stream()), "bn_bwd_apply_cb")
+                check(L.mcdseg_bn_bwd_apply_cb(_p(dy), _p(y_mask), _p(y_cb) if (ctx.relu and y_mask is None) else None, _p(z), _p(mean),
+                                               _p(rstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dz),
+                                               _p(dres) if (dres is not None and ctx.relu) else None, _p(dz_cb), _p(dz_bound),
+                                               MATH_ID[CONV_MATH], n, c, hw, int(ctx.relu), int(ctx.training), _stream()),
+                      "bn_bwd_apply_cb")
         else:
             with _timed("bn_bwd_apply", (0, rd)):
-                check(L.mcdseg_bn_bwd_apply(*bwd_args, n, c, hw, int(ctx.relu), int(ctx.training), _stream()), "bn_bwd_apply")
+                check(L.mcdseg_bn_bwd_apply(_p(dy), _p(y_mask), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dz),
+                                            _p(dres) if (dres is not None and ctx.relu) else None, n, c, hw, int(ctx.relu),
+                                            int(ctx.training), _stream()), "bn_bwd_apply")
+        if ctx.x_virtual and ctx.needs_input_grad[1] and not (wgrad_cb and dz_cb is not None and single):
+            x = materialize(x, ctx.x_cb, ctx.x_bound)  # the weight gradient falls back to a kernel that reads fp32
         dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz_cb, ctx.x_cb, dz_bound,
                                 ctx.x_bound, ctx.w_bound)
         dbias = None
@@ -578,14 +650,14 @@ class _ConvBNAct(torch.autograd.Function):
             # it is still formed, as autograd does in the reference (CBR, models/dilated_fcn.py:632-644)
             _, dbias, _ = _channel_reduce(dz, None, None, None, None, False)
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres, dbias,
-                None, None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def _conv_bn_act_inference(x, conv, bn, relu, residual):
     """eval-mode BN folded into the conv epilogue: one kernel, no z / bn_apply pass, nothing kept for backward"""
     L = lib()
-    x = _req(x, "conv input")
-    residual = _req(residual, "residual")
+    x = _req(materialize(x), "conv input")
+    residual = _req(materialize(residual) if residual is not None else None, "residual")
     desc = conv_desc(x.shape, conv.weight.shape, conv.stride[0], conv.padding[0], conv.dilation[0])
     wf, _, _ = conv._packed.get(conv.weight, desc)
     c = desc.Cout
@@ -620,12 +692,15 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None):
         raise NotImplementedError("mcdseg: eval-mode BatchNorm needs running statistics")
     momentum = 0.1 if bn.momentum is None else bn.momentum
     x_cb, x_bound = _cb_of(x)
-    res_bound = _cb_of(residual)[1] if residual is not None else None
+    res_cb, res_bound = _cb_of(residual) if residual is not None else (None, None)
+    aux = dict(x_virtual=is_virtual(x), res_virtual=is_virtual(residual), res_cb=res_cb, compact=_compact_now())
     y, y_cb, y_bound = _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, residual, conv.bias, bn.running_mean if track else None,
                                         bn.running_var if track else None, bn.num_batches_tracked if track else None, conv._packed,
-                                        geom, training, momentum, bn.eps, relu, x_cb, x_bound, res_bound)
+                                        geom, training, momentum, bn.eps, relu, x_cb, x_bound, res_bound, aux)
     if y_cb is not None or y_bound is not None:
         _attach_cb(y, y_cb, y_bound)  # the pre-split companion (and the bound) travel with the tensor object to the next convolution
+    if y.stride(0) == 0 and y.numel() > 1:
+        y._mcd_virtual = True  # compact storage: the companion IS the activation
     return y
 
 
@@ -642,7 +717,7 @@ def _cb_of(x):
     if rec is None:
         return None, None
     cb, bound, version, ptr = rec
-    if x._version != version or x.data_ptr() != ptr or not x.is_contiguous():
+    if x._version != version or x.data_ptr() != ptr or not (x.is_contiguous() or is_virtual(x)):
         return None, None
     if cb is not None and cb.numel() != PIECES.get(CONV_MATH, 0) * x.numel():
         cb = None
@@ -678,6 +753,8 @@ class _Conv2dBias(torch.autograd.Function):
 
 def conv2d_bias(x, conv):
     geom = (conv.stride[0], conv.padding[0], conv.dilation[0])
+    if is_virtual(x):
+        raise RuntimeError("mcdseg: a compact activation left its trunk (the trunk's last layer writes fp32)")
     x_cb, x_bound = _cb_of(x)
     return _Conv2dBias.apply(x, conv.weight, conv.bias, conv._packed, geom, x_cb, x_bound)
 

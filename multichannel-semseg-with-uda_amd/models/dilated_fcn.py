@@ -27,7 +27,20 @@ def _trunk(model_name, pretrained, input_ch):
     if ctor is None or not model_name.startswith("drn_"):
         raise NotImplementedError("unknown DRN variant %r" % (model_name,))
     model = ctor(pretrained=pretrained, num_classes=0, input_ch=input_ch)
-    return FusedSequential(*model.trunk()), model.out_dim
+    return Trunk(*model.trunk()), model.out_dim
+
+
+class Trunk(FusedSequential):
+    """The DRN stages as ``nn.Sequential(*children[:-2])`` (models/dilated_fcn.py:223); same state_dict keys.  Every stage but
+    the last runs inside ``ops.trunk_internal()``: with MCDSEG_ACT_STORAGE=compact those layers keep their activations only
+    as the pre-split companions (BASELINE config 5); the last stage writes fp32, so what leaves the trunk is an ordinary tensor."""
+
+    def forward(self, x):
+        mods = list(self.children())
+        with ops.trunk_internal():
+            for m in mods[:-1]:
+                x = m(x)
+        return mods[-1](x) if mods else x
 
 
 def _seg_head(cin, n_class):

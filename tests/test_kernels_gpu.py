@@ -538,6 +538,68 @@ def test_presplit_operands_are_bitwise_equivalent(math, monkeypatch):
         assert torch.equal(u, v), "%s differs between pre-split and in-loop split (max %.3e)" % (name, float((u - v).abs().max()))
 
 
+def test_compact_activation_storage_of_a_residual_block(monkeypatch):
+    """MCDSEG_ACT_STORAGE=compact inside a trunk: the fused groups hand each other companions only (no fp32 activation is
+    written, the residual add and the ReLU mask read the companion).  A residual block + projection shortcut, forward and
+    backward, against the same block with fp32 activations (the companion carries 22 of fp32's 24 bits) and against fp64."""
+    dev = _dev()
+    from mcdseg import ops
+    from models.drn import BasicBlock, BatchNorm2d, Conv2d, ConvBN, ConvBNReLU
+    monkeypatch.setattr(ops, "CONV_MATH", "f16x3")
+    g = torch.Generator().manual_seed(61)
+    stem = ConvBNReLU(Conv2d(24, 64, 3, padding=1, bias=False), BatchNorm2d(64), torch.nn.ReLU(inplace=True)).to(dev)
+    blk = BasicBlock(64, 128, stride=2, downsample=ConvBN(Conv2d(64, 128, 1, stride=2, bias=False), BatchNorm2d(128)),
+                     dilation=(1, 1)).to(dev)
+    blk2 = BasicBlock(128, 128, dilation=(2, 2)).to(dev)
+    tail = ConvBNReLU(Conv2d(128, 72, 3, padding=1, bias=False), BatchNorm2d(72), torch.nn.ReLU(inplace=True)).to(dev)
+    mods = [stem, blk, blk2, tail]
+    with torch.no_grad():
+        for m in mods:
+            for p in m.parameters():
+                if p.dim() == 1:
+                    p.copy_(1 + 0.2 * torch.randn(p.shape, generator=g).to(dev) if p.mean() > 0.5 else 0.1 * torch.randn(p.shape, generator=g).to(dev))
+    x = torch.randn(3, 24, 20, 24, generator=g).to(dev)
+    gy = torch.randn(3, 72, 10, 12, generator=g).to(dev)
+
+    def run(storage):
+        monkeypatch.setattr(ops, "ACT_STORAGE", storage)
+        for m in mods:
+            m.zero_grad()
+            for b in m.modules():
+                if isinstance(b, BatchNorm2d):
+                    b.running_mean.zero_(), b.running_var.fill_(1), b.num_batches_tracked.zero_()
+        xs = x.clone().requires_grad_()
+        seen = []
+        with ops.trunk_internal():
+            h = stem(xs)
+            seen.append(ops.is_virtual(h))
+            h = blk(h)
+            seen.append(ops.is_virtual(h))
+            h = blk2(h)
+            seen.append(ops.is_virtual(h))
+        y = tail(h)  # the trunk's last layer: fp32
+        assert not ops.is_virtual(y)
+        y.backward(gy)
+        grads = [xs.grad] + [p.grad for m in mods for p in m.parameters()]
+        stats = [b.running_var.clone() for m in mods for b in m.modules() if isinstance(b, BatchNorm2d)]
+        return seen, [t.detach().clone() for t in [y] + grads + stats]
+
+    seen_c, c = run("compact")
+    seen_f, f = run("fp32")
+    assert seen_c == [True, True, True] and seen_f == [False, False, False]
+    for i, (a, b) in enumerate(zip(c, f)):
+        err, scale = _maxerr(a, b)
+        assert err <= 2e-4 * scale, "tensor %d: compact vs fp32 activations differ by %.3e of scale %.3e" % (i, err, scale)
+    # and the virtual activation reconstructs to the fp32 one within 2^-22
+    monkeypatch.setattr(ops, "ACT_STORAGE", "compact")
+    with torch.no_grad(), ops.trunk_internal():
+        hv = stem(x)
+    monkeypatch.setattr(ops, "ACT_STORAGE", "fp32")
+    with torch.no_grad():
+        hr = stem(x)
+    assert ops.is_virtual(hv) and float((ops.materialize(hv) - hr).abs().max()) <= 3e-7 * float(hr.abs().max())
+
+
 def test_stale_presplit_companion_is_not_used(monkeypatch):
     """An in-place write to an activation between two fused groups (the reference's statements run unchanged over the
     drop-in modules may do that) must not leave the next convolution reading the old pre-split image."""

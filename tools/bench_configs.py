@@ -5,7 +5,8 @@ tool; bench.py (cfg2) is the judged benchmark.
   cfg2  MCD early fusion          drn_d_38,  N=16, 6x480x640   (same as bench.py, for reference)
   cfg3  MFNet-ScoreAddFusion      2x drn_d_38 encoders, N=16
   cfg4  multitask (seg + HHA)     drn_d_38 RGB encoder + 3 decoders, N=8
-  cfg5* drn_d_105                 N as given (fp32 activations; the bf16-storage variant of cfg5 is not built)
+  cfg5  drn_d_105                 N and image size as given (--n5, --hw5); BASELINE: N=32 per GPU at 720x1280, which needs
+                                  MCDSEG_ACT_STORAGE=compact (activations kept as their 2 x fp16 companions) to fit 288 GB
 """
 import argparse
 import os
@@ -60,22 +61,27 @@ def main():
     ap.add_argument("--cfg", default="cfg3,cfg4,cfg5")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--n5", type=int, default=8, help="pairs per GPU for the drn_d_105 run")
+    ap.add_argument("--hw5", type=int, nargs=2, default=[480, 640], help="image size of the drn_d_105 run (BASELINE: 720 1280)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for cfg in args.cfg.split(","):
         n = {"cfg2": 16, "cfg3": 16, "cfg4": 8, "cfg5": args.n5}[cfg]
         net = "drn_d_105" if cfg == "cfg5" else "drn_d_38"
         solver = build(cfg, net, dev)
-        s, l, t = batch(n, 480, 640, dev)
+        h, w = args.hw5 if cfg == "cfg5" else (480, 640)
+        s, l, t = batch(n, h, w, dev)
+        torch.cuda.reset_peak_memory_stats()
         out = solver.step(s, l, t)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = solver.step(s, l, t)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / args.steps
-        print("%s %-10s N=%-2d 6x480x640: %.1f ms/step, %.2f pairs/s  (c_loss %.4f, d_loss %.6f)" % (
-            cfg, net, n, 1e3 * dt, n / dt, float(out[0]), float(out[1])), flush=True)
+        dt = (time.perf_counter() - t0) / max(args.steps, 1)
+        from mcdseg import ops
+        print("%s %-10s N=%-2d 6x%dx%d [%s, activations %s]: %.1f ms/step, %.2f pairs/s, peak %.1f GB  (c_loss %.4f, d_loss %.6f)" % (
+            cfg, net, n, h, w, ops.CONV_MATH, ops.ACT_STORAGE, 1e3 * dt, n / dt, torch.cuda.max_memory_allocated() / 2 ** 30,
+            float(out[0]), float(out[1])), flush=True)
         del solver, s, l, t
         torch.cuda.empty_cache()
 
