@@ -111,6 +111,11 @@ int mcdseg_conv_split_dgrad(const mcdseg_conv_desc* d, int32_t math, const float
 int mcdseg_conv_split_wgrad(const mcdseg_conv_desc* d, int32_t math, const float* x, const void* x_cb, const float* x_bound,
                             const float* dy, const void* dy_cb, const float* dy_bound, float* dw, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* which kernel the two weight-gradient entry points launch for a geometry (math = 0: mcdseg_conv_wgrad): 0..3 the f32 plans
+ * (128x128, 64x64, 32x32 tiles, tap-packed thin inputs), 10 split arithmetic from fp32 operands, 11 / 12 / 13 from both
+ * pre-split companions (register-transposing, transposed-read 128x128, transposed-read 256x128).  For profilers and
+ * bench.py's per-kernel accounting. */
+int32_t mcdseg_conv_wgrad_variant(const mcdseg_conv_desc* d, int32_t math, int32_t presplit);
 /* dw = x (*) dy ; split over pixels into slabs in `workspace`, then reduced in a fixed order. */
 size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d);
 int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw,

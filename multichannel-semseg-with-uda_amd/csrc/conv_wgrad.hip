@@ -431,8 +431,34 @@ int mcdseg_internal_wgrad_split_launch(const mcdseg_conv_desc* d, int math, cons
 int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, const void* x_cb, const void* dy_cb, float* slab,
                                           int co_p, int ci_p, int chunks_per_img, int splits, hipStream_t st);
 
+int mcdseg_internal_wgrad_cb_variant(const mcdseg_conv_desc* d, int math, int co_p, int ci_p, int splits);
+int mcdseg_internal_wgrad_split_tr64_launch(const mcdseg_conv_desc* d, int math, const void* x_cb, const void* dy_cb, float* slab, int co_p,
+                                            int ci_p, int chunks_per_img, int splits, hipStream_t st);
+
+// the 64 x 64 plan (32 < min(Cin, Cout) <= 64) from both pre-split companions: f16x3 only (MCDSEG_WGRAD_TR64=0 turns it off)
+static bool tr64_applies(const mcdseg_conv_desc* d, int math, const void* x_cb, const void* dy_cb, int cfg) {
+  static const bool on = [] {
+    const char* e = getenv("MCDSEG_WGRAD_TR64");
+    return e == nullptr || atoi(e) != 0;
+  }();
+  return on && cfg == 1 && math == MCDSEG_MATH_F16X3 && x_cb && dy_cb && (d->Cin & 7) == 0 && (d->Cout & 7) == 0;
+}
+
 static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                       int math, const void* x_cb, const float* x_bound, const void* dy_cb, const float* dy_bound, void* stream);
+
+// Which kernel mcdseg_conv_wgrad / mcdseg_conv_split_wgrad launch for this geometry (math = 0 for mcdseg_conv_wgrad):
+// 0..3 the f32 plans (128x128, 64x64, 32x32 tiles, tap-packed thin), 10 split arithmetic from fp32 operands, 11 / 12 / 13 / 14 from
+// both pre-split companions: register-transposing, transposed-read 128x128, transposed-read 256x128, transposed-read 64-channel
+// tap pairs.  For profilers and the benchmark's per-kernel accounting; never needed to call the operators.
+extern "C" int32_t mcdseg_conv_wgrad_variant(const mcdseg_conv_desc* d, int32_t math, int32_t presplit) {
+  if (d == nullptr) return -22;
+  const WgradPlan pl = make_plan(d);
+  if (pl.cfg == 1 && math == MCDSEG_MATH_F16X3 && presplit && tr64_applies(d, math, d, d, 1)) return 14;
+  if (pl.cfg != 0 || math == 0) return pl.cfg;
+  if (!(presplit && (d->Cin & 7) == 0 && (d->Cout & 7) == 0)) return 10;
+  return 11 + mcdseg_internal_wgrad_cb_variant(d, math, pl.co_p, pl.ci_p, pl.splits);
+}
 
 extern "C" int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,
                                  size_t workspace_bytes, void* stream) {
@@ -456,8 +482,9 @@ extern "C" size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d) {
 static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                       int math, const void* x_cb, const float* x_bound, const void* dy_cb, const float* dy_bound, void* stream) {
   MCD_REQUIRE(d && dw && workspace, "conv_wgrad: null pointer");
-  const bool cb_path = math && x_cb && dy_cb && (d->Cin & 7) == 0 && (d->Cout & 7) == 0 && make_plan(d).cfg == 0;
-  const bool split_plan = math && make_plan(d).cfg == 0;
+  const bool tr64 = tr64_applies(d, math, x_cb, dy_cb, make_plan(d).cfg);
+  const bool cb_path = tr64 || (math && x_cb && dy_cb && (d->Cin & 7) == 0 && (d->Cout & 7) == 0 && make_plan(d).cfg == 0);
+  const bool split_plan = tr64 || (math && make_plan(d).cfg == 0);
   MCD_REQUIRE(!(split_plan && math == MCDSEG_MATH_F16X3) || (x_bound && dy_bound), "conv_split_wgrad: f16x3 needs both bound scalars");
   MCD_REQUIRE(cb_path || (x && dy), "conv_wgrad: x and dy may be NULL only when the pre-split 128x128 plan applies");
   MCD_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0, "conv_wgrad: bad dims");
@@ -498,7 +525,11 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
     return 0;
   }
   const bool scaled = split_plan && math == MCDSEG_MATH_F16X3;
-  if (cb_path) {
+  if (tr64) {
+    if (int rc = mcdseg_internal_wgrad_split_tr64_launch(d, math, x_cb, dy_cb, (float*)workspace, pl.co_p, pl.ci_p, pl.chunks_per_img,
+                                                         pl.splits, st))
+      return rc;
+  } else if (cb_path) {
     if (int rc = mcdseg_internal_wgrad_split_cb_launch(d, math, x_cb, dy_cb, (float*)workspace, pl.co_p, pl.ci_p, pl.chunks_per_img,
                                                        pl.splits, st))
       return rc;

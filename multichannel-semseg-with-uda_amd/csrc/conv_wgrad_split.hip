@@ -637,6 +637,207 @@ int mcdseg_internal_wgrad_split_launch(const mcdseg_conv_desc* d, int math, cons
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 64-channel layers (min(Cin, Cout) in (32, 64]: the plan's 64 x 64 tiles).  A 64 x 64 output tile alone leaves the matrix pipe
+// starved (6 MFMAs per wave and K-block), so a workgroup computes the tiles of TWO taps from one staged dY tile: output
+// 64 (co) x 128 (tap pair x 64 ci), wave (wm, wn) = 32 co x the 64 ci of tap 2 tp + wn.  Same staging as
+// conv_wgrad_split_tr_kernel -- LDS-DMA of 16-B units, transposing LDS reads -- except that a DMA instruction's upper half-wave
+// carries something else than its lower half: for dY (8 channel groups) the NEXT quad, for X the SECOND tap's shift; the
+// address (and the padding test) is therefore per lane.
+template <class P>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr64_kernel(WgradCbParams p) {
+  static_assert(P::NP == 2, "two-piece policies");
+  constexpr int R = 4, NSTAGE = 2;
+  constexpr int BM = 64, BNC = 64;           // co tile, ci tile (x 2 taps = 128 columns)
+  constexpr int NP = P::NP;
+  constexpr int NQD = 2 * R, KK = NQD / 4;
+  typedef typename P::frag frag;
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  constexpr int AQ = 512, BQ = 1024;         // bytes per quad image: [cg 8][pixel 4][16 B] / [tap 2][cg 8][pixel 4][16 B]
+  constexpr int A_UNIT = NQD * AQ, B_UNIT = NQD * BQ;
+  constexpr int STAGE = NP * (A_UNIT + B_UNIT);  // 24 KB
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int ci_tiles = p.ci_p / BNC;
+  const int co_tiles = p.co_p / BM;
+  const int T_ = p.KH * p.KW;
+  const int TP = (T_ + 1) >> 1;  // tap pairs
+  const int per_split = co_tiles * ci_tiles * TP;
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int split = (slot / per_split) * 8 + xcd;
+  if (split >= p.splits) return;
+  int rem = slot % per_split;
+  const int tp = rem % TP;
+  rem /= TP;
+  const int tile_ci = rem % ci_tiles;
+  const int tile_co = rem / ci_tiles;
+  const int n = split / p.chunks_per_img;
+  const int chunk_id = split - n * p.chunks_per_img;
+  const int ntiles = p.tiles_x * p.tiles_y;
+  const int t_begin = chunk_id * p.tiles_per_chunk;
+  int t_end = t_begin + p.tiles_per_chunk;
+  if (t_end > ntiles) t_end = ntiles;
+
+  // ---- DMA role of this wave: (operand, piece); per lane: half-wave selector, channel group, pixel
+  const int opnd = wave >> 1;   // 0 = dY, 1 = X
+  const int piece = wave & 1;
+  const int ps = lane & 3;
+  const int cg = (lane >> 2) & 7;
+  const int hw_sel = lane >> 5;  // dY: second quad of the pair; X: second tap of the pair
+  const int sH = opnd ? p.H : p.Ho;
+  const int sW = opnd ? p.W : p.Wo;
+  const int sS = opnd ? p.stride : 1;
+  const int tap = 2 * tp + (opnd ? hw_sel : 0);
+  const bool tap_ok = tap < T_;
+  const int ky = tap / p.KW, kx = tap - ky * p.KW;
+  const int shy = opnd ? ky * p.dil - p.pad : 0;  // per lane for X
+  const int shx = opnd ? kx * p.dil - p.pad : 0;
+  const int sC8 = (opnd ? p.Cin : p.Cout) >> 3;
+  const int cg0 = (opnd ? tile_ci : tile_co) * 8;
+  const int sHW = sH * sW;
+  const int pstride = p.N * sC8 * sHW;
+  const char* sptr = (const char*)(opnd ? p.x_cb : p.dy_cb);
+  const int sbytes = opnd ? p.x_cb_bytes : p.dy_cb_bytes;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sptr, 0, sbytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  const bool cg_ok = (cg0 + cg) < sC8 && tap_ok;
+  const int lbase = ((n * sC8 + cg0 + cg) * sHW + piece * pstride);  // 16-B units, per lane
+  unsigned char* const unit_lds = smem + (opnd ? NP * A_UNIT + piece * B_UNIT : piece * A_UNIT);
+
+  auto issue_dma = [&](int tt, int stage) {
+    const int ty = tt / p.tiles_x;
+    const int tx = tt - ty * p.tiles_x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (opnd == 0) {  // dY: instruction i carries quads 2 i (lower half-wave) and 2 i + 1 (upper)
+#pragma unroll
+      for (int i = 0; i < NQD / 2; ++i) {
+        const int j = 2 * i + hw_sel;
+        const int iy = ty * R + (j % R);
+        const int ix = tx * 8 + 4 * (j / R) + ps;
+        const bool ok = cg_ok && iy < sH && ix < sW;
+        const unsigned voff = ok ? (unsigned)(lbase + iy * sW + ix) * 16u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(unit_lds + stage * STAGE + i * 2 * AQ), 16,
+                                                 voff, 0, 0, 0);
+      }
+    } else {  // X: instruction j carries quad j of tap 2 tp (lower half-wave) and of tap 2 tp + 1 (upper)
+#pragma unroll
+      for (int j = 0; j < NQD; ++j) {
+        const int iy = (ty * R + (j % R)) * sS + shy;
+        const int ix = (tx * 8 + 4 * (j / R) + ps) * sS + shx;
+        const bool ok = cg_ok && (unsigned)iy < (unsigned)sH && (unsigned)ix < (unsigned)sW;
+        const unsigned voff = ok ? (unsigned)(lbase + iy * sW + ix) * 16u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(unit_lds + stage * STAGE + j * BQ), 16, voff,
+                                                 0, 0, 0);
+      }
+    }
+#else
+    (void)ty;
+    (void)tx;
+    (void)stage;
+#endif
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int gl = lane & 15;
+  const int tq = gl >> 2, tpp = gl & 3;
+  const int trow = ((((lane >> 4) & 1) * 2 + (tpp >> 1)) * 4 + tq) * 16 + 8 * (tpp & 1);
+  const int a_lane = (wm * 4) * 64 + trow;  // 32 co = 4 channel groups of the 8 in a dY quad
+  const int b_lane = (wn * 8) * 64 + trow;  // tap wn: its 8 channel groups of the 16 in an X quad
+
+  auto tr_read = [&](const unsigned char* addr) -> s16x4 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(addr));
+#else
+    (void)addr;
+    return s16x4{};
+#endif
+  };
+  auto load_frag = [&](const unsigned char* unit, int quad_bytes, int quad0, int lane_off) -> frag {
+    const s16x4 lo = tr_read(unit + quad0 * quad_bytes + lane_off);
+    const s16x4 hi = tr_read(unit + (quad0 + 1) * quad_bytes + lane_off);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(frag, v);
+  };
+  frag fa[NP], fb[NP][2];
+  auto read_frags = [&](const unsigned char* st, int kk) {
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) {
+      fa[pc] = load_frag(st + pc * A_UNIT, AQ, 4 * kk + 2 * lh, a_lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[pc][j] = load_frag(st + NP * A_UNIT + pc * B_UNIT, BQ, 4 * kk + 2 * lh, b_lane + j * 256);
+    }
+  };
+  auto mfma_frags = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int tm = 0; tm < P::NTERMS; ++tm) acc[j] = P::mfma(fa[P::TA[tm]], fb[P::TB[tm]][j], acc[j]);
+  };
+
+  const int nsteps = t_end - t_begin;
+  if (nsteps > 0) issue_dma(t_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int s = 0; s < nsteps; ++s) {
+    const int cur = s & 1;
+    const unsigned char* st = smem + cur * STAGE;
+    read_frags(st, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < nsteps) issue_dma(t_begin + s + 1, cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_frags();
+#pragma unroll
+    for (int kk = 1; kk < KK; ++kk) {
+      read_frags(st, kk);
+      mfma_frags();
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+
+  const int my_tap = 2 * tp + wn;
+  if (my_tap >= T_) return;
+  float* out = p.slab + ((size_t)split * T_ + my_tap) * p.co_p * p.ci_p;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = tile_co * BM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = tile_ci * BNC + j * 32 + l31;
+      out[(size_t)row * p.ci_p + col] = acc[j][r];
+    }
+  }
+}
+
+// which pre-split kernel runs: 0 = register-transposing (three-piece policy, or MCDSEG_WGRAD_TR=0), 1 = transposed-read
+// 128x128 tiles, 2 = transposed-read 256x128 tiles
+int mcdseg_internal_wgrad_cb_variant(const mcdseg_conv_desc* d, int math, int co_p, int ci_p, int splits) {
+  static const bool use_tr = [] {
+    const char* e = getenv("MCDSEG_WGRAD_TR");  // development knob: 0 = register-transposing kernel for the two-piece policy too
+    return e == nullptr || atoi(e) != 0;
+  }();
+  static const bool use_big = [] {
+    const char* e = getenv("MCDSEG_WGRAD_BIG");  // development knob: 0 = 128 x 128 tiles only
+    return e == nullptr || atoi(e) != 0;
+  }();
+  if (!(math == MCDSEG_MATH_F16X3 && use_tr)) return 0;
+  // 256 x 128 tiles (16-pixel stages) for the layers whose padded Cout is a multiple of 256 -- the plan was made for 128-row
+  // tiles, so the number of workgroups halves; taken only while that still fills the chip twice over
+  const bool big = use_big && (co_p % 256) == 0 && (int64_t)(co_p / 256) * (ci_p / 128) * d->KH * d->KW * splits >= 1024;
+  return big ? 2 : 1;
+}
+
 // pre-split operands (see conv_wgrad_split_cb_kernel); chunks_per_img / splits come from the shared plan, the pixel range
 // of a chunk is expressed in 8x4 output tiles
 int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, const void* x_cb, const void* dy_cb, float* slab,
@@ -646,19 +847,8 @@ int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, c
   p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.Ho = d->Ho; p.Wo = d->Wo;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
   p.co_p = co_p; p.ci_p = ci_p; p.chunks_per_img = chunks_per_img; p.splits = splits;
-  static const bool use_tr = [] {
-    const char* e = getenv("MCDSEG_WGRAD_TR");  // development knob: 0 = register-transposing kernel for the two-piece policy too
-    return e == nullptr || atoi(e) != 0;
-  }();
-  static const bool use_big = [] {
-    const char* e = getenv("MCDSEG_WGRAD_BIG");  // development knob: 0 = 128 x 128 tiles only
-    return e == nullptr || atoi(e) != 0;
-  }();
-  // 256 x 128 tiles (16-pixel stages) for the layers whose padded Cout is a multiple of 256 -- the plan was made for 128-row
-  // tiles, so the number of workgroups halves; taken only while that still fills the chip twice over
-  const bool tr = math == MCDSEG_MATH_F16X3 && use_tr;
-  const bool big = tr && use_big && (co_p % 256) == 0 &&
-                   (int64_t)(co_p / 256) * (ci_p / 128) * d->KH * d->KW * splits >= 1024;
+  const int variant = mcdseg_internal_wgrad_cb_variant(d, math, co_p, ci_p, splits);
+  const bool tr = variant >= 1, big = variant == 2;
   const int rows = big ? 2 : 4;  // pixel rows of a stage tile
   p.tiles_x = ceil_div(d->Wo, 8);
   p.tiles_y = ceil_div(d->Ho, rows);
@@ -686,5 +876,35 @@ int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, c
   else
     hipLaunchKernelGGL(conv_wgrad_split_cb_kernel<SplitBf16x6>, dim3((unsigned)nwg), dim3(256), 0, st, p);
   MCD_LAUNCH_CHECK("conv_wgrad_split_cb");
+  return 0;
+}
+
+// the plan's 64 x 64 tiles from both companions (two-piece policies): see conv_wgrad_split_tr64_kernel
+int mcdseg_internal_wgrad_split_tr64_launch(const mcdseg_conv_desc* d, int math, const void* x_cb, const void* dy_cb, float* slab, int co_p,
+                                            int ci_p, int chunks_per_img, int splits, hipStream_t st) {
+  WgradCbParams p;
+  p.x_cb = x_cb; p.dy_cb = dy_cb; p.slab = slab;
+  p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+  p.co_p = co_p; p.ci_p = ci_p; p.chunks_per_img = chunks_per_img; p.splits = splits;
+  p.tiles_x = ceil_div(d->Wo, 8);
+  p.tiles_y = ceil_div(d->Ho, 4);
+  p.tiles_per_chunk = ceil_div(p.tiles_x * p.tiles_y, chunks_per_img);
+  const int64_t np = mcd_math_pieces(math);
+  const int64_t xb = np * d->N * d->Cin * d->H * d->W * 2, yb = np * d->N * d->Cout * d->Ho * d->Wo * 2;
+  if (math != MCDSEG_MATH_F16X3 || (d->Cin & 7) || (d->Cout & 7) || (co_p & 63) || (ci_p & 63) || xb >= (1ll << 31) || yb >= (1ll << 31)) {
+    mcdseg_set_error("conv_wgrad_split: the 64-tile pre-split plan needs f16x3, channel counts divisible by 8 and < 2 GiB per operand");
+    return -22;
+  }
+  p.x_cb_bytes = (int)xb;
+  p.dy_cb_bytes = (int)yb;
+  const int64_t per_split = (int64_t)(co_p / 64) * (ci_p / 64) * ((d->KH * d->KW + 1) / 2);
+  const int64_t nwg = 8 * ceil_div64(splits, 8) * per_split;
+  if (nwg >= (1ll << 31)) {
+    mcdseg_set_error("conv_wgrad_split: grid too large");
+    return -22;
+  }
+  hipLaunchKernelGGL(conv_wgrad_split_tr64_kernel<SplitF16x3>, dim3((unsigned)nwg), dim3(256), 0, st, p);
+  MCD_LAUNCH_CHECK("conv_wgrad_split_tr64");
   return 0;
 }

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "mcdseg_bn_bwd_apply_cb": (c_int, [c_void_p] * 13 + [c_i32] * 6 + [c_void_p]),
     "mcdseg_conv_split_wgrad": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "mcdseg_conv_dgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mcdseg_conv_wgrad_variant": (c_i32, [_P(ConvDesc), c_i32, c_i32]),
     "mcdseg_conv_wgrad_workspace_bytes": (c_size_t, [_P(ConvDesc)]),
     "mcdseg_conv_wgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mcdseg_bn_stats_workspace_bytes": (c_size_t, [c_i64, c_i32]),

@@ -439,9 +439,21 @@ def split_companion(x, bound=None):
     return cb, bound
 
 
-def _wgrad_split_plan(desc):
-    """the 128x128 split-arithmetic plan of csrc/conv_wgrad.hip applies (else the f32 kernels run)"""
-    return CONV_MATH in MATH_ID and min(desc.Cout, desc.Cin) > 64 and not (desc.Cin <= 16 and desc.KH * desc.KW > 1)
+# mcdseg_conv_wgrad_variant code -> the kernel name rocprofv3 prints
+_WGRAD_NAMES = {10: "conv_wgrad_split_kernel<%s>", 11: "conv_wgrad_split_cb_kernel<%s>", 12: "conv_wgrad_split_tr_kernel<%s, 2, 4, 2>",
+                13: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3>", 14: "conv_wgrad_split_tr64_kernel<%s>"}
+WGRAD_TR64 = os.environ.get("MCDSEG_WGRAD_TR64", "1") != "0"
+
+
+def _wgrad_split_plan(desc, have_cb=False):
+    """a split-arithmetic plan of csrc/conv_wgrad.hip applies (else the f32 kernels run): the 128x128 plan for
+    min(Cin, Cout) > 64, and -- from both pre-split companions only, f16x3 -- the 64-channel tap-pair plan for 32 < min <= 64"""
+    if CONV_MATH not in MATH_ID or (desc.Cin <= 16 and desc.KH * desc.KW > 1):
+        return False
+    lo = min(desc.Cout, desc.Cin)
+    if lo > 64:
+        return True
+    return WGRAD_TR64 and have_cb and _scaled() and lo > 32 and desc.Cin % 8 == 0 and desc.Cout % 8 == 0
 
 
 def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None, x_bound=None, dy_bound=None):
@@ -450,15 +462,15 @@ def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None, x_bound=None, dy_bound=None)
     pieces = _batch_pieces(desc)
     if len(pieces) > 1 or x_cb is None or dy_cb is None:
         x_cb = dy_cb = None  # the piece-major split layout cannot be sliced along N; both companions or none
-    split = _wgrad_split_plan(desc)
+    split = _wgrad_split_plan(desc, x_cb is not None)
     if split and x_cb is None:
         x_bound, dy_bound = _bound_or_measure(x, x_bound), _bound_or_measure(dy, dy_bound)
     for a, b in pieces:
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
         ws = _ws(L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(d)), (x if x is not None else x_cb).device)
         dw = torch.empty((desc.Cout, desc.Cin, desc.KH, desc.KW), dtype=torch.float32, device=ws.device)
-        name = ("conv_wgrad_split_cb_kernel<%s>" if x_cb is not None else "conv_wgrad_split_kernel<%s>") % POLICY[CONV_MATH] if split else \
-            wgrad_kernel_name(desc.Cout, desc.Cin, desc.KH * desc.KW)
+        name = _WGRAD_NAMES.get(L.mcdseg_conv_wgrad_variant(ctypes.byref(d), MATH_ID[CONV_MATH], int(x_cb is not None)), "conv_wgrad") \
+            % POLICY[CONV_MATH] if split else wgrad_kernel_name(desc.Cout, desc.Cin, desc.KH * desc.KW)
         with _timed(name, conv_work(d)):
             if split:
                 check(L.mcdseg_conv_split_wgrad(ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(x, a, b)), _p(x_cb), _p(x_bound),
@@ -619,9 +631,10 @@ class _ConvBNAct(torch.autograd.Function):
             dres = torch.empty_like(z) if ctx.relu else dy
         dz_cb = None
         # the fp32 dz is skipped when every consumer reads the split companion: dgrad (pre-split gather) and wgrad
-        # (pre-split 128x128 plan); a conv bias gradient or any fallback path still needs it
-        single = len(_batch_pieces(desc)) == 1
-        wgrad_cb = (ctx.x_cb is not None and _wgrad_split_plan(desc) and desc.Cin % 8 == 0 and desc.Cout % 8 == 0)
+        # (pre-split plans); a conv bias gradient or any fallback path still needs it
+        single = single_piece = len(_batch_pieces(desc)) == 1
+        wgrad_cb = (ctx.x_cb is not None and use_cb and single_piece and _wgrad_split_plan(desc, True) and desc.Cin % 8 == 0
+                    and desc.Cout % 8 == 0)
         skip_dz = (use_cb and single and not (ctx.has_bias and ctx.needs_input_grad[5])
                    and (not ctx.needs_input_grad[1] or wgrad_cb))
         if not skip_dz:

@@ -535,6 +535,11 @@ def test_presplit_operands_are_bitwise_equivalent(math, monkeypatch):
 
     a, b = run(True), run(False)
     for name, u, v in zip(["y1", "y2", "y3", "dx", "dw1", "dw2", "dw3"], a, b):
+        if name == "dw2" and math == "f16x3":
+            # 40 -> 64 channels: with both companions the weight gradient runs the 64-channel tap-pair kernel in the split
+            # arithmetic, without them the f32-MFMA kernel -- same result to fp32 accuracy, not the same bits
+            _assert_close(u, v, 2e-5, "dw2 (split tap-pair kernel vs f32 kernel)")
+            continue
         assert torch.equal(u, v), "%s differs between pre-split and in-loop split (max %.3e)" % (name, float((u - v).abs().max()))
 
 
@@ -741,6 +746,10 @@ WGRAD_CB_CASES = [
     (128, 128, 3, 2, 1, 15, 17, 2),   # stride 2
     (72, 80, 3, 1, 1, 8, 8, 3),
     (512, 512, 3, 1, 4, 30, 40, 2),   # layer6 at 240x320: several workgroups per image along the pixels
+    (64, 64, 3, 1, 1, 12, 16, 2),     # 64-channel layers: tap pairs share one staged dY tile (f16x3; the f32 plan otherwise)
+    (64, 128, 3, 2, 1, 15, 17, 2),    # ... stride 2, two co tiles
+    (48, 64, 3, 1, 2, 13, 19, 2),     # ... ragged channel groups, dilation 2
+    (64, 128, 1, 2, 1, 11, 13, 2),    # ... 1x1 stride 2: a single tap (the pair's second half is empty)
 ]
 
 
