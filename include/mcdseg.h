@@ -254,6 +254,15 @@ int mcdseg_prob_nll(const float* p, const int64_t* labels, const float* weight, 
                     float* grad, float* loss, int32_t N, int32_t C, int32_t HW, void* workspace, size_t workspace_bytes,
                     void* stream);
 
+/* Scale(img_shape, Image.BILINEAR) / Scale(img_shape, Image.NEAREST) in front of the two transforms below (transform.py:303,
+ * 320; torchvision's Scale = PIL.Image.resize) on uint8 batches: src [N,H,W,C] -> dst [N,OH,OW,C] (bilinear; Pillow's 8-bit
+ * ImagingResample, bit for bit) and src [N,H,W] -> dst [N,OH,OW] (nearest; ImagingScaleAffine, for label maps).  workspace: 4-byte
+ * aligned scratch of mcdseg_resize_workspace_bytes (coefficient / index tables built on the device + the image between the passes). */
+size_t mcdseg_resize_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW);
+int mcdseg_resize_bilinear_u8(const uint8_t* src, uint8_t* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int mcdseg_resize_nearest_u8(const uint8_t* src, uint8_t* dst, int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW,
+                             void* workspace, size_t workspace_bytes, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * Either side of the step: input transform and evaluation histogram
  *   normalize_u8:   ToTensor() + Normalize(mean,std) (transform.py:302-315): src uint8 [N,H,W,Cs] (HWC) ->

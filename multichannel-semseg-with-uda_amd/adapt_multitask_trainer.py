@@ -50,7 +50,7 @@ def main(argv=None):
         checkpoint = load_checkpoint(args.resume)
         start_epoch = checkpoint["epoch"]
         args = checkpoint["args"]
-        for k in ("synthetic", "synthetic_raw", "synthetic_len", "seed", "no_pretrained", "solver", "no_tflog"):
+        for k in ("synthetic", "synthetic_raw", "synthetic_len", "src_file_list", "tgt_file_list", "seed", "no_pretrained", "solver", "no_tflog"):
             if k not in vars(args):
                 setattr(args, k, getattr(cli, k))
         criterion, criterion_d = criteria(args)

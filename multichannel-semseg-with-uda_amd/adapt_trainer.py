@@ -79,7 +79,7 @@ def main(argv=None):
         start_epoch = checkpoint["epoch"]
         args = checkpoint["args"]  # the pickled namespace replaces the CLI one (adapt_trainer.py:40-43)
         args.savename = infn.split("-")[0] if "savename" not in vars(args) else args.savename
-        for k in ("synthetic", "synthetic_raw", "synthetic_len", "seed", "no_pretrained", "solver", "no_tflog"):
+        for k in ("synthetic", "synthetic_raw", "synthetic_len", "src_file_list", "tgt_file_list", "seed", "no_pretrained", "solver", "no_tflog"):
             if k not in vars(args):
                 setattr(args, k, getattr(cli, k))
         model_g, model_f1, model_f2, optimizer_g, optimizer_f = build(args)

@@ -32,6 +32,10 @@ def add_mi355x_flags(parser):
     g.add_argument("--synthetic_len", type=int, default=64, help="samples per synthetic dataset")
     g.add_argument("--synthetic_raw", action="store_true",
                    help="synthetic uint8 HWC images + uint8 labels (background 255): ToTensor/Normalize/ReLabel run on the GPU")
+    g.add_argument("--src_file_list", default=None,
+                   help="real data: a list file with 'rgb_path [hha_path] label_path' per line (datasets.FileListRGBD); files are "
+                        "read with PIL, Scale / ToTensor / Normalize / ReLabel run on the GPU at --train_img_shape")
+    g.add_argument("--tgt_file_list", default=None, help="the same for the target domain (its labels are loaded but not used)")
     g.add_argument("--seed", type=int, default=1234)
     g.add_argument("--no_pretrained", action="store_true", help="He-normal init instead of ImageNet weights (no network)")
     g.add_argument("--solver", choices=["fused", "dropin"], default="fused",

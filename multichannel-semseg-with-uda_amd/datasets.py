@@ -6,8 +6,12 @@ on the MI355X path.  What the trainers need from it is kept with the reference's
 ``ConcatDataset`` (:20-28), ``check_src_tgt_ok`` (:1004-1008) -- plus ``SyntheticRGBD``, the seeded
 stand-in the BASELINE configs run on: N(0,1) images in place of ImageNet-normalised
 RGB+HHA (transform.py:307) and uniform labels with class n_class-1 as the zero-weight background
-(transform.py:319-325 maps 255 there).
+(transform.py:319-325 maps 255 there) -- and ``FileListRGBD``, a loader for real data: image / HHA / label files named in a list
+are opened with PIL (``default_loader``, datasets.py:20-28) and handed over as raw uint8 arrays; everything the reference's
+transforms then do (Scale, ToTensor, Normalize, ToLabel, ReLabel; transform.py:302-325) runs on the MI355X
+(``DeviceInputPipeline``).
 """
+import numpy as np
 import torch
 from torch.utils import data
 
@@ -65,15 +69,67 @@ CITY_MEAN = [0.290101, 0.328081, 0.286964]            # transform.py:311
 CITY_STD = [0.182954, 0.186566, 0.184475]
 
 
-class DeviceInputPipeline(object):
-    """The tensor half of ``get_img_transform`` / ``get_lbl_transform`` (transform.py:302-325) on the GPU: pinned uint8
-    batches go over PCIe as bytes (4x fewer than fp32) and one kernel each does ToTensor+Normalize (HWC->NCHW) and
-    ToLabel+ReLabel(background_id -> n_class-1).  Resizing stays with the loader (PIL), as in the reference."""
+def default_loader(path):
+    """datasets.py:27-28 of the reference"""
+    from PIL import Image
+    return Image.open(path)
 
-    def __init__(self, input_ch, n_class, device, normalize_way="imagenet", background_id=255):
+
+class FileListRGBD(data.Dataset):
+    """Real data for the trainers: ``list_file`` has one sample per line, ``rgb_path [hha_path] label_path`` (whitespace
+    separated; relative paths are taken from the list's directory).  ``__getitem__`` returns what the reference's loaders hold
+    BEFORE their transforms -- a uint8 [H,W,3 or 6] image (RGB, then HHA) and a uint8 [H,W] label map straight from the PNGs
+    (``default_loader``; palette / grey label PNGs are read as their index / grey values, as ``ToLabel`` sees them) -- so that
+    resize, normalisation and relabelling run on the device.  All files of one list must share one size (batches are stacked)."""
+
+    def __init__(self, list_file, input_ch=6, test=False):
+        import os
+        self.root = os.path.dirname(os.path.abspath(list_file))
+        self.items = []
+        for line in open(list_file):
+            parts = line.split()
+            if not parts or parts[0].startswith("#"):
+                continue
+            if len(parts) not in (2, 3):
+                raise ValueError("FileListRGBD: expected 'rgb [hha] label' per line, got %r" % line)
+            self.items.append([p if os.path.isabs(p) else os.path.join(self.root, p) for p in parts])
+        if not self.items:
+            raise ValueError("FileListRGBD: %s names no samples" % list_file)
+        self.input_ch, self.test = input_ch, test
+        if input_ch > 3 and any(len(it) != 3 for it in self.items):
+            raise ValueError("FileListRGBD: input_ch=%d needs an HHA / depth file per sample" % input_ch)
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        it = self.items[i]
+        rgb = np.array(default_loader(it[0]).convert("RGB"), dtype=np.uint8)
+        if self.input_ch > 3:
+            extra = default_loader(it[1])
+            extra = np.array(extra.convert("RGB") if self.input_ch == 6 else extra.convert("L"), dtype=np.uint8)
+            extra = extra.reshape(extra.shape[0], extra.shape[1], -1)[:, :, :self.input_ch - 3]
+            img = np.concatenate([rgb, extra], axis=2)
+        else:
+            img = rgb[:, :, :self.input_ch]
+        lbl = np.array(default_loader(it[-1]), dtype=np.uint8)  # mode "P" / "L": the class indices themselves
+        if lbl.ndim != 2:
+            raise ValueError("FileListRGBD: label image %s is not single-channel" % it[-1])
+        out = (torch.from_numpy(np.ascontiguousarray(img)), torch.from_numpy(np.ascontiguousarray(lbl)))
+        return out + (it[-1],) if self.test else out
+
+
+class DeviceInputPipeline(object):
+    """``get_img_transform`` / ``get_lbl_transform`` (transform.py:302-325) on the GPU: pinned uint8 batches go over PCIe as
+    bytes (4x fewer than fp32); ``Scale`` (bilinear for images, nearest for label maps: Pillow's 8-bit arithmetic, bit for bit),
+    ToTensor+Normalize (HWC->NCHW) and ToLabel+ReLabel(background_id -> n_class-1) each are one kernel.  ``img_shape`` = (W, H)
+    as the reference passes it to ``Scale``; None leaves the size alone (the loader already produced it)."""
+
+    def __init__(self, input_ch, n_class, device, normalize_way="imagenet", background_id=255, img_shape=None):
         from mcdseg import ops
         self._ops = ops
         self.input_ch, self.n_class, self.device, self.background_id = input_ch, n_class, device, background_id
+        self.img_shape = None if img_shape is None else (int(img_shape[0]), int(img_shape[1]))
         if normalize_way == "imagenet":
             mean, std = IMAGENET_MEAN[:input_ch], IMAGENET_STD[:input_ch]
         elif normalize_way == "city":
@@ -86,6 +142,8 @@ class DeviceInputPipeline(object):
     def images(self, *parts):
         """one or more uint8 [N,H,W,c_i] tensors (e.g. RGB and HHA) -> fp32 [N, sum c_i, H, W]"""
         parts = [p.to(self.device, non_blocking=True) for p in parts]
+        if self.img_shape is not None:
+            parts = [self._ops.resize_u8(p, self.img_shape) for p in parts]
         n, h, w = parts[0].shape[:3]
         c = sum(p.shape[3] for p in parts)
         out = torch.empty((n, c, h, w), dtype=torch.float32, device=self.device)
@@ -96,17 +154,22 @@ class DeviceInputPipeline(object):
         return out
 
     def labels(self, lbl_u8):
-        return self._ops.relabel_u8(lbl_u8.to(self.device, non_blocking=True), self.background_id, self.n_class - 1)
+        lbl_u8 = lbl_u8.to(self.device, non_blocking=True)
+        if self.img_shape is not None:
+            lbl_u8 = self._ops.resize_u8(lbl_u8, self.img_shape, nearest=True)
+        return self._ops.relabel_u8(lbl_u8, self.background_id, self.n_class - 1)
 
 
 def get_dataset(dataset_name, split, img_transform, label_transform, test, input_ch=3, joint_transform=None,
-                synthetic=None):
-    """``synthetic`` = dict(length, img_shape, n_class, seed) selects the generated data; the on-disk datasets of
-    the reference are outside this build."""
+                synthetic=None, file_list=None):
+    """``synthetic`` = dict(length, img_shape, n_class, seed) selects the generated data, ``file_list`` a list file of real
+    samples (``FileListRGBD``); the reference's own on-disk dataset classes (hard-coded lab paths) are outside this build."""
     assert dataset_name in AVAILABLE_DATASET_LIST
+    if file_list is not None:
+        return FileListRGBD(file_list, input_ch=input_ch, test=test)
     if synthetic is None:
-        raise NotImplementedError("on-disk dataset %r is outside the MI355X hot-path build; run with --synthetic"
-                                  % dataset_name)
+        raise NotImplementedError("on-disk dataset %r is outside the MI355X hot-path build; run with --synthetic, or "
+                                  "--src_file_list / --tgt_file_list for real data" % dataset_name)
     return SyntheticRGBD(synthetic["length"], input_ch, synthetic["img_shape"], synthetic["n_class"], synthetic["seed"], test,
                          raw=synthetic.get("raw", False), background_id=synthetic.get("background_id", 255))
 

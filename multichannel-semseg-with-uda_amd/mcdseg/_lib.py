@@ -82,6 +82,9 @@ _SIGNATURES = {
     "mcdseg_prob_nll": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p,
                                 c_size_t, c_void_p]),
     "mcdseg_normalize_u8": (c_int, [c_void_p] * 4 + [c_i32] * 6 + [c_void_p]),
+    "mcdseg_resize_workspace_bytes": (c_size_t, [c_i32] * 6),
+    "mcdseg_resize_bilinear_u8": (c_int, [c_void_p, c_void_p] + [c_i32] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "mcdseg_resize_nearest_u8": (c_int, [c_void_p, c_void_p] + [c_i32] * 5 + [c_void_p, c_size_t, c_void_p]),
     "mcdseg_relabel_u8": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_void_p]),
     "mcdseg_confusion_hist": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p]),
     "mcdseg_scale_by_device_scalar": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),

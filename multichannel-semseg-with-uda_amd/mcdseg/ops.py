@@ -1071,6 +1071,36 @@ def normalize_u8_(dst, src, mean, std, c_off=0):
     return dst
 
 
+def resize_u8(src, out_wh, nearest=False):
+    """Scale(img_shape, Image.BILINEAR) (images, uint8 [N,H,W,C]) / Scale(img_shape, Image.NEAREST) (label maps, uint8 [N,H,W])
+    of transform.py:303, 320 on the device -- Pillow's 8-bit resize arithmetic, bit for bit; ``out_wh`` = (W, H) as the reference
+    passes it"""
+    L = lib()
+    src = _req(src, "uint8 batch", torch.uint8)
+    ow, oh = int(out_wh[0]), int(out_wh[1])
+    if nearest:
+        if src.dim() != 3:
+            raise TypeError("mcdseg: resize_u8(nearest) takes a uint8 [N,H,W] tensor")
+        n, h, w = src.shape
+        c = 1
+    else:
+        if src.dim() != 4:
+            raise TypeError("mcdseg: resize_u8 takes a uint8 [N,H,W,C] tensor")
+        n, h, w, c = src.shape
+    if (ow, oh) == (w, h):
+        return src
+    ws = torch.empty(L.mcdseg_resize_workspace_bytes(n, h, w, c, oh, ow) // 4 + 2, dtype=torch.int32, device=src.device)
+    if nearest:
+        dst = torch.empty((n, oh, ow), dtype=torch.uint8, device=src.device)
+        check(L.mcdseg_resize_nearest_u8(_p(src), _p(dst), n, h, w, oh, ow, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
+              "resize_nearest_u8")
+    else:
+        dst = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=src.device)
+        check(L.mcdseg_resize_bilinear_u8(_p(src), _p(dst), n, h, w, c, oh, ow, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
+              "resize_bilinear_u8")
+    return dst
+
+
 def relabel_u8(src, olabel, nlabel):
     """ToLabel()+ReLabel(olabel, nlabel) (transform.py:21-48): uint8 label maps -> int64 with the background id remapped"""
     src = _req(src, "uint8 label batch", torch.uint8)

@@ -25,7 +25,7 @@ def main(argv=None):
         cli = args
         checkpoint = load_checkpoint(args.resume)
         args = checkpoint["args"]
-        for k in ("synthetic", "synthetic_raw", "synthetic_len", "seed", "no_pretrained", "solver", "no_tflog"):
+        for k in ("synthetic", "synthetic_raw", "synthetic_len", "src_file_list", "tgt_file_list", "seed", "no_pretrained", "solver", "no_tflog"):
             if k not in vars(args):
                 setattr(args, k, getattr(cli, k))
         model = get_full_model(net=args.net, res=args.res, n_class=args.n_class, input_ch=args.input_ch)

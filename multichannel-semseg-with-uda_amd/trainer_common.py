@@ -37,8 +37,10 @@ class Run:
     def _pipeline(self):
         if self._pipe is None:
             from datasets import DeviceInputPipeline
+            lists = getattr(self._args, "src_file_list", None) or getattr(self._args, "tgt_file_list", None)
             self._pipe = DeviceInputPipeline(self._args.input_ch, self._args.n_class, self.device,
-                                             background_id=getattr(self._args, "background_id", 255))
+                                             background_id=getattr(self._args, "background_id", 255),
+                                             img_shape=self._args.train_img_shape if lists else None)  # real files: Scale on the GPU
         return self._pipe
 
     @property
@@ -93,9 +95,10 @@ def synthetic_spec(args, seed_offset, rank):
 def make_loader(args, run, names_splits):
     """DataLoader over one dataset or a ConcatDataset of (source, target); per-rank shard by seed."""
     sets = []
+    lists = [getattr(args, "src_file_list", None), getattr(args, "tgt_file_list", None)]
     for i, (name, split) in enumerate(names_splits):
         spec = synthetic_spec(args, 7 * i, run.rank) if (args.synthetic or getattr(args, "synthetic_raw", False)) else None
         sets.append(get_dataset(dataset_name=name, split=split, img_transform=None, label_transform=None, test=False,
-                                input_ch=args.input_ch, synthetic=spec))
+                                input_ch=args.input_ch, synthetic=spec, file_list=lists[i] if i < 2 else None))
     ds = sets[0] if len(sets) == 1 else ConcatDataset(*sets)
     return torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=True, pin_memory=True, drop_last=True)

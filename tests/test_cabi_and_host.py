@@ -98,6 +98,46 @@ def test_dataset_helpers():
     assert len(cat) == 3 and len(cat[0]) == 2
 
 
+def test_file_list_loader(tmp_path):
+    """datasets.FileListRGBD: real files (PIL) -> the raw uint8 arrays the device pipeline takes (datasets.py:20-28 of the
+    reference opens files the same way; its transforms then run on the GPU here)"""
+    import numpy as np
+    from PIL import Image
+    import datasets
+    rng = np.random.RandomState(3)
+    lines = []
+    truth = []
+    for i in range(3):
+        rgb = rng.randint(0, 256, size=(12, 16, 3)).astype(np.uint8)
+        hha = rng.randint(0, 256, size=(12, 16, 3)).astype(np.uint8)
+        lbl = rng.randint(0, 41, size=(12, 16)).astype(np.uint8)
+        lbl[0, :3] = 255
+        Image.fromarray(rgb).save(tmp_path / ("rgb%d.png" % i))
+        Image.fromarray(hha).save(tmp_path / ("hha%d.png" % i))
+        pal = Image.fromarray(lbl, mode="P") if i == 1 else Image.fromarray(lbl)  # palette and grey label PNGs
+        if i == 1:
+            pal.putpalette([v for k in range(256) for v in (k, 255 - k, (7 * k) % 256)])
+        pal.save(tmp_path / ("lbl%d.png" % i))
+        lines.append("rgb%d.png hha%d.png lbl%d.png" % (i, i, i))
+        truth.append((rgb, hha, lbl))
+    (tmp_path / "train.txt").write_text("# rgb hha label\n" + "\n".join(lines) + "\n")
+    ds = datasets.get_dataset("nyu", "train", None, None, False, input_ch=6, file_list=str(tmp_path / "train.txt"))
+    assert len(ds) == 3
+    for i, (rgb, hha, lbl) in enumerate(truth):
+        img, lab = ds[i]
+        assert img.dtype == torch.uint8 and tuple(img.shape) == (12, 16, 6) and tuple(lab.shape) == (12, 16)
+        assert np.array_equal(img.numpy()[:, :, :3], rgb) and np.array_equal(img.numpy()[:, :, 3:], hha)
+        assert np.array_equal(lab.numpy(), lbl)
+    ds3 = datasets.FileListRGBD(str(tmp_path / "train.txt"), input_ch=3, test=True)
+    img, lab, name = ds3[2]
+    assert tuple(img.shape) == (12, 16, 3) and name.endswith("lbl2.png")
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=2)))
+    assert tuple(batch[0].shape) == (2, 12, 16, 6) and batch[0].dtype == torch.uint8
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.txt").write_text("only_one_path.png\n")
+        datasets.FileListRGBD(str(tmp_path / "bad.txt"))
+
+
 def test_util_helpers(tmp_path):
     import util
     w = util.get_class_weight_from_file(41)

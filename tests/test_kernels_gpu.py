@@ -805,6 +805,37 @@ def test_normalize_u8_is_bit_exact():
     assert torch.equal(six, got)
 
 
+def test_device_resize_matches_pillow_vectors(golden):
+    """Scale(img_shape, Image.BILINEAR / NEAREST) on the device = PIL.Image.resize, bit for bit (vectors made by the real
+    Pillow, tests/golden/make_golden_resize.py), batched, and through the pipeline: resize -> normalise / relabel = the oracle's
+    chain of the same steps"""
+    dev = _dev()
+    from datasets import DeviceInputPipeline
+    from mcdseg import ops
+    from oracle import ref_io
+    fx = golden.npz("resize_small.npz")
+    for tag in [k[4:] for k in fx.files if k.startswith("img_")]:
+        size = tuple(int(v) for v in fx["size_" + tag])
+        img = torch.from_numpy(np.stack([fx["img_" + tag], fx["img_" + tag][::-1].copy()])).to(dev)   # a batch of two
+        got = ops.resize_u8(img, size).cpu().numpy()
+        assert np.array_equal(got[0], fx["rimg_" + tag]), tag
+        assert np.array_equal(got[1], ref_io.resize_bilinear_u8(fx["img_" + tag][::-1], size)), tag
+        lbl = torch.from_numpy(fx["lbl_" + tag][None]).to(dev)
+        assert np.array_equal(ops.resize_u8(lbl, size, nearest=True).cpu().numpy()[0], fx["rlbl_" + tag]), tag
+    rng = np.random.RandomState(8)
+    rgb = rng.randint(0, 256, size=(2, 37, 53, 3)).astype(np.uint8)
+    hha = rng.randint(0, 256, size=(2, 37, 53, 3)).astype(np.uint8)
+    lbl = rng.randint(0, 41, size=(2, 37, 53)).astype(np.uint8)
+    lbl[:, :5, :5] = 255
+    pipe = DeviceInputPipeline(6, 41, dev, img_shape=(32, 24))
+    got = pipe.images(torch.from_numpy(rgb), torch.from_numpy(hha)).cpu().numpy()
+    ref = np.stack([ref_io.normalize_u8(np.concatenate([ref_io.resize_bilinear_u8(rgb[i], (32, 24)), ref_io.resize_bilinear_u8(hha[i], (32, 24))],
+                                                       axis=2), ref_io.IMAGENET_MEAN6, ref_io.IMAGENET_STD6) for i in range(2)])
+    assert got.shape == (2, 6, 24, 32) and np.array_equal(got, ref)
+    gl = pipe.labels(torch.from_numpy(lbl)).cpu().numpy()
+    assert np.array_equal(gl, np.stack([ref_io.relabel(ref_io.resize_nearest_u8(lbl[i], (32, 24)), 255, 40) for i in range(2)]))
+
+
 def test_relabel_u8_matches_reference_vector():
     dev = _dev()
     from mcdseg import ops

@@ -312,6 +312,29 @@ def test_eval_metrics_and_label_transform_match_reference_vectors():
     assert np.array_equal(ref_io.relabel(g["lbl_u8"], 255, 40), g["lbl_i64"])
 
 
+def test_resize_restatement_matches_pillow_vectors(golden):
+    """Scale(img_shape, BILINEAR / NEAREST) = PIL.Image.resize: the oracle's restatement of Pillow's 8-bit arithmetic against
+    vectors produced by the real Pillow (tests/golden/make_golden_resize.py), bit for bit -- and, where Pillow is installed,
+    against Pillow itself on fresh data"""
+    from oracle import ref_io
+    fx = golden.npz("resize_small.npz")
+    tags = [k[4:] for k in fx.files if k.startswith("img_")]
+    assert len(tags) >= 6
+    for tag in tags:
+        size = tuple(int(v) for v in fx["size_" + tag])
+        assert np.array_equal(ref_io.resize_bilinear_u8(fx["img_" + tag], size), fx["rimg_" + tag]), tag
+        assert np.array_equal(ref_io.resize_nearest_u8(fx["lbl_" + tag], size), fx["rlbl_" + tag]), tag
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    rng = np.random.RandomState(5)
+    img = rng.randint(0, 256, size=(45, 61, 3)).astype(np.uint8)
+    for size in ((30, 22), (100, 77), (61, 20)):
+        assert np.array_equal(ref_io.resize_bilinear_u8(img, size), np.asarray(Image.fromarray(img).resize(size, Image.BILINEAR)))
+        assert np.array_equal(ref_io.resize_nearest_u8(img[:, :, 0], size), np.asarray(Image.fromarray(img[:, :, 0]).resize(size, Image.NEAREST)))
+
+
 def test_normalize_restatement_is_torch_totensor_normalize_arithmetic():
     """torchvision is absent, so ToTensor()+Normalize() are pinned to their published arithmetic executed by torch itself:
     byte -> float -> div(255), then sub_(mean).div_(std) per channel, all in fp32."""

@@ -161,6 +161,32 @@ def test_adapt_trainer_raw_uint8_input_pipeline(tmp_path):
     assert os.path.exists(os.path.join(out, "suncg-train2nyu-train_6ch", "pth", "MCD-normal-drn_d_38-1.pth.tar"))
 
 
+def test_adapt_trainer_from_image_files(tmp_path):
+    """--src_file_list / --tgt_file_list: PNG files on disk (RGB, HHA, label; other sizes than --train_img_shape) are opened
+    with PIL and resized / normalised / relabelled on the device; the trainer runs end to end on them"""
+    _need_gpu()
+    import numpy as np
+    from PIL import Image
+    rng = np.random.RandomState(4)
+    for dom in ("src", "tgt"):
+        lines = []
+        for i in range(4):
+            for kind in ("rgb", "hha"):
+                Image.fromarray(rng.randint(0, 256, size=(80, 120, 3)).astype(np.uint8)).save(tmp_path / ("%s_%s%d.png" % (dom, kind, i)))
+            lbl = rng.randint(0, 40, size=(80, 120)).astype(np.uint8)
+            lbl[rng.rand(80, 120) < 0.1] = 255
+            Image.fromarray(lbl).save(tmp_path / ("%s_lbl%d.png" % (dom, i)))
+            lines.append("%s_rgb%d.png %s_hha%d.png %s_lbl%d.png" % (dom, i, dom, i, dom, i))
+        (tmp_path / (dom + ".txt")).write_text("\n".join(lines) + "\n")
+    import adapt_trainer
+    out = str(tmp_path / "out")
+    args = [a for a in COMMON if a != "--synthetic"] + ["--src_file_list", str(tmp_path / "src.txt"), "--tgt_file_list", str(tmp_path / "tgt.txt")]
+    assert adapt_trainer.main(["suncg", "nyu", "--base_outdir", out] + args) == 0
+    ck = torch.load(os.path.join(out, "suncg-train2nyu-train_6ch", "pth", "MCD-normal-drn_d_38-1.pth.tar"), weights_only=False)
+    assert all(torch.isfinite(v).all() for v in ck["g_state_dict"].values())
+    assert int(ck["g_state_dict"]["base.0.1.num_batches_tracked"]) == 14  # 4 files, batch 2: two iterations x 7 forwards
+
+
 def test_adapt_mfnet_trainer_score_gate_fusion_matches_oracle(tmp_path):
     """MFNet-ScoreGateFusion with ProbCrossEntropyLoss2d (adapt_mfnet_trainer.py:149): one full three-step update on the
     HIP path against the CPU oracle running the reference's statements from the same initial state."""
