@@ -59,9 +59,9 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   }
 }
 
-// Stage 2: grid = C/32 blocks; thread (cx, g) folds slices g, g+8, ... of channel 32*blockIdx.x + cx, the 8 groups meet in
-// LDS.  Also forms the bound of the tensor bn_apply is about to write (see mcdseg.h): per-block maximum, then an integer
-// atomic max on the bit pattern (non-negative floats order like their bits; the scalar was zeroed by stage 1).
+// Stage 2: one wave per channel (4 channels per block): lanes stride over the S slices, fp64 wave reduction.  Also forms the
+// bound of the tensor bn_apply is about to write (see mcdseg.h): an integer atomic max on the bit pattern (non-negative floats
+// order like their bits; the scalar was zeroed by stage 1).
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ sl, int S, int C,
                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                                 float* __restrict__ running_mean,
@@ -69,60 +69,37 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
                                                                 float momentum, float eps, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta,
                                                                 const float* __restrict__ res_bound, float* __restrict__ y_bound) {
-  __shared__ double sh[3][8][33];
-  __shared__ float shb[32];
-  const int cx = threadIdx.x & 31;
-  const int g = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
+  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= C) return;  // wave-uniform
   double n = 0.0, s1 = 0.0, q = 0.0;
-  if (c < C) {
-    for (int k = g; k < S; k += 8) {
-      n += sl[((size_t)k * 3 + 0) * C + c];
-      s1 += sl[((size_t)k * 3 + 1) * C + c];
-      q += sl[((size_t)k * 3 + 2) * C + c];
-    }
+  for (int k = lane; k < S; k += 64) {
+    n += sl[((size_t)k * 3 + 0) * C + c];
+    s1 += sl[((size_t)k * 3 + 1) * C + c];
+    q += sl[((size_t)k * 3 + 2) * C + c];
   }
-  sh[0][g][cx] = n;
-  sh[1][g][cx] = s1;
-  sh[2][g][cx] = q;
-  __syncthreads();
-  float bound = 0.f;
-  if (g == 0 && c < C) {
-    n = s1 = q = 0.0;
-    for (int k = 0; k < 8; ++k) {
-      n += sh[0][k][cx];
-      s1 += sh[1][k][cx];
-      q += sh[2][k][cx];
-    }
-    const double mean = n > 0.0 ? s1 / n : 0.0;
-    double m2 = q - s1 * mean;
-    if (m2 < 0.0) m2 = 0.0;
-    const double var = n > 0.0 ? m2 / n : 0.0;
-    mean_out[c] = (float)mean;
-    rstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean != nullptr) {
-      const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
-      running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
-      running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
-    }
-    if (y_bound != nullptr) bound = fabsf(gamma[c]) * (float)sqrt(n > 1.0 ? n - 1.0 : 1.0) * 1.0001f + fabsf(beta[c]);
+  n = wave_sum_d(n);
+  s1 = wave_sum_d(s1);
+  q = wave_sum_d(q);
+  if (lane != 0) return;
+  const double mean = n > 0.0 ? s1 / n : 0.0;
+  double m2 = q - s1 * mean;
+  if (m2 < 0.0) m2 = 0.0;
+  const double var = n > 0.0 ? m2 / n : 0.0;
+  mean_out[c] = (float)mean;
+  rstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean != nullptr) {
+    const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
   }
   if (y_bound != nullptr) {
-    if (g == 0) shb[cx] = bound;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float m = 0.f;
-      bool bad = false;
-      for (int k = 0; k < 32; ++k) {
-        bad = bad || !(shb[k] == shb[k]);
-        m = fmaxf(m, shb[k]);
-      }
-      m += res_bound ? *res_bound : 0.f;
-      if (bad || !(m == m)) m = __uint_as_float(0x7FC00000u);  // NaN parameters -> non-finite bound
-      atomicMax(reinterpret_cast<unsigned*>(y_bound), __float_as_uint(m) & 0x7FFFFFFFu);
-    }
+    float bound = fabsf(gamma[c]) * (float)sqrt(n > 1.0 ? n - 1.0 : 1.0) * 1.0001f + fabsf(beta[c]);
+    bound += res_bound ? *res_bound : 0.f;
+    if (!(bound == bound)) bound = __uint_as_float(0x7FC00000u);  // NaN parameters -> non-finite bound
+    atomicMax(reinterpret_cast<unsigned*>(y_bound), __float_as_uint(bound) & 0x7FFFFFFFu);
   }
-  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
 }
 
 __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int C, float eps,
@@ -600,7 +577,7 @@ extern "C" int mcdseg_bn_stats_finalize(const float* stat_partials, int64_t rows
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ceil_div(C, 32), S), dim3(256), 0, st, stat_partials, rows, C, Mp,
                      (double*)workspace, y_bound);
   MCD_LAUNCH_CHECK("bn_stats_partial");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, st, (const double*)workspace, S, C, mean,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)workspace, S, C, mean,
                      rstd, running_mean, running_var, num_batches_tracked, momentum, eps, gamma, beta, res_bound, y_bound);
   MCD_LAUNCH_CHECK("bn_stats_finalize");
   return 0;

@@ -406,21 +406,45 @@ __global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(const float* __r
 
 // x_bound / dy_bound (NULL unless the slabs come from the SplitF16x3 kernels): the slab sums are in scaled units and are
 // multiplied by scale(x) * scale(dy), an exact power of two
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int T, int co_p,
-                                    int ci_p, int splits, const float* __restrict__ x_bound, const float* __restrict__ dy_bound) {
-  const int64_t total = (int64_t)T * Cout * Cin;
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int ci = (int)(i % Cin);
-  const int64_t r = i / Cin;
-  const int co = (int)(r % Cout);
-  const int tap = (int)(r / Cout);
+// A block owns PB consecutive (co, ci) pairs x T taps -- one contiguous run of dw [Cout][Cin][T].  Its threads stride over the
+// (tap, pair) items, pair fastest, so the slab reads are coalesced along ci; each item is summed over the splits in a fixed
+// order (fp64) and parked in LDS, from where the run is written out contiguously (writing from registers would scatter 4-byte
+// stores 4 T bytes apart).  PB = 64 (256 for 1x1 kernels), halved down to 16 while the layer has fewer than 512 blocks.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin,
+                                                           int T, int co_p, int ci_p, int splits, int PB,
+                                                           const float* __restrict__ x_bound, const float* __restrict__ dy_bound) {
+  extern __shared__ float stage[];  // [PB][T]
+  const int64_t pairs = (int64_t)Cout * Cin;
+  const int64_t p0 = blockIdx.x * (int64_t)PB;
+  const int64_t left = pairs - p0;
+  const int npair = (int)(left < PB ? left : PB);
+  const double sc = x_bound != nullptr ? (double)mcd_scale_of_bound(*x_bound) * (double)mcd_scale_of_bound(*dy_bound) : 1.0;
   const size_t stride = (size_t)T * co_p * ci_p;
-  const float* src = slab + ((size_t)tap * co_p + co) * ci_p + ci;
-  double s = 0.0;
-  for (int k = 0; k < splits; ++k) s += (double)src[(size_t)k * stride];
-  if (x_bound != nullptr) s *= (double)mcd_scale_of_bound(*x_bound) * (double)mcd_scale_of_bound(*dy_bound);
-  dw[((size_t)co * Cin + ci) * T + tap] = (float)s;
+  for (int i = threadIdx.x; i < PB * T; i += 256) {
+    const int tap = i / PB;
+    const int pl = i - tap * PB;
+    if (pl >= npair) continue;
+    const int64_t pr = p0 + pl;
+    const int ci = (int)(pr % Cin);
+    const int co = (int)(pr / Cin);
+    const float* src = slab + ((size_t)tap * co_p + co) * ci_p + ci;
+    double s = 0.0;
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {  // four loads in flight, added in slab order
+      const float v0 = src[(size_t)k * stride], v1 = src[(size_t)(k + 1) * stride];
+      const float v2 = src[(size_t)(k + 2) * stride], v3 = src[(size_t)(k + 3) * stride];
+      s += (double)v0;
+      s += (double)v1;
+      s += (double)v2;
+      s += (double)v3;
+    }
+    for (; k < splits; ++k) s += (double)src[(size_t)k * stride];
+    stage[pl * T + tap] = (float)(s * sc);
+  }
+  __syncthreads();
+  const int n = npair * T;
+  float* out = dw + p0 * T;
+  for (int i = threadIdx.x; i < n; i += 256) out[i] = stage[i];
 }
 
 }  // namespace
@@ -544,8 +568,12 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
   else
     hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 1, 32>), grid, dim3(64), 0, st, p);
   MCD_LAUNCH_CHECK("conv_wgrad");
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
-                     d->Cout, d->Cin, T, pl.co_p, pl.ci_p, pl.splits, scaled ? x_bound : (const float*)nullptr,
+  const int64_t pairs_all = (int64_t)d->Cout * d->Cin;
+  int PB = T == 1 ? 256 : 64;
+  while (PB > 16 && pairs_all / PB < 512) PB >>= 1;  // small layers: more, smaller blocks
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64((int64_t)d->Cout * d->Cin, PB)), dim3(256),
+                     (size_t)PB * T * sizeof(float), st, (const float*)workspace, dw,
+                     d->Cout, d->Cin, T, pl.co_p, pl.ci_p, pl.splits, PB, scaled ? x_bound : (const float*)nullptr,
                      scaled ? dy_bound : (const float*)nullptr);
   MCD_LAUNCH_CHECK("conv_wgrad_reduce");
   return 0;
