@@ -212,6 +212,16 @@ int mcdseg_softmax_ce_l1(const float* z1, const float* z2, const int64_t* labels
                          int64_t ignore_index, float ce_coef, float diff_coef, const float* wsum_in,
                          float* g1, float* g2, float* losses,
                          int32_t N, int32_t C, int32_t HW, void* workspace, size_t workspace_bytes, void* stream);
+/* The same losses and gradients for z_k = up8(s_k, w_k) (the x8 up-sampler above) WITHOUT the full-resolution logits ever being
+ * stored: the MCD classifiers are exactly that up-sampler (models/dilated_fcn.py:357-366; F1(G(x)), F2(G(x)) of
+ * adapt_trainer.py:163-212), so the kernel forms each pixel's logits from the [N,C,Hi,Wi] score maps on the fly.  s1 and s2 may
+ * be the same tensor (both heads read the generator's scores); s2 / w2 NULL = single head.  g1 / g2 are [N,C,8Hi,8Wi], to be
+ * fed to mcdseg_up8_bwd_input / mcdseg_up8_bwd_weight; they equal the two-pass result bit for bit. */
+size_t mcdseg_up8_loss_workspace_bytes(int32_t N, int32_t Hi, int32_t Wi);
+int mcdseg_up8_softmax_ce_l1(const float* s1, const float* w1, const float* s2, const float* w2, const int64_t* labels,
+                             const float* class_weight, int64_t ignore_index, float ce_coef, float diff_coef, const float* wsum_in,
+                             float* g1, float* g2, float* losses, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
+                             void* workspace, size_t workspace_bytes, void* stream);
 /* out[0] = sum_i w[labels_i] over P pixels (ignore_index and out-of-range labels contribute 0) */
 size_t mcdseg_label_weight_sum_workspace_bytes(int64_t P);
 int mcdseg_label_weight_sum(const int64_t* labels, const float* class_weight, int64_t ignore_index, int32_t C, int64_t P,

@@ -41,6 +41,69 @@ __global__ __launch_bounds__(256) void wsum_finalize_kernel(const float* __restr
   if (threadIdx.x == 0) *out = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
 }
 
+// The per-pixel maths shared by the two front ends below: a[] / b[] hold the pixel's logits (-inf past C) and leave as its
+// probabilities; the gradients go to g1 / g2 at base + c * HW.
+template <int NCMAX, bool TWO>
+__device__ __forceinline__ void pixel_losses(float (&a)[NCMAX], float (&b)[NCMAX], int y, float wy, float ce_coef, float diff_coef,
+                                             const float* __restrict__ losses_w, float* __restrict__ g1, float* __restrict__ g2,
+                                             size_t base, size_t HW, int C, float inv_m, float& ce1, float& ce2, float& dsum) {
+  float m1 = a[0], m2 = TWO ? b[0] : 0.f;
+#pragma unroll
+  for (int c = 1; c < NCMAX; ++c) {
+    m1 = fmaxf(m1, a[c]);
+    if (TWO) m2 = fmaxf(m2, b[c]);
+  }
+  float s1 = 0.f, s2 = 0.f, zy1 = 0.f, zy2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCMAX; ++c) {
+    if (c == y) {
+      zy1 = a[c];
+      if (TWO) zy2 = b[c];
+    }
+    a[c] = (c < C) ? expf(a[c] - m1) : 0.f;
+    s1 += a[c];
+    if (TWO) {
+      b[c] = (c < C) ? expf(b[c] - m2) : 0.f;
+      s2 += b[c];
+    }
+  }
+  if (y >= 0) {
+    ce1 = wy * ((m1 + logf(s1)) - zy1);
+    if (TWO) ce2 = wy * ((m2 + logf(s2)) - zy2);
+  }
+  const float r1 = 1.f / s1, r2 = TWO ? 1.f / s2 : 0.f;
+  float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCMAX; ++c) {
+    a[c] *= r1;
+    if (TWO) {
+      b[c] *= r2;
+      const float d = a[c] - b[c];
+      const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+      dsum += fabsf(d);
+      t1 = fmaf(sg, a[c], t1);
+      t2 = fmaf(sg, b[c], t2);
+    }
+  }
+  if (g1 != nullptr || g2 != nullptr) {
+    const float kce = (ce_coef != 0.f && y >= 0) ? ce_coef * wy / losses_w[3] : 0.f;
+    const float kd = diff_coef * inv_m;
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c) {
+      if (c < C) {
+        const float oh = (c == y) ? 1.f : 0.f;
+        float sg = 0.f;
+        if (TWO) {
+          const float d = a[c] - b[c];
+          sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+        }
+        if (g1 != nullptr) g1[base + (size_t)c * HW] = kce * (a[c] - oh) + (TWO ? kd * a[c] * (sg - t1) : 0.f);
+        if (TWO && g2 != nullptr) g2[base + (size_t)c * HW] = kce * (b[c] - oh) - kd * b[c] * (sg - t2);
+      }
+    }
+  }
+}
+
 template <int NCMAX, bool TWO>
 __global__ __launch_bounds__(256) void softmax_ce_l1_kernel(const float* __restrict__ z1, const float* __restrict__ z2,
                                                             const int64_t* __restrict__ labels, const float* __restrict__ cw,
@@ -59,7 +122,7 @@ __global__ __launch_bounds__(256) void softmax_ce_l1_kernel(const float* __restr
 #pragma unroll
     for (int c = 0; c < NCMAX; ++c) {
       a[c] = (c < C) ? z1[base + (size_t)c * HW] : -INFINITY;
-      if (TWO) b[c] = (c < C) ? z2[base + (size_t)c * HW] : -INFINITY;
+      b[c] = (TWO && c < C) ? z2[base + (size_t)c * HW] : -INFINITY;
     }
     int y = -1;
     float wy = 0.f;
@@ -70,61 +133,7 @@ __global__ __launch_bounds__(256) void softmax_ce_l1_kernel(const float* __restr
         wy = cw ? cw[y] : 1.f;
       }
     }
-    float m1 = a[0], m2 = TWO ? b[0] : 0.f;
-#pragma unroll
-    for (int c = 1; c < NCMAX; ++c) {
-      m1 = fmaxf(m1, a[c]);
-      if (TWO) m2 = fmaxf(m2, b[c]);
-    }
-    float s1 = 0.f, s2 = 0.f, zy1 = 0.f, zy2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCMAX; ++c) {
-      if (c == y) {
-        zy1 = a[c];
-        if (TWO) zy2 = b[c];
-      }
-      a[c] = (c < C) ? expf(a[c] - m1) : 0.f;
-      s1 += a[c];
-      if (TWO) {
-        b[c] = (c < C) ? expf(b[c] - m2) : 0.f;
-        s2 += b[c];
-      }
-    }
-    if (y >= 0) {
-      ce1 = wy * ((m1 + logf(s1)) - zy1);
-      if (TWO) ce2 = wy * ((m2 + logf(s2)) - zy2);
-    }
-    const float r1 = 1.f / s1, r2 = TWO ? 1.f / s2 : 0.f;
-    float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCMAX; ++c) {
-      a[c] *= r1;
-      if (TWO) {
-        b[c] *= r2;
-        const float d = a[c] - b[c];
-        const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-        dsum += fabsf(d);
-        t1 = fmaf(sg, a[c], t1);
-        t2 = fmaf(sg, b[c], t2);
-      }
-    }
-    if (g1 != nullptr || g2 != nullptr) {
-      const float kce = (ce_coef != 0.f && y >= 0) ? ce_coef * wy / losses_w[3] : 0.f;
-      const float kd = diff_coef * inv_m;
-#pragma unroll
-      for (int c = 0; c < NCMAX; ++c) {
-        if (c < C) {
-          const float oh = (c == y) ? 1.f : 0.f;
-          float sg = 0.f;
-          if (TWO) {
-            const float d = a[c] - b[c];
-            sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-          }
-          if (g1 != nullptr) g1[base + (size_t)c * HW] = kce * (a[c] - oh) + (TWO ? kd * a[c] * (sg - t1) : 0.f);
-          if (TWO && g2 != nullptr) g2[base + (size_t)c * HW] = kce * (b[c] - oh) - kd * b[c] * (sg - t2);
-        }
-      }
-    }
+    pixel_losses<NCMAX, TWO>(a, b, y, wy, ce_coef, diff_coef, losses_w, g1, g2, base, (size_t)HW, C, inv_m, ce1, ce2, dsum);
   }
   __shared__ float sh[3][4];
   ce1 = wave_sum(ce1);
@@ -139,6 +148,103 @@ __global__ __launch_bounds__(256) void softmax_ce_l1_kernel(const float* __restr
   if (threadIdx.x < 3) {
     const int q = threadIdx.x;
     part[(size_t)blockIdx.x * 3 + q] = (sh[q][0] + sh[q][1]) + (sh[q][2] + sh[q][3]);
+  }
+}
+
+// The same losses with the x8 learned up-sampler (up8.hip) computed on the fly: the classifiers of the MCD configuration are
+// nothing but that up-sampler (models/dilated_fcn.py:357-366 behind DRNSegPixelClassifier), so their full-resolution logits
+// need never exist in memory -- each is four multiply-adds on the 64x smaller score map.  A workgroup of 128 lanes owns 128
+// consecutive pixels of one output row: every lane then has the same kernel rows ky0, ky0+8 and the same two input rows, so
+// the stage in LDS is 2 rows x 18 columns of scores and 2 x 16 kernel taps per class and head.  The multiply-adds run in the
+// order of up8_fwd_kernel (absent inputs staged as zeros), so logits, losses' summands and gradients equal the two-pass
+// result bit for bit; only the order of the block partial sums differs.
+constexpr int UP_SEG = 128, UP_JJ = 18;
+
+template <int NCMAX, bool TWO>
+__global__ __launch_bounds__(128) void up8_softmax_ce_l1_kernel(const float* __restrict__ s1, const float* __restrict__ w1,
+                                                                const float* __restrict__ s2, const float* __restrict__ w2,
+                                                                const int64_t* __restrict__ labels, const float* __restrict__ cw,
+                                                                int64_t ignore_index, float ce_coef, float diff_coef,
+                                                                const float* __restrict__ losses_w, float* __restrict__ g1,
+                                                                float* __restrict__ g2, float* __restrict__ part, int C, int Hi,
+                                                                int Wi, float inv_m) {
+  extern __shared__ __attribute__((aligned(16))) float up_sm[];
+  constexpr int HEADS = TWO ? 2 : 1;
+  float* wl = up_sm;                   // [head][c][kx0 8][a 2][b 2]
+  float* sin = up_sm + HEADS * C * 32;  // [head][c][a 2][UP_JJ]
+  const int n = blockIdx.z, oy = blockIdx.y, x0 = blockIdx.x * UP_SEG;
+  const int Wo = 8 * Wi, Ho = 8 * Hi;
+  const int iy_hi = (oy + 4) >> 3, ky0 = (oy + 4) & 7;
+  const int ixb = ((x0 + 4) >> 3) - 1;  // first staged input column (-1 at the left edge)
+  for (int i = threadIdx.x; i < HEADS * C * 32; i += UP_SEG) {
+    const int b = i & 1, a = (i >> 1) & 1, k = (i >> 2) & 7, hc = i >> 5;
+    const int c = hc % C;
+    wl[i] = (hc >= C ? w2 : w1)[c * 256 + (ky0 + 8 * a) * 16 + k + 8 * b];
+  }
+  for (int i = threadIdx.x; i < HEADS * C * 2 * UP_JJ; i += UP_SEG) {
+    const int jj = i % UP_JJ, r = i / UP_JJ;
+    const int a = r & 1, hc = r >> 1;
+    const int c = hc % C;
+    const int iy = iy_hi - a, ix = ixb + jj;
+    float v = 0.f;
+    if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) v = (hc >= C ? s2 : s1)[(((size_t)n * C + c) * Hi + iy) * Wi + ix];
+    sin[i] = v;
+  }
+  __syncthreads();
+  const int ox = x0 + threadIdx.x;
+  float ce1 = 0.f, ce2 = 0.f, dsum = 0.f;
+  if (ox < Wo) {
+    const int kx0 = (ox + 4) & 7;
+    const int jj = ((ox + 4) >> 3) - ixb;  // column of the b = 0 input; b = 1 is the one to its left
+    float a[NCMAX], b[NCMAX];
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c) {
+      a[c] = -INFINITY;
+      b[c] = -INFINITY;
+      if (c < C) {
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) {
+          const float4 wv = *reinterpret_cast<const float4*>(wl + ((h * C + c) * 8 + kx0) * 4);
+          const float* sp = sin + ((h * C + c) * 2) * UP_JJ + jj;
+          float o = 0.f;
+          o = fmaf(sp[0], wv.x, o);
+          o = fmaf(sp[-1], wv.y, o);
+          o = fmaf(sp[UP_JJ], wv.z, o);
+          o = fmaf(sp[UP_JJ - 1], wv.w, o);
+          if (h == 0)
+            a[c] = o;
+          else
+            b[c] = o;
+        }
+      }
+    }
+    const size_t HW = (size_t)Ho * Wo;
+    const size_t hw = (size_t)oy * Wo + ox;
+    int y = -1;
+    float wy = 0.f;
+    if (labels != nullptr) {
+      const int64_t yl = labels[(size_t)n * HW + hw];
+      if (yl != ignore_index && yl >= 0 && yl < C) {
+        y = (int)yl;
+        wy = cw ? cw[y] : 1.f;
+      }
+    }
+    pixel_losses<NCMAX, TWO>(a, b, y, wy, ce_coef, diff_coef, losses_w, g1, g2, (size_t)n * C * HW + hw, HW, C, inv_m, ce1, ce2, dsum);
+  }
+  __shared__ float sh[3][2];
+  ce1 = wave_sum(ce1);
+  ce2 = wave_sum(ce2);
+  dsum = wave_sum(dsum);
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = ce1;
+    sh[1][threadIdx.x >> 6] = ce2;
+    sh[2][threadIdx.x >> 6] = dsum;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int q = threadIdx.x;
+    const size_t blk = ((size_t)n * gridDim.y + oy) * gridDim.x + blockIdx.x;
+    part[blk * 3 + q] = sh[q][0] + sh[q][1];
   }
 }
 
@@ -264,6 +370,18 @@ void launch_loss(bool two, dim3 grid, hipStream_t st, const float* z1, const flo
                        ce_coef, diff_coef, losses, g1, g2, part, C, HW, P, inv_m);
 }
 
+template <int NCMAX>
+void launch_up_loss(bool two, dim3 grid, size_t lds, hipStream_t st, const float* s1, const float* w1, const float* s2, const float* w2,
+                    const int64_t* labels, const float* cw, int64_t ignore_index, float ce_coef, float diff_coef, const float* losses,
+                    float* g1, float* g2, float* part, int C, int Hi, int Wi, float inv_m) {
+  if (two)
+    hipLaunchKernelGGL((up8_softmax_ce_l1_kernel<NCMAX, true>), grid, dim3(UP_SEG), lds, st, s1, w1, s2, w2, labels, cw, ignore_index,
+                       ce_coef, diff_coef, losses, g1, g2, part, C, Hi, Wi, inv_m);
+  else
+    hipLaunchKernelGGL((up8_softmax_ce_l1_kernel<NCMAX, false>), grid, dim3(UP_SEG), lds, st, s1, w1, s2, w2, labels, cw, ignore_index,
+                       ce_coef, diff_coef, losses, g1, g2, part, C, Hi, Wi, inv_m);
+}
+
 }  // namespace
 
 extern "C" size_t mcdseg_loss_workspace_bytes(int32_t N, int32_t HW) {
@@ -327,6 +445,61 @@ extern "C" int mcdseg_softmax_ce_l1(const float* z1, const float* z2, const int6
     launch_loss<48>(two, grid, st, z1, z2, labels, class_weight, ignore_index, ce_coef, diff_coef, losses, g1, g2, part, C, HW, P,
                     (float)inv_m);
   MCD_LAUNCH_CHECK("softmax_ce_l1");
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nblk, losses, inv_m,
+                     labels != nullptr ? 1 : 0);
+  MCD_LAUNCH_CHECK("loss_finalize");
+  return 0;
+}
+
+static int64_t up_loss_blocks(int32_t N, int32_t Hi, int32_t Wi) { return (int64_t)N * (8 * Hi) * ceil_div(8 * Wi, UP_SEG); }
+
+extern "C" size_t mcdseg_up8_loss_workspace_bytes(int32_t N, int32_t Hi, int32_t Wi) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0) return 0;
+  return (size_t)(up_loss_blocks(N, Hi, Wi) * 3 + wsum_blocks((int64_t)N * Hi * Wi * 64)) * sizeof(float);
+}
+
+extern "C" int mcdseg_up8_softmax_ce_l1(const float* s1, const float* w1, const float* s2, const float* w2, const int64_t* labels,
+                                        const float* class_weight, int64_t ignore_index, float ce_coef, float diff_coef,
+                                        const float* wsum_in, float* g1, float* g2, float* losses, int32_t N, int32_t C, int32_t Hi,
+                                        int32_t Wi, void* workspace, size_t workspace_bytes, void* stream) {
+  MCD_REQUIRE(s1 && w1 && losses && workspace, "up8_softmax_ce_l1: null pointer");
+  MCD_REQUIRE(N > 0 && C > 0 && Hi > 0 && Wi > 0, "up8_softmax_ce_l1: bad dims");
+  MCD_REQUIRE(C <= 48, "up8_softmax_ce_l1: at most 48 classes are kept in registers (got %d)", C);
+  MCD_REQUIRE((s2 == nullptr) == (w2 == nullptr), "up8_softmax_ce_l1: s2 and w2 come together");
+  MCD_REQUIRE(s2 != nullptr || (g2 == nullptr && diff_coef == 0.f), "up8_softmax_ce_l1: discrepancy needs the second head");
+  MCD_REQUIRE(labels != nullptr || ce_coef == 0.f, "up8_softmax_ce_l1: cross-entropy needs labels");
+  MCD_REQUIRE(N <= 65535 && 8 * Hi <= 65535, "up8_softmax_ce_l1: grid too large");
+  MCD_REQUIRE(workspace_bytes >= mcdseg_up8_loss_workspace_bytes(N, Hi, Wi), "up8_softmax_ce_l1: workspace too small");
+  const int64_t P = (int64_t)N * Hi * Wi * 64;
+  const int64_t nblk = up_loss_blocks(N, Hi, Wi);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  float* wpart = part + nblk * 3;
+  const int wb = wsum_blocks(P);
+  if (wsum_in != nullptr) {
+    (void)hipMemcpyAsync(losses + 3, wsum_in, sizeof(float), hipMemcpyDeviceToDevice, st);
+  } else if (labels != nullptr) {
+    hipLaunchKernelGGL(label_wsum_kernel, dim3(wb), dim3(256), 0, st, labels, class_weight, ignore_index, C, P, wpart);
+    MCD_LAUNCH_CHECK("label_wsum");
+    hipLaunchKernelGGL(wsum_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)wpart, wb, losses + 3);
+    MCD_LAUNCH_CHECK("wsum_finalize");
+  } else {
+    (void)hipMemsetAsync(losses + 3, 0, sizeof(float), st);
+  }
+  const double inv_m = 1.0 / ((double)P * (double)C);
+  const bool two = s2 != nullptr;
+  dim3 grid((unsigned)ceil_div(8 * Wi, UP_SEG), (unsigned)(8 * Hi), (unsigned)N);
+  const size_t lds = (size_t)(two ? 2 : 1) * C * (32 + 2 * UP_JJ) * sizeof(float);
+  if (C <= 16)
+    launch_up_loss<16>(two, grid, lds, st, s1, w1, s2, w2, labels, class_weight, ignore_index, ce_coef, diff_coef, losses, g1, g2, part,
+                       C, Hi, Wi, (float)inv_m);
+  else if (C <= 24)
+    launch_up_loss<24>(two, grid, lds, st, s1, w1, s2, w2, labels, class_weight, ignore_index, ce_coef, diff_coef, losses, g1, g2, part,
+                       C, Hi, Wi, (float)inv_m);
+  else
+    launch_up_loss<48>(two, grid, lds, st, s1, w1, s2, w2, labels, class_weight, ignore_index, ce_coef, diff_coef, losses, g1, g2, part,
+                       C, Hi, Wi, (float)inv_m);
+  MCD_LAUNCH_CHECK("up8_softmax_ce_l1");
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nblk, losses, inv_m,
                      labels != nullptr ? 1 : 0);
   MCD_LAUNCH_CHECK("loss_finalize");

@@ -68,6 +68,9 @@ _SIGNATURES = {
     "mcdseg_loss_workspace_bytes": (c_size_t, [c_i32, c_i32]),
     "mcdseg_softmax_ce_l1": (c_int, [c_void_p] * 4 + [c_i64, c_float, c_float] + [c_void_p] * 4 + [c_i32] * 3 +
                              [c_void_p, c_size_t, c_void_p]),
+    "mcdseg_up8_loss_workspace_bytes": (c_size_t, [c_i32] * 3),
+    "mcdseg_up8_softmax_ce_l1": (c_int, [c_void_p] * 6 + [c_i64, c_float, c_float] + [c_void_p] * 4 + [c_i32] * 4 +
+                                 [c_void_p, c_size_t, c_void_p]),
     "mcdseg_label_weight_sum_workspace_bytes": (c_size_t, [c_i64]),
     "mcdseg_label_weight_sum": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mcdseg_bilinear8_fwd": (c_int, [c_void_p, c_void_p] + [c_i32] * 4 + [c_void_p]),

@@ -224,6 +224,7 @@ def _bound_or_measure(x, bound):
 _PACK_REGISTRY = weakref.WeakSet()   # every PackedWeights alive
 _PACK_TABLES = {}                    # (device, math) -> cached device tables of the last group pack
 GROUP_PACK = os.environ.get("MCDSEG_GROUP_PACK", "1") != "0"
+FUSED_UP_LOSS = os.environ.get("MCDSEG_FUSED_UP_LOSS", "1") != "0"  # MCDSolver: up-sampler folded into the loss kernel
 
 
 class PackedWeights:
@@ -956,6 +957,50 @@ def mcd_losses(z1, z2, labels, class_weight, ignore_index=-100, ce_coef=0.0, dif
                                      float(diff_coef), _p(wsum), _p(g1), _p(g2), _p(losses), n, c, h * w, _p(ws),
                                      ctypes.c_size_t(ws.numel() * 4), _stream()), "softmax_ce_l1")
     return losses, g1, g2
+
+
+def up8_mcd_losses(s1, w1, s2, w2, labels, class_weight, ignore_index=-100, ce_coef=0.0, diff_coef=0.0, want_grad=True, wsum=None):
+    """``mcd_losses(up8(s1, w1), up8(s2, w2), ...)`` without the full-resolution logits: the kernel forms each pixel's logits
+    from the score maps [N,C,Hi,Wi] on the fly.  Returns (losses[4], g1, g2) with g_k [N,C,8Hi,8Wi] = the gradient w.r.t.
+    the (never stored) logits of head k -- what ``_up8_bwd_input`` / ``_up8_bwd_weight`` consume."""
+    L = lib()
+    s1, w1, s2, w2 = _req(s1, "scores"), _req(w1, "up8 weight"), _req(s2, "scores"), _req(w2, "up8 weight")
+    _check_up(s1, w1)
+    if s2 is not None:
+        _check_up(s2, w2)
+        if s2.shape != s1.shape:
+            raise ValueError("mcdseg: the two score maps differ in shape")
+    n, c, hi, wi = s1.shape
+    h, w = 8 * hi, 8 * wi
+    if labels is not None:
+        labels = _req(labels, "labels", torch.int64)
+        if tuple(labels.shape) != (n, h, w):
+            raise ValueError("mcdseg: labels must be [N,H,W] = %s, got %s" % ((n, h, w), tuple(labels.shape)))
+    class_weight = _req(class_weight, "class weights")
+    if class_weight is not None and class_weight.numel() != c:
+        raise ValueError("mcdseg: class weight has %d entries for %d classes" % (class_weight.numel(), c))
+    if labels is not None and ce_coef != 0.0 and wsum is None:
+        wsum = ce_normaliser(labels, class_weight, c, ignore_index)
+    wsum = _req(wsum, "CE normaliser")
+    losses = torch.empty(4, dtype=torch.float32, device=s1.device)
+    g1 = torch.empty((n, c, h, w), dtype=torch.float32, device=s1.device) if want_grad else None
+    g2 = torch.empty((n, c, h, w), dtype=torch.float32, device=s1.device) if (want_grad and s2 is not None) else None
+    ws = _ws(L.mcdseg_up8_loss_workspace_bytes(n, hi, wi), s1.device)
+    heads = 1 if s2 is None else 2
+    byts = 4 * heads * n * c * h * w * (1 if want_grad else 0) + 4 * heads * n * c * hi * wi + (8 * n * h * w if labels is not None else 0)
+    with _timed("up8_softmax_ce_l1_kernel<48, %s>" % ("true" if s2 is not None else "false") if c > 24 else "up8_softmax_ce_l1_kernel",
+                (0, byts)):
+        check(L.mcdseg_up8_softmax_ce_l1(_p(s1), _p(w1), _p(s2), _p(w2), _p(labels), _p(class_weight), int(ignore_index),
+                                         float(ce_coef), float(diff_coef), _p(wsum), _p(g1), _p(g2), _p(losses), n, c, hi, wi,
+                                         _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()), "up8_softmax_ce_l1")
+    return losses, g1, g2
+
+
+def up8_backward(g, s, w, want_input, want_weight):
+    """(d/ds, d/dw) of the up-sampler for the logit gradient ``g`` (either may be skipped)."""
+    n, c, hi, wi = s.shape
+    return (_up8_bwd_input(g, w, n, c, hi, wi) if want_input else None,
+            _up8_bwd_weight(g, s, n, c, hi, wi) if want_weight else None)
 
 
 def predict_labels(z1, z2=None, n_used=None):

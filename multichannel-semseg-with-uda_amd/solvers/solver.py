@@ -15,7 +15,11 @@ result:
   * step B never back-propagates through G: only ``optimizer_f.step()`` follows and the generator
     gradients are zeroed before any use (adapt_trainer.py:187-205), so G runs without saving
     activations there -- its BatchNorm running statistics still move on every forward (7 per step);
-  * step C does not form the (unused) classifier weight gradients.
+  * step C does not form the (unused) classifier weight gradients;
+  * when both classifiers are the bare x8 up-sampler (``DRNSegPixelClassifier`` ver1 -- the MCD configuration), the loss
+    kernel forms their logits on the fly from the generator's score map (``mcdseg.ops.up8_mcd_losses``): the two
+    full-resolution logit tensors are never written or read.  Logits, losses and gradients are those of the two-pass form
+    (bit for bit, up to the order of the loss's block partial sums).
 """
 import torch
 
@@ -61,6 +65,35 @@ class MCDSolver:
             raise NotImplementedError("the fused solver implements d_loss='diff' (loss.py:93-100)")
         self.num_k = num_k
         self.mult = float(num_multiply_d_loss)
+        self.fused_up = (self.prob_criterion is None and ops.FUSED_UP_LOSS
+                         and all(type(f).__name__ == "DRNSegPixelClassifier" and getattr(f, "ver", None) == "ver1"
+                                 and type(getattr(f, "up", None)).__name__ == "Up8" for f in (model_f1, model_f2)))
+
+    def _loss_backward(self, feats, labels, ce_coef=0.0, diff_coef=0.0):
+        """Heads + loss + backward down to ``feats`` (and into the classifiers' parameters); returns losses[4]."""
+        if self.fused_up and len(feats) == 1:
+            s = feats[0]
+            w1, w2 = self.f1.up.weight, self.f2.up.weight
+            losses, g1, g2 = ops.up8_mcd_losses(s, w1, s, w2, labels, self.class_weight, self.ignore_index, ce_coef=ce_coef,
+                                                diff_coef=diff_coef)
+            sd = s.detach()
+            ds = None
+            for w, g in ((w1, g1), (w2, g2)):
+                dx, dw = ops.up8_backward(g, sd, w.detach(), s.requires_grad, w.requires_grad)
+                if dw is not None:
+                    w.grad = dw if w.grad is None else w.grad.add_(dw)
+                if dx is not None:
+                    ds = dx if ds is None else ds.add_(dx)
+            if ds is not None:
+                torch.autograd.backward([s], [ds])
+            return losses
+        o1, o2 = self._heads(feats)
+        if labels is not None:
+            losses, g1, g2 = self._ce(o1, o2, labels)
+        else:
+            losses, g1, g2 = ops.mcd_losses(o1, o2, None, None, diff_coef=diff_coef)
+        torch.autograd.backward([o1, o2], [g1, g2])
+        return losses
 
     # -- hooks the MFNet variant overrides
     def _features(self, x):
@@ -89,11 +122,8 @@ class MCDSolver:
         # ---- A: generator and classifiers on source
         self.opt_g.zero_grad()
         self.opt_f.zero_grad()
-        o1, o2 = self._heads(self._features(src_imgs))
-        losses, g1, g2 = self._ce(o1, o2, src_lbls)
-        torch.autograd.backward([o1, o2], [g1, g2])
+        losses = self._loss_backward(self._features(src_imgs), src_lbls, ce_coef=1.0)
         c_loss = losses[0] + losses[1]
-        del o1, o2, g1, g2
         self.opt_g.step()
         self.opt_f.step()
 
@@ -102,15 +132,11 @@ class MCDSolver:
         self.opt_f.zero_grad()
         with torch.no_grad():
             feats = self._features(src_imgs)
-        o1, o2 = self._heads(feats)
-        _, g1, g2 = self._ce(o1, o2, src_lbls)
-        torch.autograd.backward([o1, o2], [g1, g2])
+        self._loss_backward(feats, src_lbls, ce_coef=1.0)
         with torch.no_grad():
             feats = self._features(tgt_imgs)
-        o1, o2 = self._heads(feats)
-        _, g1, g2 = ops.mcd_losses(o1, o2, None, None, diff_coef=-1.0)
-        torch.autograd.backward([o1, o2], [g1, g2])
-        del o1, o2, g1, g2, feats
+        self._loss_backward(feats, None, diff_coef=-1.0)
+        del feats
         self.opt_f.step()
         self._after_b()
 
@@ -119,11 +145,8 @@ class MCDSolver:
         with _frozen(_params([self.f1, self.f2])):
             for _ in range(self.num_k):
                 self.opt_g.zero_grad()
-                o1, o2 = self._heads(self._features(tgt_imgs))
-                losses, g1, g2 = ops.mcd_losses(o1, o2, None, None, diff_coef=self.mult)
-                torch.autograd.backward([o1, o2], [g1, g2])
+                losses = self._loss_backward(self._features(tgt_imgs), None, diff_coef=self.mult)
                 d_last = losses[2] * self.mult
-                del o1, o2, g1, g2
                 self.opt_g.step()
         d_loss = d_last / self.num_k  # only the last inner loss is logged (adapt_trainer.py:214)
         return c_loss, d_loss

@@ -196,6 +196,40 @@ def test_up8_fwd_bwd(shape):
         _assert_close(a, b, 2e-5, "up8_dual " + name)
 
 
+@pytest.mark.parametrize("shape", [(2, 41, 5, 7), (1, 12, 3, 20), (2, 20, 4, 33), (1, 41, 2, 80)])
+@pytest.mark.parametrize("mode", ["ce+diff", "diff", "ce-single", "shared-scores"])
+def test_up8_loss_fused_equals_two_pass(shape, mode):
+    """The loss kernel that forms the up-sampled logits on the fly (mcdseg_up8_softmax_ce_l1) against up8 followed by the
+    plain loss kernel: identical logit gradients (bitwise), loss values up to the order of the block partial sums; ragged
+    row segments (8 Wi not a multiple of 128), the image border and ignore_index pixels included."""
+    dev = _dev()
+    from mcdseg import ops
+    n, c, hi, wi = shape
+    g = torch.Generator().manual_seed(11)
+    s1 = (2 * torch.randn(n, c, hi, wi, generator=g)).to(dev)
+    s2 = s1 if mode == "shared-scores" else (2 * torch.randn(n, c, hi, wi, generator=g)).to(dev)
+    w1 = (torch.randn(c, 1, 16, 16, generator=g) * 0.2).to(dev)
+    w2 = (torch.randn(c, 1, 16, 16, generator=g) * 0.2).to(dev)
+    lab = torch.randint(0, c, (n, 8 * hi, 8 * wi), generator=g)
+    lab[0, 0, :5] = -100
+    lab = lab.to(dev)
+    cw = (0.5 + torch.rand(c, generator=g)).to(dev)
+    single = mode == "ce-single"
+    kw = dict(ce_coef=0.0 if mode == "diff" else 1.0, diff_coef=0.0 if single else 0.7)
+    labels = None if mode == "diff" else lab
+    z1, z2 = ops.up8(s1, w1), (None if single else ops.up8(s2, w2))
+    ref_l, ref_g1, ref_g2 = ops.mcd_losses(z1, z2, labels, cw if labels is not None else None, **kw)
+    got_l, got_g1, got_g2 = ops.up8_mcd_losses(s1, w1, None if single else s2, None if single else w2, labels,
+                                               cw if labels is not None else None, **kw)
+    assert torch.equal(got_g1, ref_g1)
+    if not single:
+        assert torch.equal(got_g2, ref_g2)
+    assert float((got_l - ref_l).abs().max()) <= 2e-6 * float(ref_l.abs().max())
+    vals, _, _ = ops.up8_mcd_losses(s1, w1, None if single else s2, None if single else w2, labels,
+                                    cw if labels is not None else None, want_grad=False, **kw)
+    assert torch.equal(vals, got_l)
+
+
 def test_loss_kernel_against_golden_and_closed_forms(golden):
     dev = _dev()
     from mcdseg import ops

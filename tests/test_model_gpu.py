@@ -266,6 +266,36 @@ def test_solver_matches_drop_in_loop(golden):
     assert int(g.state_dict()["base.0.1.num_batches_tracked"]) == 14
 
 
+def test_solver_fused_up_loss_is_bitwise_the_two_pass_step(golden, monkeypatch):
+    """MCDSolver with the up-sampler folded into the loss kernel (the default for the MCD classifiers) against the same
+    solver on materialised logits: every parameter and buffer after two A/B/C iterations is bit-identical."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, get_prob_distance_criterion
+    from mcdseg import ops
+    from models.model_util import get_optimizer
+    from solvers.solver import MCDSolver
+    tr = golden.json("traces.json")["mcd_small"]
+    n, ch, h, w = tr["shape"]
+    s, l, t = (v.to(dev) for v in make_batch(tr["seed_batch"], n, ch, h, w, NC))
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    states, losses = [], []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "FUSED_UP_LOSS", fused)
+        g, f1, f2 = _mcd_models(dev)
+        og = get_optimizer(g.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+        of = get_optimizer(list(f1.parameters()) + list(f2.parameters()), "sgd", 1e-3, 0.9, 2e-5)
+        solver = MCDSolver(g, f1, f2, og, of, CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff"), num_k=4)
+        assert solver.fused_up == fused
+        out = [solver.step(s, l, t) for _ in range(2)]
+        losses.append([(float(a), float(b)) for a, b in out])
+        states.append({k: v.clone() for m in (g, f1, f2) for k, v in m.state_dict().items()})
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
+    for (c0, d0), (c1, d1) in zip(*losses):
+        assert abs(c0 - c1) <= 1e-6 * abs(c1) and abs(d0 - d1) <= 1e-6 * abs(d1)
+
+
 def test_mfnet_vs_reference(golden):
     dev = _dev()
     from loss import CrossEntropyLoss2d, get_prob_distance_criterion
