@@ -43,6 +43,14 @@ __global__ __launch_bounds__(256) void wsum_finalize_kernel(const float* __restr
 
 // The per-pixel maths shared by the two front ends below: a[] / b[] hold the pixel's logits (-inf past C) and leave as its
 // probabilities; the gradients go to g1 / g2 at base + c * HW.
+// Precondition: a[c] = b[c] = -inf for c >= C, so the exponentials need no per-class select (exp(-inf) = 0).  The class loops
+// are cut into groups by branches on an opaque, always-true scalar: basic-block boundaries are the only fence the instruction
+// scheduler respects here, and without them it interleaves the exponential chains of all classes (about seven registers
+// each) and spills hundreds of registers.
+#define MCD_OPAQUE_TRUE(name) \
+  int name = 1;               \
+  asm volatile("" : "+s"(name))
+
 template <int NCMAX, bool TWO>
 __device__ __forceinline__ void pixel_losses(float (&a)[NCMAX], float (&b)[NCMAX], int y, float wy, float ce_coef, float diff_coef,
                                              const float* __restrict__ losses_w, float* __restrict__ g1, float* __restrict__ g2,
@@ -55,16 +63,23 @@ __device__ __forceinline__ void pixel_losses(float (&a)[NCMAX], float (&b)[NCMAX
   }
   float s1 = 0.f, s2 = 0.f, zy1 = 0.f, zy2 = 0.f;
 #pragma unroll
-  for (int c = 0; c < NCMAX; ++c) {
-    if (c == y) {
-      zy1 = a[c];
-      if (TWO) zy2 = b[c];
-    }
-    a[c] = (c < C) ? expf(a[c] - m1) : 0.f;
-    s1 += a[c];
-    if (TWO) {
-      b[c] = (c < C) ? expf(b[c] - m2) : 0.f;
-      s2 += b[c];
+  for (int c0 = 0; c0 < NCMAX; c0 += 4) {
+    MCD_OPAQUE_TRUE(go);
+    if (go) {
+#pragma unroll
+      for (int c = c0; c < c0 + 4; ++c) {
+        if (c >= NCMAX) continue;
+        if (c == y) {
+          zy1 = a[c];
+          if (TWO) zy2 = b[c];
+        }
+        a[c] = expf(a[c] - m1);
+        s1 += a[c];
+        if (TWO) {
+          b[c] = expf(b[c] - m2);
+          s2 += b[c];
+        }
+      }
     }
   }
   if (y >= 0) {
@@ -74,15 +89,22 @@ __device__ __forceinline__ void pixel_losses(float (&a)[NCMAX], float (&b)[NCMAX
   const float r1 = 1.f / s1, r2 = TWO ? 1.f / s2 : 0.f;
   float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-  for (int c = 0; c < NCMAX; ++c) {
-    a[c] *= r1;
-    if (TWO) {
-      b[c] *= r2;
-      const float d = a[c] - b[c];
-      const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-      dsum += fabsf(d);
-      t1 = fmaf(sg, a[c], t1);
-      t2 = fmaf(sg, b[c], t2);
+  for (int c0 = 0; c0 < NCMAX; c0 += 8) {
+    MCD_OPAQUE_TRUE(go);
+    if (go) {
+#pragma unroll
+      for (int c = c0; c < c0 + 8; ++c) {
+        if (c >= NCMAX) continue;
+        a[c] *= r1;
+        if (TWO) {
+          b[c] *= r2;
+          const float d = a[c] - b[c];
+          const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+          dsum += fabsf(d);
+          t1 = fmaf(sg, a[c], t1);
+          t2 = fmaf(sg, b[c], t2);
+        }
+      }
     }
   }
   if (g1 != nullptr || g2 != nullptr) {
@@ -153,98 +175,153 @@ __global__ __launch_bounds__(256) void softmax_ce_l1_kernel(const float* __restr
 
 // The same losses with the x8 learned up-sampler (up8.hip) computed on the fly: the classifiers of the MCD configuration are
 // nothing but that up-sampler (models/dilated_fcn.py:357-366 behind DRNSegPixelClassifier), so their full-resolution logits
-// need never exist in memory -- each is four multiply-adds on the 64x smaller score map.  A workgroup of 128 lanes owns 128
-// consecutive pixels of one output row: every lane then has the same kernel rows ky0, ky0+8 and the same two input rows, so
-// the stage in LDS is 2 rows x 18 columns of scores and 2 x 16 kernel taps per class and head.  The multiply-adds run in the
-// order of up8_fwd_kernel (absent inputs staged as zeros), so logits, losses' summands and gradients equal the two-pass
-// result bit for bit; only the order of the block partial sums differs.
-constexpr int UP_SEG = 128, UP_JJ = 18;
+// need never exist in memory -- each is four multiply-adds on the 64x smaller score map.
+//
+// Persistent workgroups of 8 waves, one per CU.  The 16x16 kernels of every class and head stay in LDS for the workgroup's
+// life (re-ordered so that the four taps a pixel needs are one 16-byte read); the work items are patches of 8 rows x 64
+// columns whose rows share their two input rows -- output rows 8i-4 .. 8i+3 -- so an item stages only 2 x 10 scores per class
+// and head, fetched into registers while the previous item is being computed.  Wave k of the workgroup owns the patch row with
+// kernel rows (k, k+8).  The multiply-adds run in the order of up8_fwd_kernel (absent inputs staged as zeros), so logits,
+// the losses' summands and the gradients equal the two-pass result bit for bit; only the summation order of the loss
+// values differs (per lane over its items, then the block, then fp64 over blocks).
+constexpr int UP_COLS = 64, UP_JP = 9, UP_NT = 512;  // UP_JP: input-column pairs (ix-1, ix) a 64-pixel row segment touches
 
 template <int NCMAX, bool TWO>
-__global__ __launch_bounds__(128) void up8_softmax_ce_l1_kernel(const float* __restrict__ s1, const float* __restrict__ w1,
-                                                                const float* __restrict__ s2, const float* __restrict__ w2,
-                                                                const int64_t* __restrict__ labels, const float* __restrict__ cw,
-                                                                int64_t ignore_index, float ce_coef, float diff_coef,
-                                                                const float* __restrict__ losses_w, float* __restrict__ g1,
-                                                                float* __restrict__ g2, float* __restrict__ part, int C, int Hi,
-                                                                int Wi, float inv_m) {
+__global__ __launch_bounds__(UP_NT) void up8_softmax_ce_l1_kernel(const float* __restrict__ s1, const float* __restrict__ w1,
+                                                                  const float* __restrict__ s2, const float* __restrict__ w2,
+                                                                  const int64_t* __restrict__ labels, const float* __restrict__ cw,
+                                                                  int64_t ignore_index, float ce_coef, float diff_coef,
+                                                                  const float* __restrict__ losses_w, float* __restrict__ g1,
+                                                                  float* __restrict__ g2, float* __restrict__ part, int N, int C,
+                                                                  int Hi, int Wi, float inv_m) {
   extern __shared__ __attribute__((aligned(16))) float up_sm[];
   constexpr int HEADS = TWO ? 2 : 1;
-  float* wl = up_sm;                   // [head][c][kx0 8][a 2][b 2]
-  float* sin = up_sm + HEADS * C * 32;  // [head][c][a 2][UP_JJ]
-  const int n = blockIdx.z, oy = blockIdx.y, x0 = blockIdx.x * UP_SEG;
+  constexpr int SREG = (HEADS * NCMAX * UP_JP * 4 + UP_NT - 1) / UP_NT;  // staged scores per thread and item
+  // Class stride NCMAX, not C, and the four taps / four scores of a pixel as one 16-byte unit: every LDS read below is then
+  // the lane's base address plus an immediate offset.  (With C in the stride, or with the scores as plain rows read by
+  // ds_read2_b32 -- whose offset field reaches 1 KB -- the 2 x NCMAX addresses become registers of their own and the
+  // kernel spills hundreds of them.)
+  float* wl = up_sm;                         // [head][NCMAX][ky0 8][kx0 8][a 2][b 2]
+  float* sin = up_sm + HEADS * NCMAX * 256;  // [head][NCMAX][pair UP_JP][a 2][b 2]: score (row iyg - a, column ixb + pair + 1 - b)
   const int Wo = 8 * Wi, Ho = 8 * Hi;
-  const int iy_hi = (oy + 4) >> 3, ky0 = (oy + 4) & 7;
-  const int ixb = ((x0 + 4) >> 3) - 1;  // first staged input column (-1 at the left edge)
-  for (int i = threadIdx.x; i < HEADS * C * 32; i += UP_SEG) {
-    const int b = i & 1, a = (i >> 1) & 1, k = (i >> 2) & 7, hc = i >> 5;
-    const int c = hc % C;
-    wl[i] = (hc >= C ? w2 : w1)[c * 256 + (ky0 + 8 * a) * 16 + k + 8 * b];
+  const int nseg = (Wo + UP_COLS - 1) / UP_COLS;
+  const int items = N * (Hi + 1) * nseg;
+  const int ky0 = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < HEADS * NCMAX * 256; i += UP_NT) {
+    const int b = i & 1, a = (i >> 1) & 1, kx = (i >> 2) & 7, ky = (i >> 5) & 7, hc = i >> 8;
+    const int c = hc % NCMAX;
+    // classes past C: taps (1, 0, 0, 0) against scores (-inf, 0, 0, 0) below give the logit -inf with no test in the pixel loop
+    wl[i] = c < C ? (hc >= NCMAX ? w2 : w1)[c * 256 + (ky + 8 * a) * 16 + kx + 8 * b] : ((a | b) == 0 ? 1.f : 0.f);
   }
-  for (int i = threadIdx.x; i < HEADS * C * 2 * UP_JJ; i += UP_SEG) {
-    const int jj = i % UP_JJ, r = i / UP_JJ;
-    const int a = r & 1, hc = r >> 1;
-    const int c = hc % C;
-    const int iy = iy_hi - a, ix = ixb + jj;
-    float v = 0.f;
-    if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) v = (hc >= C ? s2 : s1)[(((size_t)n * C + c) * Hi + iy) * Wi + ix];
-    sin[i] = v;
-  }
-  __syncthreads();
-  const int ox = x0 + threadIdx.x;
+  constexpr int nstage = HEADS * NCMAX * UP_JP * 4;
+  float sreg[SREG];
+  auto fetch = [&](int item) {  // scores of one item -> registers (zeros outside the map)
+    const int seg = item % nseg, r = item / nseg;
+    const int iyg = r % (Hi + 1), n = r / (Hi + 1);
+    const int ixb = seg * (UP_COLS / 8) - 1;
+#pragma unroll
+    for (int k = 0; k < SREG; ++k) {
+      const int i = threadIdx.x + k * UP_NT;
+      float v = 0.f;
+      if (i < nstage) {
+        const int b = i & 1, a = (i >> 1) & 1, q = i >> 2;
+        const int j = q % UP_JP, hc = q / UP_JP;
+        const int c = hc % NCMAX;
+        const int iy = iyg - a, ix = ixb + j + 1 - b;
+        if (c >= C)
+          v = (a | b) == 0 ? -INFINITY : 0.f;
+        else if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi)
+          v = (hc >= NCMAX ? s2 : s1)[(((size_t)n * C + c) * Hi + iy) * Wi + ix];
+      }
+      sreg[k] = v;
+    }
+  };
   float ce1 = 0.f, ce2 = 0.f, dsum = 0.f;
-  if (ox < Wo) {
-    const int kx0 = (ox + 4) & 7;
-    const int jj = ((ox + 4) >> 3) - ixb;  // column of the b = 0 input; b = 1 is the one to its left
-    float a[NCMAX], b[NCMAX];
+  int item = blockIdx.x;
+  if (item < items) fetch(item);
+  for (; item < items; item += gridDim.x) {
+    __syncthreads();  // the previous item's readers are done (and, first time round, the kernels are staged)
 #pragma unroll
-    for (int c = 0; c < NCMAX; ++c) {
-      a[c] = -INFINITY;
-      b[c] = -INFINITY;
-      if (c < C) {
+    for (int k = 0; k < SREG; ++k) {
+      const int i = threadIdx.x + k * UP_NT;
+      if (i < nstage) sin[i] = sreg[k];
+    }
+    __syncthreads();
+    if (item + (int)gridDim.x < items) fetch(item + gridDim.x);
+    const int seg = item % nseg, r = item / nseg;
+    const int iyg = r % (Hi + 1), n = r / (Hi + 1);
+    const int oy = 8 * iyg - 4 + ky0;
+    const int ox = seg * UP_COLS + lane;
+    if (oy >= 0 && oy < Ho && ox < Wo) {
+      // the class count re-read as an opaque scalar: otherwise the NCMAX "c < C" store guards are hoisted out of the item loop
+      // and their results spill
+      int Cv = C;
+      asm volatile("" : "+s"(Cv));
+      const int kx0 = (ox + 4) & 7;
+      const int jp = ((ox + 4) >> 3) - seg * (UP_COLS / 8);  // pair whose b = 0 member is this pixel's right-hand input column
+      // the lane's LDS offsets, opaque too: the kernel taps do not depend on the item ((ox + 4) & 7 is the lane's), and left
+      // alone the compiler hoists all 2 x NCMAX 16-byte reads out of the item loop
+      int woff = (ky0 * 8 + kx0) * 4, soff = jp * 4;
+      asm volatile("" : "+v"(woff), "+v"(soff));
+      float a[NCMAX], b[NCMAX];
 #pragma unroll
-        for (int h = 0; h < HEADS; ++h) {
-          const float4 wv = *reinterpret_cast<const float4*>(wl + ((h * C + c) * 8 + kx0) * 4);
-          const float* sp = sin + ((h * C + c) * 2) * UP_JJ + jj;
-          float o = 0.f;
-          o = fmaf(sp[0], wv.x, o);
-          o = fmaf(sp[-1], wv.y, o);
-          o = fmaf(sp[UP_JJ], wv.z, o);
-          o = fmaf(sp[UP_JJ - 1], wv.w, o);
-          if (h == 0)
-            a[c] = o;
-          else
-            b[c] = o;
+      for (int c0 = 0; c0 < NCMAX; c0 += 4) {
+        MCD_OPAQUE_TRUE(go);  // groups of four classes in basic blocks of their own (see pixel_losses)
+        if (go) {
+#pragma unroll
+          for (int c = c0; c < c0 + 4; ++c) {
+            if (c >= NCMAX) continue;
+            b[c] = -INFINITY;
+#pragma unroll
+            for (int h = 0; h < HEADS; ++h) {
+              const float4 wv = *reinterpret_cast<const float4*>(wl + woff + (h * NCMAX + c) * 256);
+              const float4 sv = *reinterpret_cast<const float4*>(sin + soff + (h * NCMAX + c) * (UP_JP * 4));
+              float o = 0.f;
+              o = fmaf(sv.x, wv.x, o);
+              o = fmaf(sv.y, wv.y, o);
+              o = fmaf(sv.z, wv.z, o);
+              o = fmaf(sv.w, wv.w, o);
+              if (h == 0)
+                a[c] = o;
+              else
+                b[c] = o;
+            }
+          }
         }
       }
-    }
-    const size_t HW = (size_t)Ho * Wo;
-    const size_t hw = (size_t)oy * Wo + ox;
-    int y = -1;
-    float wy = 0.f;
-    if (labels != nullptr) {
-      const int64_t yl = labels[(size_t)n * HW + hw];
-      if (yl != ignore_index && yl >= 0 && yl < C) {
-        y = (int)yl;
-        wy = cw ? cw[y] : 1.f;
+      const size_t HW = (size_t)Ho * Wo;
+      const size_t hw = (size_t)oy * Wo + ox;
+      int y = -1;
+      float wy = 0.f;
+      if (labels != nullptr) {
+        const int64_t yl = labels[(size_t)n * HW + hw];
+        if (yl != ignore_index && yl >= 0 && yl < C) {
+          y = (int)yl;
+          wy = cw ? cw[y] : 1.f;
+        }
       }
+      float e1 = 0.f, e2 = 0.f, ds = 0.f;
+      pixel_losses<NCMAX, TWO>(a, b, y, wy, ce_coef, diff_coef, losses_w, g1, g2, (size_t)n * C * HW + hw, HW, Cv, inv_m, e1, e2, ds);
+      ce1 += e1;
+      ce2 += e2;
+      dsum += ds;
     }
-    pixel_losses<NCMAX, TWO>(a, b, y, wy, ce_coef, diff_coef, losses_w, g1, g2, (size_t)n * C * HW + hw, HW, C, inv_m, ce1, ce2, dsum);
   }
-  __shared__ float sh[3][2];
+  __shared__ float sh[3][UP_NT / 64];
   ce1 = wave_sum(ce1);
   ce2 = wave_sum(ce2);
   dsum = wave_sum(dsum);
-  if ((threadIdx.x & 63) == 0) {
-    sh[0][threadIdx.x >> 6] = ce1;
-    sh[1][threadIdx.x >> 6] = ce2;
-    sh[2][threadIdx.x >> 6] = dsum;
+  if (lane == 0) {
+    sh[0][ky0] = ce1;
+    sh[1][ky0] = ce2;
+    sh[2][ky0] = dsum;
   }
   __syncthreads();
   if (threadIdx.x < 3) {
     const int q = threadIdx.x;
-    const size_t blk = ((size_t)n * gridDim.y + oy) * gridDim.x + blockIdx.x;
-    part[blk * 3 + q] = sh[q][0] + sh[q][1];
+    float t = 0.f;
+    for (int k = 0; k < UP_NT / 64; ++k) t += sh[q][k];
+    part[(size_t)blockIdx.x * 3 + q] = t;
   }
 }
 
@@ -371,15 +448,22 @@ void launch_loss(bool two, dim3 grid, hipStream_t st, const float* z1, const flo
 }
 
 template <int NCMAX>
-void launch_up_loss(bool two, dim3 grid, size_t lds, hipStream_t st, const float* s1, const float* w1, const float* s2, const float* w2,
-                    const int64_t* labels, const float* cw, int64_t ignore_index, float ce_coef, float diff_coef, const float* losses,
-                    float* g1, float* g2, float* part, int C, int Hi, int Wi, float inv_m) {
-  if (two)
-    hipLaunchKernelGGL((up8_softmax_ce_l1_kernel<NCMAX, true>), grid, dim3(UP_SEG), lds, st, s1, w1, s2, w2, labels, cw, ignore_index,
-                       ce_coef, diff_coef, losses, g1, g2, part, C, Hi, Wi, inv_m);
-  else
-    hipLaunchKernelGGL((up8_softmax_ce_l1_kernel<NCMAX, false>), grid, dim3(UP_SEG), lds, st, s1, w1, s2, w2, labels, cw, ignore_index,
-                       ce_coef, diff_coef, losses, g1, g2, part, C, Hi, Wi, inv_m);
+int launch_up_loss(bool two, int blocks, size_t lds, hipStream_t st, const float* s1, const float* w1, const float* s2, const float* w2,
+                   const int64_t* labels, const float* cw, int64_t ignore_index, float ce_coef, float diff_coef, const float* losses,
+                   float* g1, float* g2, float* part, int N, int C, int Hi, int Wi, float inv_m) {
+  auto go = [&](auto kern) {
+    if (lds > 64 * 1024) {
+      const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        mcdseg_set_error("up8_softmax_ce_l1: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+        return -5;
+      }
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(UP_NT), lds, st, s1, w1, s2, w2, labels, cw, ignore_index, ce_coef, diff_coef, losses,
+                       g1, g2, part, N, C, Hi, Wi, inv_m);
+    return 0;
+  };
+  return two ? go(up8_softmax_ce_l1_kernel<NCMAX, true>) : go(up8_softmax_ce_l1_kernel<NCMAX, false>);
 }
 
 }  // namespace
@@ -451,7 +535,11 @@ extern "C" int mcdseg_softmax_ce_l1(const float* z1, const float* z2, const int6
   return 0;
 }
 
-static int64_t up_loss_blocks(int32_t N, int32_t Hi, int32_t Wi) { return (int64_t)N * (8 * Hi) * ceil_div(8 * Wi, UP_SEG); }
+// persistent workgroups: one per CU (the kernels of all classes fill most of a CU's LDS), never more than there are items
+static int up_loss_blocks(int32_t N, int32_t Hi, int32_t Wi) {
+  const int64_t items = (int64_t)N * (Hi + 1) * ceil_div(8 * Wi, UP_COLS);
+  return (int)(items < 256 ? items : 256);
+}
 
 extern "C" size_t mcdseg_up8_loss_workspace_bytes(int32_t N, int32_t Hi, int32_t Wi) {
   if (N <= 0 || Hi <= 0 || Wi <= 0) return 0;
@@ -468,13 +556,13 @@ extern "C" int mcdseg_up8_softmax_ce_l1(const float* s1, const float* w1, const 
   MCD_REQUIRE((s2 == nullptr) == (w2 == nullptr), "up8_softmax_ce_l1: s2 and w2 come together");
   MCD_REQUIRE(s2 != nullptr || (g2 == nullptr && diff_coef == 0.f), "up8_softmax_ce_l1: discrepancy needs the second head");
   MCD_REQUIRE(labels != nullptr || ce_coef == 0.f, "up8_softmax_ce_l1: cross-entropy needs labels");
-  MCD_REQUIRE(N <= 65535 && 8 * Hi <= 65535, "up8_softmax_ce_l1: grid too large");
+  MCD_REQUIRE((int64_t)N * (Hi + 1) * ceil_div(8 * Wi, UP_COLS) < (1ll << 31), "up8_softmax_ce_l1: too many patches");
   MCD_REQUIRE(workspace_bytes >= mcdseg_up8_loss_workspace_bytes(N, Hi, Wi), "up8_softmax_ce_l1: workspace too small");
   const int64_t P = (int64_t)N * Hi * Wi * 64;
-  const int64_t nblk = up_loss_blocks(N, Hi, Wi);
+  const int nblk = up_loss_blocks(N, Hi, Wi);
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
-  float* wpart = part + nblk * 3;
+  float* wpart = part + (size_t)nblk * 3;
   const int wb = wsum_blocks(P);
   if (wsum_in != nullptr) {
     (void)hipMemcpyAsync(losses + 3, wsum_in, sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -488,19 +576,21 @@ extern "C" int mcdseg_up8_softmax_ce_l1(const float* s1, const float* w1, const 
   }
   const double inv_m = 1.0 / ((double)P * (double)C);
   const bool two = s2 != nullptr;
-  dim3 grid((unsigned)ceil_div(8 * Wi, UP_SEG), (unsigned)(8 * Hi), (unsigned)N);
-  const size_t lds = (size_t)(two ? 2 : 1) * C * (32 + 2 * UP_JJ) * sizeof(float);
+  const int ncmax = C <= 16 ? 16 : (C <= 24 ? 24 : 48);  // the instantiation chosen below
+  const size_t lds = (size_t)(two ? 2 : 1) * ncmax * (256 + 4 * UP_JP) * sizeof(float);
+  int rc;
   if (C <= 16)
-    launch_up_loss<16>(two, grid, lds, st, s1, w1, s2, w2, labels, class_weight, ignore_index, ce_coef, diff_coef, losses, g1, g2, part,
-                       C, Hi, Wi, (float)inv_m);
+    rc = launch_up_loss<16>(two, nblk, lds, st, s1, w1, s2, w2, labels, class_weight, ignore_index, ce_coef, diff_coef, losses, g1, g2,
+                            part, N, C, Hi, Wi, (float)inv_m);
   else if (C <= 24)
-    launch_up_loss<24>(two, grid, lds, st, s1, w1, s2, w2, labels, class_weight, ignore_index, ce_coef, diff_coef, losses, g1, g2, part,
-                       C, Hi, Wi, (float)inv_m);
+    rc = launch_up_loss<24>(two, nblk, lds, st, s1, w1, s2, w2, labels, class_weight, ignore_index, ce_coef, diff_coef, losses, g1, g2,
+                            part, N, C, Hi, Wi, (float)inv_m);
   else
-    launch_up_loss<48>(two, grid, lds, st, s1, w1, s2, w2, labels, class_weight, ignore_index, ce_coef, diff_coef, losses, g1, g2, part,
-                       C, Hi, Wi, (float)inv_m);
+    rc = launch_up_loss<48>(two, nblk, lds, st, s1, w1, s2, w2, labels, class_weight, ignore_index, ce_coef, diff_coef, losses, g1, g2,
+                            part, N, C, Hi, Wi, (float)inv_m);
+  if (rc != 0) return rc;
   MCD_LAUNCH_CHECK("up8_softmax_ce_l1");
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nblk, losses, inv_m,
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, (int64_t)nblk, losses, inv_m,
                      labels != nullptr ? 1 : 0);
   MCD_LAUNCH_CHECK("loss_finalize");
   return 0;
