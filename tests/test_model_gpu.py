@@ -471,12 +471,16 @@ def test_cfg2_full_batch_vs_oracle():
         assert rel <= 5e-2, "%s: relative L2 difference %.3e" % (k, rel)
 
 
-def test_d105_bottleneck_vs_reference(golden):
+@pytest.mark.parametrize("storage,k", [("fp32", 4.0), ("compact", 6.0)])
+def test_d105_bottleneck_vs_reference(golden, storage, k, monkeypatch):
     """drn_d_105 (Bottleneck blocks; BASELINE config 5 trunk) forward + CE backward.  105 BN layers amplify fp32
     re-association noise well beyond drn_d_38's, so the yardstick is the reference's own fp32 noise floor: the
     CPU oracle (pinned to the reference's d105 fixture) is run in fp32 and fp64 and our error against fp64 has to
-    stay within a small multiple of the fp32 oracle's."""
+    stay within a small multiple k of the fp32 oracle's.  "compact" is the storage mode cfg5 runs in at its stated batch
+    (trunk activations kept only as their 2 x fp16 companions, MCDSEG_ACT_STORAGE=compact)."""
     dev = _dev()
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "ACT_STORAGE", storage)
     from loss import CrossEntropyLoss2d
     from models.model_util import get_models
     from oracle import ref_loss, ref_models
@@ -516,13 +520,13 @@ def test_d105_bottleneck_vs_reference(golden):
     scale = float(f64.abs().max())
     noise = float((f32 - f64).abs().max())
     err = float((feat.detach().double().cpu() - f64).abs().max())
-    assert err <= max(4 * noise, 2e-5 * scale), "feat err %.3e, fp32-oracle noise %.3e, scale %.3e" % (err, noise, scale)
-    assert abs(float(loss) - l64) <= max(4 * abs(l32 - l64), 1e-5 * abs(l64))
+    assert err <= max(k * noise, 2e-5 * scale), "feat err %.3e, fp32-oracle noise %.3e, scale %.3e" % (err, noise, scale)
+    assert abs(float(loss) - l64) <= max(k * abs(l32 - l64), 1e-5 * abs(l64))
     named = dict(g.named_parameters())
-    for k in g64:
-        nz = float((g32[k] - g64[k]).abs().max())
-        e = float((named[k].grad.double().cpu() - g64[k]).abs().max())
-        assert e <= max(4 * nz, 1e-3 * float(g64[k].abs().max())), "%s: err %.3e noise %.3e" % (k, e, nz)
+    for name in g64:
+        nz = float((g32[name] - g64[name]).abs().max())
+        e = float((named[name].grad.double().cpu() - g64[name]).abs().max())
+        assert e <= max(k * nz, 1e-3 * float(g64[name].abs().max())), "%s: err %.3e noise %.3e" % (name, e, nz)
 
 
 def test_multitask_cfg4_vs_reference(golden):
