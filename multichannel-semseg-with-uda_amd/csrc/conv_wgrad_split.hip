@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_split_cb_kernel(WgradCbPara
 // takes quads 4 kk + 2 lh and 4 kk + 2 lh + 1 of k-block kk; which pixel sits in which k slot is irrelevant as long as dY and
 // X agree.  Transposed-read addresses of a 32-lane half cover 256 contiguous bytes: conflict-free.
 //
-//   <WM = 2, R = 4, NSTAGE = 2>   128 (co) x 128 (ci) tile, 32-pixel stages of 32 KB, two stages
+//   <WM = 2, R = 2, NSTAGE = 3>   128 (co) x 128 (ci) tile, 16-pixel stages of 16 KB, three stages: 48 KB and 105 VGPRs, so
+//                                 three workgroups share a CU (two 32-pixel stages -- 64 KB, two workgroups -- ran 10 % slower)
 //   <WM = 4, R = 2, NSTAGE = 3>   256 (co) x 128 (ci) tile (each wave 128 x 64), 16-pixel stages of 24 KB, three stages: the
 //                                 DMAs of tile s+2 fly while tile s multiplies -- the structure of the forward kernel's
 //                                 256 x 128 configuration, for the layers with Cout a multiple of 256
@@ -849,7 +850,7 @@ int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, c
   p.co_p = co_p; p.ci_p = ci_p; p.chunks_per_img = chunks_per_img; p.splits = splits;
   const int variant = mcdseg_internal_wgrad_cb_variant(d, math, co_p, ci_p, splits);
   const bool tr = variant >= 1, big = variant == 2;
-  const int rows = big ? 2 : 4;  // pixel rows of a stage tile
+  const int rows = tr ? 2 : 4;  // pixel rows of a stage tile (the transposing-read kernels run 16-pixel stages)
   p.tiles_x = ceil_div(d->Wo, 8);
   p.tiles_y = ceil_div(d->Ho, rows);
   p.tiles_per_chunk = ceil_div(p.tiles_x * p.tiles_y, chunks_per_img);
@@ -870,7 +871,7 @@ int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, c
   if (big)
     hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x3, 4, 2, 3>), dim3((unsigned)nwg), dim3(256), 0, st, p);
   else if (tr)
-    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x3, 2, 4, 2>), dim3((unsigned)nwg), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x3, 2, 2, 3>), dim3((unsigned)nwg), dim3(256), 0, st, p);
   else if (math == MCDSEG_MATH_F16X3)
     hipLaunchKernelGGL(conv_wgrad_split_cb_kernel<SplitF16x3>, dim3((unsigned)nwg), dim3(256), 0, st, p);
   else
