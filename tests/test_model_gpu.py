@@ -529,6 +529,57 @@ def test_d105_bottleneck_vs_reference(golden, storage, k, monkeypatch):
         assert e <= max(k * nz, 1e-3 * float(g64[name].abs().max())), "%s: err %.3e noise %.3e" % (name, e, nz)
 
 
+def test_cfg5_size_compact_storage_step(monkeypatch):
+    """BASELINE config 5 at its stated image size (drn_d_105, 6x720x1280; N=2 here, N=32 is measured in DESIGN 6a): one full
+    A+B+C step in compact activation storage against the same step in fp32 storage -- losses and every parameter update.
+    The yardstick for the updates is the network's own fp32-grade noise at this depth (105 BatchNorm layers): the same
+    step with the f32-MFMA convolution arithmetic differs from the default arithmetic by a few per cent, and compact
+    storage may differ by at most twice that.  Exercises the 720x1280 geometry (90x160 feature maps: ragged pixel tiles,
+    2-row stage tiles of the weight-gradient kernels, batch cutting of the full-resolution layers) in the storage mode
+    that configuration runs in."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, get_prob_distance_criterion
+    from mcdseg import ops
+    from models.model_util import get_models, get_optimizer
+    from solvers.solver import MCDSolver
+    s, l, t = (v.to(dev) for v in make_batch(5, 2, 6, 720, 1280, NC))
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    out = {}
+    for name, math, storage in (("ref", "f16x3", "fp32"), ("compact", "f16x3", "compact"), ("f32", "f32", "fp32")):
+        monkeypatch.setattr(ops, "CONV_MATH", math)
+        monkeypatch.setattr(ops, "ACT_STORAGE", storage)
+        ops.bump_weight_epoch()
+        g, f1, f2 = get_models("drn_d_105", 6, NC)
+        for m, seed in ((g, 71), (f1, 72), (f2, 73)):
+            fill_state_(m, seed)
+            m.to(dev).train()
+        before = {k: v.detach().clone() for k, v in g.named_parameters()}
+        og = get_optimizer(g.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+        of = get_optimizer(list(f1.parameters()) + list(f2.parameters()), "sgd", 1e-3, 0.9, 2e-5)
+        solver = MCDSolver(g, f1, f2, og, of, CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff"), num_k=2)
+        c_loss, d_loss = solver.step(s, l, t)
+        out[name] = (float(c_loss), float(d_loss), {k: (v.detach() - before[k]).double() for k, v in g.named_parameters()})
+        del g, f1, f2, og, of, solver, before
+        torch.cuda.empty_cache()
+
+    def dist(a, b):
+        num = sum(float(((a[k] - b[k]) ** 2).sum()) for k in a)
+        den = sum(float((b[k] ** 2).sum()) for k in b)
+        return (num / den) ** 0.5
+
+    (c0, d0, u0), (c1, d1, u1), (c2, d2, u2) = out["ref"], out["compact"], out["f32"]
+    assert np.isfinite(c0) and abs(c1 - c0) <= 1e-4 * abs(c0), (c0, c1)
+    assert abs(d1 - d0) <= max(5e-3 * abs(d0), 2 * abs(d2 - d0)), (d0, d1, d2)
+    noise, err = dist(u2, u0), dist(u1, u0)
+    assert 0 < noise < 0.2, noise
+    assert err <= 2 * noise, "compact storage moves the updates by %.3e, the arithmetic's own noise is %.3e" % (err, noise)
+    for k in ("base.0.0.weight", "seg.weight", "base.5.11.conv2.weight", "base.7.0.weight"):
+        e = float((u1[k] - u0[k]).norm() / u0[k].norm().clamp_min(1e-30))
+        nz = float((u2[k] - u0[k]).norm() / u0[k].norm().clamp_min(1e-30))
+        assert e <= max(3 * nz, 1e-2), "%s: update differs by %.3e (arithmetic noise %.3e)" % (k, e, nz)
+
+
 def test_multitask_cfg4_vs_reference(golden):
     """BASELINE config 4: RGB encoder + MCD multitask decoder (bilinear x8, MSE on HHA, learned task weights)."""
     dev = _dev()
