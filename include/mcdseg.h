@@ -157,6 +157,11 @@ int mcdseg_bn_apply(const float* z, const float* mean, const float* rstd, const 
  * y == NULL and the residual as a companion (res_cb, res_bound) instead of fp32; the backward kernels accept y == NULL with y_cb,
  * reading the ReLU mask from the companion's leading piece. */
 int mcdseg_split_cb(const float* x, void* x_cb, const float* x_bound, int32_t math, int32_t N, int32_t C, int32_t HW, void* stream);
+/* The same for a channel count that is not a multiple of 8 (the 6-channel RGB+HHA network input, adapt_trainer.py:157-160): the
+ * companion has ceil(C/8) channel groups -- [piece][N][ceil(C/8)][H*W][8 x 16 bit] -- with zeros in the missing channels.  Read
+ * by the weight-gradient kernel of the 7x7 stem (models/drn.py:126-131) only. */
+int mcdseg_split_cb_padded(const float* x, void* x_cb, const float* x_bound, int32_t math, int32_t N, int32_t C, int32_t HW,
+                           void* stream);
 int mcdseg_unsplit_cb(const void* x_cb, const float* x_bound, int32_t math, int32_t N, int32_t C, int32_t HW, float* x, void* stream);
 int mcdseg_bn_apply_cb(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                        const float* residual, const void* res_cb, const float* res_bound, float* y, void* y_cb,

@@ -566,6 +566,25 @@ __global__ __launch_bounds__(256) void split_cb_kernel(const float* __restrict__
   split_store<P>(v, inv_scale, cb, (size_t)N * C * HW, (size_t)ng * HW + pix);
 }
 
+// the same for a channel count that is not a multiple of 8 (the 6-channel network input): the companion has ceil(C/8) channel
+// groups, the missing channels are zeros
+template <class P>
+__global__ __launch_bounds__(256) void split_cb_padded_kernel(const float* __restrict__ x, typename P::elem* __restrict__ cb,
+                                                              const float* __restrict__ x_bound, int N, int C, int HW) {
+  const int C8 = (C + 7) >> 3;
+  const int ng = blockIdx.y;
+  const int g = ng % C8;
+  const int n = ng / C8;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= HW) return;
+  const float inv_scale = 1.f / operand_scale<P>(x_bound);
+  const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (8 * g + e < C) ? x[base + (size_t)e * HW] : 0.f;
+  split_store<P>(v, inv_scale, cb, (size_t)N * C8 * 8 * HW, (size_t)ng * HW + pix);
+}
+
 int plane_chunks(int HW, bool vec) {
   const int work = vec ? HW / 4 : HW;
   int chunks = ceil_div(work, 256 * 4);  // ~4 elements (float4s) per thread
@@ -656,6 +675,21 @@ extern "C" int mcdseg_split_cb(const float* x, void* x_cb, const float* x_bound,
   else
     hipLaunchKernelGGL(split_cb_kernel<SplitBf16x6>, grid, dim3(256), 0, (hipStream_t)stream, x, (__bf16*)x_cb, x_bound, N, C, HW);
   MCD_LAUNCH_CHECK("split_cb");
+  return 0;
+}
+
+extern "C" int mcdseg_split_cb_padded(const float* x, void* x_cb, const float* x_bound, int32_t math, int32_t N, int32_t C, int32_t HW,
+                                      void* stream) {
+  MCD_REQUIRE(x && x_cb, "split_cb_padded: null pointer");
+  MCD_REQUIRE(math == MCDSEG_MATH_BF16X6 || math == MCDSEG_MATH_F16X3, "split_cb_padded: unknown math %d", math);
+  MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || x_bound != nullptr, "split_cb_padded: the f16x3 split needs the bound scalar of the tensor");
+  MCD_REQUIRE(N > 0 && C > 0 && HW > 0 && (int64_t)N * ((C + 7) / 8) <= 65535, "split_cb_padded: bad dims");
+  const dim3 grid(ceil_div(HW, 256), N * ((C + 7) / 8));
+  if (math == MCDSEG_MATH_F16X3)
+    hipLaunchKernelGGL(split_cb_padded_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, x, (_Float16*)x_cb, x_bound, N, C, HW);
+  else
+    hipLaunchKernelGGL(split_cb_padded_kernel<SplitBf16x6>, grid, dim3(256), 0, (hipStream_t)stream, x, (__bf16*)x_cb, x_bound, N, C, HW);
+  MCD_LAUNCH_CHECK("split_cb_padded");
   return 0;
 }
 

@@ -459,6 +459,19 @@ int mcdseg_internal_wgrad_cb_variant(const mcdseg_conv_desc* d, int math, int co
 int mcdseg_internal_wgrad_split_tr64_launch(const mcdseg_conv_desc* d, int math, const void* x_cb, const void* dy_cb, float* slab, int co_p,
                                             int ci_p, int chunks_per_img, int splits, hipStream_t st);
 
+// thin layers (Cin = 16, Cout 16 / 32, 3x3) from both pre-split companions: conv_wgrad_thin_tr.hip (MCDSEG_WGRAD_THIN_TR=0 turns it off)
+int mcdseg_internal_wgrad_thin_tr_ok(const mcdseg_conv_desc* d);
+size_t mcdseg_internal_wgrad_thin_tr_ws(const mcdseg_conv_desc* d);
+int mcdseg_internal_wgrad_thin_tr_launch(const mcdseg_conv_desc* d, const void* x_cb, const float* x_bound, const void* dy_cb,
+                                         const float* dy_bound, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
+static bool thin_tr_applies(const mcdseg_conv_desc* d, int math, const void* x_cb, const void* dy_cb) {
+  static const bool on = [] {
+    const char* e = getenv("MCDSEG_WGRAD_THIN_TR");
+    return e == nullptr || atoi(e) != 0;
+  }();
+  return on && math == MCDSEG_MATH_F16X3 && x_cb && dy_cb && mcdseg_internal_wgrad_thin_tr_ok(d);
+}
+
 // the 64 x 64 plan (32 < min(Cin, Cout) <= 64) from both pre-split companions: f16x3 only (MCDSEG_WGRAD_TR64=0 turns it off)
 static bool tr64_applies(const mcdseg_conv_desc* d, int math, const void* x_cb, const void* dy_cb, int cfg) {
   static const bool on = [] {
@@ -474,10 +487,11 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
 // Which kernel mcdseg_conv_wgrad / mcdseg_conv_split_wgrad launch for this geometry (math = 0 for mcdseg_conv_wgrad):
 // 0..3 the f32 plans (128x128, 64x64, 32x32 tiles, tap-packed thin), 10 split arithmetic from fp32 operands, 11 / 12 / 13 / 14 from
 // both pre-split companions: register-transposing, transposed-read 128x128, transposed-read 256x128, transposed-read 64-channel
-// tap pairs.  For profilers and the benchmark's per-kernel accounting; never needed to call the operators.
+// tap pairs, 15 the thin-layer window kernel.  For profilers and the benchmark's per-kernel accounting; never needed to call the operators.
 extern "C" int32_t mcdseg_conv_wgrad_variant(const mcdseg_conv_desc* d, int32_t math, int32_t presplit) {
   if (d == nullptr) return -22;
   const WgradPlan pl = make_plan(d);
+  if (presplit && thin_tr_applies(d, math, d, d)) return 15;
   if (pl.cfg == 1 && math == MCDSEG_MATH_F16X3 && presplit && tr64_applies(d, math, d, d, 1)) return 14;
   if (pl.cfg != 0 || math == 0) return pl.cfg;
   if (!(presplit && (d->Cin & 7) == 0 && (d->Cout & 7) == 0)) return 10;
@@ -500,12 +514,15 @@ extern "C" int mcdseg_conv_split_wgrad(const mcdseg_conv_desc* d, int32_t math, 
 
 extern "C" size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d) {
   if (d == nullptr) return 0;
-  return (size_t)make_plan(d).slab_floats * sizeof(float);
+  const size_t a = (size_t)make_plan(d).slab_floats * sizeof(float), b = mcdseg_internal_wgrad_thin_tr_ws(d);
+  return a > b ? a : b;
 }
 
 static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                       int math, const void* x_cb, const float* x_bound, const void* dy_cb, const float* dy_bound, void* stream) {
   MCD_REQUIRE(d && dw && workspace, "conv_wgrad: null pointer");
+  if (thin_tr_applies(d, math, x_cb, dy_cb) && x_bound && dy_bound)
+    return mcdseg_internal_wgrad_thin_tr_launch(d, x_cb, x_bound, dy_cb, dy_bound, dw, workspace, workspace_bytes, (hipStream_t)stream);
   const bool tr64 = tr64_applies(d, math, x_cb, dy_cb, make_plan(d).cfg);
   const bool cb_path = tr64 || (math && x_cb && dy_cb && (d->Cin & 7) == 0 && (d->Cout & 7) == 0 && make_plan(d).cfg == 0);
   const bool split_plan = tr64 || (math && make_plan(d).cfg == 0);

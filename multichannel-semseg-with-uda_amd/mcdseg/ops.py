@@ -440,17 +440,42 @@ def split_companion(x, bound=None):
     return cb, bound
 
 
+def split_companion_padded(x, bound=None):
+    """companion of a tensor whose channel count is not a multiple of 8 (the 6-channel network input): ceil(C/8) channel groups,
+    zeros in the missing channels -- read by the stem's weight-gradient kernel only.  Cached on the tensor object (same guard
+    as ``_mcd_cb``): one MCD step back-propagates through the stem several times with the same batch."""
+    rec = getattr(x, "_mcd_cbp", None)
+    if rec is not None and rec[2] == x._version and rec[3] == x.data_ptr() and rec[4] == CONV_MATH:
+        return rec[0], rec[1]
+    x = _req(x, "tensor to split")
+    n, c, h, w = x.shape
+    bound = _bound_or_measure(x, bound)
+    cb = torch.empty(PIECES[CONV_MATH] * n * ((c + 7) // 8) * 8 * h * w, dtype=torch.int16, device=x.device)
+    check(lib().mcdseg_split_cb_padded(_p(x), _p(cb), _p(bound), MATH_ID[CONV_MATH], n, c, h * w, _stream()), "split_cb_padded")
+    x._mcd_cbp = (cb, bound, x._version, x.data_ptr(), CONV_MATH)
+    return cb, bound
+
+
 # mcdseg_conv_wgrad_variant code -> the kernel name rocprofv3 prints
 _WGRAD_NAMES = {10: "conv_wgrad_split_kernel<%s>", 11: "conv_wgrad_split_cb_kernel<%s>", 12: "conv_wgrad_split_tr_kernel<%s, 2, 2, 3>",
-                13: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3>", 14: "conv_wgrad_split_tr64_kernel<%s>"}
+                13: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3>", 14: "conv_wgrad_split_tr64_kernel<%s>",
+                15: "conv_wgrad_thin_tr_kernel<%s>"}
 WGRAD_TR64 = os.environ.get("MCDSEG_WGRAD_TR64", "1") != "0"
+
+
+def _wgrad_thin_tr(desc):
+    """the thin-layer window kernel (csrc/conv_wgrad_thin_tr.hip) takes this geometry when both companions exist"""
+    return _scaled() and desc.Cin <= 16 and lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), MATH_ID[CONV_MATH], 1) == 15
 
 
 def _wgrad_split_plan(desc, have_cb=False):
     """a split-arithmetic plan of csrc/conv_wgrad.hip applies (else the f32 kernels run): the 128x128 plan for
-    min(Cin, Cout) > 64, and -- from both pre-split companions only, f16x3 -- the 64-channel tap-pair plan for 32 < min <= 64"""
-    if CONV_MATH not in MATH_ID or (desc.Cin <= 16 and desc.KH * desc.KW > 1):
+    min(Cin, Cout) > 64, and -- from both pre-split companions only, f16x3 -- the 64-channel tap-pair plan for 32 < min <= 64
+    and the window kernel of the thin 3x3 layers"""
+    if CONV_MATH not in MATH_ID:
         return False
+    if desc.Cin <= 16 and desc.KH * desc.KW > 1:
+        return bool(have_cb and _wgrad_thin_tr(desc))
     lo = min(desc.Cout, desc.Cin)
     if lo > 64:
         return True
@@ -618,13 +643,21 @@ class _ConvBNAct(torch.autograd.Function):
         dy = _req(dy, "grad_output")
         n, c, hw = desc.N, desc.Cout, desc.Ho * desc.Wo
         split_d = _is_split(ctx.wd)
-        want_cb = ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and ctx.x_cb is not None)
-        use_cb = want_cb and split_d and _cb_wanted(c) and n * (c // 8) <= 65535
+        x_cb, x_bound = ctx.x_cb, ctx.x_bound
+        # the stem: no input gradient and an input without a companion, but its weight gradient runs on split operands too
+        # (conv_wgrad_thin_tr.hip) -- from the zero-padded companion of the network input and the companion of dz
+        stem_tr = (ctx.needs_input_grad[1] and not ctx.needs_input_grad[0] and x_cb is None and desc.Cin % 8 != 0 and PRESPLIT
+                   and not ctx.x_virtual and len(_batch_pieces(desc)) == 1 and c % 8 == 0 and n * (c // 8) <= 65535
+                   and _wgrad_thin_tr(desc))
+        if stem_tr:
+            x_cb, x_bound = split_companion_padded(x)
+        want_cb = ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and x_cb is not None)
+        use_cb = stem_tr or (want_cb and split_d and _cb_wanted(c) and n * (c // 8) <= 65535)
         if ctx.compact and not use_cb:  # the plain backward kernels read the fp32 activation for the ReLU mask
             y, y_cb = materialize(y, y_cb, y_bound), None
         y_mask = (y if y_cb is None else None) if ctx.relu else None
         dgamma, dbeta, dz_bound = _channel_reduce(dy, y_mask, z, mean, rstd, ctx.relu, gamma,
-                                                  want_bound=_scaled() and (split_d or _wgrad_split_plan(desc)), train=ctx.training,
+                                                  want_bound=_scaled() and (split_d or stem_tr or _wgrad_split_plan(desc)), train=ctx.training,
                                                   y_cb=y_cb if ctx.relu else None)
         dz = None
         dres = None
@@ -634,8 +667,8 @@ class _ConvBNAct(torch.autograd.Function):
         # the fp32 dz is skipped when every consumer reads the split companion: dgrad (pre-split gather) and wgrad
         # (pre-split plans); a conv bias gradient or any fallback path still needs it
         single = single_piece = len(_batch_pieces(desc)) == 1
-        wgrad_cb = (ctx.x_cb is not None and use_cb and single_piece and _wgrad_split_plan(desc, True) and desc.Cin % 8 == 0
-                    and desc.Cout % 8 == 0)
+        wgrad_cb = stem_tr or (x_cb is not None and use_cb and single_piece and _wgrad_split_plan(desc, True) and desc.Cin % 8 == 0
+                               and desc.Cout % 8 == 0)
         skip_dz = (use_cb and single and not (ctx.has_bias and ctx.needs_input_grad[5])
                    and (not ctx.needs_input_grad[1] or wgrad_cb))
         if not skip_dz:
@@ -656,8 +689,8 @@ class _ConvBNAct(torch.autograd.Function):
                                             int(ctx.training), _stream()), "bn_bwd_apply")
         if ctx.x_virtual and ctx.needs_input_grad[1] and not (wgrad_cb and dz_cb is not None and single):
             x = materialize(x, ctx.x_cb, ctx.x_bound)  # the weight gradient falls back to a kernel that reads fp32
-        dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz_cb, ctx.x_cb, dz_bound,
-                                ctx.x_bound, ctx.w_bound)
+        dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz_cb, x_cb, dz_bound,
+                                x_bound, ctx.w_bound)
         dbias = None
         if ctx.has_bias and ctx.needs_input_grad[5]:
             # a bias in front of train-mode BN has zero gradient up to rounding (BN removes the channel mean);

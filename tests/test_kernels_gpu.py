@@ -784,6 +784,9 @@ WGRAD_CB_CASES = [
     (64, 128, 3, 2, 1, 15, 17, 2),    # ... stride 2, two co tiles
     (48, 64, 3, 1, 2, 13, 19, 2),     # ... ragged channel groups, dilation 2
     (64, 128, 1, 2, 1, 11, 13, 2),    # ... 1x1 stride 2: a single tap (the pair's second half is empty)
+    (16, 16, 3, 1, 1, 16, 64, 1),     # thin layers (layer1): the window kernel, whole 8 x 32 tiles
+    (16, 16, 3, 1, 1, 21, 45, 2),     # ... ragged rows and columns
+    (16, 32, 3, 2, 1, 23, 70, 2),     # ... layer2: stride 2, two row tiles of output channels
 ]
 
 
@@ -805,12 +808,44 @@ def test_conv_wgrad_presplit_operands(case, math, monkeypatch):
     x_cb, x_bound = ops.split_companion(xg)
     gy_cb, gy_bound = ops.split_companion(gyg)
     assert x_cb is not None and gy_cb is not None
+    if cin <= 16 and math == "f16x3":  # the thin-layer window kernel is what the companions select here
+        import ctypes
+        assert ops.lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), ops.MATH_ID[math], 1) == 15
     dw_loop = ops._conv_wgrad(desc, xg, gyg, None, None, x_bound, gy_bound)
     dw_cb = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
     _assert_close(dw_loop, gw_ref, 2e-5, "wgrad (in-loop split)")
     _assert_close(dw_cb, gw_ref, 2e-5, "wgrad (pre-split operands)")
     e_loop, e_cb = _maxerr(dw_loop, gw_ref)[0], _maxerr(dw_cb, gw_ref)[0]
     assert e_cb <= max(2.0 * e_loop, 2e-6 * _maxerr(dw_loop, gw_ref)[1])
+
+
+@pytest.mark.parametrize("cin,h,w,n", [(6, 21, 45, 2), (3, 16, 64, 1), (1, 9, 33, 2)])
+def test_stem_wgrad_from_padded_companion(cin, h, w, n, monkeypatch):
+    """7x7 stem weight gradient in the split arithmetic: the 6- (3-, 1-) channel input's zero-padded companion
+    (mcdseg_split_cb_padded) and the companion of dz through the thin-layer window kernel, against fp64 and the f32 kernel"""
+    dev = _dev()
+    import ctypes
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "CONV_MATH", "f16x3")
+    x, wt, _, s, pad, d = _conv_inputs((cin, 16, 7, 1, 1, h, w, n, False), 31)
+    desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
+    assert ops.lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), ops.MATH_ID["f16x3"], 1) == 15
+    x64, w64 = x.double(), wt.double().requires_grad_()
+    ref = F.conv2d(x64, w64, None, stride=s, padding=pad, dilation=d)
+    gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(32))
+    (gw_ref,) = torch.autograd.grad(ref, [w64], gy.double())
+    xg, gyg = x.to(dev), gy.to(dev)
+    x_cb, x_bound = ops.split_companion_padded(xg)
+    again, _ = ops.split_companion_padded(xg)
+    assert again is x_cb  # cached on the tensor
+    xg2 = xg.clone()
+    xg2.mul_(2.0)
+    assert ops.split_companion_padded(xg2)[0] is not x_cb
+    gy_cb, gy_bound = ops.split_companion(gyg)
+    dw_f32 = ops._conv_wgrad(desc, xg, gyg, None, None, None, None)
+    dw_tr = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
+    _assert_close(dw_f32, gw_ref, 2e-5, "stem wgrad (f32 kernel)")
+    _assert_close(dw_tr, gw_ref, 2e-5, "stem wgrad (window kernel, split operands)")
 
 
 # ------------------------------------------------------------------------------ input pipeline and evaluation kernels
