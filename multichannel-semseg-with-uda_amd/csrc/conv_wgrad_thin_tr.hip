@@ -12,9 +12,9 @@
 // (Cin <= 8: lanes 4q+2, 4q+3 of a transposing read simply point at the other tap's unit).  Every lane always reads
 // in-bounds LDS (the window is sized for the whole tile) and EXEC stays all ones, as the transposing read requires.
 //
-// Each wave owns the output rows w, w+4, .. of the tile and ALL column tiles, accumulates over the workgroup's tiles
-// (grid-stride), and writes its accumulators as one partial; a second kernel sums the partials in a fixed order in fp64,
-// applies scale(x) * scale(dz) and scatters into dw[Cout][Cin][T].
+// Each wave owns the output rows w, w+4, .. of the tile and ALL column tiles and accumulates over the workgroup's tiles; at
+// the end the four waves' accumulators are summed through LDS (fixed order) into one partial per workgroup, and a second
+// kernel sums the partials in a fixed order in fp64, applies scale(x) * scale(dz) and scatters into dw[Cout][Cin][T].
 #include "split.h"
 
 namespace {
@@ -26,7 +26,7 @@ constexpr unsigned TT_OOB = 0x80000000u;
 struct ThinTrParams {
   const void* x_cb;   // [piece 2][N][CIN8][H*W][8 x fp16]
   const void* dy_cb;  // [piece 2][N][Co8][Ho*Wo][8 x fp16]
-  float* slab;        // [partial][MT * NTL * 4][64]
+  float* slab;        // [workgroup][MT * NTL * 4][64]
   int N, H, W, Ho, Wo, KH, KW, stride, pad, dil;
   int x_cb_bytes, dy_cb_bytes;
   int x_piece_bytes, dy_piece_bytes;
@@ -121,7 +121,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_tr_kernel(ThinTrParams p)
   };
 
   const int per_img = p.tiles_x * p.tiles_y;
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  // workgroup b runs on XCD b % 8: every XCD gets one contiguous band of tiles, walked in order by its gridDim.x / 8
+  // workgroups, so the halo rows two neighbouring tiles share are fetched into ONE L2 (gridDim.x is a multiple of 8)
+  const int per_xcd = (p.ntiles + 7) >> 3;
+  const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+  const int band_end = (xcd + 1) * per_xcd < p.ntiles ? (xcd + 1) * per_xcd : p.ntiles;
+  for (int tile = xcd * per_xcd + wg_in_xcd; tile < band_end; tile += wgs_per_xcd) {
     const int n = tile / per_img;
     const int tr_ = tile - n * per_img;
     const int ty = tr_ / p.tiles_x, tx = tr_ - ty * p.tiles_x;
@@ -183,7 +188,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_tr_kernel(ThinTrParams p)
     __syncthreads();  // everyone is done with the stage before the next tile's DMAs overwrite it
   }
 
-  float* out = p.slab + ((size_t)(blockIdx.x * 4 + wave) * (MT * NTL * 4)) * 64 + lane;
+  // ---- one partial per workgroup: waves 2, 3 hand their accumulators to waves 0, 1 through LDS, then wave 1 to wave 0 (a fixed
+  // order; the stage buffers are free by now -- the launcher sizes LDS for two accumulator images)
+  constexpr int NACC = MT * NTL * 4;
+  float* red = reinterpret_cast<float*>(tt_smem);
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    const int senders_from = round == 0 ? 2 : 1;  // round 0: waves 2,3 -> 0,1; round 1: wave 1 -> 0
+    if (wave >= senders_from && wave < 2 * senders_from) {
+      float* dst = red + (size_t)(wave - senders_from) * NACC * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[((i * NTL + j) * 4 + r) * 64] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wave < senders_from) {
+      const float* src = red + (size_t)wave * NACC * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] += src[((i * NTL + j) * 4 + r) * 64];
+    }
+    __syncthreads();
+  }
+  if (wave != 0) return;
+  float* out = p.slab + ((size_t)blockIdx.x * NACC) * 64 + lane;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -242,6 +276,8 @@ ThinTrPlan thin_tr_plan(const mcdseg_conv_desc* d) {
   pl.uxp = round_up(pl.cin8 * pl.WR * pl.WC, 64);
   pl.ud = 2 * pl.mt * pl.tr * TT_TC;
   pl.lds = 2 * (pl.uxp + pl.ud) * 16;
+  const int red_bytes = 2 * pl.mt * pl.ntl * 4 * 64 * 4;  // two accumulator images for the cross-wave sum at the end
+  if (pl.lds < red_bytes) pl.lds = red_bytes;
   const int slots = (pl.uxp + pl.ud) / 64;
   if (pl.lds > 64 * 1024 || slots > 4 * TT_MAXK || pl.WR >= 32768 || pl.WC >= 65536) return pl;
   pl.tiles_x = ceil_div(d->Wo, TT_TC);
@@ -249,7 +285,11 @@ ThinTrPlan thin_tr_plan(const mcdseg_conv_desc* d) {
   const int64_t nt = (int64_t)d->N * pl.tiles_x * pl.tiles_y;
   if (nt >= (1ll << 31)) return pl;
   pl.ntiles = (int)nt;
-  pl.blocks = pl.ntiles < 768 ? pl.ntiles : 768;
+  // persistent workgroups: exactly as many as are resident at once (256 CUs x 2 / 4 / 3 by registers and LDS -- a third
+  // workgroup per CU of the 216-register stem kernel would only start when another has finished); a multiple of 8: one band
+  // of tiles per XCD
+  const int resident = 256 * (pl.cin8 == 1 ? 2 : (pl.mt == 1 ? 4 : 3));
+  pl.blocks = pl.ntiles < resident ? round_up(pl.ntiles, 8) : resident;
   pl.nraw = pl.mt * pl.ntl * 256;
   const int64_t xb = 2ll * d->N * (8 * pl.cin8) * d->H * d->W * 2, yb = 2ll * d->N * d->Cout * d->Ho * d->Wo * 2;
   if (xb + 4096 >= (1ll << 31) || yb + 4096 >= (1ll << 31)) return pl;
@@ -263,7 +303,7 @@ int mcdseg_internal_wgrad_thin_tr_ok(const mcdseg_conv_desc* d) { return thin_tr
 
 size_t mcdseg_internal_wgrad_thin_tr_ws(const mcdseg_conv_desc* d) {
   const ThinTrPlan pl = thin_tr_plan(d);
-  return pl.ok ? (size_t)pl.blocks * 4 * pl.nraw * sizeof(float) : 0;
+  return pl.ok ? (size_t)pl.blocks * pl.nraw * sizeof(float) : 0;
 }
 
 int mcdseg_internal_wgrad_thin_tr_launch(const mcdseg_conv_desc* d, const void* x_cb, const float* x_bound, const void* dy_cb,
@@ -289,7 +329,7 @@ int mcdseg_internal_wgrad_thin_tr_launch(const mcdseg_conv_desc* d, const void* 
     hipLaunchKernelGGL((conv_wgrad_thin_tr_kernel<2, 2, 9, 4>), dim3(pl.blocks), dim3(256), pl.lds, st, p);
   MCD_LAUNCH_CHECK("conv_wgrad_thin_tr");
   hipLaunchKernelGGL(wgrad_thin_tr_reduce_kernel, dim3(ceil_div(pl.nraw, 16)), dim3(256), 0, st, (const float*)ws, dw, pl.nraw,
-                     pl.blocks * 4, pl.ntl, pl.cin8, d->Cout, d->Cin, d->KH * d->KW, x_bound, dy_bound);
+                     pl.blocks, pl.ntl, pl.cin8, d->Cout, d->Cin, d->KH * d->KW, x_bound, dy_bound);
   MCD_LAUNCH_CHECK("conv_wgrad_thin_tr_reduce");
   return 0;
 }
