@@ -95,7 +95,7 @@ def main():
         tot["wgrad"] += tw * cnt
         print("%-18s %8.1f | %9.3f %7.1f | %9.3f %7.1f | %9.3f %7.1f%s" % (name, gf, tf, gf / tf, td, gf / td, tw, gf / tw, extra))
     print("per pass (weighted by layer count): fprop %.1f ms  dgrad %.1f ms  wgrad %.1f ms" % (tot["fprop"], tot["dgrad"], tot["wgrad"]))
-    if not args.only:
+    if not args.only or args.only == "stream":  # --only stream: just these
         # streaming kernels
         c = 41
         feat = torch.randn(n, c, 60, 80, device=dev)
