@@ -81,6 +81,14 @@ int mcdseg_conv_split_packed_bytes(const mcdseg_conv_desc* d, int32_t math, int6
  * buffer mcdseg_conv_split_fprop writes (differs from mcdseg_conv_stat_rows for the direct kernel). */
 int32_t mcdseg_conv_split_direct_ok(const mcdseg_conv_desc* d);
 int64_t mcdseg_conv_split_stat_rows(const mcdseg_conv_desc* d);
+/* The thin full-resolution 3x3 layers (16 contraction channels, 16 / 32 outputs; models/drn.py:195-205 "_make_conv_layers") run,
+ * with MCDSEG_MATH_F16X3 and a pre-split operand, on an LDS-window kernel whose partial-statistics rows differ (one per tile of
+ * 8 (4) x 32 pixels and wave): mcdseg_conv_split_stat_rows_for gives the row count mcdseg_conv_split_fprop will write for this
+ * (math, x_cb != NULL) combination; mcdseg_conv_split_window_ok tells whether that kernel takes the forward (dgrad = 0) or the
+ * data gradient (dgrad = 1, stride 1 only).  It has no bias / affine epilogue: calling mcdseg_conv_split_fprop with a companion AND a
+ * bias for such a geometry is rejected. */
+int64_t mcdseg_conv_split_stat_rows_for(const mcdseg_conv_desc* d, int32_t math, int32_t presplit);
+int32_t mcdseg_conv_split_window_ok(const mcdseg_conv_desc* d, int32_t math, int32_t presplit, int32_t dgrad);
 /* bound[0] = max |x[i]| (exact, order-independent; non-finite data gives a non-finite bound) */
 int mcdseg_absmax(const float* x, int64_t n, float* bound, void* stream);
 /* w [Cout,Cin,KH,KW] -> fprop and/or dgrad image; F16X3 first measures w_bound = max |w| (device float, written here) */

@@ -825,6 +825,12 @@ int mcdseg_internal_stem_pack(const mcdseg_conv_desc* d, const float* w, void* o
 int mcdseg_internal_stem_fprop(const mcdseg_conv_desc* d, const float* x, const void* wp, const float* bias, float* y, float* stats,
                                const float* ep_scale, const float* ep_shift, const float* ep_res, int ep_relu, hipStream_t st);
 
+// LDS-window kernels of the thin 3x3 layers (conv_thin_window.hip): forward and stride-1 dgrad, f16x3 with a pre-split operand
+int mcdseg_internal_thin_window_ok(const mcdseg_conv_desc* d, int dgrad);
+int64_t mcdseg_internal_thin_window_stat_rows(const mcdseg_conv_desc* d);
+int mcdseg_internal_thin_window_launch(const mcdseg_conv_desc* d, int dgrad, const void* src_cb, const float* src_bound, const void* wp,
+                                       int64_t wp_bytes, const float* w_bound, float* dst, float* stats, hipStream_t st);
+
 extern "C" int32_t mcdseg_conv_split_direct_ok(const mcdseg_conv_desc* d) { return d != nullptr && mcdseg_internal_stem_ok(d) ? 1 : 0; }
 
 extern "C" int64_t mcdseg_conv_split_stat_rows(const mcdseg_conv_desc* d) {
@@ -834,6 +840,18 @@ extern "C" int64_t mcdseg_conv_split_stat_rows(const mcdseg_conv_desc* d) {
   const int64_t bn = bm == 128 ? 128 : 256;  // pixel tile and column waves of launch<>
   const int64_t waves_n = bm == 128 ? 2 : 4;
   return ceil_div64((int64_t)d->N * d->Ho * d->Wo, bn) * waves_n;
+}
+
+extern "C" int64_t mcdseg_conv_split_stat_rows_for(const mcdseg_conv_desc* d, int32_t math, int32_t presplit) {
+  if (d == nullptr) return -22;
+  if (math == MCDSEG_MATH_F16X3 && presplit && !mcdseg_internal_stem_ok(d) && mcdseg_internal_thin_window_ok(d, 0))
+    return mcdseg_internal_thin_window_stat_rows(d);
+  return mcdseg_conv_split_stat_rows(d);
+}
+
+// 1 when mcdseg_conv_split_fprop / _dgrad run this geometry on the LDS-window kernel (for profilers and the benchmark's accounting)
+extern "C" int32_t mcdseg_conv_split_window_ok(const mcdseg_conv_desc* d, int32_t math, int32_t presplit, int32_t dgrad) {
+  return d != nullptr && math == MCDSEG_MATH_F16X3 && presplit && !mcdseg_internal_stem_ok(d) && mcdseg_internal_thin_window_ok(d, dgrad) ? 1 : 0;
 }
 
 extern "C" int mcdseg_absmax(const float* x, int64_t n, float* bound, void* stream) {
@@ -929,6 +947,12 @@ static int split_fprop_impl(const mcdseg_conv_desc* d, int math, const float* x,
     return mcdseg_internal_stem_fprop(d, x, wp, bias, y, stats, ep_scale, ep_shift, ep_res, ep_relu, (hipStream_t)stream);
   }
   MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || (x_bound && w_bound), "conv_split_fprop: f16x3 needs the operand and weight bound scalars");
+  if (math == MCDSEG_MATH_F16X3 && x_cb != nullptr && mcdseg_internal_thin_window_ok(d, 0)) {
+    // the window kernel has no bias / affine epilogue: those callers (conv+bias heads, folded-BN inference) have no companion
+    MCD_REQUIRE(bias == nullptr && ep_scale == nullptr, "conv_split_fprop: the thin-layer window kernel takes no bias / affine epilogue");
+    return mcdseg_internal_thin_window_launch(d, 0, x_cb, x_bound, wp, split_image_bytes(math, d->Cout, d->Cin, d->KH * d->KW), w_bound, y,
+                                              stats, (hipStream_t)stream);
+  }
   ConvSplitParams p;
   if (int rc = split_cb_bytes(math, d->N, d->Cin, d->H * d->W, x_cb, &p.cb_bytes)) return rc;
   p.src_cb = x_cb;
@@ -969,6 +993,9 @@ extern "C" int mcdseg_conv_split_dgrad(const mcdseg_conv_desc* d, int32_t math, 
   if (int rc = split_check(d, math, "conv_split_dgrad")) return rc;
   MCD_REQUIRE((dy || dy_cb) && wp_dgrad && dx, "conv_split_dgrad: null pointer");
   MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || (dy_bound && w_bound), "conv_split_dgrad: f16x3 needs the operand and weight bound scalars");
+  if (math == MCDSEG_MATH_F16X3 && dy_cb != nullptr && mcdseg_internal_thin_window_ok(d, 1))
+    return mcdseg_internal_thin_window_launch(d, 1, dy_cb, dy_bound, wp_dgrad, split_image_bytes(math, d->Cin, d->Cout, d->KH * d->KW),
+                                              w_bound, dx, nullptr, (hipStream_t)stream);
   ConvSplitParams p;
   if (int rc = split_cb_bytes(math, d->N, d->Cout, d->Ho * d->Wo, dy_cb, &p.cb_bytes)) return rc;
   p.src_cb = dy_cb;

@@ -31,6 +31,8 @@ _SIGNATURES = {
     "mcdseg_conv_pack_weights": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcdseg_conv_stat_rows": (c_i64, [_P(ConvDesc)]),
     "mcdseg_conv_split_stat_rows": (c_i64, [_P(ConvDesc)]),
+    "mcdseg_conv_split_stat_rows_for": (c_i64, [_P(ConvDesc), c_i32, c_i32]),
+    "mcdseg_conv_split_window_ok": (c_i32, [_P(ConvDesc), c_i32, c_i32, c_i32]),
     "mcdseg_conv_split_direct_ok": (c_i32, [_P(ConvDesc)]),
     "mcdseg_conv_fprop": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcdseg_conv_fprop_affine": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p]),

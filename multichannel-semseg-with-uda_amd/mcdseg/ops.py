@@ -373,9 +373,9 @@ def _conv_fprop(desc, x, wf, bias, want_stats, mpf, x_cb=None, x_bound=None, w_b
     split = _is_split(wf)
     part, rows, row_off = None, 0, [0]
     if want_stats:
-        stat_rows = L.mcdseg_conv_split_stat_rows if split else L.mcdseg_conv_stat_rows
         for d in descs:
-            row_off.append(row_off[-1] + stat_rows(ctypes.byref(d)))
+            row_off.append(row_off[-1] + (L.mcdseg_conv_split_stat_rows_for(ctypes.byref(d), MATH_ID[CONV_MATH], int(x_cb is not None))
+                                          if split else L.mcdseg_conv_stat_rows(ctypes.byref(d))))
         rows = row_off[-1]
         part = torch.empty(rows * 3 * mpf, dtype=torch.float32, device=x.device)
     direct = split and bool(L.mcdseg_conv_split_direct_ok(ctypes.byref(desc)))
@@ -383,7 +383,8 @@ def _conv_fprop(desc, x, wf, bias, want_stats, mpf, x_cb=None, x_bound=None, w_b
         x_bound = _bound_or_measure(x, x_bound)
     for i, ((a, b), d) in enumerate(zip(pieces, descs)):
         pp = None if part is None else ctypes.c_void_p(part.data_ptr() + 4 * row_off[i] * 3 * mpf)
-        with _timed(gemm_kernel_name(desc.Cout, desc.Cin, False, split, x_cb is not None, direct, d.N * d.Ho * d.Wo), conv_work(d)):
+        with _timed((_window_name(d, x_cb is not None, False) if split else None)
+                    or gemm_kernel_name(desc.Cout, desc.Cin, False, split, x_cb is not None, direct, d.N * d.Ho * d.Wo), conv_work(d)):
             if split:
                 check(L.mcdseg_conv_split_fprop(ctypes.byref(d), MATH_ID[CONV_MATH], _p(x[a:b]), _p(x_cb), _p(x_bound), _p(wf), _p(w_bound),
                                                 _p(bias), _p(y[a:b]), pp, _stream()), "conv_split_fprop")
@@ -394,6 +395,14 @@ def _conv_fprop(desc, x, wf, bias, want_stats, mpf, x_cb=None, x_bound=None, w_b
 
 def _sl(t, a, b):
     return None if t is None else t[a:b]
+
+
+def _window_name(d, presplit, dgrad):
+    """rocprofv3's name of the LDS-window kernel when it takes this thin 3x3 geometry (csrc/conv_thin_window.hip), else None"""
+    if not lib().mcdseg_conv_split_window_ok(ctypes.byref(d), MATH_ID.get(CONV_MATH, 0), int(presplit), int(dgrad)):
+        return None
+    m = d.Cin if dgrad else d.Cout
+    return "conv_thin_window_kernel<%d, %d, %s>" % (m // 16, 8 if d.stride == 1 else 4, "true" if dgrad else "false")
 
 
 def _conv_dgrad(desc, dy, wd, dy_cb=None, dy_bound=None, w_bound=None):
@@ -408,7 +417,8 @@ def _conv_dgrad(desc, dy, wd, dy_cb=None, dy_bound=None, w_bound=None):
         dy_bound = _bound_or_measure(dy, dy_bound)
     for a, b in pieces:
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
-        with _timed(gemm_kernel_name(desc.Cin, desc.Cout, True, split, dy_cb is not None, False, d.N * d.H * d.W), conv_work(d)):
+        with _timed((_window_name(d, dy_cb is not None, True) if split else None)
+                    or gemm_kernel_name(desc.Cin, desc.Cout, True, split, dy_cb is not None, False, d.N * d.H * d.W), conv_work(d)):
             if split:
                 check(L.mcdseg_conv_split_dgrad(ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(dy, a, b)), _p(dy_cb), _p(dy_bound), _p(wd),
                                                 _p(w_bound), _p(dx[a:b]), _stream()), "conv_split_dgrad")

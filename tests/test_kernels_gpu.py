@@ -742,6 +742,48 @@ def test_conv_large_tile_kernels(case):
     _assert_close(rstd, (r.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt(), 1e-5, "fused BN rstd")
 
 
+@pytest.mark.parametrize("cout,stride,h,w,n", [(16, 1, 16, 64, 1), (16, 1, 21, 45, 2), (32, 2, 23, 70, 2), (32, 1, 9, 33, 1),
+                                               (16, 2, 12, 40, 2)])
+def test_thin_layer_window_kernels(cout, stride, h, w, n, monkeypatch):
+    """The LDS-window kernels of the thin 3x3 layers (16 contraction channels; conv_thin_window.hip): forward with fused
+    BatchNorm partial statistics, and the stride-1 data gradient, from pre-split companions -- against fp64, against the
+    implicit-GEMM kernel of the same arithmetic, and the statistics against the output's moments; ragged tiles included."""
+    dev = _dev()
+    import ctypes
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "CONV_MATH", "f16x3")
+    x, wt, _, s, pad, d = _conv_inputs((16, cout, 3, stride, 1, h, w, n, False), 41)
+    desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
+    L = ops.lib()
+    assert L.mcdseg_conv_split_window_ok(ctypes.byref(desc), ops.MATH_ID["f16x3"], 1, 0) == (1 if stride == 1 else 0)
+    x64, w64 = x.double().requires_grad_(), wt.double().requires_grad_()
+    ref = F.conv2d(x64, w64, None, stride=s, padding=pad, dilation=d)
+    gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(42))
+    (gx_ref,) = torch.autograd.grad(ref, [x64], gy.double())
+    xg, gyg = x.to(dev), gy.to(dev)
+    pk = ops.PackedWeights()
+    wf, wd, mpf = pk.get(wt.to(dev), desc)
+    x_cb, x_bound = ops.split_companion(xg)
+    y_w, part, rows = ops._conv_fprop(desc, xg, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)
+    y_g, _, _ = ops._conv_fprop(desc, xg, wf, None, True, mpf, None, x_bound, pk.w_bound)
+    _assert_close(y_w, ref, 2e-5, "window forward")
+    assert float((y_w - y_g).abs().max()) <= 4e-6 * float(ref.detach().abs().max()), "window kernel vs implicit GEMM"
+    mean = torch.empty(cout, device=dev)
+    rstd = torch.empty(cout, device=dev)
+    ws = torch.empty(L.mcdseg_bn_stats_workspace_bytes(rows, cout) // 8 + 1, dtype=torch.float64, device=dev)
+    ops.check(L.mcdseg_bn_stats_finalize(ops._p(part), rows, cout, mpf, ops._p(mean), ops._p(rstd), None, None, None, 0.1, 1e-5,
+                                         None, None, None, None, ops._p(ws), ctypes.c_size_t(ws.numel() * 8), ops._stream()),
+              "bn_stats_finalize")
+    r = ref.detach()
+    assert float((mean.double().cpu() - r.mean((0, 2, 3))).abs().max()) <= 1e-5 * float(r.std())
+    _assert_close(rstd, (r.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt(), 1e-5, "fused BN rstd (window kernel)")
+    gy_cb, gy_bound = ops.split_companion(gyg)
+    took = L.mcdseg_conv_split_window_ok(ctypes.byref(desc), ops.MATH_ID["f16x3"], 1, 1)
+    assert took == (1 if (stride == 1 and cout == 16) else 0)
+    dx_w = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound)
+    _assert_close(dx_w, gx_ref, 2e-5, "dgrad from the companion (window kernel where it applies)")
+
+
 def test_conv_nonfinite_operands():
     """Contract of the split-precision convolutions for non-finite data: an output that a NaN / inf operand reaches is
     non-finite (an fp32 FMA chain would give +-inf where the split gives NaN: inf - inf in the remainder), every other output
