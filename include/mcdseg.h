@@ -178,6 +178,16 @@ int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const void* y_cb, co
                            const float* gamma, const float* dgamma, const float* dbeta, float* dz, float* dres,
                            void* dz_cb, const float* dz_bound, int32_t math, int32_t N, int32_t C, int32_t HW, int32_t relu,
                            int32_t train, void* stream);
+/* The backward pair for a ReLU group WITHOUT a residual branch (models/drn.py:43-47 bn1; the conv-BN-ReLU chains of
+ * _make_conv_layers): the mask y > 0 is recomputed from z -- y > 0 <=> fma(z, gamma rstd, beta - mean gamma rstd) > 0, which is the
+ * forward kernels' own expression, bit for bit -- so y is not read at all: 8 instead of 12 bytes per element in the reduce, 12
+ * instead of 16 in the apply.  Same results as mcdseg_bn_bwd_reduce / mcdseg_bn_bwd_apply_cb with relu = 1 and the group's fp32 y. */
+int mcdseg_bn_bwd_reduce_zmask(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, float* dgamma, float* dbeta, float* dz_bound, int32_t train, int32_t N, int32_t C,
+                               int32_t HW, void* workspace, size_t workspace_bytes, void* stream);
+int mcdseg_bn_bwd_apply_cb_zmask(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, const float* dgamma, const float* dbeta, float* dz, void* dz_cb,
+                                 const float* dz_bound, int32_t math, int32_t N, int32_t C, int32_t HW, int32_t train, void* stream);
 /* Backward.  dy is the gradient w.r.t. y; y (the saved forward output) -- or, when y == NULL, its companion y_cb of
  * arithmetic `math` -- supplies the ReLU mask when relu != 0.  reduce: dgamma[c] = sum dy_m*xhat, dbeta[c] = sum dy_m.
  * With z == NULL only dbeta is produced (used for the conv bias gradient, models/dilated_fcn.py:227).

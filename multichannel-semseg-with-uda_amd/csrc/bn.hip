@@ -193,12 +193,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ part, int N,
                                                             int C, int HW, int relu, int cpp, int chunk,
-                                                            float* __restrict__ dz_bound) {
+                                                            float* __restrict__ dz_bound, const float* __restrict__ mgamma,
+                                                            const float* __restrict__ mbeta) {
   const int c = blockIdx.x;
   const int S = gridDim.y;
   if (dz_bound != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *dz_bound = 0.f;  // finalize: atomic max
   const float mu = z ? mean[c] : 0.f;
   const float rs = z ? rstd[c] : 0.f;
+  // ReLU mask without reading y (mbeta != NULL; a group WITHOUT residual): y > 0 <=> fma(z, a, b) > 0 with the forward kernels'
+  // own a = gamma rstd, b = beta - mean a (bn_apply_kernel / bn_apply_cb_kernel: the same expressions, bit for bit)
+  const bool zm = relu && mbeta != nullptr;
+  const float ma = zm ? mgamma[c] * rs : 0.f;
+  const float mb = zm ? mbeta[c] - mu * ma : 0.f;
   float s_dy = 0.f, s_dyx = 0.f, m_g = 0.f;
   const int items = N * cpp;
   for (int item = blockIdx.y; item < items; item += S) {
@@ -214,7 +220,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       const float4* z4 = reinterpret_cast<const float4*>(z ? z + base : nullptr);
       for (int i = (e0 >> 2) + threadIdx.x; i < (e1 >> 2); i += 256) {
         float4 g = dy4[i];
-        if (relu) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (z) v = z4[i];
+        if (zm) {
+          g.x = fmaf(v.x, ma, mb) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, ma, mb) > 0.f ? g.y : 0.f;
+          g.z = fmaf(v.z, ma, mb) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, ma, mb) > 0.f ? g.w : 0.f;
+        } else if (relu) {
           const float4 o = y4[i];
           g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
           g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
@@ -222,14 +233,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         s_dy += (g.x + g.y) + (g.z + g.w);
         m_g = fmaxf(m_g, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
         if (z) {
-          const float4 v = z4[i];
           s_dyx += (g.x * ((v.x - mu) * rs) + g.y * ((v.y - mu) * rs)) + (g.z * ((v.z - mu) * rs) + g.w * ((v.w - mu) * rs));
         }
       }
     } else {
       for (int i = e0 + threadIdx.x; i < e1; i += 256) {
         float g = dy[base + i];
-        if (relu && !(y[base + i] > 0.f)) g = 0.f;
+        if (zm) {
+          if (!(fmaf(z[base + i], ma, mb) > 0.f)) g = 0.f;
+        } else if (relu && !(y[base + i] > 0.f)) {
+          g = 0.f;
+        }
         s_dy += g;
         m_g = fmaxf(m_g, fabsf(g));
         if (z) s_dyx += g * ((z[base + i] - mu) * rs);
@@ -433,20 +447,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_kernel(const float* __res
                                                               float* __restrict__ dz, float* __restrict__ dres,
                                                               typename P::elem* __restrict__ cb, const float* __restrict__ dz_bound,
                                                               const typename P::elem* __restrict__ y_cb, int N, int C, int HW, int relu,
-                                                              int train) {
+                                                              int train, const float* __restrict__ mbeta) {
   const int C8 = C >> 3;
   const int ng = blockIdx.y;
   const int g = ng % C8;
   const int n = ng / C8;
   const float inv_scale = 1.f / operand_scale<P>(dz_bound);
   const float inv_n = 1.f / ((float)N * (float)HW);
-  float cmu[8], crs[8], ca[8], k1[8], k2[8];
+  const bool zm = relu && mbeta != nullptr;  // mask from z (see bn_bwd_reduce_kernel): y is not read
+  float cmu[8], crs[8], ca[8], k1[8], k2[8], cmb[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int c = 8 * g + e;
     cmu[e] = mean[c];
     crs[e] = rstd[c];
     ca[e] = gamma[c] * crs[e];
+    cmb[e] = zm ? mbeta[c] - cmu[e] * ca[e] : 0.f;
     k1[e] = train ? dbeta[c] * inv_n : 0.f;
     k2[e] = train ? dgamma[c] * inv_n : 0.f;
   }
@@ -455,14 +471,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_kernel(const float* __res
     const int pix = (blockIdx.x * BN_PIX_ITERS + it) * 256 + threadIdx.x;
     if (pix >= HW) continue;
     const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
-    const unsigned ymask = (relu && y == nullptr) ? mask_load<P>(y_cb, (size_t)ng * HW + pix) : 0xFFu;
+    const unsigned ymask = (relu && !zm && y == nullptr) ? mask_load<P>(y_cb, (size_t)ng * HW + pix) : 0xFFu;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float gv = dy[base + (size_t)e * HW];
-      if (relu && (y != nullptr ? !(y[base + (size_t)e * HW] > 0.f) : !((ymask >> e) & 1u))) gv = 0.f;
+      const float zv = z[base + (size_t)e * HW];
+      if (zm) {
+        if (!(fmaf(zv, ca[e], cmb[e]) > 0.f)) gv = 0.f;
+      } else if (relu && (y != nullptr ? !(y[base + (size_t)e * HW] > 0.f) : !((ymask >> e) & 1u))) {
+        gv = 0.f;
+      }
       if (dres) dres[base + (size_t)e * HW] = gv;
-      const float t = ca[e] * (gv - k1[e] - ((z[base + (size_t)e * HW] - cmu[e]) * crs[e]) * k2[e]);
+      const float t = ca[e] * (gv - k1[e] - ((zv - cmu[e]) * crs[e]) * k2[e]);
       v[e] = t;
       if (dz) dz[base + (size_t)e * HW] = t;  // optional: the split dgrad and wgrad read only the companion
     }
@@ -735,11 +756,32 @@ extern "C" int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const voi
   const dim3 grid(ceil_div(HW, 256 * BN_PIX_ITERS), N * (C / 8));
   if (math == MCDSEG_MATH_F16X3)
     hipLaunchKernelGGL(bn_bwd_apply_cb_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, z, mean, rstd, gamma, dgamma,
-                       dbeta, dz, dres, (_Float16*)dz_cb, dz_bound, (const _Float16*)y_cb, N, C, HW, relu, train);
+                       dbeta, dz, dres, (_Float16*)dz_cb, dz_bound, (const _Float16*)y_cb, N, C, HW, relu, train, (const float*)nullptr);
   else
     hipLaunchKernelGGL(bn_bwd_apply_cb_kernel<SplitBf16x6>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, z, mean, rstd, gamma, dgamma,
-                       dbeta, dz, dres, (__bf16*)dz_cb, dz_bound, (const __bf16*)y_cb, N, C, HW, relu, train);
+                       dbeta, dz, dres, (__bf16*)dz_cb, dz_bound, (const __bf16*)y_cb, N, C, HW, relu, train, (const float*)nullptr);
   MCD_LAUNCH_CHECK("bn_bwd_apply_cb");
+  return 0;
+}
+
+// the same for a ReLU group WITHOUT residual, the mask recomputed from z (y > 0 <=> fma(z, gamma rstd, beta - mean gamma rstd) > 0, the
+// forward kernels' own expression): y is not read -- 12 instead of 16 bytes per element
+extern "C" int mcdseg_bn_bwd_apply_cb_zmask(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                                            const float* beta, const float* dgamma, const float* dbeta, float* dz, void* dz_cb,
+                                            const float* dz_bound, int32_t math, int32_t N, int32_t C, int32_t HW, int32_t train,
+                                            void* stream) {
+  MCD_REQUIRE(dy && z && mean && rstd && gamma && beta && dz_cb, "bn_bwd_apply_cb_zmask: null pointer");
+  MCD_REQUIRE(!train || (dgamma && dbeta), "bn_bwd_apply_cb_zmask: train mode needs dgamma/dbeta");
+  if (int rc = cb_check("bn_bwd_apply_cb_zmask", math, dz_bound, N, C, HW)) return rc;
+  const dim3 grid(ceil_div(HW, 256 * BN_PIX_ITERS), N * (C / 8));
+  if (math == MCDSEG_MATH_F16X3)
+    hipLaunchKernelGGL(bn_bwd_apply_cb_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, dy, (const float*)nullptr, z, mean, rstd,
+                       gamma, dgamma, dbeta, dz, (float*)nullptr, (_Float16*)dz_cb, dz_bound, (const _Float16*)nullptr, N, C, HW, 1, train,
+                       beta);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_cb_kernel<SplitBf16x6>, grid, dim3(256), 0, (hipStream_t)stream, dy, (const float*)nullptr, z, mean, rstd,
+                       gamma, dgamma, dbeta, dz, (float*)nullptr, (__bf16*)dz_cb, dz_bound, (const __bf16*)nullptr, N, C, HW, 1, train, beta);
+  MCD_LAUNCH_CHECK("bn_bwd_apply_cb_zmask");
   return 0;
 }
 
@@ -786,14 +828,38 @@ extern "C" int mcdseg_bn_bwd_reduce(const float* dy, const float* y, const void*
     dim3 grid(C, pl.S);
     if (vec)
       hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, (float*)workspace, N, C, HW, relu,
-                         pl.cpp, pl.chunk, dz_bound);
+                         pl.cpp, pl.chunk, dz_bound, (const float*)nullptr, (const float*)nullptr);
     else
       hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, (float*)workspace, N, C, HW,
-                         relu, pl.cpp, pl.chunk, dz_bound);
+                         relu, pl.cpp, pl.chunk, dz_bound, (const float*)nullptr, (const float*)nullptr);
   }
   MCD_LAUNCH_CHECK("bn_bwd_reduce");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, S, C,
                      z ? dgamma : nullptr, dbeta, gamma, rstd, (float)N * (float)HW, train, dz_bound);
+  MCD_LAUNCH_CHECK("bn_bwd_finalize");
+  return 0;
+}
+
+extern "C" int mcdseg_bn_bwd_reduce_zmask(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                                          const float* beta, float* dgamma, float* dbeta, float* dz_bound, int32_t train, int32_t N,
+                                          int32_t C, int32_t HW, void* workspace, size_t workspace_bytes, void* stream) {
+  MCD_REQUIRE(dy && z && mean && rstd && gamma && beta && dgamma && dbeta && workspace, "bn_bwd_reduce_zmask: null pointer");
+  MCD_REQUIRE(N > 0 && C > 0 && HW > 0, "bn_bwd_reduce_zmask: bad dims");
+  MCD_REQUIRE(workspace_bytes >= mcdseg_bn_bwd_workspace_bytes(N, C, HW), "bn_bwd_reduce_zmask: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const BwdPlan pl = bwd_plan(N, C, HW);
+  MCD_REQUIRE(pl.S <= 65535, "bn_bwd_reduce_zmask: too many splits");
+  const bool vec = (HW % 4 == 0) && aligned16(dy) && aligned16(z);
+  dim3 grid(C, pl.S);
+  if (vec)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, st, dy, (const float*)nullptr, z, mean, rstd, (float*)workspace, N, C,
+                       HW, 1, pl.cpp, pl.chunk, dz_bound, gamma, beta);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, st, dy, (const float*)nullptr, z, mean, rstd, (float*)workspace, N, C,
+                       HW, 1, pl.cpp, pl.chunk, dz_bound, gamma, beta);
+  MCD_LAUNCH_CHECK("bn_bwd_reduce_zmask");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, pl.S, C, dgamma, dbeta, gamma,
+                     rstd, (float)N * (float)HW, train, dz_bound);
   MCD_LAUNCH_CHECK("bn_bwd_finalize");
   return 0;
 }

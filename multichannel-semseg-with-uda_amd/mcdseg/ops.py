@@ -225,6 +225,8 @@ _PACK_REGISTRY = weakref.WeakSet()   # every PackedWeights alive
 _PACK_TABLES = {}                    # (device, math) -> cached device tables of the last group pack
 GROUP_PACK = os.environ.get("MCDSEG_GROUP_PACK", "1") != "0"
 FUSED_UP_LOSS = os.environ.get("MCDSEG_FUSED_UP_LOSS", "1") != "0"  # MCDSolver: up-sampler folded into the loss kernel
+# BatchNorm backward of a ReLU group without residual: the mask y > 0 recomputed from z (bit-identical), y never read
+BN_ZMASK = os.environ.get("MCDSEG_BN_ZMASK", "1") != "0"
 
 
 class PackedWeights:
@@ -549,9 +551,10 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_
     return dx, dw
 
 
-def _channel_reduce(dy, y, z, mean, rstd, relu, gamma=None, want_bound=False, train=True, y_cb=None):
+def _channel_reduce(dy, y, z, mean, rstd, relu, gamma=None, want_bound=False, train=True, y_cb=None, zmask_beta=None):
     """(dgamma, dbeta) of a BN (z given) or just the per-channel sum of dy (z None); with ``want_bound`` also the device
-    scalar bounding |dz| of the tensor bn_bwd_apply will write from these sums (include/mcdseg.h)"""
+    scalar bounding |dz| of the tensor bn_bwd_apply will write from these sums (include/mcdseg.h).  ``zmask_beta``: the group
+    has a ReLU and no residual, so the mask is recomputed from z and ``y`` is not read."""
     L = lib()
     n, c = dy.shape[0], dy.shape[1]
     hw = dy.shape[2] * dy.shape[3]
@@ -559,6 +562,12 @@ def _channel_reduce(dy, y, z, mean, rstd, relu, gamma=None, want_bound=False, tr
     dgamma = torch.empty(c, dtype=torch.float32, device=dy.device) if z is not None else None
     dbeta = torch.empty(c, dtype=torch.float32, device=dy.device)
     bound = torch.empty(1, dtype=torch.float32, device=dy.device) if want_bound else None
+    if zmask_beta is not None:
+        with _timed("bn_bwd_reduce", (0, 4 * n * c * hw * 2)):
+            check(L.mcdseg_bn_bwd_reduce_zmask(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(zmask_beta), _p(dgamma), _p(dbeta), _p(bound),
+                                               int(train), n, c, hw, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
+                  "bn_bwd_reduce_zmask")
+        return dgamma, dbeta, bound
     with _timed("bn_bwd_reduce", (0, 4 * n * c * hw * (1 + (y is not None) + (z is not None)))):
         check(L.mcdseg_bn_bwd_reduce(_p(dy), _p(y), _p(y_cb) if y is None else None, MATH_ID.get(CONV_MATH, 0), _p(z), _p(mean), _p(rstd),
                                      _p(dgamma), _p(dbeta), _p(gamma) if want_bound else None, _p(bound), int(train), n, c, hw,
@@ -636,7 +645,7 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.has_bias = conv_bias is not None
         ctx.x_cb, ctx.x_bound = x_cb, x_bound  # wgrad reads the input's split companion too (an input of this node: safe to hold)
         ctx.x_virtual, ctx.compact = x_virtual, compact
-        ctx.save_for_backward(x, z, y, mean, rstd, gamma, y_cb if compact else None, y_bound if compact else None)
+        ctx.save_for_backward(x, z, y, mean, rstd, gamma, y_cb if compact else None, y_bound if compact else None, beta)
         ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the non-differentiable companions
         for t in (y_cb, y_bound):
             if t is not None:
@@ -648,7 +657,7 @@ class _ConvBNAct(torch.autograd.Function):
         L = lib()
         if dy is None:
             return (None,) * 19
-        x, z, y, mean, rstd, gamma, y_cb, y_bound = ctx.saved_tensors
+        x, z, y, mean, rstd, gamma, y_cb, y_bound, beta = ctx.saved_tensors
         desc = ctx.desc
         dy = _req(dy, "grad_output")
         n, c, hw = desc.N, desc.Cout, desc.Ho * desc.Wo
@@ -666,9 +675,11 @@ class _ConvBNAct(torch.autograd.Function):
         if ctx.compact and not use_cb:  # the plain backward kernels read the fp32 activation for the ReLU mask
             y, y_cb = materialize(y, y_cb, y_bound), None
         y_mask = (y if y_cb is None else None) if ctx.relu else None
+        # a ReLU group without residual: y > 0 <=> fma(z, gamma rstd, beta - mean gamma rstd) > 0 -- neither pass below reads y
+        zmask = BN_ZMASK and ctx.relu and not ctx.has_res and y_cb is None
         dgamma, dbeta, dz_bound = _channel_reduce(dy, y_mask, z, mean, rstd, ctx.relu, gamma,
                                                   want_bound=_scaled() and (split_d or stem_tr or _wgrad_split_plan(desc)), train=ctx.training,
-                                                  y_cb=y_cb if ctx.relu else None)
+                                                  y_cb=y_cb if ctx.relu else None, zmask_beta=beta if zmask else None)
         dz = None
         dres = None
         if ctx.has_res and ctx.needs_input_grad[4]:
@@ -684,7 +695,13 @@ class _ConvBNAct(torch.autograd.Function):
         if not skip_dz:
             dz = torch.empty_like(z)
         rd = 4 * n * c * hw * (2 + int(ctx.relu)) + 4 * n * c * hw * ((dz is not None) + (dres is not None and ctx.relu))
-        if use_cb:
+        if use_cb and zmask:
+            dz_cb = _cb_alloc(n, c, hw, dy.device)
+            with _timed("bn_bwd_apply_cb", (0, rd - 4 * n * c * hw + 2 * PIECES[CONV_MATH] * n * c * hw)):
+                check(L.mcdseg_bn_bwd_apply_cb_zmask(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dgamma), _p(dbeta), _p(dz),
+                                                     _p(dz_cb), _p(dz_bound), MATH_ID[CONV_MATH], n, c, hw, int(ctx.training), _stream()),
+                      "bn_bwd_apply_cb_zmask")
+        elif use_cb:
             dz_cb = _cb_alloc(n, c, hw, dy.device)
             with _timed("bn_bwd_apply_cb", (0, rd + 2 * PIECES[CONV_MATH] * n * c * hw)):
                 check(L.mcdseg_bn_bwd_apply_cb(_p(dy), _p(y_mask), _p(y_cb) if (ctx.relu and y_mask is None) else None, _p(z), _p(mean),

@@ -813,6 +813,38 @@ def test_conv_nonfinite_operands():
         assert float((y.cpu()[ok] - clean.cpu()[ok]).abs().max()) <= 2e-5 * float(clean.abs().max())
 
 
+@pytest.mark.parametrize("cin,cout,hw,n", [(64, 128, (13, 19), 2), (16, 16, (21, 45), 2), (32, 41, (9, 11), 3), (6, 16, (20, 28), 2)])
+def test_bn_backward_mask_from_z_is_bitwise(cin, cout, hw, n, monkeypatch):
+    """BatchNorm backward of a ReLU group without residual recomputes the mask from z (y > 0 <=> fma(z, a, b) > 0 with the
+    forward kernels' own a, b) instead of reading y: every gradient is bit-identical to the y-reading form -- negative and
+    zero gammas, exact zeros of the pre-activation included."""
+    dev = _dev()
+    from mcdseg import ops
+    from models.drn import BatchNorm2d, Conv2d
+    g = torch.Generator().manual_seed(9)
+    k = 7 if cin <= 8 else 3
+    x = torch.randn(n, cin, *hw, generator=g).to(dev)
+    gy = torch.randn(n, cout, *hw, generator=g).to(dev)
+
+    def run(zmask):
+        monkeypatch.setattr(ops, "BN_ZMASK", zmask)
+        torch.manual_seed(6)
+        conv, bn = Conv2d(cin, cout, k, padding=k // 2, bias=False).to(dev), BatchNorm2d(cout).to(dev)
+        with torch.no_grad():
+            bn.weight.uniform_(-1.0, 1.5)
+            bn.weight[0] = 0.0
+            bn.bias.uniform_(-0.5, 0.5)
+            bn.bias[0] = 0.0  # gamma = beta = 0: the pre-activation is exactly 0 everywhere in this channel
+        bn.train()
+        xin = x.clone().requires_grad_(cin > 8)
+        y = ops.conv_bn_act(xin, conv, bn)
+        y.backward(gy)
+        return [xin.grad, conv.weight.grad, bn.weight.grad, bn.bias.grad]
+
+    for a, b in zip(run(True), run(False)):
+        assert (a is None and b is None) or torch.equal(a, b)
+
+
 # (Cin, Cout, k, stride, dil, H, W, N): 128x128-plan layers only (min(C) > 64, C % 8 == 0)
 WGRAD_CB_CASES = [
     (128, 128, 3, 1, 1, 12, 16, 2),   # whole 8x4 tiles
