@@ -164,6 +164,15 @@ def _compact_now():
     return ACT_STORAGE == "compact" and _TRUNK_DEPTH > 0 and _scaled()
 
 
+# A fused ReLU group WITHOUT residual whose output only the next split convolution consumes (conv1 of a BasicBlock, conv1 / conv2
+# of a Bottleneck: ``conv_bn_act(..., internal=True)``) need not write its fp32 output at all, in ANY storage mode and without
+# changing a bit: the consumer's forward and weight gradient read the companion either way, and the group's own backward
+# takes its ReLU mask from z (BN_ZMASK).  8 instead of 12 bytes written per element, 4 bytes per element less kept for backward.
+# (Taken for more than 32 channels and un-cut batches only: there the consumer's forward, data and weight gradient all run on the
+# split kernels.  A consumer that needs fp32 after all reconstructs it from the companion, 22 bits, as in compact storage.)
+INTERNAL_SKIP_Y = os.environ.get("MCDSEG_INTERNAL_SKIP_Y", "1") != "0"
+
+
 def _virtual(shape, device):
     """stand-in for an activation that exists only as its companion: right shape / device / dtype, 4 bytes of storage"""
     return torch.empty(1, dtype=torch.float32, device=device).expand(shape)
@@ -602,6 +611,8 @@ class _ConvBNAct(torch.autograd.Function):
         # give one (Samuelson), eval-mode running statistics do not (the consumer then measures y)
         want_cb = _cb_wanted(c) and desc.N * (c // 8) <= 65535 and (training or not _scaled())
         compact = aux["compact"] and want_cb and training
+        if compact and aux.get("single_piece_only") and (len(_batch_pieces(desc)) != 1 or c <= 32):
+            compact = False  # the consumer would cut the batch, or run its weight gradient on the f32 kernels, and read fp32
         res_cb = aux["res_cb"] if aux["res_virtual"] else None
         if aux["res_virtual"] and not want_cb:
             residual, res_cb = materialize(residual, aux["res_cb"], res_bound), None  # plain bn_apply reads fp32
@@ -672,11 +683,11 @@ class _ConvBNAct(torch.autograd.Function):
             x_cb, x_bound = split_companion_padded(x)
         want_cb = ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and x_cb is not None)
         use_cb = stem_tr or (want_cb and split_d and _cb_wanted(c) and n * (c // 8) <= 65535)
+        # a ReLU group without residual: y > 0 <=> fma(z, gamma rstd, beta - mean gamma rstd) > 0 -- neither pass below reads y
+        zmask = BN_ZMASK and ctx.relu and not ctx.has_res and (y_cb is None or use_cb)
         if ctx.compact and not use_cb:  # the plain backward kernels read the fp32 activation for the ReLU mask
             y, y_cb = materialize(y, y_cb, y_bound), None
         y_mask = (y if y_cb is None else None) if ctx.relu else None
-        # a ReLU group without residual: y > 0 <=> fma(z, gamma rstd, beta - mean gamma rstd) > 0 -- neither pass below reads y
-        zmask = BN_ZMASK and ctx.relu and not ctx.has_res and y_cb is None
         dgamma, dbeta, dz_bound = _channel_reduce(dy, y_mask, z, mean, rstd, ctx.relu, gamma,
                                                   want_bound=_scaled() and (split_d or stem_tr or _wgrad_split_plan(desc)), train=ctx.training,
                                                   y_cb=y_cb if ctx.relu else None, zmask_beta=beta if zmask else None)
@@ -755,8 +766,9 @@ def _conv_bn_act_inference(x, conv, bn, relu, residual):
     return y
 
 
-def conv_bn_act(x, conv, bn, relu=True, residual=None):
-    """y = act(bn(conv(x)) + residual) with the HIP kernels; ``conv``/``bn`` are the parameter-holding modules."""
+def conv_bn_act(x, conv, bn, relu=True, residual=None, internal=False):
+    """y = act(bn(conv(x)) + residual) with the HIP kernels; ``conv``/``bn`` are the parameter-holding modules.
+    ``internal``: the caller promises that only the next fused group reads the result (see INTERNAL_SKIP_Y)."""
     geom = (conv.stride[0], conv.padding[0], conv.dilation[0])
     training = bn.training
     if not training and not torch.is_grad_enabled() and bn.track_running_stats and bn.running_mean is not None:
@@ -767,7 +779,9 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None):
     momentum = 0.1 if bn.momentum is None else bn.momentum
     x_cb, x_bound = _cb_of(x)
     res_cb, res_bound = _cb_of(residual) if residual is not None else (None, None)
-    aux = dict(x_virtual=is_virtual(x), res_virtual=is_virtual(residual), res_cb=res_cb, compact=_compact_now())
+    skip_y = internal and INTERNAL_SKIP_Y and BN_ZMASK and relu and residual is None and _scaled()
+    aux = dict(x_virtual=is_virtual(x), res_virtual=is_virtual(residual), res_cb=res_cb, compact=_compact_now() or skip_y,
+               single_piece_only=skip_y and not _compact_now())
     y, y_cb, y_bound = _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, residual, conv.bias, bn.running_mean if track else None,
                                         bn.running_var if track else None, bn.num_batches_tracked if track else None, conv._packed,
                                         geom, training, momentum, bn.eps, relu, x_cb, x_bound, res_bound, aux)

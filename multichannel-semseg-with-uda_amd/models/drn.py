@@ -90,7 +90,7 @@ class BasicBlock(nn.Module):
         self.residual = residual
 
     def forward(self, x):
-        h = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        h = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, internal=True)  # only conv2 below reads h
         shortcut = None
         if self.residual:
             shortcut = x if self.downsample is None else self.downsample(x)
@@ -114,8 +114,8 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        h = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True)
-        h = ops.conv_bn_act(h, self.conv2, self.bn2, relu=True)
+        h = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, internal=True)  # only the next convolution reads these two
+        h = ops.conv_bn_act(h, self.conv2, self.bn2, relu=True, internal=True)
         shortcut = x if self.downsample is None else self.downsample(x)
         return ops.conv_bn_act(h, self.conv3, self.bn3, relu=True, residual=shortcut)
 

@@ -845,6 +845,55 @@ def test_bn_backward_mask_from_z_is_bitwise(cin, cout, hw, n, monkeypatch):
         assert (a is None and b is None) or torch.equal(a, b)
 
 
+@pytest.mark.parametrize("block,planes,stride,dil,hw", [("basic", 64, 1, 1, (12, 20)), ("basic", 128, 2, 1, (13, 19)),
+                                                        ("basic", 256, 1, 2, (9, 12)), ("bottleneck", 64, 1, 1, (10, 14))])
+def test_internal_groups_skip_the_fp32_output_bitwise(block, planes, stride, dil, hw, monkeypatch):
+    """conv1 of a BasicBlock (conv1 / conv2 of a Bottleneck) writes only its companion: the block's output and every gradient
+    are bit-identical to the form that also writes the fp32 activation (MCDSEG_INTERNAL_SKIP_Y=0), and the intermediate tensor
+    handed on is the 4-byte stand-in."""
+    dev = _dev()
+    from mcdseg import ops
+    from models import drn
+    g = torch.Generator().manual_seed(13)
+    inpl = planes * (4 if block == "bottleneck" else 1) if stride == 1 else planes // 2
+    x = torch.randn(2, inpl, *hw, generator=g).to(dev)
+
+    def run(skip):
+        monkeypatch.setattr(ops, "INTERNAL_SKIP_Y", skip)
+        torch.manual_seed(4)
+        cls = drn.BasicBlock if block == "basic" else drn.Bottleneck
+        outpl = planes * cls.expansion
+        down = None
+        if stride != 1 or inpl != outpl:
+            down = drn.ConvBN(drn.Conv2d(inpl, outpl, kernel_size=1, stride=stride, bias=False), drn.BatchNorm2d(outpl))
+        blk = cls(inpl, planes, stride, down, dilation=(dil, dil)).to(dev).train()
+        pre_c, pre_b = drn.Conv2d(inpl, inpl, 3, padding=1, bias=False).to(dev), drn.BatchNorm2d(inpl).to(dev).train()
+        xin = x.clone().requires_grad_()
+        h0 = ops.conv_bn_act(xin, pre_c, pre_b)  # gives the block an input with a companion, as inside the network
+        seen = []
+        orig = ops.conv_bn_act
+
+        def spy(*a, **kw):
+            y = orig(*a, **kw)
+            seen.append(ops.is_virtual(y))
+            return y
+
+        monkeypatch.setattr(ops, "conv_bn_act", spy)
+        out = blk(h0)
+        monkeypatch.setattr(ops, "conv_bn_act", orig)
+        gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(14)).to(dev)
+        out.backward(gy)
+        grads = [xin.grad] + [p.grad for p in blk.parameters()] + [pre_c.weight.grad, pre_b.weight.grad]
+        return out.detach(), grads, seen
+
+    o1, g1, seen1 = run(True)
+    o0, g0, seen0 = run(False)
+    assert any(seen1) and not any(seen0), (seen1, seen0)
+    assert torch.equal(o1, o0)
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)
+
+
 # (Cin, Cout, k, stride, dil, H, W, N): 128x128-plan layers only (min(C) > 64, C % 8 == 0)
 WGRAD_CB_CASES = [
     (128, 128, 3, 1, 1, 12, 16, 2),   # whole 8x4 tiles
