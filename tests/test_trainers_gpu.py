@@ -262,3 +262,55 @@ def test_adapt_mfnet_tester_label_maps_match_oracle(tmp_path):
         assert got.shape == ref.shape == (64, 96)
         assert (got == ref)[safe].all() and (got == ref).mean() > 0.995
     assert abs(ent - sum(ents) / 2) <= 1e-4 * abs(sum(ents) / 2)
+
+
+def _run_ranks(world, script, args, extra_env=None, timeout=600):
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MCDSEG_SINGLE_DEVICE="1", MCDSEG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4",
+               MCDSEG_PRETRAINED="0")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path):
+    """Data parallelism through the real kernels: two ranks (both on cuda:0, gloo -- RCCL refuses two ranks on one device) run one
+    MCD step on the SAME batch; the summed gradients times 1/world and the all-reduced cross-entropy normaliser over world then
+    equal the single-process quantities exactly, so every parameter and buffer matches the one-rank run bit for bit."""
+    _need_gpu()
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    worker = os.path.join(here, "dp_worker.py")
+    out = {}
+    for world in (1, 2):
+        fn = str(tmp_path / ("fp%d.json" % world))
+        r = _run_ranks(world, worker, [fn])
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        out[world] = json.load(open(fn))
+    assert out[1].pop("world") == 1 and out[2].pop("world") == 2
+    assert out[1].keys() == out[2].keys() and len(out[1]) > 200
+    for k in out[1]:
+        assert out[1][k] == out[2][k], k
+
+
+def test_bench_with_two_ranks_on_one_gpu():
+    """``bench.py --gpus 2`` under a launcher, both ranks on cuda:0 over gloo: the multi-rank branch of the benchmark (per-rank
+    batches, barrier + MAX-over-ranks timing, rank 0's single JSON line with the whole-job rate) on the real step."""
+    _need_gpu()
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = _run_ranks(2, os.path.join(root, "bench.py"), ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--height", "64",
+                                                       "--width", "96", "--no_cpu_baseline"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["cpu_baseline"] is None
+    assert abs(line["value"] - 2 * 2 / (line["ms_per_step"] * 1e-3)) <= 1e-2 * line["value"]
+    assert line["config"]["global_pairs"] == 4 and line["config"]["parallelism"] == "dp2"
