@@ -95,6 +95,44 @@ def test_conv_rejects_bad_geometry():
         ops._req(torch.zeros(2), "cpu tensor")
 
 
+def test_new_entry_points_reject_what_they_cannot_do(monkeypatch):
+    """error behaviour of this round's entry points: the LDS-window forward has no bias epilogue (rejected, not ignored), the
+    padded companion needs its bound scalar, the z-mask BatchNorm backward its beta, a weight gradient on split operands both
+    bound scalars -- each with a reason in mcdseg_last_error()"""
+    dev = _dev()
+    import ctypes
+    from mcdseg import ops
+    L = ops.lib()
+    monkeypatch.setattr(ops, "CONV_MATH", "f16x3")
+    x = torch.randn(1, 16, 8, 32, device=dev)
+    wt = torch.randn(16, 16, 3, 3, device=dev) * 0.1
+    desc = ops.conv_desc(x.shape, wt.shape, 1, 1, 1)
+    pk = ops.PackedWeights()
+    wf, wd, mpf = pk.get(wt, desc)
+    x_cb, x_bound = ops.split_companion(x)
+    y = torch.empty(1, 16, 8, 32, device=dev)
+    bias = torch.zeros(16, device=dev)
+    rc = L.mcdseg_conv_split_fprop(ctypes.byref(desc), 3, ops._p(x), ops._p(x_cb), ops._p(x_bound), ops._p(wf), ops._p(pk.w_bound),
+                                   ops._p(bias), ops._p(y), None, ops._stream())
+    assert rc != 0 and b"no bias" in L.mcdseg_last_error()
+    x6 = torch.randn(1, 6, 8, 8, device=dev)
+    cb = torch.empty(2 * 8 * 64, dtype=torch.int16, device=dev)
+    rc = L.mcdseg_split_cb_padded(ops._p(x6), ops._p(cb), None, 3, 1, 6, 64, ops._stream())
+    assert rc != 0 and b"bound" in L.mcdseg_last_error()
+    z = torch.randn(1, 16, 8, 32, device=dev)
+    v = torch.ones(16, device=dev)
+    ws = torch.empty(L.mcdseg_bn_bwd_workspace_bytes(1, 16, 256) // 4 + 1, device=dev)
+    rc = L.mcdseg_bn_bwd_reduce_zmask(ops._p(z), ops._p(z), ops._p(v), ops._p(v), ops._p(v), None, ops._p(v.clone()), ops._p(v.clone()), None,
+                                      1, 1, 16, 256, ops._p(ws), ctypes.c_size_t(ws.numel() * 4), ops._stream())
+    assert rc != 0 and b"null pointer" in L.mcdseg_last_error()
+    dw = torch.empty_like(wt)
+    wsz = torch.empty(L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(desc)) // 4 + 1, device=dev)
+    gy_cb, gy_bound = ops.split_companion(z)
+    rc = L.mcdseg_conv_split_wgrad(ctypes.byref(desc), 3, None, ops._p(x_cb), None, None, ops._p(gy_cb), ops._p(gy_bound), ops._p(dw), ops._p(wsz),
+                                   ctypes.c_size_t(wsz.numel() * 4), ops._stream())
+    assert rc != 0  # companions without the operand's bound scalar, and no fp32 operand to fall back to
+
+
 @pytest.mark.parametrize("cfg", [
     # Cin, Cout, k, stride, dil, H, W, N, relu, residual, train
     (16, 16, 3, 1, 1, 20, 28, 2, True, False, True),
