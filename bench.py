@@ -257,8 +257,8 @@ def pmc_traffic(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="(src,tgt) pairs per GPU")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
