@@ -296,6 +296,31 @@ def test_solver_fused_up_loss_is_bitwise_the_two_pass_step(golden, monkeypatch):
         assert abs(c0 - c1) <= 1e-6 * abs(c1) and abs(d0 - d1) <= 1e-6 * abs(d1)
 
 
+def test_training_on_a_fixed_batch_reduces_the_source_loss():
+    """End-to-end sanity of the whole update path over many steps (weights, BN statistics and the per-tensor fp16 scales all
+    move): 40 MCD steps on one fixed batch drive the source cross-entropy down and keep every parameter finite."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, get_prob_distance_criterion
+    from models.model_util import get_models, get_optimizer
+    from solvers.solver import MCDSolver
+    torch.manual_seed(0)
+    g, f1, f2 = get_models("drn_d_38", 6, NC)
+    for m in (g, f1, f2):
+        m.to(dev).train()
+    s, l, t = (v.to(dev) for v in make_batch(3, 2, 6, 96, 128, NC))
+    l = (l % 5).contiguous()  # five classes: learnable from one batch in a few dozen steps
+    og = get_optimizer(g.parameters(), "sgd", 1e-2, 0.9, 2e-5)
+    of = get_optimizer(list(f1.parameters()) + list(f2.parameters()), "sgd", 1e-2, 0.9, 2e-5)
+    cw = torch.ones(NC)
+    solver = MCDSolver(g, f1, f2, og, of, CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff"), num_k=2)
+    hist = [float(solver.step(s, l, t)[0]) for _ in range(40)]
+    assert all(np.isfinite(hist)), hist
+    assert np.mean(hist[-5:]) < 0.75 * np.mean(hist[:3]) and hist[-1] < hist[-10] < hist[-20], hist
+    for m in (g, f1, f2):
+        for k, v in m.state_dict().items():
+            assert bool(torch.isfinite(v.float()).all()), k
+
+
 def test_mfnet_vs_reference(golden):
     dev = _dev()
     from loss import CrossEntropyLoss2d, get_prob_distance_criterion
