@@ -1,6 +1,5 @@
 // Forward and data gradient of the thin full-resolution stride-1 3x3 layers (16 contraction channels, 16 or 32 output channels:
-// layer1 16 -> 16 of the DRN trunk) in the split arithmetic, from the pre-split companion.  (The kernel is written for strides 1
-// and 2; the launcher takes stride 1 only -- see thin_win_plan.)
+// layer1 16 -> 16 of the DRN trunk) in the split arithmetic, from the pre-split companion.
 //
 // The implicit-GEMM kernel (conv_gemm_split_kernel<..,1,2,1,4,..>) fetches the pixel operand once per tap from L2 -- nine
 // tap-shifted copies of a tensor that is the whole HBM traffic of the layer -- and runs at 2.4-3.4x the layer's HBM floor.  Here
@@ -10,8 +9,9 @@
 // fragment of lane (pixel n, k-group g) is ONE unit -- channels 8 (g & 1) .. +7 of tap 2 ks + (g >> 1) at pixel n -- i.e. one
 // aligned ds_read_b128, no transposition; the A fragments (weights, 5 K-steps) come straight from the packed image of
 // mcdseg_conv_split_pack_weights and stay in registers for the workgroup's life.  Three cross terms, accumulators scaled by
-// scale(x) * scale(w); the forward form also emits the BatchNorm partial statistics (count, mean, M2 per channel and wave:
-// one row per tile and wave) that mcdseg_bn_stats_finalize merges.
+// scale(x) * scale(w); the forward form also emits the BatchNorm partial statistics (count, mean, M2 per channel: one row per
+// workgroup and wave, kept as running values over the workgroup's tiles) that mcdseg_bn_stats_finalize merges.  The output
+// goes through a per-wave LDS image so that a store instruction covers whole 128-byte rows.
 #include "split.h"
 
 namespace {
@@ -27,7 +27,7 @@ struct ThinWinParams {
   const float* src_bound;
   const float* w_bound;
   float* dst;          // [N][M][Hd][Wd]
-  float* stats;        // forward only, may be NULL: [(tile * 4 + wave)][3][32]
+  float* stats;        // forward only, may be NULL: [(workgroup * 4 + wave)][3][32]
   int N, Hs, Ws, Hd, Wd, M, KH, KW, stride, pad, dil;
   int src_bytes, src_piece_bytes, wp_bytes;
   int tiles_x, tiles_y, ntiles;
@@ -36,6 +36,7 @@ struct ThinWinParams {
 
 template <int MT, int TR, bool DGRAD>
 __global__ __launch_bounds__(256) void conv_thin_window_kernel(ThinWinParams p) {
+  static_assert(TR == 8, "a wave owns two rows of the tile (the output stage below relies on it)");
   extern __shared__ __attribute__((aligned(16))) unsigned char tw_smem[];
   constexpr int GR = (TR + 3) / 4;  // rows of the tile a wave owns
   constexpr int NG = 2 * GR;        // 16-pixel groups a wave owns
@@ -94,6 +95,15 @@ __global__ __launch_bounds__(256) void conv_thin_window_kernel(ThinWinParams p) 
   const float osc = mcd_scale_of_bound(*p.src_bound) * mcd_scale_of_bound(*p.w_bound);
   const int b_lane = ((g & 1) * wrc + n16 * p.stride) * 16;
 
+  // BatchNorm partial statistics: every lane keeps a running (count, mean, M2) of the pixels it has produced for each of its
+  // channels (Welford's update, shifted form as everywhere in this library); merged over the 16 pixel lanes of a channel group and
+  // written ONCE per wave at the end -- one row per (workgroup, wave) instead of one per (tile, wave)
+  float st_n = 0.f, st_mean[MT][4], st_m2[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st_mean[i][r] = st_m2[i][r] = 0.f;
+
   const int per_img = p.tiles_x * p.tiles_y;
   const int per_xcd = (p.ntiles + 7) >> 3;
   const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
@@ -149,59 +159,94 @@ __global__ __launch_bounds__(256) void conv_thin_window_kernel(ThinWinParams p) 
     }
     // ---- epilogue: D[row = channel 4 g + r][column = pixel n16]; scale, store, BatchNorm partial statistics
     bool pv[NG];
-    int cnt = 0;  // valid pixels of this wave in the tile (wave-uniform)
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
       const int rt = wave + 4 * (gi >> 1);
       const int oy = oy0 + rt, ox = ox0 + 16 * (gi & 1) + n16;
       const bool rowv = rt < TR && oy < p.Hd;
       pv[gi] = rowv && ox < p.Wd;
-      if (rowv) {
-        const int left = p.Wd - (ox0 + 16 * (gi & 1));
-        cnt += left >= 16 ? 16 : (left > 0 ? left : 0);
-      }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          acc[gi][i][r] *= osc;
-          const int co = 16 * i + 4 * g + r;
-          if (pv[gi] && co < p.M) p.dst[(((size_t)n * p.M + co) * p.Hd + oy) * p.Wd + ox] = acc[gi][i][r];
-        }
+        for (int r = 0; r < 4; ++r) acc[gi][i][r] *= osc;
+    }
+    // ---- output through LDS: the 16x16 accumulator layout would store 64-byte runs (16 pixels of one channel per instruction
+    // and lane group), which cost as much as the rest of the kernel; transposed through a per-wave [channel][32 * GR pixels]
+    // image a store instruction covers GR whole 128-byte rows instead
+    {
+      constexpr int OP = 32 * GR + 1;  // padded pixel stride (floats)
+      float* ot = reinterpret_cast<float*>(tw_smem + 2 * piece_lds) + wave * (16 * MT * OP);
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ot[(16 * i + 4 * g + r) * OP + 32 * (gi >> 1) + 16 * (gi & 1) + n16] = acc[gi][i][r];
+      // the image is private to the wave: its own LDS writes only have to land
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int rsel = lane >> 5, pcol = lane & 31;  // lanes 0-31: the wave's first row, 32-63: its second
+      const int rt = wave + 4 * rsel;
+      const int oy = oy0 + rt, ox = ox0 + pcol;
+      const bool ok = oy < p.Hd && ox < p.Wd;
+#pragma unroll
+      for (int co = 0; co < 16 * MT; ++co) {
+        const float v = ot[co * OP + 32 * rsel + pcol];
+        if (ok && co < p.M) p.dst[(((size_t)n * p.M + co) * p.Hd + oy) * p.Wd + ox] = v;
+      }
     }
     if (!DGRAD && p.stats != nullptr) {
-      const float inv = cnt > 0 ? 1.f / (float)cnt : 0.f;
-      float* row = p.stats + (size_t)(tile * 4 + wave) * 3 * 32;
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi)
+        if (pv[gi]) {
+          st_n += 1.f;
+          const float inv = 1.f / st_n;
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float dlt = acc[gi][i][r] - st_mean[i][r];
+              st_mean[i][r] = fmaf(dlt, inv, st_mean[i][r]);
+              st_m2[i][r] = fmaf(dlt, acc[gi][i][r] - st_mean[i][r], st_m2[i][r]);
+            }
+        }
+    }
+    __syncthreads();  // the stage is free for the next tile's DMAs
+  }
+  if (!DGRAD && p.stats != nullptr) {
+    // Chan's merge over the 16 lanes that hold the same channels (xor 1, 2, 4, 8 stay inside a 16-lane group)
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const float nb = __shfl_xor(st_n, o);
+      const float nt = st_n + nb;
+      const float wgt = nt > 0.f ? nb / nt : 0.f;
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float s = 0.f;
-#pragma unroll
-          for (int gi = 0; gi < NG; ++gi) s += pv[gi] ? acc[gi][i][r] : 0.f;
-          s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-          const float mean = s * inv;
-          float q = 0.f;
-#pragma unroll
-          for (int gi = 0; gi < NG; ++gi) {
-            const float dlt = acc[gi][i][r] - mean;
-            q += pv[gi] ? dlt * dlt : 0.f;
-          }
-          q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
-          if (n16 == 0) {
-            const int co = 16 * i + 4 * g + r;
-            row[co] = (float)cnt;
-            row[32 + co] = mean;
-            row[64 + co] = q;
-          }
+          const float mb = __shfl_xor(st_mean[i][r], o), qb = __shfl_xor(st_m2[i][r], o);
+          const float dlt = mb - st_mean[i][r];
+          st_m2[i][r] = st_m2[i][r] + qb + dlt * dlt * st_n * wgt;
+          st_mean[i][r] = fmaf(dlt, wgt, st_mean[i][r]);
         }
-      if (MT == 1 && lane < 16) {  // channels 16..31 of the 32-wide row do not exist: empty entries
-        row[16 + lane] = 0.f;
-        row[32 + 16 + lane] = 0.f;
-        row[64 + 16 + lane] = 0.f;
-      }
+      st_n = nt;
     }
-    __syncthreads();  // the stage is free for the next tile's DMAs
+    float* row = p.stats + (size_t)(blockIdx.x * 4 + wave) * 3 * 32;
+    if (n16 == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = 16 * i + 4 * g + r;
+          row[co] = st_n;
+          row[32 + co] = st_mean[i][r];
+          row[64 + co] = st_m2[i][r];
+        }
+    }
+    if (MT == 1 && lane < 16) {  // channels 16..31 of the 32-wide row do not exist: empty entries
+      row[16 + lane] = 0.f;
+      row[32 + 16 + lane] = 0.f;
+      row[64 + 16 + lane] = 0.f;
+    }
   }
 }
 
@@ -223,11 +268,11 @@ ThinWinPlan thin_win_plan(const mcdseg_conv_desc* d, bool dgrad) {
   if (dgrad && (d->stride != 1 || m != 16)) return pl;
   if (!dgrad && d->stride != 1) return pl;  // the stride-2 forward (16 -> 32, half the output pixels) measured no faster: 0.134 vs 0.131 ms
   pl.mt = m / 16;
-  pl.tr = d->stride == 1 ? 8 : 4;
+  pl.tr = 8;
   pl.WR = (pl.tr - 1) * d->stride + (d->KH - 1) * d->dil + 1;
   pl.WC = (TW_TC - 1) * d->stride + (d->KW - 1) * d->dil + 1;
   pl.uxp = round_up(2 * pl.WR * pl.WC, 64);
-  pl.lds = 2 * pl.uxp * 16;
+  pl.lds = 2 * pl.uxp * 16 + 4 * 16 * pl.mt * (32 * ((pl.tr + 3) / 4) + 1) * 4;  // window (two pieces) + the waves' output images
   if (pl.lds > 64 * 1024 || pl.uxp / 64 > 4 * TW_MAXK || pl.WC >= 65536) return pl;
   const int hd = dgrad ? d->H : d->Ho, wd = dgrad ? d->W : d->Wo;
   pl.tiles_x = ceil_div(wd, TW_TC);
@@ -249,7 +294,7 @@ int mcdseg_internal_thin_window_ok(const mcdseg_conv_desc* d, int dgrad) { retur
 
 int64_t mcdseg_internal_thin_window_stat_rows(const mcdseg_conv_desc* d) {
   const ThinWinPlan pl = thin_win_plan(d, false);
-  return pl.ok ? (int64_t)pl.ntiles * 4 : 0;
+  return pl.ok ? (int64_t)pl.blocks * 4 : 0;
 }
 
 int mcdseg_internal_thin_window_launch(const mcdseg_conv_desc* d, int dgrad, const void* src_cb, const float* src_bound, const void* wp,
@@ -271,14 +316,10 @@ int mcdseg_internal_thin_window_launch(const mcdseg_conv_desc* d, int dgrad, con
   const dim3 grid(pl.blocks), block(256);
   if (dgrad)
     hipLaunchKernelGGL((conv_thin_window_kernel<1, 8, true>), grid, block, pl.lds, st, p);
-  else if (pl.mt == 1 && pl.tr == 8)
-    hipLaunchKernelGGL((conv_thin_window_kernel<1, 8, false>), grid, block, pl.lds, st, p);
-  else if (pl.mt == 2 && pl.tr == 8)
-    hipLaunchKernelGGL((conv_thin_window_kernel<2, 8, false>), grid, block, pl.lds, st, p);
   else if (pl.mt == 1)
-    hipLaunchKernelGGL((conv_thin_window_kernel<1, 4, false>), grid, block, pl.lds, st, p);
+    hipLaunchKernelGGL((conv_thin_window_kernel<1, 8, false>), grid, block, pl.lds, st, p);
   else
-    hipLaunchKernelGGL((conv_thin_window_kernel<2, 4, false>), grid, block, pl.lds, st, p);
+    hipLaunchKernelGGL((conv_thin_window_kernel<2, 8, false>), grid, block, pl.lds, st, p);
   MCD_LAUNCH_CHECK("conv_thin_window");
   return 0;
 }
