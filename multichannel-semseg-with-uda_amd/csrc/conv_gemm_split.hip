@@ -831,6 +831,11 @@ int64_t mcdseg_internal_thin_window_stat_rows(const mcdseg_conv_desc* d);
 int mcdseg_internal_thin_window_launch(const mcdseg_conv_desc* d, int dgrad, const void* src_cb, const float* src_bound, const void* wp,
                                        int64_t wp_bytes, const float* w_bound, float* dst, float* stats, hipStream_t st);
 
+// the stem's forward image: [standard split image (window kernel)][the direct kernel's own image]
+static int64_t stem_image_offset(const mcdseg_conv_desc* d, int math) {
+  return (split_image_bytes(math, d->Cout, d->Cin, d->KH * d->KW) + 255) / 256 * 256;
+}
+
 extern "C" int32_t mcdseg_conv_split_direct_ok(const mcdseg_conv_desc* d) { return d != nullptr && mcdseg_internal_stem_ok(d) ? 1 : 0; }
 
 extern "C" int64_t mcdseg_conv_split_stat_rows(const mcdseg_conv_desc* d) {
@@ -844,14 +849,13 @@ extern "C" int64_t mcdseg_conv_split_stat_rows(const mcdseg_conv_desc* d) {
 
 extern "C" int64_t mcdseg_conv_split_stat_rows_for(const mcdseg_conv_desc* d, int32_t math, int32_t presplit) {
   if (d == nullptr) return -22;
-  if (math == MCDSEG_MATH_F16X3 && presplit && !mcdseg_internal_stem_ok(d) && mcdseg_internal_thin_window_ok(d, 0))
-    return mcdseg_internal_thin_window_stat_rows(d);
+  if (math == MCDSEG_MATH_F16X3 && presplit && mcdseg_internal_thin_window_ok(d, 0)) return mcdseg_internal_thin_window_stat_rows(d);
   return mcdseg_conv_split_stat_rows(d);
 }
 
 // 1 when mcdseg_conv_split_fprop / _dgrad run this geometry on the LDS-window kernel (for profilers and the benchmark's accounting)
 extern "C" int32_t mcdseg_conv_split_window_ok(const mcdseg_conv_desc* d, int32_t math, int32_t presplit, int32_t dgrad) {
-  return d != nullptr && math == MCDSEG_MATH_F16X3 && presplit && !mcdseg_internal_stem_ok(d) && mcdseg_internal_thin_window_ok(d, dgrad) ? 1 : 0;
+  return d != nullptr && math == MCDSEG_MATH_F16X3 && presplit && mcdseg_internal_thin_window_ok(d, dgrad) ? 1 : 0;
 }
 
 extern "C" int mcdseg_absmax(const float* x, int64_t n, float* bound, void* stream) {
@@ -871,7 +875,7 @@ extern "C" int mcdseg_conv_split_packed_bytes(const mcdseg_conv_desc* d, int32_t
   const int T = d->KH * d->KW;
   if (fprop_bytes) {
     *fprop_bytes = split_image_bytes(math, d->Cout, d->Cin, T);
-    if (mcdseg_internal_stem_ok(d) && *fprop_bytes < mcdseg_internal_stem_image_bytes()) *fprop_bytes = mcdseg_internal_stem_image_bytes();
+    if (mcdseg_internal_stem_ok(d)) *fprop_bytes = stem_image_offset(d, math) + mcdseg_internal_stem_image_bytes();
   }
   if (dgrad_bytes) *dgrad_bytes = split_image_bytes(math, d->Cin, d->Cout, T);
   return 0;
@@ -884,11 +888,8 @@ extern "C" int mcdseg_conv_split_pack_weights(const mcdseg_conv_desc* d, int32_t
   MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || w_bound != nullptr, "conv_split_pack_weights: the f16x3 images need the weight bound scalar");
   const int T = d->KH * d->KW;
   hipStream_t st = (hipStream_t)stream;
-  if (wp_fprop != nullptr && mcdseg_internal_stem_ok(d)) {  // the stem's forward image has its own layout (conv_stem_x6.hip)
-    if (int rc = mcdseg_internal_stem_pack(d, w, wp_fprop, st)) return rc;
-    wp_fprop = nullptr;
-    if (wp_dgrad == nullptr) return 0;
-  }
+  if (wp_fprop != nullptr && mcdseg_internal_stem_ok(d))  // the stem: the direct kernel's own image behind the standard one
+    if (int rc = mcdseg_internal_stem_pack(d, w, (char*)wp_fprop + stem_image_offset(d, math), st)) return rc;
   if (math == MCDSEG_MATH_F16X3)
     if (int rc = mcdseg_absmax(w, (int64_t)d->Cout * d->Cin * T, w_bound, stream)) return rc;
   int64_t most = 0;
@@ -942,9 +943,15 @@ static int split_fprop_impl(const mcdseg_conv_desc* d, int math, const float* x,
                             const float* ep_shift, const float* ep_res, int ep_relu, void* stream) {
   if (int rc = split_check(d, math, "conv_split_fprop")) return rc;
   MCD_REQUIRE((x || x_cb) && wp && y, "conv_split_fprop: null pointer");
-  if (mcdseg_internal_stem_ok(d)) {
+  const bool stem = mcdseg_internal_stem_ok(d);
+  // the stem with a (zero-padded, 8-channel) companion of the network input runs on the window kernel; its fp32 form (and every
+  // bias / affine epilogue) on the direct bf16x6 kernel
+  const bool stem_window = stem && math == MCDSEG_MATH_F16X3 && x_cb != nullptr && bias == nullptr && ep_scale == nullptr &&
+                           mcdseg_internal_thin_window_ok(d, 0);
+  if (stem && !stem_window) {
     MCD_REQUIRE(x != nullptr, "conv_split_fprop: the stem kernel reads the fp32 input");
-    return mcdseg_internal_stem_fprop(d, x, wp, bias, y, stats, ep_scale, ep_shift, ep_res, ep_relu, (hipStream_t)stream);
+    return mcdseg_internal_stem_fprop(d, x, (const char*)wp + stem_image_offset(d, math), bias, y, stats, ep_scale, ep_shift, ep_res,
+                                      ep_relu, (hipStream_t)stream);
   }
   MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || (x_bound && w_bound), "conv_split_fprop: f16x3 needs the operand and weight bound scalars");
   if (math == MCDSEG_MATH_F16X3 && x_cb != nullptr && mcdseg_internal_thin_window_ok(d, 0)) {

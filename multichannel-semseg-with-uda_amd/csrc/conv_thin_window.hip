@@ -18,11 +18,12 @@ namespace {
 
 constexpr int TW_TC = 32;
 constexpr int TW_MAXK = 8;
-constexpr int TW_KS = 5;  // K-steps of two taps for a 3x3 kernel (the tenth tap is zero weights)
+// K-steps: K = 32 = two taps x 16 channels (CIN8 = 2; 5 steps for a 3x3 kernel, the tenth tap is zero weights) or four taps x one
+// 8-channel unit (CIN8 = 1: the 7x7 stem on its zero-padded companion; 13 steps)
 constexpr unsigned TW_OOB = 0x80000000u;
 
 struct ThinWinParams {
-  const void* src_cb;  // [piece 2][N][2][Hs*Ws][8 x fp16]
+  const void* src_cb;  // [piece 2][N][CIN8][Hs*Ws][8 x fp16]
   const void* wp;      // packed weight image [tap][piece][half][Mp 32][8]
   const float* src_bound;
   const float* w_bound;
@@ -34,9 +35,9 @@ struct ThinWinParams {
   int WR, WC, uxp;
 };
 
-template <int MT, int TR, bool DGRAD>
+template <int CIN8, int MT, int TW_KS, bool DGRAD>
 __global__ __launch_bounds__(256) void conv_thin_window_kernel(ThinWinParams p) {
-  static_assert(TR == 8, "a wave owns two rows of the tile (the output stage below relies on it)");
+  constexpr int TR = 8;  // a wave owns two rows of the tile (the output stage below relies on it)
   extern __shared__ __attribute__((aligned(16))) unsigned char tw_smem[];
   constexpr int GR = (TR + 3) / 4;  // rows of the tile a wave owns
   constexpr int NG = 2 * GR;        // 16-pixel groups a wave owns
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void conv_thin_window_kernel(ThinWinParams p) 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int T = p.KH * p.KW;
   const int wrc = p.WR * p.WC;
-  const int ux = 2 * wrc;
+  const int ux = CIN8 * wrc;
   const int sx = p.uxp >> 6;
   const int piece_lds = p.uxp * 16;
   const int n16 = lane & 15, g = lane >> 4;
@@ -71,12 +72,14 @@ __global__ __launch_bounds__(256) void conv_thin_window_kernel(ThinWinParams p) 
   const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src_cb, 0, p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wp_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.wp_bytes, 0x00020000);
 
-  // ---- weights: A fragment of lane (row m = n16, k-group g) for K-step ks = 8 channels (half g & 1) of tap 2 ks + (g >> 1)
+  // ---- weights: A fragment of lane (row m = n16, k-group g) for K-step ks = 8 channels (half g & 1) of tap 2 ks + (g >> 1), or
+  // (CIN8 = 1) the one 8-channel unit of tap 4 ks + g
+  const int half = CIN8 == 2 ? (g & 1) : 0;
   f16x8 fa[MT][TW_KS][2];
   int toff[TW_KS];  // this lane's window offset (bytes) of its tap in each K-step
 #pragma unroll
   for (int ks = 0; ks < TW_KS; ++ks) {
-    const int tap = 2 * ks + (g >> 1);
+    const int tap = CIN8 == 2 ? 2 * ks + (g >> 1) : 4 * ks + g;
     const bool tv = tap < T;
     const int tc = tv ? tap : 0;
     const int ky = tc / p.KW, kx = tc - ky * p.KW;
@@ -87,13 +90,13 @@ __global__ __launch_bounds__(256) void conv_thin_window_kernel(ThinWinParams p) 
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int pc = 0; pc < 2; ++pc) {
-        const unsigned voff = tv ? (unsigned)((((tap * 2 + pc) * 2 + (g & 1)) * 32 + 16 * i + n16) * 16) : TW_OOB;
+        const unsigned voff = tv ? (unsigned)((((tap * 2 + pc) * 2 + half) * 32 + 16 * i + n16) * 16) : TW_OOB;
         const auto q = __builtin_amdgcn_raw_buffer_load_b128(wp_rs, voff, 0, 0);
         fa[i][ks][pc] = __builtin_bit_cast(f16x8, q);
       }
   }
   const float osc = mcd_scale_of_bound(*p.src_bound) * mcd_scale_of_bound(*p.w_bound);
-  const int b_lane = ((g & 1) * wrc + n16 * p.stride) * 16;
+  const int b_lane = (half * wrc + n16 * p.stride) * 16;
 
   // BatchNorm partial statistics: every lane keeps a running (count, mean, M2) of the pixels it has produced for each of its
   // channels (Welford's update, shifted form as everywhere in this library); merged over the 16 pixel lanes of a channel group and
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_thin_window_kernel(ThinWinParams p) 
     const int oy0 = ty * TR, ox0 = tx * TW_TC;
     const int wy0 = DGRAD ? oy0 + p.pad - (p.KH - 1) * p.dil : oy0 * p.stride - p.pad;
     const int wx0 = DGRAD ? ox0 + p.pad - (p.KW - 1) * p.dil : ox0 * p.stride - p.pad;
-    const int xbase = n * 2 * p.Hs * p.Ws + wy0 * p.Ws + wx0;
+    const int xbase = n * CIN8 * p.Hs * p.Ws + wy0 * p.Ws + wx0;
 #pragma unroll
     for (int k = 0; k < TW_MAXK; ++k) {
       const int s = wave + 4 * k;
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(256) void conv_thin_window_kernel(ThinWinParams p) 
 
 struct ThinWinPlan {
   bool ok;
-  int mt, tr, WR, WC, uxp, lds, tiles_x, tiles_y, ntiles, blocks;
+  int cin8, mt, tr, WR, WC, uxp, lds, tiles_x, tiles_y, ntiles, blocks;
 };
 
 ThinWinPlan thin_win_plan(const mcdseg_conv_desc* d, bool dgrad) {
@@ -262,16 +265,21 @@ ThinWinPlan thin_win_plan(const mcdseg_conv_desc* d, bool dgrad) {
     const char* e = getenv("MCDSEG_THIN_WINDOW");  // development knob: 0 = the implicit-GEMM kernels for these layers too
     return e == nullptr || atoi(e) != 0;
   }();
-  if (!on || d->KH * d->KW != 9) return pl;
+  if (!on || d->stride != 1) return pl;  // (a stride-2 form, 16 -> 32, measured no faster than the implicit GEMM: 0.134 vs 0.131 ms)
+  const int T = d->KH * d->KW;
   const int ks = dgrad ? d->Cout : d->Cin, m = dgrad ? d->Cin : d->Cout;
-  if (ks != 16 || (m != 16 && m != 32)) return pl;
-  if (dgrad && (d->stride != 1 || m != 16)) return pl;
-  if (!dgrad && d->stride != 1) return pl;  // the stride-2 forward (16 -> 32, half the output pixels) measured no faster: 0.134 vs 0.131 ms
+  if (ks == 16 && T == 9 && (m == 16 || (m == 32 && !dgrad))) {
+    pl.cin8 = 2;  // instantiated: <2,1,5,fwd>, <2,2,5,fwd>, <2,1,5,dgrad>
+  } else if (!dgrad && ks <= 8 && T == 49 && m == 16) {
+    pl.cin8 = 1;  // <1,1,13,fwd>: the stem on the zero-padded companion of the network input
+  } else {
+    return pl;
+  }
   pl.mt = m / 16;
   pl.tr = 8;
   pl.WR = (pl.tr - 1) * d->stride + (d->KH - 1) * d->dil + 1;
   pl.WC = (TW_TC - 1) * d->stride + (d->KW - 1) * d->dil + 1;
-  pl.uxp = round_up(2 * pl.WR * pl.WC, 64);
+  pl.uxp = round_up(pl.cin8 * pl.WR * pl.WC, 64);
   pl.lds = 2 * pl.uxp * 16 + 4 * 16 * pl.mt * (32 * ((pl.tr + 3) / 4) + 1) * 4;  // window (two pieces) + the waves' output images
   if (pl.lds > 64 * 1024 || pl.uxp / 64 > 4 * TW_MAXK || pl.WC >= 65536) return pl;
   const int hd = dgrad ? d->H : d->Ho, wd = dgrad ? d->W : d->Wo;
@@ -280,10 +288,10 @@ ThinWinPlan thin_win_plan(const mcdseg_conv_desc* d, bool dgrad) {
   const int64_t nt = (int64_t)d->N * pl.tiles_x * pl.tiles_y;
   if (nt * 4 >= (1ll << 31)) return pl;
   pl.ntiles = (int)nt;
-  const int resident = 256 * 4;
+  const int resident = 256 * ((pl.mt == 2 || pl.cin8 == 1) ? 2 : 4);  // by registers (196 / ~200 vs 124 VGPRs) and LDS
   pl.blocks = pl.ntiles < resident ? round_up(pl.ntiles, 8) : resident;
   const int hs = dgrad ? d->Ho : d->H, ws = dgrad ? d->Wo : d->W;
-  if (2ll * d->N * 16 * hs * ws * 2 + 4096 >= (1ll << 31) || (int64_t)d->N * m * hd * wd * 4 >= (1ll << 31)) return pl;
+  if (2ll * d->N * (8 * pl.cin8) * hs * ws * 2 + 4096 >= (1ll << 31) || (int64_t)d->N * m * hd * wd * 4 >= (1ll << 31)) return pl;
   pl.ok = true;
   return pl;
 }
@@ -308,18 +316,20 @@ int mcdseg_internal_thin_window_launch(const mcdseg_conv_desc* d, int dgrad, con
   p.Hd = dgrad ? d->H : d->Ho; p.Wd = dgrad ? d->W : d->Wo;
   p.M = dgrad ? d->Cin : d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
-  p.src_piece_bytes = (int)((int64_t)d->N * 16 * p.Hs * p.Ws * 2);
+  p.src_piece_bytes = (int)((int64_t)d->N * (8 * pl.cin8) * p.Hs * p.Ws * 2);
   p.src_bytes = 2 * p.src_piece_bytes;
   p.wp_bytes = (int)wp_bytes;
   p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles;
   p.WR = pl.WR; p.WC = pl.WC; p.uxp = pl.uxp;
   const dim3 grid(pl.blocks), block(256);
   if (dgrad)
-    hipLaunchKernelGGL((conv_thin_window_kernel<1, 8, true>), grid, block, pl.lds, st, p);
+    hipLaunchKernelGGL((conv_thin_window_kernel<2, 1, 5, true>), grid, block, pl.lds, st, p);
+  else if (pl.cin8 == 1)
+    hipLaunchKernelGGL((conv_thin_window_kernel<1, 1, 13, false>), grid, block, pl.lds, st, p);
   else if (pl.mt == 1)
-    hipLaunchKernelGGL((conv_thin_window_kernel<1, 8, false>), grid, block, pl.lds, st, p);
+    hipLaunchKernelGGL((conv_thin_window_kernel<2, 1, 5, false>), grid, block, pl.lds, st, p);
   else
-    hipLaunchKernelGGL((conv_thin_window_kernel<2, 8, false>), grid, block, pl.lds, st, p);
+    hipLaunchKernelGGL((conv_thin_window_kernel<2, 2, 5, false>), grid, block, pl.lds, st, p);
   MCD_LAUNCH_CHECK("conv_thin_window");
   return 0;
 }

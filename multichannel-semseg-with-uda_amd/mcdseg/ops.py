@@ -134,6 +134,7 @@ PIECES = {"f16x3": 2, "bf16x6": 3}
 BIGTILE_MIN_SLOTS = int(os.environ.get("MCDSEG_BIGTILE_MIN_SLOTS", "1024"))  # launch<> rule of csrc/conv_gemm_split.hip
 
 
+STEM_WINDOW = os.environ.get("MCDSEG_STEM_WINDOW", "1") != "0"  # the stem's training forward on the LDS-window kernel (f16x3)
 STEM_DIRECT = os.environ.get("MCDSEG_STEM_DIRECT", "1") != "0"  # the stem's forward as the direct (bf16x6) convolution
 
 # Activation storage inside a DRN trunk (MCDSEG_ACT_STORAGE):
@@ -326,7 +327,7 @@ def _pack_group(device):
         bounds = torch.zeros(n, dtype=torch.float32, device=device)
         ptrs, dims = [], []
         for i, (pw, w) in enumerate(members):
-            ptrs += [w.data_ptr(), 0 if pw._dims[3] else pw.wf.data_ptr(), pw.wd.data_ptr(), bounds.data_ptr() + 4 * i]
+            ptrs += [w.data_ptr(), pw.wf.data_ptr(), pw.wd.data_ptr(), bounds.data_ptr() + 4 * i]
             dims += [pw._dims[0], pw._dims[1], pw._dims[2], 0]
         tab = dict(sig=sig, bounds=bounds, ptrs=torch.tensor(ptrs, dtype=torch.int64).to(device),
                    dims=torch.tensor(dims, dtype=torch.int32).to(device))
@@ -340,7 +341,7 @@ def _pack_group(device):
         check(L.mcdseg_conv_split_pack_weights_multi(_p(tab["ptrs"]), _p(tab["dims"]), n, MATH_ID[CONV_MATH],
                                                      _p(tab["bounds"]) if _scaled() else None, _stream()), "conv_split_pack_weights_multi")
     for pw, w in members:
-        if pw._dims[3]:  # the stem's direct-kernel forward image has its own layout
+        if pw._dims[3]:  # the stem's direct-kernel forward image (behind the standard one) has its own layout
             d = ConvDesc(1, pw._dims[1], 8, 8, pw._dims[0], 7, 7, 1, 3, 1, 8, 8)
             check(L.mcdseg_conv_split_pack_weights(ctypes.byref(d), MATH_ID[CONV_MATH], _p(w.detach()), _p(pw.wf), None,
                                                    _p(pw.w_bound) if _scaled() else None, _stream()), "conv_split_pack_weights")
@@ -413,7 +414,8 @@ def _window_name(d, presplit, dgrad):
     if not lib().mcdseg_conv_split_window_ok(ctypes.byref(d), MATH_ID.get(CONV_MATH, 0), int(presplit), int(dgrad)):
         return None
     m = d.Cin if dgrad else d.Cout
-    return "conv_thin_window_kernel<%d, %d, %s>" % (m // 16, 8 if d.stride == 1 else 4, "true" if dgrad else "false")
+    stem = d.KH * d.KW == 49
+    return "conv_thin_window_kernel<%d, %d, %d, %s>" % (1 if stem else 2, m // 16, 13 if stem else 5, "true" if dgrad else "false")
 
 
 def _conv_dgrad(desc, dy, wd, dy_cb=None, dy_bound=None, w_bound=None):
@@ -463,7 +465,7 @@ def split_companion(x, bound=None):
 
 def split_companion_padded(x, bound=None):
     """companion of a tensor whose channel count is not a multiple of 8 (the 6-channel network input): ceil(C/8) channel groups,
-    zeros in the missing channels -- read by the stem's weight-gradient kernel only.  Cached on the tensor object (same guard
+    zeros in the missing channels -- read by the stem's window-forward and weight-gradient kernels.  Cached on the tensor object (same guard
     as ``_mcd_cb``): one MCD step back-propagates through the stem several times with the same batch."""
     rec = getattr(x, "_mcd_cbp", None)
     if rec is not None and rec[2] == x._version and rec[3] == x.data_ptr() and rec[4] == CONV_MATH:
@@ -602,7 +604,13 @@ class _ConvBNAct(torch.autograd.Function):
             x = _req(x, "conv input")
         if _is_split(wf) and _scaled():
             x_bound = _bound_or_measure(x, x_bound)
-        z, part, rows = _conv_fprop(desc, x, wf, _req(conv_bias, "conv bias"), training, mpf, x_cb, x_bound, w_bound)
+        f_cb = x_cb
+        if (STEM_WINDOW and _is_split(wf) and x_cb is None and conv_bias is None and PRESPLIT and desc.Cin % 8 != 0 and not x_virtual
+                and len(_batch_pieces(desc)) == 1 and L.mcdseg_conv_split_window_ok(ctypes.byref(desc), MATH_ID[CONV_MATH], 1, 0)):
+            # the stem: forward on the LDS-window kernel from the zero-padded companion of the network input (cached on the
+            # tensor: the same batch goes through the stem several times per MCD step, forward and weight gradient)
+            f_cb, x_bound = split_companion_padded(x, x_bound)
+        z, part, rows = _conv_fprop(desc, x, wf, _req(conv_bias, "conv bias"), training, mpf, f_cb, x_bound, w_bound)
         c = desc.Cout
         hw = desc.Ho * desc.Wo
         mean = torch.empty(c, dtype=torch.float32, device=z.device)

@@ -822,6 +822,56 @@ def test_thin_layer_window_kernels(cout, stride, h, w, n, monkeypatch):
     _assert_close(dx_w, gx_ref, 2e-5, "dgrad from the companion (window kernel where it applies)")
 
 
+@pytest.mark.parametrize("cin,h,w,n", [(6, 37, 70, 2), (3, 16, 33, 1), (6, 64, 96, 3)])
+def test_stem_forward_on_the_window_kernel(cin, h, w, n, monkeypatch):
+    """The 7x7 stem (3 / 6 -> 16 channels) on the LDS-window kernel from the zero-padded 8-channel companion of the network
+    input: against fp64, against the direct bf16x6 stem kernel, statistics against the output's moments, and the fused group
+    (ops.conv_bn_act) takes it -- same outputs and gradients as with the direct kernel within the arithmetic's tolerance."""
+    dev = _dev()
+    import ctypes
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "CONV_MATH", "f16x3")
+    x, wt, _, s, pad, d = _conv_inputs((cin, 16, 7, 1, 3, h, w, n, False), 43)
+    desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
+    L = ops.lib()
+    assert L.mcdseg_conv_split_window_ok(ctypes.byref(desc), ops.MATH_ID["f16x3"], 1, 0) == 1
+    assert L.mcdseg_conv_split_window_ok(ctypes.byref(desc), ops.MATH_ID["f16x3"], 0, 0) == 0
+    ref = F.conv2d(x.double(), wt.double(), None, stride=s, padding=pad, dilation=d)
+    xg = x.to(dev)
+    pk = ops.PackedWeights()
+    wf, wd, mpf = pk.get(wt.to(dev), desc)
+    x_cb, x_bound = ops.split_companion_padded(xg)
+    y_w, part, rows = ops._conv_fprop(desc, xg, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)
+    y_d, part_d, rows_d = ops._conv_fprop(desc, xg, wf, None, True, mpf, None, None, pk.w_bound)
+    _assert_close(y_w, ref, 2e-5, "stem window forward")
+    _assert_close(y_d, ref, 2e-5, "stem direct forward (image behind the standard one)")
+    mean = torch.empty(16, device=dev)
+    rstd = torch.empty(16, device=dev)
+    ws = torch.empty(L.mcdseg_bn_stats_workspace_bytes(rows, 16) // 8 + 1, dtype=torch.float64, device=dev)
+    ops.check(L.mcdseg_bn_stats_finalize(ops._p(part), rows, 16, mpf, ops._p(mean), ops._p(rstd), None, None, None, 0.1, 1e-5,
+                                         None, None, None, None, ops._p(ws), ctypes.c_size_t(ws.numel() * 8), ops._stream()),
+              "bn_stats_finalize")
+    assert float((mean.double().cpu() - ref.mean((0, 2, 3))).abs().max()) <= 1e-5 * float(ref.std())
+    _assert_close(rstd, (ref.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt(), 1e-5, "fused BN rstd (stem window kernel)")
+
+    # the fused group: window kernel by default, direct kernel with the knob off
+    conv = torch.nn.Conv2d(cin, 16, 7, 1, 3, bias=False).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(wt)
+    bn = torch.nn.BatchNorm2d(16).to(dev)
+    conv._packed = ops.PackedWeights()
+    gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(44)).to(dev)
+    outs = []
+    for window in (True, False):
+        monkeypatch.setattr(ops, "STEM_WINDOW", window)
+        conv.weight.grad = None
+        y = ops.conv_bn_act(xg.clone(), conv, bn, relu=True)
+        y.backward(gy)
+        outs.append((y.detach().clone(), conv.weight.grad.clone()))
+    _assert_close(outs[0][0], outs[1][0], 2e-5, "fused group output, window vs direct stem")
+    _assert_close(outs[0][1], outs[1][1], 1e-4, "stem weight gradient, window vs direct stem forward")
+
+
 def test_conv_nonfinite_operands():
     """Contract of the split-precision convolutions for non-finite data: an output that a NaN / inf operand reaches is
     non-finite (an fp32 FMA chain would give +-inf where the split gives NaN: inf - inf in the remainder), every other output

@@ -89,7 +89,8 @@ def main():
         elif ops.CONV_MATH == "f16x3" and cin % 8 != 0 and ops._wgrad_thin_tr(desc):  # the stem: padded input companion
             (x_cb, _), (gy_cb, _) = ops.split_companion_padded(x, xb), ops.split_companion(gy, gb)
             tw2 = timeit(lambda: ops._conv_wgrad(desc, x, gy, x_cb, gy_cb, xb, gb), args.reps)
-            extra = " | pre-split: wgrad %.3f ms %.1f TF" % (tw2, gf / tw2)
+            tf2 = timeit(lambda: ops._conv_fprop(desc, x, wf, None, True, mpf, x_cb, xb, wb), args.reps)
+            extra = " | pre-split: fprop %.3f ms %.1f TF, wgrad %.3f ms %.1f TF" % (tf2, gf / tf2, tw2, gf / tw2)
         tot["fprop"] += tf * cnt
         tot["dgrad"] += td * cnt
         tot["wgrad"] += tw * cnt
