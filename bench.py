@@ -110,6 +110,8 @@ def build_hip(args, dev):
     w = torch.ones(args.n_class)
     w[args.n_class - 1] = 0
     solver = MCDSolver(g, f1, f2, og, of, CrossEntropyLoss2d(w.to(dev)), get_prob_distance_criterion("diff"), num_k=4)
+    if args.no_forward_reuse:
+        solver.reuse_tgt = False
     return solver, (g, f1, f2)
 
 
@@ -269,6 +271,9 @@ def main():
     ap.add_argument("--cpu_steps", type=int, default=3, help="timed CPU-oracle steps after one warm-up (fewer if the budget runs out)")
     ap.add_argument("--cpu_budget_s", type=float, default=150.0)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_forward_reuse", action="store_true",
+                    help="literal schedule of adapt_trainer.py: step B's target forward and step C's first one run separately "
+                         "(7 generator forwards per step instead of 6; same weights, statistics and losses bit for bit)")
     ap.add_argument("--timer", choices=sorted(TIMED_FAMILIES), default="all", help="kernel families bracketed by HIP events")
     ap.add_argument("--timer_steps", type=int, default=2,
                     help="how many of the timed steps (the last ones) carry the per-launch HIP events: bracketing all ~1 500 launches "
@@ -343,7 +348,8 @@ def main():
         # whole-step accounting on the algorithmic work of SURVEY.md 8d (drn_d_38 @ 6x480x640 only)
         step_acc = None
         if args.net == "drn_d_38" and (args.height, args.width, args.input_ch) == (480, 640, 6):
-            fwd_p, bwd_p = 7, 5  # passes actually executed per pair (step-B generator backward elided)
+            # passes actually executed per pair: step B's two generator backward passes elided; its target forward is step C's first
+            fwd_p, bwd_p = (6 if solver.reuse_tgt else 7), 5
             gf = GF_FWD_PER_IMG * (fwd_p + 2 * bwd_p)
             gb = GB_FWD_PER_IMG * fwd_p + GB_BWD_PER_IMG * bwd_p
             t_pair = elapsed / (args.batch * args.steps)
@@ -368,7 +374,13 @@ def main():
                                    % (args.net, args.input_ch, args.batch, args.height, args.width),
                        "pairs_per_gpu": args.batch, "global_pairs": args.batch * world, "parallelism": "dp%d" % world,
                        "n_class": args.n_class, "conv_math": ops.CONV_MATH, "c_loss": c_loss, "d_loss": d_loss, "timer": args.timer,
-                       "timer_steps": min(args.steps, args.timer_steps)},
+                       "timer_steps": min(args.steps, args.timer_steps),
+                       "schedule": "the reference's A+B+C statements with the results-neutral elisions of solvers/solver.py: no generator "
+                                   "backward in step B (its gradients are zeroed unused)" + (
+                                       "; step B's target forward doubles as step C's first (generator unchanged in between; BatchNorm "
+                                       "running update applied twice) -- %d generator forwards + 5 backwards per step, bit-identical "
+                                       "weights/statistics/losses to the literal 7-forward schedule (--no_forward_reuse runs that)"
+                                       % 6 if solver.reuse_tgt else "; literal 7 generator forwards + 5 backwards per step")},
             "roofline": roofline,
             "roofline_forward": roofline_fwd,
             "step_accounting": step_acc,

@@ -15,15 +15,47 @@ result:
   * step B never back-propagates through G: only ``optimizer_f.step()`` follows and the generator
     gradients are zeroed before any use (adapt_trainer.py:187-205), so G runs without saving
     activations there -- its BatchNorm running statistics still move on every forward (7 per step);
+  * step B's generator forward on the target batch IS step C's first one: the generator does not change in between
+    (only ``optimizer_f.step()`` runs), so the reference computes the same features twice (adapt_trainer.py:196 and :209).
+    Here that forward runs once, with its tape, and each of its BatchNorm layers applies the running-statistics update twice
+    (``ops.bn_running_updates``) -- weights, losses and running statistics are bit for bit those of the literal schedule
+    (``MCDSEG_REUSE_TARGET_FORWARD=0`` or ``solver.reuse_tgt = False`` runs that one: 7 generator forwards instead of 6);
+    switched off by itself when a generator holds dropout or a BatchNorm that does not run through the fused groups;
   * step C does not form the (unused) classifier weight gradients;
   * when both classifiers are the bare x8 up-sampler (``DRNSegPixelClassifier`` ver1 -- the MCD configuration), the loss
     kernel forms their logits on the fly from the generator's score map (``mcdseg.ops.up8_mcd_losses``): the two
     full-resolution logit tensors are never written or read.  Logits, losses and gradients are those of the two-pass form
     (bit for bit, up to the order of the loss's block partial sums).
 """
+import os
+
 import torch
 
 from mcdseg import ops
+
+REUSE_TARGET_FORWARD = os.environ.get("MCDSEG_REUSE_TARGET_FORWARD", "1") != "0"
+
+
+def _detached(t):
+    """``t.detach()`` that keeps the pre-split companion the producer attached (same storage, same version counter)"""
+    d = t.detach()
+    for a in ("_mcd_cb", "_mcd_virtual"):
+        if hasattr(t, a):
+            setattr(d, a, getattr(t, a))
+    return d
+
+
+def _forward_is_repeatable(modules):
+    """two forwards of these modules on one batch give the same features, and every BatchNorm in them honours
+    ``ops.bn_running_updates``: no dropout, and no BatchNorm that runs outside the fused conv+BN groups"""
+    from models.drn import BatchNorm2d
+    for g in modules:
+        for m in g.modules():
+            if isinstance(m, torch.nn.modules.dropout._DropoutNd) and m.p > 0:
+                return False
+            if isinstance(m, torch.nn.modules.batchnorm._NormBase) and not isinstance(m, BatchNorm2d):
+                return False
+    return True
 
 
 def _params(modules):
@@ -65,6 +97,7 @@ class MCDSolver:
             raise NotImplementedError("the fused solver implements d_loss='diff' (loss.py:93-100)")
         self.num_k = num_k
         self.mult = float(num_multiply_d_loss)
+        self.reuse_tgt = REUSE_TARGET_FORWARD  # step B's target forward doubles as step C's first (see the module docstring)
         self.fused_up = (self.prob_criterion is None and ops.FUSED_UP_LOSS
                          and all(type(f).__name__ == "DRNSegPixelClassifier" and getattr(f, "ver", None) == "ver1"
                                  and type(getattr(f, "up", None)).__name__ == "Up8" for f in (model_f1, model_f2)))
@@ -133,8 +166,14 @@ class MCDSolver:
         with torch.no_grad():
             feats = self._features(src_imgs)
         self._loss_backward(feats, src_lbls, ce_coef=1.0)
-        with torch.no_grad():
-            feats = self._features(tgt_imgs)
+        taped = None
+        if self.reuse_tgt and self.num_k > 0 and _forward_is_repeatable(self._generators()):
+            with ops.bn_running_updates(2):  # this forward is also the first one of step C
+                taped = self._features(tgt_imgs)
+            feats = tuple(_detached(f) for f in taped)
+        else:
+            with torch.no_grad():
+                feats = self._features(tgt_imgs)
         self._loss_backward(feats, None, diff_coef=-1.0)
         del feats
         self.opt_f.step()
@@ -143,9 +182,12 @@ class MCDSolver:
         # ---- C: generator only, num_k times
         d_last = None
         with _frozen(_params([self.f1, self.f2])):
-            for _ in range(self.num_k):
+            for k in range(self.num_k):
                 self.opt_g.zero_grad()
-                losses = self._loss_backward(self._features(tgt_imgs), None, diff_coef=self.mult)
+                feats = taped if (k == 0 and taped is not None) else self._features(tgt_imgs)
+                taped = None
+                losses = self._loss_backward(feats, None, diff_coef=self.mult)
+                del feats
                 d_last = losses[2] * self.mult
                 self.opt_g.step()
         d_loss = d_last / self.num_k  # only the last inner loss is logged (adapt_trainer.py:214)

@@ -296,6 +296,47 @@ def test_solver_fused_up_loss_is_bitwise_the_two_pass_step(golden, monkeypatch):
         assert abs(c0 - c1) <= 1e-6 * abs(c1) and abs(d0 - d1) <= 1e-6 * abs(d1)
 
 
+def test_solver_target_forward_reuse_is_bitwise_the_literal_schedule(golden):
+    """Step B's generator forward on the target batch doubling as step C's first one (solvers/solver.py; each BatchNorm applies
+    its running update twice) against the literal schedule of adapt_trainer.py:196/:209 (7 generator forwards): every
+    parameter, running statistic, num_batches_tracked and logged loss after three A/B/C iterations is bit-identical.  A
+    generator holding dropout switches the reuse off by itself."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, get_prob_distance_criterion
+    from mcdseg import ops
+    from models.model_util import get_optimizer
+    from solvers import solver as S
+    tr = golden.json("traces.json")["mcd_small"]
+    n, ch, h, w = tr["shape"]
+    s, l, t = (v.to(dev) for v in make_batch(tr["seed_batch"], n, ch, h, w, NC))
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    states, losses, forwards = [], [], []
+    for reuse in (True, False):
+        g, f1, f2 = _mcd_models(dev)
+        og = get_optimizer(g.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+        of = get_optimizer(list(f1.parameters()) + list(f2.parameters()), "sgd", 1e-3, 0.9, 2e-5)
+        solver = S.MCDSolver(g, f1, f2, og, of, CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff"), num_k=4)
+        solver.reuse_tgt = reuse
+        count = [0]
+        hook = g.register_forward_hook(lambda *a: count.__setitem__(0, count[0] + 1))
+        out = [solver.step(s, l, t) for _ in range(3)]
+        hook.remove()
+        forwards.append(count[0])
+        losses.append([(float(a), float(b)) for a, b in out])
+        states.append({k: v.clone() for m in (g, f1, f2) for k, v in m.state_dict().items()})
+    assert forwards == [18, 21]
+    assert ops.BN_RUNNING_REPEAT == 1
+    assert any(k.endswith("num_batches_tracked") and int(v) == 21 for k, v in states[0].items())
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
+    assert losses[0] == losses[1]
+    g, f1, f2 = _mcd_models(dev)
+    assert S._forward_is_repeatable([g])
+    g.add_module("drop", torch.nn.Dropout2d(0.1))
+    assert not S._forward_is_repeatable([g])
+
+
 def test_training_on_a_fixed_batch_reduces_the_source_loss():
     """End-to-end sanity of the whole update path over many steps (weights, BN statistics and the per-tensor fp16 scales all
     move): 40 MCD steps on one fixed batch drive the source cross-entropy down and keep every parameter finite."""
