@@ -37,7 +37,10 @@ REUSE_TARGET_FORWARD = os.environ.get("MCDSEG_REUSE_TARGET_FORWARD", "1") != "0"
 
 
 def _detached(t):
-    """``t.detach()`` that keeps the pre-split companion the producer attached (same storage, same version counter)"""
+    """``t.detach()`` that keeps the pre-split companion the producer attached (same storage, same version counter); maps over
+    tuples / lists of tensors"""
+    if isinstance(t, (tuple, list)):
+        return type(t)(_detached(v) for v in t)
     d = t.detach()
     for a in ("_mcd_cb", "_mcd_virtual"):
         if hasattr(t, a):
@@ -222,12 +225,14 @@ class MultiTaskMCDSolver:
 
     Elisions that change no result: step B only steps the decoder optimizer, so the encoder runs there without a
     tape; the ``semseg_forward(src_fet)`` whose result the reference throws away (``:208``) still runs -- it moves
-    the BatchNorm running statistics of both segmentation decoders -- but builds no graph."""
+    the BatchNorm running statistics of both segmentation decoders -- but builds no graph; step B's encoder forward on the
+    target batch is step C's first one (see the module docstring; ``reuse_tgt``)."""
 
     def __init__(self, model_enc, model_dec, optimizer_enc, optimizer_dec, num_k=4, num_multiply_d_loss=1):
         self.enc, self.dec = model_enc, model_dec
         self.opt_enc, self.opt_dec = optimizer_enc, optimizer_dec
         self.num_k, self.mult = num_k, num_multiply_d_loss
+        self.reuse_tgt = REUSE_TARGET_FORWARD
 
     def step(self, src_imgs, src_gt_semseg, tgt_imgs):
         enc, dec = self.enc, self.dec
@@ -252,8 +257,14 @@ class MultiTaskMCDSolver:
             src_fet = enc(src_rgbs)
             dec.semseg_forward(src_fet)
         src_semseg_loss, src_depth_loss = dec.get_loss(src_fet, src_gt_semseg, src_depths, separately_returning=True)
-        with torch.no_grad():
-            tgt_fet = enc(tgt_rgbs)
+        taped = None
+        if self.reuse_tgt and self.num_k > 0 and _forward_is_repeatable([enc]):
+            with ops.bn_running_updates(2):  # this forward is also the first one of step C
+                taped = enc(tgt_rgbs)
+            tgt_fet = _detached(taped)
+        else:
+            with torch.no_grad():
+                tgt_fet = enc(tgt_rgbs)
         tgt_depth_loss = dec.get_depth_loss(tgt_fet, tgt_depths)
         tgt_discrepancy = dec.get_cls_descrepancy(tgt_fet)
         loss = src_semseg_loss + src_depth_loss + tgt_depth_loss - tgt_discrepancy
@@ -261,9 +272,10 @@ class MultiTaskMCDSolver:
         self.opt_dec.step()
         parts = (src_semseg_loss.detach(), src_depth_loss.detach(), tgt_depth_loss.detach())
 
-        for _ in range(self.num_k):
+        for k in range(self.num_k):
             self.opt_enc.zero_grad()
-            tgt_fet = enc(tgt_rgbs)
+            tgt_fet = taped if (k == 0 and taped is not None) else enc(tgt_rgbs)
+            taped = None
             loss = dec.get_cls_descrepancy(tgt_fet) * self.mult
             loss.backward()
             self.opt_enc.step()

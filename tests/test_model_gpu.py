@@ -687,6 +687,36 @@ def test_multitask_cfg4_vs_reference(golden):
     assert int(sd["semsegcls_dec1.cbr1.bn.num_batches_tracked"]) == 8 and int(sd["deprgr_dec.cbr1.bn.num_batches_tracked"]) == 4
 
 
+def test_multitask_target_forward_reuse_is_bitwise(golden):
+    """MultiTaskMCDSolver: step B's encoder forward on the target batch doubling as step C's first one against the literal
+    schedule of adapt_multitask_trainer.py:166-239 -- every parameter, buffer and returned loss is bit-identical."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, Diff2d
+    from models.model_util import get_multitask_models, get_optimizer
+    from solvers.solver import MultiTaskMCDSolver
+    tr = golden.json("traces.json")["multitask_small"]
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    n, ch, h, w = tr["shape"]
+    s, l, t = (v.to(dev) for v in make_batch(tr["seed_batch"], n, ch, h, w, NC))
+    states, outs = [], []
+    for reuse in (True, False):
+        enc, dec = get_multitask_models("drn_d_38", 6, NC, CrossEntropyLoss2d(cw), Diff2d())
+        fill_state_(enc, 81), fill_state_(dec, 82)
+        enc.to(dev).train(), dec.to(dev).train()
+        oe = get_optimizer(enc.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+        od = get_optimizer(dec.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+        solver = MultiTaskMCDSolver(enc, dec, oe, od, num_k=4)
+        solver.reuse_tgt = reuse
+        res = [solver.step(s, l, t) for _ in range(2)]
+        outs.append([(float(c), float(d)) + tuple(float(p) for p in parts) for c, d, parts in res])
+        states.append({("enc." if m is enc else "dec.") + k: v.clone() for m in (enc, dec) for k, v in m.state_dict().items()})
+    assert outs[0] == outs[1]
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
+    assert int(states[0]["enc.base.0.1.num_batches_tracked"]) == 16
+
+
 @pytest.mark.parametrize("net,method", [("drn_d_38_ver2", "MCD"), ("drn_d_38", "MFNet-AddFusion"), ("drn_d_22", "MCD")])
 def test_model_variants_vs_oracle(net, method):
     """ver2 (1x1 ``seg`` head inside F, models/dilated_fcn.py:240-241, 346-351), feature-level AddFusion
