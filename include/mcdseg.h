@@ -217,6 +217,13 @@ int mcdseg_up8_bwd_input(const float* dy, const float* w, float* dx, int32_t N, 
 size_t mcdseg_up8_bwd_weight_workspace_bytes(int32_t N, int32_t C, int32_t Hi, int32_t Wi);
 int mcdseg_up8_bwd_weight(const float* dy, const float* x, float* dw, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* Both backward passes of the up-sampler (either may be skipped: dx == NULL or dw == NULL) from ONE staged read of dy -- the
+ * backward of DRNSegPixelClassifier.up (models/dilated_fcn.py:357-366) as autograd runs it in adapt_trainer.py:172-212.  Same
+ * results as mcdseg_up8_bwd_input / mcdseg_up8_bwd_weight up to the order of the fp32 sums; falls back to those two kernels
+ * when a dy row band does not fit the LDS ring (Wi > 192). */
+size_t mcdseg_up8_bwd_workspace_bytes(int32_t N, int32_t C, int32_t Hi, int32_t Wi);
+int mcdseg_up8_bwd(const float* dy, const float* w, const float* x, float* dx, float* dw, int32_t N, int32_t C, int32_t Hi,
+                   int32_t Wi, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused per-pixel softmax -> weighted CE (both heads) -> L1 discrepancy, forward + gradient

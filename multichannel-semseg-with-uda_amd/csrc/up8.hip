@@ -144,6 +144,140 @@ __global__ void up8_bwd_weight_reduce_kernel(const float* __restrict__ part, flo
   dw[i] = (float)s;
 }
 
+// ---- both backward passes from ONE staged read of the logit gradient -------------------------------------------------------
+// The two kernels above read every dy value from L1/L2 two (weights) to four (input) times through 16- or 4-byte accesses of
+// overlapping windows and reach 0.2-0.3 of the HBM rate.  Here a workgroup owns a band of input rows of one (n, c) plane and
+// walks it row by row over a ring of three LDS slots, each holding 8 rows of dy (chunk k = rows 8k-4 .. 8k+3; input row iy
+// reads chunks iy and iy+1), filled by LDS-DMA two rows ahead; rows outside the plane are zero-filled by the buffer
+// resource's range check.  LDS row stride = whole 1 KB DMA units + 64 B, i.e. = 16 banks mod 64: the weight-gradient access
+// (lane = tap (ky, kx): 4 rows x 16 consecutive floats per wave) and the input-gradient access (consecutive lanes read
+// consecutive float4) are both conflict-free.  dx: item = (ix, quarter v4 of the 16 kernel columns), 16 float4 reads x the
+// thread's 16 weight float4 in registers, quad sum.  dw: thread = tap, x[iy][ix] is wave-uniform (scalar loads).
+constexpr unsigned UB_OOB = 0x80000000u;
+
+struct Up8BandParams {
+  int N, C, Hi, Wi, bands, rows_per_band;
+  int row_insts, row_stride;  // 1 KB DMA units per dy row; LDS row stride in bytes
+};
+
+template <bool DX, bool DW>
+__global__ __launch_bounds__(256) void up8_bwd_band_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                           const float* __restrict__ x, float* __restrict__ dx,
+                                                           float* __restrict__ part, Up8BandParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ub_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int plane = blockIdx.x, band = blockIdx.y;
+  const int c = plane % p.C, n = plane / p.C;
+  const int Wi = p.Wi, Hi = p.Hi, Wo = 8 * Wi, Ho = 8 * Hi;
+  const int iy0 = band * p.rows_per_band;
+  const int iy1 = iy0 + p.rows_per_band < Hi ? iy0 + p.rows_per_band : Hi;
+  const int slot_bytes = 8 * p.row_stride;
+  const float* g = dy + (size_t)plane * Ho * Wo;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, Ho * Wo * 4, 0x00020000);
+  const int chunk_insts = 8 * p.row_insts;
+  const int row_bytes = 4 * Wo;
+
+  auto issue = [&](int k) {  // chunk k -> slot k % 3
+    unsigned char* slot = ub_smem + (k % 3) * slot_bytes;
+    for (int q = wave; q < chunk_insts; q += 4) {  // wave-uniform
+      const int r = q / p.row_insts, j = q - r * p.row_insts;
+      const int oy = 8 * k - 4 + r;
+      const int cb = j * 1024 + lane * 16;
+      const unsigned voff = ((unsigned)oy < (unsigned)Ho && cb < row_bytes) ? (unsigned)(oy * row_bytes + cb) : UB_OOB;
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(slot + r * p.row_stride + j * 1024), 16, voff,
+                                               0, 0, 0);
+#else
+      (void)voff; (void)slot;
+#endif
+    }
+  };
+
+  // dx: this thread's quarter of the kernel columns
+  const int v4 = tid & 3;
+  float4 wq[16];
+  if (DX) {
+#pragma unroll
+    for (int ky = 0; ky < 16; ++ky) wq[ky] = *reinterpret_cast<const float4*>(w + c * 256 + ky * 16 + 4 * v4);
+  }
+  // dw: this thread's tap
+  const int ky_t = tid >> 4, kx_t = tid & 15;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* xin = DW ? x + (size_t)plane * Hi * Wi : nullptr;
+
+  issue(iy0);
+  issue(iy0 + 1);
+  for (int iy = iy0; iy < iy1; ++iy) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // chunks iy, iy+1 are in LDS; every wave is done with row iy-1, whose older slot is refilled now
+    if (iy + 1 < iy1) issue(iy + 2);
+    const unsigned char* sa = ub_smem + (iy % 3) * slot_bytes;
+    const unsigned char* sb = ub_smem + ((iy + 1) % 3) * slot_bytes;
+    if (DX) {
+      for (int item = tid; item < 4 * Wi; item += 256) {
+        const int ix = item >> 2;
+        const int colb = (8 * ix - 4 + 4 * v4) * 4;
+        const bool ok = !((ix == 0 && v4 == 0) || (ix == Wi - 1 && v4 == 3));
+        float a = 0.f;
+        if (ok) {
+#pragma unroll
+          for (int ky = 0; ky < 16; ++ky) {
+            const float4 gv = *reinterpret_cast<const float4*>((ky < 8 ? sa : sb) + (ky & 7) * p.row_stride + colb);
+            a = fmaf(gv.x, wq[ky].x, a); a = fmaf(gv.y, wq[ky].y, a); a = fmaf(gv.z, wq[ky].z, a); a = fmaf(gv.w, wq[ky].w, a);
+          }
+        }
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        if (v4 == 0) dx[((size_t)plane * Hi + iy) * Wi + ix] = a;
+      }
+    }
+    if (DW) {
+      const unsigned char* row = (ky_t < 8 ? sa : sb) + (ky_t & 7) * p.row_stride + (kx_t - 4) * 4;
+      const float* xr = xin + iy * Wi;
+      {  // first and last input column: part of the window lies outside the row
+        const float g0 = (kx_t >= 4 && (Wi > 1 || kx_t < 12)) ? *reinterpret_cast<const float*>(row) : 0.f;
+        acc[0] = fmaf(xr[0], g0, acc[0]);
+        if (Wi > 1) {
+          const float g1 = kx_t < 12 ? *reinterpret_cast<const float*>(row + 32 * (Wi - 1)) : 0.f;
+          acc[1] = fmaf(xr[Wi - 1], g1, acc[1]);
+        }
+      }
+      int ix = 1;
+      for (; ix + 4 <= Wi - 1; ix += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(xr[ix + j], *reinterpret_cast<const float*>(row + 32 * (ix + j)), acc[j]);
+      }
+      for (; ix < Wi - 1; ++ix) acc[0] = fmaf(xr[ix], *reinterpret_cast<const float*>(row + 32 * ix), acc[0]);
+    }
+  }
+  if (DW) part[((size_t)(n * p.bands + band) * p.C + c) * 256 + tid] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+struct Up8BandPlan {
+  bool ok;
+  int rows_per_band, bands, row_insts, row_stride, lds;
+};
+
+Up8BandPlan up8_band_plan(int N, int C, int Hi, int Wi) {
+  Up8BandPlan pl{};
+  static const int knob = [] {
+    const char* e = getenv("MCDSEG_UP8_BAND_ROWS");  // development knob: 0 = the two separate kernels, n = rows per band
+    return e ? atoi(e) : -1;
+  }();
+  if (knob == 0) return pl;
+  pl.row_insts = ceil_div(32 * Wi, 1024);
+  pl.row_stride = pl.row_insts * 1024 + 64;
+  pl.lds = 3 * 8 * pl.row_stride;
+  if (pl.lds > 160 * 1024 - 1024 || (int64_t)Hi * Wi * 256 >= (1ll << 31)) return pl;
+  pl.rows_per_band = knob > 0 ? knob : (Hi >= 20 ? 10 : Hi);
+  if (pl.rows_per_band > Hi) pl.rows_per_band = Hi;
+  pl.bands = ceil_div(Hi, pl.rows_per_band);
+  if (pl.bands > 65535 || (int64_t)N * C >= (1ll << 31)) return pl;
+  pl.ok = true;
+  return pl;
+}
+
 int bands_for(int N, int C, int Hi) {
   int bands = ceil_div(2048, N * C);
   if (bands < 1) bands = 1;
@@ -199,5 +333,55 @@ extern "C" int mcdseg_up8_bwd_weight(const float* dy, const float* x, float* dw,
   hipLaunchKernelGGL(up8_bwd_weight_reduce_kernel, dim3(ceil_div(C * 256, 256)), dim3(256), 0, st, (const float*)workspace, dw, C,
                      N * bands);
   MCD_LAUNCH_CHECK("up8_bwd_weight_reduce");
+  return 0;
+}
+
+extern "C" size_t mcdseg_up8_bwd_workspace_bytes(int32_t N, int32_t C, int32_t Hi, int32_t Wi) {
+  if (N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0) return 0;
+  const Up8BandPlan pl = up8_band_plan(N, C, Hi, Wi);
+  const size_t two = mcdseg_up8_bwd_weight_workspace_bytes(N, C, Hi, Wi);
+  const size_t one = pl.ok ? (size_t)N * pl.bands * C * 256 * sizeof(float) : 0;
+  return one > two ? one : two;
+}
+
+extern "C" int mcdseg_up8_bwd(const float* dy, const float* w, const float* x, float* dx, float* dw, int32_t N, int32_t C, int32_t Hi,
+                              int32_t Wi, void* workspace, size_t workspace_bytes, void* stream) {
+  MCD_REQUIRE(dy && (dx || dw), "up8_bwd: null pointer");
+  MCD_REQUIRE((dx == nullptr || w != nullptr) && (dw == nullptr || (x != nullptr && workspace != nullptr)),
+              "up8_bwd: the input gradient needs w, the weight gradient needs x and a workspace");
+  MCD_REQUIRE(N > 0 && C > 0 && Hi > 0 && Wi > 0, "up8_bwd: bad dims");
+  const Up8BandPlan pl = up8_band_plan(N, C, Hi, Wi);
+  if (!pl.ok) {  // wider than the LDS ring allows: the two separate kernels
+    if (dx)
+      if (int rc = mcdseg_up8_bwd_input(dy, w, dx, N, C, Hi, Wi, stream)) return rc;
+    if (dw)
+      if (int rc = mcdseg_up8_bwd_weight(dy, x, dw, N, C, Hi, Wi, workspace, workspace_bytes, stream)) return rc;
+    return 0;
+  }
+  MCD_REQUIRE(dw == nullptr || workspace_bytes >= (size_t)N * pl.bands * C * 256 * sizeof(float), "up8_bwd: workspace too small");
+  Up8BandParams p;
+  p.N = N; p.C = C; p.Hi = Hi; p.Wi = Wi; p.bands = pl.bands; p.rows_per_band = pl.rows_per_band;
+  p.row_insts = pl.row_insts; p.row_stride = pl.row_stride;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(N * C, pl.bands), block(256);
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute((const void*)up8_bwd_band_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)up8_bwd_band_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)up8_bwd_band_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();
+  (void)attr;
+  if (dx && dw)
+    hipLaunchKernelGGL((up8_bwd_band_kernel<true, true>), grid, block, pl.lds, st, dy, w, x, dx, (float*)workspace, p);
+  else if (dx)
+    hipLaunchKernelGGL((up8_bwd_band_kernel<true, false>), grid, block, pl.lds, st, dy, w, x, dx, (float*)workspace, p);
+  else
+    hipLaunchKernelGGL((up8_bwd_band_kernel<false, true>), grid, block, pl.lds, st, dy, w, x, dx, (float*)workspace, p);
+  MCD_LAUNCH_CHECK("up8_bwd");
+  if (dw) {
+    hipLaunchKernelGGL(up8_bwd_weight_reduce_kernel, dim3(ceil_div(C * 256, 256)), dim3(256), 0, st, (const float*)workspace, dw, C,
+                       N * pl.bands);
+    MCD_LAUNCH_CHECK("up8_bwd_weight_reduce");
+  }
   return 0;
 }

@@ -70,6 +70,8 @@ _SIGNATURES = {
     "mcdseg_up8_bwd_input": (c_int, [c_void_p] * 3 + [c_i32] * 4 + [c_void_p]),
     "mcdseg_up8_bwd_weight_workspace_bytes": (c_size_t, [c_i32] * 4),
     "mcdseg_up8_bwd_weight": (c_int, [c_void_p] * 3 + [c_i32] * 4 + [c_void_p, c_size_t, c_void_p]),
+    "mcdseg_up8_bwd_workspace_bytes": (c_size_t, [c_i32] * 4),
+    "mcdseg_up8_bwd": (c_int, [c_void_p] * 5 + [c_i32] * 4 + [c_void_p, c_size_t, c_void_p]),
     "mcdseg_loss_workspace_bytes": (c_size_t, [c_i32, c_i32]),
     "mcdseg_softmax_ce_l1": (c_int, [c_void_p] * 4 + [c_i64, c_float, c_float] + [c_void_p] * 4 + [c_i32] * 3 +
                              [c_void_p, c_size_t, c_void_p]),

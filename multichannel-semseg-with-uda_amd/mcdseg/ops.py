@@ -896,6 +896,22 @@ def _up8_bwd_weight(dy, x, n, c, hi, wi):
     return dw
 
 
+def _up8_bwd(dy, w, x, want_dx, want_dw):
+    """(dx, dw) of the up-sampler from one staged read of ``dy`` (csrc/up8.hip: up8_bwd_band_kernel); either may be skipped"""
+    if not (want_dx or want_dw):
+        return None, None
+    L = lib()
+    n, c, hi, wi = x.shape
+    dx = torch.empty((n, c, hi, wi), dtype=torch.float32, device=dy.device) if want_dx else None
+    dw = torch.empty((c, 1, 16, 16), dtype=torch.float32, device=dy.device) if want_dw else None
+    ws = _ws(L.mcdseg_up8_bwd_workspace_bytes(n, c, hi, wi), dy.device) if want_dw else None
+    name = "up8_bwd_band_kernel<%s, %s>" % ("true" if want_dx else "false", "true" if want_dw else "false")
+    with _timed(name, (0, 4 * n * c * hi * wi * (64 + int(want_dx) + int(want_dw)))):
+        check(L.mcdseg_up8_bwd(_p(dy), _p(w), _p(x), _p(dx), _p(dw), n, c, hi, wi, _p(ws),
+                               ctypes.c_size_t(ws.numel() * 4 if ws is not None else 0), _stream()), "up8_bwd")
+    return dx, dw
+
+
 def _check_up(x, w):
     if x.dim() != 4 or tuple(w.shape) != (x.shape[1], 1, 16, 16):
         raise ValueError("mcdseg: up8 expects x [N,C,H,W] and w [C,1,16,16], got %s / %s" % (tuple(x.shape), tuple(w.shape)))
@@ -918,9 +934,7 @@ class _Up8(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy = _req(dy, "grad_output")
         n, c, hi, wi = x.shape
-        dx = _up8_bwd_input(dy, w, n, c, hi, wi) if ctx.needs_input_grad[0] else None
-        dw = _up8_bwd_weight(dy, x, n, c, hi, wi) if ctx.needs_input_grad[1] else None
-        return dx, dw
+        return _up8_bwd(dy, w, x, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
 
 
 class _Up8Dual(torch.autograd.Function):
@@ -945,8 +959,7 @@ class _Up8Dual(torch.autograd.Function):
         dy = _req(dy, "grad_output")
         n, c, hi, wi = x1.shape
         need = ctx.needs_input_grad
-        return (_up8_bwd_input(dy, w1, n, c, hi, wi) if need[0] else None, _up8_bwd_weight(dy, x1, n, c, hi, wi) if need[1] else None,
-                _up8_bwd_input(dy, w2, n, c, hi, wi) if need[2] else None, _up8_bwd_weight(dy, x2, n, c, hi, wi) if need[3] else None)
+        return _up8_bwd(dy, w1, x1, need[0], need[1]) + _up8_bwd(dy, w2, x2, need[2], need[3])
 
 
 def up8(x, w):
@@ -1103,9 +1116,7 @@ def up8_mcd_losses(s1, w1, s2, w2, labels, class_weight, ignore_index=-100, ce_c
 
 def up8_backward(g, s, w, want_input, want_weight):
     """(d/ds, d/dw) of the up-sampler for the logit gradient ``g`` (either may be skipped)."""
-    n, c, hi, wi = s.shape
-    return (_up8_bwd_input(g, w, n, c, hi, wi) if want_input else None,
-            _up8_bwd_weight(g, s, n, c, hi, wi) if want_weight else None)
+    return _up8_bwd(g, w, s, want_input, want_weight)
 
 
 def predict_labels(z1, z2=None, n_used=None):

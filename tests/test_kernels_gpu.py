@@ -234,6 +234,34 @@ def test_up8_fwd_bwd(shape):
         _assert_close(a, b, 2e-5, "up8_dual " + name)
 
 
+@pytest.mark.parametrize("shape", [(2, 41, 23, 80), (1, 3, 60, 37), (2, 4, 1, 1), (1, 2, 21, 160), (1, 1, 4, 200)])
+def test_up8_backward_band_kernel(shape):
+    """The single-pass backward of the up-sampler (mcdseg_up8_bwd: dy staged through an LDS ring, both gradients or either one)
+    against fp64 and against the two separate kernels: several row bands per plane (Hi >= 20), ragged last band, a row that is
+    not a whole number of DMA units, Wi = 1 (both window edges in one column), Wi = 200 (falls back to the two kernels)."""
+    dev = _dev()
+    from mcdseg import ops
+    n, c, hi, wi = shape
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(n, c, hi, wi, generator=g)
+    w = torch.randn(c, 1, 16, 16, generator=g) * 0.1
+    gy = torch.randn(n, c, 8 * hi, 8 * wi, generator=g)
+    x64, w64 = x.double().requires_grad_(), w.double().requires_grad_()
+    ref = F.conv_transpose2d(x64, w64, stride=8, padding=4, groups=c)
+    rx, rw = torch.autograd.grad(ref, [x64, w64], gy.double())
+    xg, wg, gg = x.to(dev), w.to(dev), gy.to(dev)
+    dx, dw = ops._up8_bwd(gg, wg, xg, True, True)
+    _assert_close(dx, rx, 2e-5, "band kernel dx")
+    _assert_close(dw, rw, 2e-5, "band kernel dw")
+    dx1, none = ops._up8_bwd(gg, wg, xg, True, False)
+    none2, dw1 = ops._up8_bwd(gg, wg, xg, False, True)
+    assert none is None and none2 is None
+    assert torch.equal(dx1, dx) and torch.equal(dw1, dw), "the one-gradient forms differ from the combined launch"
+    _assert_close(ops._up8_bwd_input(gg, wg, n, c, hi, wi), rx, 2e-5, "separate dx kernel")
+    _assert_close(ops._up8_bwd_weight(gg, xg, n, c, hi, wi), rw, 2e-5, "separate dw kernel")
+    assert ops._up8_bwd(gg, wg, xg, False, False) == (None, None)
+
+
 @pytest.mark.parametrize("shape", [(2, 41, 5, 7), (1, 12, 3, 20), (2, 20, 4, 33), (1, 41, 2, 80)])
 @pytest.mark.parametrize("mode", ["ce+diff", "diff", "ce-single", "shared-scores"])
 def test_up8_loss_fused_equals_two_pass(shape, mode):

@@ -112,6 +112,9 @@ def main():
         print("up8_bwd_input      %.3f ms  %.0f GB/s (read)" % (t, nb / t / 1e6))
         t = timeit(lambda: ops._up8_bwd_weight(z1, feat, n, c, 60, 80), args.reps)
         print("up8_bwd_weight     %.3f ms  %.0f GB/s (read)" % (t, nb / t / 1e6))
+        for dxw in ((True, True), (True, False), (False, True)):
+            t = timeit(lambda: ops._up8_bwd(z1, upw, feat, *dxw), args.reps)
+            print("up8_bwd dx=%d dw=%d  %.3f ms  %.0f GB/s (read)" % (dxw[0], dxw[1], t, nb / t / 1e6))
         t = timeit(lambda: ops.mcd_losses(z1, z2, lab, cw, ce_coef=1.0, diff_coef=-1.0), args.reps)
         print("softmax_ce_l1      %.3f ms  %.0f GB/s (2 reads + 2 writes)" % (t, 4 * nb / t / 1e6))
         x = torch.randn(n, 64, 120, 160, device=dev)
