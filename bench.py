@@ -271,6 +271,8 @@ def main():
     ap.add_argument("--cpu_steps", type=int, default=3, help="timed CPU-oracle steps after one warm-up (fewer if the budget runs out)")
     ap.add_argument("--cpu_budget_s", type=float, default=150.0)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--literal_steps", type=int, default=4,
+                    help="extra steps with the literal 7-forward schedule after the timed region, reported as 'literal_schedule' (0 = skip)")
     ap.add_argument("--no_forward_reuse", action="store_true",
                     help="literal schedule of adapt_trainer.py: step B's target forward and step C's first one run separately "
                          "(7 generator forwards per step instead of 6; same weights, statistics and losses bit for bit)")
@@ -322,6 +324,29 @@ def main():
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(el)
     c_loss, d_loss = float(c_loss), float(d_loss)
+
+    # for reference, outside the timed region: the same step with the reference's literal schedule (7 generator forwards)
+    literal = None
+    if solver.reuse_tgt and args.literal_steps > 0:
+        solver.reuse_tgt = False
+        solver.step(src, lbl, tgt)
+        torch.cuda.synchronize()
+        mdist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.literal_steps):
+            solver.step(src, lbl, tgt)
+        torch.cuda.synchronize()
+        mdist.barrier()
+        torch.cuda.synchronize()
+        lt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(lt, op=torch.distributed.ReduceOp.MAX)
+        solver.reuse_tgt = True
+        literal = {"steps": args.literal_steps, "ms_per_step": round(1e3 * float(lt) / args.literal_steps, 2),
+                   "value": round(args.batch * world * args.literal_steps / float(lt), 3),
+                   "note": "same build with solver.reuse_tgt = False (7 generator forwards + 5 backwards per step), measured after the "
+                           "timed region; identical weights, statistics and losses"}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -381,6 +406,7 @@ def main():
                                        "running update applied twice) -- %d generator forwards + 5 backwards per step, bit-identical "
                                        "weights/statistics/losses to the literal 7-forward schedule (--no_forward_reuse runs that)"
                                        % 6 if solver.reuse_tgt else "; literal 7 generator forwards + 5 backwards per step")},
+            "literal_schedule": literal,
             "roofline": roofline,
             "roofline_forward": roofline_fwd,
             "step_accounting": step_acc,

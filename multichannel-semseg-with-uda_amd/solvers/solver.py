@@ -14,7 +14,7 @@ result:
     (``mcdseg.ops.mcd_losses``) instead of separate CE / CE / Diff criteria;
   * step B never back-propagates through G: only ``optimizer_f.step()`` follows and the generator
     gradients are zeroed before any use (adapt_trainer.py:187-205), so G runs without saving
-    activations there -- its BatchNorm running statistics still move on every forward (7 per step);
+    activations there -- its BatchNorm running statistics still move as on the reference's 7 forwards per step;
   * step B's generator forward on the target batch IS step C's first one: the generator does not change in between
     (only ``optimizer_f.step()`` runs), so the reference computes the same features twice (adapt_trainer.py:196 and :209).
     Here that forward runs once, with its tape, and each of its BatchNorm layers applies the running-statistics update twice
