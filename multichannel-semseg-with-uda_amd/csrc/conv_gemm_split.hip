@@ -694,8 +694,17 @@ __global__ __launch_bounds__(256) void absmax_multi_kernel(const int64_t* __rest
   const float* __restrict__ x = reinterpret_cast<const float*>(ptrs[4 * e + 0]);
   unsigned* __restrict__ out = reinterpret_cast<unsigned*>(ptrs[4 * e + 3]);
   const int64_t n = (int64_t)dims[4 * e + 0] * dims[4 * e + 1] * dims[4 * e + 2];
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
   unsigned m = 0u;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i + 3 * step < n; i += 4 * step) {  // four loads in flight
+    const unsigned b0 = __float_as_uint(x[i]) & 0x7FFFFFFFu, b1 = __float_as_uint(x[i + step]) & 0x7FFFFFFFu;
+    const unsigned b2 = __float_as_uint(x[i + 2 * step]) & 0x7FFFFFFFu, b3 = __float_as_uint(x[i + 3 * step]) & 0x7FFFFFFFu;
+    const unsigned c0 = b0 > b1 ? b0 : b1, c1 = b2 > b3 ? b2 : b3;
+    const unsigned c = c0 > c1 ? c0 : c1;
+    m = c > m ? c : m;
+  }
+  for (; i < n; i += step) {
     const unsigned b = __float_as_uint(x[i]) & 0x7FFFFFFFu;
     m = b > m ? b : m;
   }
@@ -706,9 +715,13 @@ __global__ __launch_bounds__(256) void absmax_multi_kernel(const int64_t* __rest
   if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
 }
 
+// A workgroup moves tiles of (MT output rows) x (16 contraction channels) x (all taps) through LDS: the fp32 kernel is read in
+// contiguous runs (16 T floats per row for the forward image, MT T floats per channel for the dgrad image -- a thread-per-unit
+// gather strides 18 KB between lanes and pays a DRAM row miss per 64 bytes), the image is written in runs of MT 16-byte units.
 template <class P>
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* __restrict__ ptrs, const int32_t* __restrict__ dims) {
   constexpr int NP = P::NP;
+  __shared__ float tile[32 * 16 * 9 + 32];
   const int e = blockIdx.y >> 1, mode = blockIdx.y & 1;
   const float* __restrict__ w = reinterpret_cast<const float*>(ptrs[4 * e + 0]);
   typename P::elem* __restrict__ out = reinterpret_cast<typename P::elem*>(ptrs[4 * e + 1 + mode]);
@@ -719,24 +732,39 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* 
   const int K = mode == 0 ? Cin : Cout;
   const int Mp = M <= 32 ? 32 : (M <= 64 ? 64 : ((M + 127) / 128) * 128);  // mcd_mp
   const int Kp = ((K + 15) / 16) * 16;
-  const int64_t total = (int64_t)(Kp / 16) * T * 2 * Mp * 8;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int el = (int)(i & 7);
-    int64_t r = i >> 3;
-    const int m = (int)(r % Mp);
-    r /= Mp;
-    const int h = (int)(r & 1);
-    const int64_t kstep = r >> 1;
-    const int tap = (int)(kstep % T);
-    const int chunk = (int)(kstep / T);
-    const int k = chunk * 16 + 8 * h + el;
-    float v = 0.f;
-    if (m < M && k < K) v = mode == 0 ? w[((int64_t)m * Cin + k) * T + tap] : w[((int64_t)k * Cin + m) * T + tap];
-    typename P::elem q[NP];
-    P::split(v, inv_scale, q);
-    const int64_t base = kstep * (2 * NP) * (int64_t)Mp * 8;
+  const int MT = T <= 9 ? 32 : (T <= 18 ? 16 : (T <= 36 ? 8 : 4));  // rows per tile: MT * 16 * T floats of LDS (T <= 72)
+  const int row_len = 16 * T + 1;                                   // one tile row (16 channels x T taps), padded
+  const int m_tiles = Mp / MT, chunks = Kp / 16;
+  const int t = threadIdx.x;
+  for (int tl = blockIdx.x; tl < m_tiles * chunks; tl += gridDim.x) {
+    const int chunk = tl / m_tiles, m0 = (tl - chunk * m_tiles) * MT, k0 = chunk * 16;
+    __syncthreads();  // the previous tile has been consumed
+    if (mode == 0) {  // rows of the source = output rows: 16 T contiguous floats each
+      for (int idx = t; idx < MT * 16 * T; idx += 256) {
+        const int mm = idx / (16 * T), col = idx - mm * (16 * T);
+        const int kk = col / T;
+        tile[mm * row_len + col] = (m0 + mm < M && k0 + kk < K) ? w[((int64_t)(m0 + mm) * Cin + k0) * T + col] : 0.f;
+      }
+    } else {  // rows of the source = contraction channels: MT T contiguous floats each
+      for (int idx = t; idx < 16 * MT * T; idx += 256) {
+        const int kk = idx / (MT * T), col = idx - kk * (MT * T);
+        const int mm = col / T, tap = col - mm * T;
+        tile[mm * row_len + kk * T + tap] = (m0 + mm < M && k0 + kk < K) ? w[((int64_t)(k0 + kk) * Cin + m0) * T + col] : 0.f;
+      }
+    }
+    __syncthreads();
+    for (int u = t; u < T * 2 * MT; u += 256) {  // unit = (tap, half, row): MT consecutive units are contiguous in the image
+      const int mm = u % MT, r = u / MT;
+      const int h = r & 1, tap = r >> 1;
+      float v[8];
 #pragma unroll
-    for (int pc = 0; pc < NP; ++pc) out[base + ((pc * 2 + h) * (int64_t)Mp + m) * 8 + el] = q[pc];
+      for (int el = 0; el < 8; ++el) v[el] = tile[mm * row_len + (8 * h + el) * T + tap];
+      typename P::frag q[NP];
+      split_frag<P>(v, inv_scale, q);
+      const int64_t base = ((int64_t)chunk * T + tap) * (2 * NP) * (int64_t)Mp * 8;
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<typename P::frag*>(out + base + ((pc * 2 + h) * (int64_t)Mp + m0 + mm) * 8) = q[pc];
+    }
   }
 }
 
@@ -915,14 +943,16 @@ extern "C" int mcdseg_conv_split_pack_weights_multi(const int64_t* ptrs, const i
   MCD_REQUIRE(ptrs && dims && n > 0 && n <= 32767, "conv_split_pack_weights_multi: bad table");
   MCD_REQUIRE(math == MCDSEG_MATH_BF16X6 || math == MCDSEG_MATH_F16X3, "conv_split_pack_weights_multi: unknown math %d", math);
   MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || bounds != nullptr, "conv_split_pack_weights_multi: f16x3 needs the bounds array");
+  // (kernels of up to 72 taps: the pack kernel stages tiles of 4 rows x 16 channels x T taps in 18 KB of LDS; larger ones
+  // take mcdseg_conv_split_pack_weights)
   hipStream_t st = (hipStream_t)stream;
   if (math == MCDSEG_MATH_F16X3) {
     (void)hipMemsetAsync(bounds, 0, sizeof(float) * (size_t)n, st);
-    hipLaunchKernelGGL(absmax_multi_kernel, dim3(16, (unsigned)n), dim3(256), 0, st, ptrs, dims);
+    hipLaunchKernelGGL(absmax_multi_kernel, dim3(48, (unsigned)n), dim3(256), 0, st, ptrs, dims);
     MCD_LAUNCH_CHECK("absmax_multi");
-    hipLaunchKernelGGL(pack_weights_multi_kernel<SplitF16x3>, dim3(48, 2u * (unsigned)n), dim3(256), 0, st, ptrs, dims);
+    hipLaunchKernelGGL(pack_weights_multi_kernel<SplitF16x3>, dim3(96, 2u * (unsigned)n), dim3(256), 0, st, ptrs, dims);
   } else {
-    hipLaunchKernelGGL(pack_weights_multi_kernel<SplitBf16x6>, dim3(48, 2u * (unsigned)n), dim3(256), 0, st, ptrs, dims);
+    hipLaunchKernelGGL(pack_weights_multi_kernel<SplitBf16x6>, dim3(96, 2u * (unsigned)n), dim3(256), 0, st, ptrs, dims);
   }
   MCD_LAUNCH_CHECK("conv_split_pack_weights_multi");
   return 0;

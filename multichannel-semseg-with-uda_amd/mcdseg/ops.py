@@ -336,7 +336,8 @@ def _pack_group(device):
     members = []
     for pw in list(_PACK_REGISTRY):
         w = pw._weight() if pw._weight is not None else None
-        if w is None or pw._dims is None or pw._dims[4] != CONV_MATH or w.device != device or pw.wd is None or pw.wf is None:
+        if (w is None or pw._dims is None or pw._dims[4] != CONV_MATH or w.device != device or pw.wd is None or pw.wf is None
+                or pw._dims[2] > 72):  # (the table-driven pack kernel stages up to 72 taps per tile)
             continue
         members.append((pw, w))
     if len(members) < 2:

@@ -900,6 +900,33 @@ def test_stem_forward_on_the_window_kernel(cin, h, w, n, monkeypatch):
     _assert_close(outs[0][1], outs[1][1], 1e-4, "stem weight gradient, window vs direct stem forward")
 
 
+def test_group_weight_pack_equals_the_per_layer_pack(monkeypatch):
+    """After an optimizer step every stale weight image of the device is rebuilt by two table-driven launches
+    (mcdseg_conv_split_pack_weights_multi); images and bound scalars are bit-identical to the per-layer pack, including the
+    stem (its direct kernel's image sits behind the standard one), a layer with a ragged channel count and a 1x1 layer."""
+    dev = _dev()
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "CONV_MATH", "f16x3")
+    shapes = [((16, 6, 7, 7), 1, 3, 1), ((16, 16, 3, 3), 1, 1, 1), ((64, 32, 3, 3), 2, 1, 1), ((41, 512, 1, 1), 1, 0, 1),
+              ((256, 128, 3, 3), 1, 2, 2), ((24, 40, 3, 3), 1, 1, 1)]
+    g = torch.Generator().manual_seed(21)
+    ws = [(torch.randn(sh, generator=g) * 0.1).to(dev) for sh, _, _, _ in shapes]
+    descs = [ops.conv_desc((1, sh[1], 16, 16), sh, st, pad, dil) for sh, st, pad, dil in shapes]
+    pks = [ops.PackedWeights() for _ in shapes]
+    for pk, w, d in zip(pks, ws, descs):
+        pk.get(w, d)  # first use: per-layer pack (registers the layer for group packs)
+    for w in ws:
+        w.mul_(1.5).add_(0.01)  # an "optimizer step": every image is stale now
+    pks[0].get(ws[0], descs[0])  # the first stale get re-packs all of them
+    grouped = [(pk.wf.clone(), pk.wd.clone(), pk.w_bound.clone()) for pk in pks]
+    assert all(pk.key == ops.PackedWeights._key_of(w) for pk, w in zip(pks, ws)), "the group pack did not refresh every layer"
+    monkeypatch.setattr(ops, "GROUP_PACK", False)
+    for (wf, wd, wb), w, d in zip(grouped, ws, descs):
+        ref = ops.PackedWeights()
+        ref.get(w, d)
+        assert torch.equal(ref.wf, wf) and torch.equal(ref.wd, wd) and torch.equal(ref.w_bound, wb), tuple(w.shape)
+
+
 def test_conv_nonfinite_operands():
     """Contract of the split-precision convolutions for non-finite data: an output that a NaN / inf operand reaches is
     non-finite (an fp32 FMA chain would give +-inf where the split gives NaN: inf - inf in the remainder), every other output
