@@ -676,7 +676,30 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, typename 
 // independent of the order of arrival; a NaN pattern compares above inf, so non-finite data yields a non-finite bound
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
   unsigned m = 0u;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {  // 16-byte loads, four in flight
+    const uint4* __restrict__ x4 = reinterpret_cast<const uint4*>(x);
+    const int64_t n4 = n >> 2;
+    auto amax4 = [](uint4 q) {
+      const unsigned a = q.x & 0x7FFFFFFFu, b = q.y & 0x7FFFFFFFu, c = q.z & 0x7FFFFFFFu, d = q.w & 0x7FFFFFFFu;
+      const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+      return ab > cd ? ab : cd;
+    };
+    int64_t j = i;
+    for (; j + 3 * step < n4; j += 4 * step) {
+      const uint4 q0 = x4[j], q1 = x4[j + step], q2 = x4[j + 2 * step], q3 = x4[j + 3 * step];
+      const unsigned a = amax4(q0), b = amax4(q1), c = amax4(q2), d = amax4(q3);
+      const unsigned ab = a > b ? a : b, cd = c > d ? c : d, t = ab > cd ? ab : cd;
+      m = t > m ? t : m;
+    }
+    for (; j < n4; j += step) {
+      const unsigned t = amax4(x4[j]);
+      m = t > m ? t : m;
+    }
+    i += n4 << 2;  // the tail of up to three elements
+  }
+  for (; i < n; i += step) {
     const unsigned b = __float_as_uint(x[i]) & 0x7FFFFFFFu;
     m = b > m ? b : m;
   }

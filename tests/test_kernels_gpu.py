@@ -927,6 +927,25 @@ def test_group_weight_pack_equals_the_per_layer_pack(monkeypatch):
         assert torch.equal(ref.wf, wf) and torch.equal(ref.wd, wd) and torch.equal(ref.w_bound, wb), tuple(w.shape)
 
 
+@pytest.mark.parametrize("n,off", [(1, 0), (3, 0), (5, 1), (1027, 0), (4096 + 3, 3), (3 * 1000 * 1000 + 1, 0), (1 << 20, 2)])
+def test_absmax_scalar_is_the_exact_maximum(n, off):
+    """mcdseg_absmax (the bound scalar every fp16 scale is derived from): exactly max |x| for aligned and unaligned starts,
+    vector body and scalar tail, with the maximum planted in the first / last element; NaN propagates as a non-finite bound."""
+    dev = _dev()
+    from mcdseg import ops
+    g = torch.Generator().manual_seed(n)
+    base = torch.randn(n + off, generator=g).to(dev)
+    for where in (0, n - 1, n // 2):
+        x = base.clone()[off:]
+        x[where] = -37.5
+        got = ops.absmax(x)
+        assert float(got) == 37.5 and float(got) == float(x.abs().max())
+    x = base.clone()[off:]
+    assert float(ops.absmax(x)) == float(x.abs().max())
+    x[n - 1] = float("nan")
+    assert not np.isfinite(float(ops.absmax(x)))
+
+
 def test_conv_nonfinite_operands():
     """Contract of the split-precision convolutions for non-finite data: an output that a NaN / inf operand reaches is
     non-finite (an fp32 FMA chain would give +-inf where the split gives NaN: inf - inf in the remainder), every other output
