@@ -439,6 +439,78 @@ __global__ __launch_bounds__(256) void bn_apply_cb_kernel(const float* __restric
   }
 }
 
+// The same pass with 16-byte accesses to the fp32 planes: one thread = FOUR adjacent pixels x 8 channels (HW % 4 == 0).  The
+// thread's four companion units would be 16-byte stores 64 bytes apart; they go through a wave-private LDS image instead, so
+// that every store instruction of the wave covers 1 KB of consecutive units.
+template <class P>
+__device__ __forceinline__ void split_store_x4(const float (&v)[4][8], float inv_scale, typename P::elem* __restrict__ cb,
+                                               size_t piece_stride, size_t unit0_wave, int units_wave, typename P::frag* lds_wave) {
+  const int lane = threadIdx.x & 63;
+  typename P::frag pieces[4][P::NP];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split_frag<P>(v[j], inv_scale, pieces[j]);
+#pragma unroll
+  for (int pc = 0; pc < P::NP; ++pc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lds_wave[4 * lane + j] = pieces[j][pc];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int u = 64 * j + lane;
+      const typename P::frag q = lds_wave[u];
+      if (u < units_wave) *reinterpret_cast<typename P::frag*>(cb + pc * piece_stride + (unit0_wave + u) * 8) = q;
+    }
+  }
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void bn_apply_cb_v4_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ res,
+                                                             float* __restrict__ y, typename P::elem* __restrict__ cb,
+                                                             const float* __restrict__ y_bound, int N, int C, int HW, int relu) {
+  __shared__ typename P::frag lds[4][256];
+  const int C8 = C >> 3;
+  const int ng = blockIdx.y;  // n * C8 + g
+  const int g = ng % C8;
+  const int n = ng / C8;
+  const float inv_scale = 1.f / operand_scale<P>(y_bound);
+  float ca[8], cbeta[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = 8 * g + e;
+    ca[e] = gamma[c] * rstd[c];
+    cbeta[e] = beta[c] - mean[c] * ca[e];
+  }
+  const int wave = threadIdx.x >> 6;
+  const int pix_wave = (blockIdx.x * 256 + 64 * wave) * 4;  // first pixel of this wave's 256
+  const int pix = pix_wave + 4 * (threadIdx.x & 63);
+  float v[4][8];
+  if (pix < HW) {
+    const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float4 zv = *reinterpret_cast<const float4*>(z + base + (size_t)e * HW);
+      float4 t;
+      t.x = fmaf(zv.x, ca[e], cbeta[e]); t.y = fmaf(zv.y, ca[e], cbeta[e]);
+      t.z = fmaf(zv.z, ca[e], cbeta[e]); t.w = fmaf(zv.w, ca[e], cbeta[e]);
+      if (res) {
+        const float4 rv = *reinterpret_cast<const float4*>(res + base + (size_t)e * HW);
+        t.x += rv.x; t.y += rv.y; t.z += rv.z; t.w += rv.w;
+      }
+      if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+      v[0][e] = t.x; v[1][e] = t.y; v[2][e] = t.z; v[3][e] = t.w;
+      if (y != nullptr) *reinterpret_cast<float4*>(y + base + (size_t)e * HW) = t;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+  }
+  if (pix_wave < HW)  // wave-uniform
+    split_store_x4<P>(v, inv_scale, cb, (size_t)N * C * HW, (size_t)ng * HW + pix_wave, HW - pix_wave < 256 ? HW - pix_wave : 256, lds[wave]);
+}
+
 template <class P>
 __global__ __launch_bounds__(256) void bn_bwd_apply_cb_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                               const float* __restrict__ z, const float* __restrict__ mean,
@@ -489,6 +561,77 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_kernel(const float* __res
     }
     split_store<P>(v, inv_scale, cb, (size_t)N * C * HW, (size_t)ng * HW + pix);
   }
+}
+
+// four adjacent pixels per thread (see bn_apply_cb_v4_kernel); the ReLU mask comes from z (mbeta) or from the fp32 y
+template <class P>
+__global__ __launch_bounds__(256) void bn_bwd_apply_cb_v4_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                 const float* __restrict__ z, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                                 float* __restrict__ dz, float* __restrict__ dres,
+                                                                 typename P::elem* __restrict__ cb, const float* __restrict__ dz_bound,
+                                                                 int N, int C, int HW, int relu, int train,
+                                                                 const float* __restrict__ mbeta) {
+  __shared__ typename P::frag lds[4][256];
+  const int C8 = C >> 3;
+  const int ng = blockIdx.y;
+  const int g = ng % C8;
+  const int n = ng / C8;
+  const float inv_scale = 1.f / operand_scale<P>(dz_bound);
+  const float inv_n = 1.f / ((float)N * (float)HW);
+  const bool zm = relu && mbeta != nullptr;
+  float cmu[8], crs[8], ca[8], k1[8], k2[8], cmb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = 8 * g + e;
+    cmu[e] = mean[c];
+    crs[e] = rstd[c];
+    ca[e] = gamma[c] * crs[e];
+    cmb[e] = zm ? mbeta[c] - cmu[e] * ca[e] : 0.f;
+    k1[e] = train ? dbeta[c] * inv_n : 0.f;
+    k2[e] = train ? dgamma[c] * inv_n : 0.f;
+  }
+  const int wave = threadIdx.x >> 6;
+  const int pix_wave = (blockIdx.x * 256 + 64 * wave) * 4;
+  const int pix = pix_wave + 4 * (threadIdx.x & 63);
+  float v[4][8];
+  if (pix < HW) {
+    const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float4 g4 = *reinterpret_cast<const float4*>(dy + base + (size_t)e * HW);
+      const float4 z4 = *reinterpret_cast<const float4*>(z + base + (size_t)e * HW);
+      float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+      const float zv[4] = {z4.x, z4.y, z4.z, z4.w};
+      if (zm) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!(fmaf(zv[j], ca[e], cmb[e]) > 0.f)) gv[j] = 0.f;
+      } else if (relu) {
+        const float4 y4 = *reinterpret_cast<const float4*>(y + base + (size_t)e * HW);
+        const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!(yv[j] > 0.f)) gv[j] = 0.f;
+      }
+      if (dres) *reinterpret_cast<float4*>(dres + base + (size_t)e * HW) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+      float t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[j] = ca[e] * (gv[j] - k1[e] - ((zv[j] - cmu[e]) * crs[e]) * k2[e]);
+        v[j][e] = t[j];
+      }
+      if (dz) *reinterpret_cast<float4*>(dz + base + (size_t)e * HW) = make_float4(t[0], t[1], t[2], t[3]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+  }
+  if (pix_wave < HW)  // wave-uniform
+    split_store_x4<P>(v, inv_scale, cb, (size_t)N * C * HW, (size_t)ng * HW + pix_wave, HW - pix_wave < 256 ? HW - pix_wave : 256, lds[wave]);
 }
 
 // backward reduce with the ReLU mask read from the activation's companion (compact activation storage: no fp32 y exists).
@@ -714,6 +857,15 @@ extern "C" int mcdseg_split_cb_padded(const float* x, void* x_cb, const float* x
   return 0;
 }
 
+// the four-pixels-per-thread forms of the two companion-writing apply kernels (MCDSEG_BN_V4=0: the one-pixel forms)
+static bool bn_v4_on() {
+  static const bool on = [] {
+    const char* e = getenv("MCDSEG_BN_V4");
+    return e == nullptr || atoi(e) != 0;
+  }();
+  return on;
+}
+
 extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                   const float* residual, const void* res_cb, const float* res_bound, float* y, void* y_cb,
                                   const float* y_bound, int32_t math, int32_t N, int32_t C, int32_t HW, int32_t relu, void* stream) {
@@ -721,6 +873,17 @@ extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float
   MCD_REQUIRE(!(residual && res_cb), "bn_apply_cb: the residual comes either as fp32 or as its companion, not both");
   MCD_REQUIRE(res_cb == nullptr || math != MCDSEG_MATH_F16X3 || res_bound != nullptr, "bn_apply_cb: the residual companion needs its bound");
   if (int rc = cb_check("bn_apply_cb", math, y_bound, N, C, HW)) return rc;
+  if (bn_v4_on() && (HW & 3) == 0 && res_cb == nullptr && (((uintptr_t)z | (uintptr_t)y | (uintptr_t)residual) & 15) == 0) {
+    const dim3 grid4(ceil_div(HW, 1024), N * (C / 8));
+    if (math == MCDSEG_MATH_F16X3)
+      hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitF16x3>, grid4, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
+                         y, (_Float16*)y_cb, y_bound, N, C, HW, relu);
+    else
+      hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitBf16x6>, grid4, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
+                         y, (__bf16*)y_cb, y_bound, N, C, HW, relu);
+    MCD_LAUNCH_CHECK("bn_apply_cb");
+    return 0;
+  }
   const dim3 grid(ceil_div(HW, 256 * BN_PIX_ITERS), N * (C / 8));
   if (math == MCDSEG_MATH_F16X3)
     hipLaunchKernelGGL(bn_apply_cb_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
@@ -745,6 +908,22 @@ extern "C" int mcdseg_unsplit_cb(const void* x_cb, const float* x_bound, int32_t
   return 0;
 }
 
+static bool bwd_apply_v4(const float* dy, const float* y, const void* y_cb, const float* z, const float* mean, const float* rstd,
+                         const float* gamma, const float* dgamma, const float* dbeta, float* dz, float* dres, void* dz_cb,
+                         const float* dz_bound, int math, int N, int C, int HW, int relu, int train, const float* mbeta, hipStream_t st) {
+  if (!bn_v4_on() || (HW & 3) != 0 || (relu && mbeta == nullptr && y == nullptr)) return false;  // (mask from the companion: one-pixel form)
+  (void)y_cb;
+  if ((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)dres) & 15) != 0) return false;
+  const dim3 grid(ceil_div(HW, 1024), N * (C / 8));
+  if (math == MCDSEG_MATH_F16X3)
+    hipLaunchKernelGGL(bn_bwd_apply_cb_v4_kernel<SplitF16x3>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres,
+                       (_Float16*)dz_cb, dz_bound, N, C, HW, relu, train, mbeta);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_cb_v4_kernel<SplitBf16x6>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres,
+                       (__bf16*)dz_cb, dz_bound, N, C, HW, relu, train, mbeta);
+  return true;
+}
+
 extern "C" int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const void* y_cb, const float* z, const float* mean,
                                       const float* rstd, const float* gamma, const float* dgamma, const float* dbeta, float* dz,
                                       float* dres, void* dz_cb, const float* dz_bound, int32_t math, int32_t N, int32_t C, int32_t HW,
@@ -753,6 +932,11 @@ extern "C" int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const voi
   MCD_REQUIRE(!relu || y || y_cb, "bn_bwd_apply_cb: relu mask needs y or its companion");
   MCD_REQUIRE(!train || (dgamma && dbeta), "bn_bwd_apply_cb: train mode needs dgamma/dbeta");
   if (int rc = cb_check("bn_bwd_apply_cb", math, dz_bound, N, C, HW)) return rc;
+  if (bwd_apply_v4(dy, y, y_cb, z, mean, rstd, gamma, dgamma, dbeta, dz, dres, dz_cb, dz_bound, math, N, C, HW, relu, train, nullptr,
+                   (hipStream_t)stream)) {
+    MCD_LAUNCH_CHECK("bn_bwd_apply_cb");
+    return 0;
+  }
   const dim3 grid(ceil_div(HW, 256 * BN_PIX_ITERS), N * (C / 8));
   if (math == MCDSEG_MATH_F16X3)
     hipLaunchKernelGGL(bn_bwd_apply_cb_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, z, mean, rstd, gamma, dgamma,
@@ -773,6 +957,11 @@ extern "C" int mcdseg_bn_bwd_apply_cb_zmask(const float* dy, const float* z, con
   MCD_REQUIRE(dy && z && mean && rstd && gamma && beta && dz_cb, "bn_bwd_apply_cb_zmask: null pointer");
   MCD_REQUIRE(!train || (dgamma && dbeta), "bn_bwd_apply_cb_zmask: train mode needs dgamma/dbeta");
   if (int rc = cb_check("bn_bwd_apply_cb_zmask", math, dz_bound, N, C, HW)) return rc;
+  if (bwd_apply_v4(dy, nullptr, nullptr, z, mean, rstd, gamma, dgamma, dbeta, dz, nullptr, dz_cb, dz_bound, math, N, C, HW, 1, train, beta,
+                   (hipStream_t)stream)) {
+    MCD_LAUNCH_CHECK("bn_bwd_apply_cb_zmask");
+    return 0;
+  }
   const dim3 grid(ceil_div(HW, 256 * BN_PIX_ITERS), N * (C / 8));
   if (math == MCDSEG_MATH_F16X3)
     hipLaunchKernelGGL(bn_bwd_apply_cb_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, dy, (const float*)nullptr, z, mean, rstd,
