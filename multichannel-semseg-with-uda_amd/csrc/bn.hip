@@ -466,8 +466,10 @@ template <class P>
 __global__ __launch_bounds__(256) void bn_apply_cb_v4_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ res,
-                                                             float* __restrict__ y, typename P::elem* __restrict__ cb,
-                                                             const float* __restrict__ y_bound, int N, int C, int HW, int relu) {
+                                                             const typename P::elem* __restrict__ res_cb,
+                                                             const float* __restrict__ res_bound, float* __restrict__ y,
+                                                             typename P::elem* __restrict__ cb, const float* __restrict__ y_bound, int N,
+                                                             int C, int HW, int relu) {
   __shared__ typename P::frag lds[4][256];
   const int C8 = C >> 3;
   const int ng = blockIdx.y;  // n * C8 + g
@@ -487,6 +489,12 @@ __global__ __launch_bounds__(256) void bn_apply_cb_v4_kernel(const float* __rest
   float v[4][8];
   if (pix < HW) {
     const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
+    float r[4][8];
+    if (res_cb != nullptr) {  // compact activation storage: the residual exists only as its companion
+      const float rscale = operand_scale<P>(res_bound);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) join_load<P>(res_cb, rscale, (size_t)N * C * HW, (size_t)ng * HW + pix + j, r[j]);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float4 zv = *reinterpret_cast<const float4*>(z + base + (size_t)e * HW);
@@ -497,6 +505,7 @@ __global__ __launch_bounds__(256) void bn_apply_cb_v4_kernel(const float* __rest
         const float4 rv = *reinterpret_cast<const float4*>(res + base + (size_t)e * HW);
         t.x += rv.x; t.y += rv.y; t.z += rv.z; t.w += rv.w;
       }
+      if (res_cb != nullptr) { t.x += r[0][e]; t.y += r[1][e]; t.z += r[2][e]; t.w += r[3][e]; }
       if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
       v[0][e] = t.x; v[1][e] = t.y; v[2][e] = t.z; v[3][e] = t.w;
       if (y != nullptr) *reinterpret_cast<float4*>(y + base + (size_t)e * HW) = t;
@@ -571,8 +580,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_v4_kernel(const float* __
                                                                  const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                                  float* __restrict__ dz, float* __restrict__ dres,
                                                                  typename P::elem* __restrict__ cb, const float* __restrict__ dz_bound,
-                                                                 int N, int C, int HW, int relu, int train,
-                                                                 const float* __restrict__ mbeta) {
+                                                                 const typename P::elem* __restrict__ y_cb, int N, int C, int HW,
+                                                                 int relu, int train, const float* __restrict__ mbeta) {
   __shared__ typename P::frag lds[4][256];
   const int C8 = C >> 3;
   const int ng = blockIdx.y;
@@ -598,6 +607,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_v4_kernel(const float* __
   float v[4][8];
   if (pix < HW) {
     const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
+    unsigned ymask[4] = {0xFFu, 0xFFu, 0xFFu, 0xFFu};
+    if (relu && !zm && y == nullptr) {  // compact activation storage: the mask from the leading piece of y's companion
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ymask[j] = mask_load<P>(y_cb, (size_t)ng * HW + pix + j);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float4 g4 = *reinterpret_cast<const float4*>(dy + base + (size_t)e * HW);
@@ -608,12 +622,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_v4_kernel(const float* __
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (!(fmaf(zv[j], ca[e], cmb[e]) > 0.f)) gv[j] = 0.f;
-      } else if (relu) {
+      } else if (relu && y != nullptr) {
         const float4 y4 = *reinterpret_cast<const float4*>(y + base + (size_t)e * HW);
         const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (!(yv[j] > 0.f)) gv[j] = 0.f;
+      } else if (relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!((ymask[j] >> e) & 1u)) gv[j] = 0.f;
       }
       if (dres) *reinterpret_cast<float4*>(dres + base + (size_t)e * HW) = make_float4(gv[0], gv[1], gv[2], gv[3]);
       float t[4];
@@ -873,14 +891,14 @@ extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float
   MCD_REQUIRE(!(residual && res_cb), "bn_apply_cb: the residual comes either as fp32 or as its companion, not both");
   MCD_REQUIRE(res_cb == nullptr || math != MCDSEG_MATH_F16X3 || res_bound != nullptr, "bn_apply_cb: the residual companion needs its bound");
   if (int rc = cb_check("bn_apply_cb", math, y_bound, N, C, HW)) return rc;
-  if (bn_v4_on() && (HW & 3) == 0 && res_cb == nullptr && (((uintptr_t)z | (uintptr_t)y | (uintptr_t)residual) & 15) == 0) {
+  if (bn_v4_on() && (HW & 3) == 0 && (((uintptr_t)z | (uintptr_t)y | (uintptr_t)residual) & 15) == 0) {
     const dim3 grid4(ceil_div(HW, 1024), N * (C / 8));
     if (math == MCDSEG_MATH_F16X3)
       hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitF16x3>, grid4, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
-                         y, (_Float16*)y_cb, y_bound, N, C, HW, relu);
+                         (const _Float16*)res_cb, res_bound, y, (_Float16*)y_cb, y_bound, N, C, HW, relu);
     else
       hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitBf16x6>, grid4, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
-                         y, (__bf16*)y_cb, y_bound, N, C, HW, relu);
+                         (const __bf16*)res_cb, res_bound, y, (__bf16*)y_cb, y_bound, N, C, HW, relu);
     MCD_LAUNCH_CHECK("bn_apply_cb");
     return 0;
   }
@@ -911,16 +929,15 @@ extern "C" int mcdseg_unsplit_cb(const void* x_cb, const float* x_bound, int32_t
 static bool bwd_apply_v4(const float* dy, const float* y, const void* y_cb, const float* z, const float* mean, const float* rstd,
                          const float* gamma, const float* dgamma, const float* dbeta, float* dz, float* dres, void* dz_cb,
                          const float* dz_bound, int math, int N, int C, int HW, int relu, int train, const float* mbeta, hipStream_t st) {
-  if (!bn_v4_on() || (HW & 3) != 0 || (relu && mbeta == nullptr && y == nullptr)) return false;  // (mask from the companion: one-pixel form)
-  (void)y_cb;
+  if (!bn_v4_on() || (HW & 3) != 0) return false;
   if ((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)dres) & 15) != 0) return false;
   const dim3 grid(ceil_div(HW, 1024), N * (C / 8));
   if (math == MCDSEG_MATH_F16X3)
     hipLaunchKernelGGL(bn_bwd_apply_cb_v4_kernel<SplitF16x3>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres,
-                       (_Float16*)dz_cb, dz_bound, N, C, HW, relu, train, mbeta);
+                       (_Float16*)dz_cb, dz_bound, (const _Float16*)y_cb, N, C, HW, relu, train, mbeta);
   else
     hipLaunchKernelGGL(bn_bwd_apply_cb_v4_kernel<SplitBf16x6>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres,
-                       (__bf16*)dz_cb, dz_bound, N, C, HW, relu, train, mbeta);
+                       (__bf16*)dz_cb, dz_bound, (const __bf16*)y_cb, N, C, HW, relu, train, mbeta);
   return true;
 }
 
