@@ -439,6 +439,9 @@ __global__ __launch_bounds__(256) void bn_apply_cb_kernel(const float* __restric
   }
 }
 
+#ifndef BN_V4_NT
+#define BN_V4_NT 256  // threads per workgroup of the four-pixel kernels
+#endif
 // The same pass with 16-byte accesses to the fp32 planes: one thread = FOUR adjacent pixels x 8 channels (HW % 4 == 0).  The
 // thread's four companion units would be 16-byte stores 64 bytes apart; they go through a wave-private LDS image instead, so
 // that every store instruction of the wave covers 1 KB of consecutive units.
@@ -463,14 +466,14 @@ __device__ __forceinline__ void split_store_x4(const float (&v)[4][8], float inv
 }
 
 template <class P>
-__global__ __launch_bounds__(256) void bn_apply_cb_v4_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+__global__ __launch_bounds__(BN_V4_NT) void bn_apply_cb_v4_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ res,
                                                              const typename P::elem* __restrict__ res_cb,
                                                              const float* __restrict__ res_bound, float* __restrict__ y,
                                                              typename P::elem* __restrict__ cb, const float* __restrict__ y_bound, int N,
                                                              int C, int HW, int relu) {
-  __shared__ typename P::frag lds[4][256];
+  __shared__ typename P::frag lds[BN_V4_NT / 64][256];
   const int C8 = C >> 3;
   const int ng = blockIdx.y;  // n * C8 + g
   const int g = ng % C8;
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(256) void bn_apply_cb_v4_kernel(const float* __rest
     cbeta[e] = beta[c] - mean[c] * ca[e];
   }
   const int wave = threadIdx.x >> 6;
-  const int pix_wave = (blockIdx.x * 256 + 64 * wave) * 4;  // first pixel of this wave's 256
+  const int pix_wave = (blockIdx.x * BN_V4_NT + 64 * wave) * 4;  // first pixel of this wave's 256
   const int pix = pix_wave + 4 * (threadIdx.x & 63);
   float v[4][8];
   if (pix < HW) {
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_kernel(const float* __res
 
 // four adjacent pixels per thread (see bn_apply_cb_v4_kernel); the ReLU mask comes from z (mbeta) or from the fp32 y
 template <class P>
-__global__ __launch_bounds__(256) void bn_bwd_apply_cb_v4_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+__global__ __launch_bounds__(BN_V4_NT) void bn_bwd_apply_cb_v4_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                  const float* __restrict__ z, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                  const float* __restrict__ dgamma, const float* __restrict__ dbeta,
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_v4_kernel(const float* __
                                                                  typename P::elem* __restrict__ cb, const float* __restrict__ dz_bound,
                                                                  const typename P::elem* __restrict__ y_cb, int N, int C, int HW,
                                                                  int relu, int train, const float* __restrict__ mbeta) {
-  __shared__ typename P::frag lds[4][256];
+  __shared__ typename P::frag lds[BN_V4_NT / 64][256];
   const int C8 = C >> 3;
   const int ng = blockIdx.y;
   const int g = ng % C8;
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_v4_kernel(const float* __
     k2[e] = train ? dgamma[c] * inv_n : 0.f;
   }
   const int wave = threadIdx.x >> 6;
-  const int pix_wave = (blockIdx.x * 256 + 64 * wave) * 4;
+  const int pix_wave = (blockIdx.x * BN_V4_NT + 64 * wave) * 4;
   const int pix = pix_wave + 4 * (threadIdx.x & 63);
   float v[4][8];
   if (pix < HW) {
@@ -892,12 +895,12 @@ extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float
   MCD_REQUIRE(res_cb == nullptr || math != MCDSEG_MATH_F16X3 || res_bound != nullptr, "bn_apply_cb: the residual companion needs its bound");
   if (int rc = cb_check("bn_apply_cb", math, y_bound, N, C, HW)) return rc;
   if (bn_v4_on() && (HW & 3) == 0 && (((uintptr_t)z | (uintptr_t)y | (uintptr_t)residual) & 15) == 0) {
-    const dim3 grid4(ceil_div(HW, 1024), N * (C / 8));
+    const dim3 grid4(ceil_div(HW, 4 * BN_V4_NT), N * (C / 8));
     if (math == MCDSEG_MATH_F16X3)
-      hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitF16x3>, grid4, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
+      hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitF16x3>, grid4, dim3(BN_V4_NT), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
                          (const _Float16*)res_cb, res_bound, y, (_Float16*)y_cb, y_bound, N, C, HW, relu);
     else
-      hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitBf16x6>, grid4, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
+      hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitBf16x6>, grid4, dim3(BN_V4_NT), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
                          (const __bf16*)res_cb, res_bound, y, (__bf16*)y_cb, y_bound, N, C, HW, relu);
     MCD_LAUNCH_CHECK("bn_apply_cb");
     return 0;
@@ -931,12 +934,12 @@ static bool bwd_apply_v4(const float* dy, const float* y, const void* y_cb, cons
                          const float* dz_bound, int math, int N, int C, int HW, int relu, int train, const float* mbeta, hipStream_t st) {
   if (!bn_v4_on() || (HW & 3) != 0) return false;
   if ((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)dres) & 15) != 0) return false;
-  const dim3 grid(ceil_div(HW, 1024), N * (C / 8));
+  const dim3 grid(ceil_div(HW, 4 * BN_V4_NT), N * (C / 8));
   if (math == MCDSEG_MATH_F16X3)
-    hipLaunchKernelGGL(bn_bwd_apply_cb_v4_kernel<SplitF16x3>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres,
+    hipLaunchKernelGGL(bn_bwd_apply_cb_v4_kernel<SplitF16x3>, grid, dim3(BN_V4_NT), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres,
                        (_Float16*)dz_cb, dz_bound, (const _Float16*)y_cb, N, C, HW, relu, train, mbeta);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_cb_v4_kernel<SplitBf16x6>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres,
+    hipLaunchKernelGGL(bn_bwd_apply_cb_v4_kernel<SplitBf16x6>, grid, dim3(BN_V4_NT), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres,
                        (__bf16*)dz_cb, dz_bound, (const __bf16*)y_cb, N, C, HW, relu, train, mbeta);
   return true;
 }
