@@ -609,6 +609,9 @@ def _channel_reduce(dy, y, z, mean, rstd, relu, gamma=None, want_bound=False, tr
     return dgamma, dbeta, bound
 
 
+DEBUG_TAPE = None  # a list: _ConvBNAct.backward appends its intermediate tensors (development only)
+
+
 # ------------------------------------------------------------------------------------------------ conv + BN + act
 class _ConvBNAct(torch.autograd.Function):
     @staticmethod
@@ -759,6 +762,9 @@ class _ConvBNAct(torch.autograd.Function):
                                             int(ctx.training), _stream()), "bn_bwd_apply")
         if ctx.x_virtual and ctx.needs_input_grad[1] and not (wgrad_cb and dz_cb is not None and single):
             x = materialize(x, ctx.x_cb, ctx.x_bound)  # the weight gradient falls back to a kernel that reads fp32
+        if DEBUG_TAPE is not None:  # kernel development (tools/op_contention.py): what the BN backward handed to the conv backward
+            DEBUG_TAPE.append(dict(dy=dy, dz=dz, dz_cb=dz_cb, dz_bound=dz_bound, dgamma=dgamma, dbeta=dbeta, dres=dres, shape=(n, c, hw), z=z,
+                                   y=y_mask, mean=mean, rstd=rstd, gamma=gamma, beta=beta, zmask=zmask))
         dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz_cb, x_cb, dz_bound,
                                 x_bound, ctx.w_bound)
         dbias = None

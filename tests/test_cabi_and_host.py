@@ -15,6 +15,19 @@ def _no_pretrained(monkeypatch):
     monkeypatch.setenv("MCDSEG_PRETRAINED", "0")
 
 
+def test_no_packed_fp32_instruction_with_op_sel_in_the_library():
+    """the gfx950 quirk behind round 2's red two-rank test (mcdseg/_lib.py NO_PACKED_F32): no kernel of the built library may hold a
+    packed-fp32 VALU instruction that routes a source's high dword to the low lane -- checked on the disassembly, no GPU needed"""
+    import mcdseg
+    from mcdseg import _lib
+    mcdseg.build()
+    if not os.path.exists(os.path.join(os.environ.get("ROCM_LLVM_BIN", "/opt/rocm/lib/llvm/bin"), "llvm-objdump")):
+        pytest.skip("llvm-objdump of the ROCm toolchain not found")
+    text = _lib.device_disassembly()
+    assert text.count("v_mfma_f32_32x32x16_f16") > 500, "the disassembly does not look like libmcdseg's"
+    assert _lib.packed_f32_opsel_sites() == []
+
+
 def test_library_exports_every_header_symbol():
     import mcdseg
     from mcdseg import _lib

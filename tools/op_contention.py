@@ -1,0 +1,141 @@
+"""Op-level determinism probe (kernel development): two fused conv+BN+ReLU groups, forward + backward in a loop; every iteration's
+outputs AND the BatchNorm-backward intermediates (dz companion, dgamma, dbeta, bound) are compared bit for bit with iteration 0.
+Run it alone, or twice at once on one device (``--procs 2`` spawns the children before any GPU call) to load the chip.
+
+  python tools/op_contention.py --procs 2 --iters 300 --shape 4,256,24,32
+"""
+import argparse
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multichannel-semseg-with-uda_amd"))
+sys.path.insert(0, ROOT)
+os.environ["MCDSEG_PRETRAINED"] = "0"
+
+
+def worker(a):
+    import torch
+    from mcdseg import ops
+    from models.drn import BatchNorm2d, Conv2d
+    dev = torch.device("cuda:0")
+    n, c, h, w = (int(v) for v in a.shape.split(","))
+    g = torch.Generator().manual_seed(5)
+    convs, bns = [], []
+    for i in range(2):
+        cv = Conv2d(c, c, 3, padding=a.dil, dilation=a.dil, bias=False)
+        bn = BatchNorm2d(c)
+        with torch.no_grad():
+            cv.weight.copy_(torch.randn(cv.weight.shape, generator=g) * (2.0 / (9 * c)) ** 0.5)
+            bn.weight.copy_(1 + 0.2 * torch.randn(c, generator=g))
+            bn.bias.copy_(0.1 * torch.randn(c, generator=g))
+        convs.append(cv.to(dev)), bns.append(bn.to(dev).train())
+    x0 = (torch.randn(n, c, h, w, generator=g) + 0.3).to(dev)
+    gy = torch.randn(n, c, h, w, generator=g).to(dev)
+
+    def bits(t):
+        return None if t is None else t.detach().clone()
+
+    def run():
+        for m in convs + bns:
+            m.zero_grad(set_to_none=True)
+        ops.DEBUG_TAPE = []
+        x = x0.clone().requires_grad_()
+        y0 = ops.conv_bn_act(x, convs[0], bns[0], relu=True)            # residual source, fp32 + companion
+        h1 = ops.conv_bn_act(y0, convs[1], bns[1], relu=True, internal=True)
+        y = ops.conv_bn_act(h1, convs[0], bns[0], relu=True, residual=y0)
+        y.backward(gy)
+        out = {"y": bits(y), "dx": bits(x.grad), "dw0": bits(convs[0].weight.grad), "dw1": bits(convs[1].weight.grad),
+               "dgamma0": bits(bns[0].weight.grad), "dbeta0": bits(bns[0].bias.grad), "dgamma1": bits(bns[1].weight.grad),
+               "dbeta1": bits(bns[1].bias.grad)}
+        for i, rec in enumerate(ops.DEBUG_TAPE):
+            nn, cc, hw = rec["shape"]
+            for k in ("dy", "dz", "dgamma", "dbeta", "dz_bound", "dres", "z", "y", "mean", "rstd", "gamma", "beta"):
+                if rec[k] is not None:
+                    out["bwd%d.%s" % (i, k)] = bits(rec[k])
+            out["bwd%d.zmask" % i] = torch.tensor(1 if rec["zmask"] else 0)
+            if rec["dz_cb"] is not None:
+                out["bwd%d.dz_cb" % i] = bits(rec["dz_cb"])
+        ops.DEBUG_TAPE = None
+        return out
+
+    ref = run()
+    torch.cuda.synchronize()
+    bad = 0
+    for it in range(a.iters):
+        cur = run()
+        msgs = []
+        for k, v in ref.items():
+            u = cur[k]
+            same = torch.equal(v.view(torch.int32), u.view(torch.int32)) if v.dtype == torch.float32 else torch.equal(v, u)
+            if not same:
+                if v.dtype == torch.int16 and k.endswith("dz_cb"):
+                    # [piece][N][C/8][HW][8]
+                    ne = (v != u).view(2, n, c // 8, -1, 8)
+                    ch = ne.sum(dim=(0, 1, 3)).view(-1)  # per channel (g*8+e)
+                    msgs.append("%s: %d elems, channels %s, piece counts %s" % (k, int(ne.sum()), ch.nonzero().flatten().tolist()[:16], ne.sum(dim=(1, 2, 3, 4)).tolist()))
+                elif v.dim() == 4:
+                    ne = v != u
+                    if k.endswith(".dz") and int(ne.sum()) <= 64:
+                        pre = k[:-3]
+                        idx = ne.nonzero()
+                        for (i0, i1, i2, i3) in idx.tolist()[:20]:
+                            if pre + ".gamma" in ref:
+                                f32 = torch.float32
+                                ga, rs, mu = (ref[pre + "." + q].cpu() for q in ("gamma", "rstd", "mean"))
+                                db, dg = ref[pre + ".dbeta"].cpu(), ref[pre + ".dgamma"].cpu()
+                                inv_n = torch.tensor(1.0, dtype=f32) / (torch.tensor(float(n), dtype=f32) * torch.tensor(float(h * w), dtype=f32))
+                                gvv = ref[pre + ".dy"][i0, i1, i2, i3].cpu()
+                                zv = ref[pre + ".z"][i0, i1, i2, i3].cpu()
+                                if bool(ref[pre + ".zmask"]) and not float(torch.addcmul(ref[pre + ".beta"].cpu()[i1] - mu[i1] * (ga[i1] * rs[i1]), zv, ga[i1] * rs[i1])) > 0:
+                                    gvv = torch.tensor(0.0)
+                                def form(cd):
+                                    return float((ga[i1] * rs[i1]) * (gvv - db[cd] * inv_n - ((zv - mu[i1]) * rs[i1]) * (dg[i1] * inv_n)))
+                                obs = float(u[i0, i1, i2, i3])
+                                a_c = float(ga[i1] * rs[i1])
+                                k1p = float(gvv) - float((zv - mu[i1]) * rs[i1]) * float(dg[i1] * inv_n) - obs / a_c
+                                allk1 = (db * inv_n).double()
+                                near = int((allk1 - k1p).abs().argmin())
+                                allk2 = (dg * inv_n).double()
+                                near2 = int((allk2 - k1p).abs().argmin())
+                                msgs.append("        implied k1' %.9g (own %.9g); nearest dbeta*inv_n: channel %d (%.9g); nearest dgamma*inv_n: channel %d (%.9g); mean[c] %.6g rstd %.6g ca %.6g"
+                                            % (k1p, float(allk1[i1]), near, float(allk1[near]), near2, float(allk2[near2]), float(mu[i1]), float(rs[i1]), a_c))
+                                msgs.append("        formula: own k1 %.9g | k1 of c-1 %.9g | k1 of c+1 %.9g" % (form(i1), form(i1 - 1), form(min(i1 + 1, c - 1))))
+                            ex = " ".join("%s=%.9g/%.9g" % (nm, float(ref[pre + "." + nm][i0, i1, i2, i3]), float(cur[pre + "." + nm][i0, i1, i2, i3]))
+                                          for nm in ("dy", "z") if pre + "." + nm in ref)
+                            msgs.append("      at n=%d c=%d y=%d x=%d (pix %d): dz %.9g -> %.9g   %s" % (i0, i1, i2, i3, i2 * v.shape[3] + i3, float(v[i0, i1, i2, i3]), float(u[i0, i1, i2, i3]), ex))
+                    ch = ne.sum(dim=(0, 2, 3)) if v.shape[1] == c and v.shape[0] == n else ne.sum(dim=(1, 2, 3))
+                    msgs.append("%s: %d elems, channels/rows %s maxrel %.2e" % (k, int(ne.sum()), ch.nonzero().flatten().tolist()[:16], float((v - u).abs().max() / v.abs().max())))
+                else:
+                    ne = v != u
+                    msgs.append("%s: idx %s  %s -> %s" % (k, ne.nonzero().flatten().tolist()[:8], v[ne][:4].tolist(), u[ne][:4].tolist()))
+        if msgs:
+            bad += 1
+            print("[pid %d] iter %d differs:\n    %s" % (os.getpid(), it, "\n    ".join(msgs)), flush=True)
+            if bad >= 6:
+                break
+    print("[pid %d] done: %d of %d iterations differ" % (os.getpid(), bad, a.iters), flush=True)
+    return 1 if bad else 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--procs", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--shape", default="4,256,24,32")
+    ap.add_argument("--dil", type=int, default=2)
+    ap.add_argument("--worker", action="store_true")
+    a = ap.parse_args()
+    if a.worker or a.procs == 1:
+        sys.exit(worker(a))
+    cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--iters", str(a.iters), "--shape", a.shape, "--dil", str(a.dil)]
+    ps = [subprocess.Popen(cmd) for _ in range(a.procs)]
+    rc = 0
+    for p in ps:
+        rc |= p.wait()
+    sys.exit(rc)
+
+
+if __name__ == "__main__":
+    main()
