@@ -3,9 +3,12 @@
 
 One *step* = one full three-step MCD update (A: G+F on source, B: F on source CE - target discrepancy,
 C: num_k = 4 generator updates on the target discrepancy; adapt_trainer.py:155-220 of the reference) over
-one synthetic batch of N (source, target) RGB+HHA pairs per GPU, i.e. 7 generator forward passes and
-5 generator backward passes (the reference-faithful count is 7; the two unused step-B backward passes are
-elided).  ``value`` = pairs/s over the whole job, inputs resident in HBM.
+one synthetic batch of N (source, target) RGB+HHA pairs per GPU.  The timed schedule runs 6 generator forward and 5 generator
+backward passes per step: the reference's literal 7 + 7, minus the two step-B backward passes whose gradients it zeroes unused
+(SURVEY.md section 3.1), minus step B's target forward, which IS step C's first one (solvers/solver.py; bit-identical results).
+The literal 7-forward schedule is measured in the same run and printed next to it (``value_literal_schedule``).
+``value`` = pairs/s over the whole job, inputs resident in HBM; every step gets a batch it has not seen (a pool of pre-staged
+batches, per-tensor caches dropped), so the per-batch work -- the input's bound and its padded companion -- is inside the timed region.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python bench.py --gpus 8 --steps 5 --warmup 2          # starts the 8 ranks itself (before touching a GPU)
@@ -15,7 +18,7 @@ elided).  ``value`` = pairs/s over the whole job, inputs 
 Rank 0 prints ONE JSON line.  Every kernel family of the step is bracketed by HIP events on the launch stream inside
 the timed region; ``roofline`` prices the kernel with the largest summed time (``dominant``): its algorithmic FLOPs or
 bytes per launch / its average launch duration, against the MFMA peak of the arithmetic it executes or the HBM peak.
-``roofline_forward`` is the same for the forward convolution carrying the most FLOPs.  The pass is matrix-rate bound,
+``roofline_forward`` / ``roofline_wgrad`` are the same for the forward / weight-gradient convolution carrying the most FLOPs.  The pass is matrix-rate bound,
 not HBM bound: ``step_accounting`` says so next to the raw HBM fraction the metric asks for.
 ``cpu_baseline`` times the CPU oracle (plain PyTorch restatement of the reference) on a bounded sample of the same
 workload on the host cores (rank 0, N = 1 only).
@@ -271,6 +274,7 @@ def main():
     ap.add_argument("--cpu_steps", type=int, default=3, help="timed CPU-oracle steps after one warm-up (fewer if the budget runs out)")
     ap.add_argument("--cpu_budget_s", type=float, default=150.0)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--batch_pool", type=int, default=4, help="distinct pre-staged (src, lbl, tgt) batches visited round-robin")
     ap.add_argument("--literal_steps", type=int, default=4,
                     help="extra steps with the literal 7-forward schedule after the timed region, reported as 'literal_schedule' (0 = skip)")
     ap.add_argument("--no_forward_reuse", action="store_true",
@@ -300,20 +304,33 @@ def main():
     torch.cuda.set_device(dev)
 
     solver, models = build_hip(args, dev)
-    src, lbl, tgt = (t.to(dev) for t in synthetic_batch(args.batch, args.input_ch, args.height, args.width, args.n_class,
-                                                        1234 + rank))
+    # a pool of pre-staged batches (device-resident, as the metric asks), visited round-robin; the caches ops.py hangs on a batch
+    # tensor (its bound scalar, the stem's zero-padded companion) are dropped before every step, as for a batch never seen before
+    pool = [tuple(t.to(dev) for t in synthetic_batch(args.batch, args.input_ch, args.height, args.width, args.n_class,
+                                                     1234 + rank + 1000 * j)) for j in range(max(1, args.batch_pool))]
+    turn = [0]
+
+    def next_batch():
+        b = pool[turn[0] % len(pool)]
+        turn[0] += 1
+        for t in b:
+            for a in ("_mcd_cbp", "_mcd_bound", "_mcd_cb"):
+                if hasattr(t, a):
+                    delattr(t, a)
+        return b
+
     timer = LaunchTimer(TIMED_FAMILIES[args.timer])
     ops.LAUNCH_TIMER = timer
 
     for _ in range(args.warmup):
-        c_loss, d_loss = solver.step(src, lbl, tgt)
+        c_loss, d_loss = solver.step(*next_batch())
     torch.cuda.synchronize()
     mdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         timer.enabled = i >= args.steps - args.timer_steps
-        c_loss, d_loss = solver.step(src, lbl, tgt)
+        c_loss, d_loss = solver.step(*next_batch())
     torch.cuda.synchronize()
     mdist.barrier()
     torch.cuda.synchronize()
@@ -329,13 +346,13 @@ def main():
     literal = None
     if solver.reuse_tgt and args.literal_steps > 0:
         solver.reuse_tgt = False
-        solver.step(src, lbl, tgt)
+        solver.step(*next_batch())
         torch.cuda.synchronize()
         mdist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.literal_steps):
-            solver.step(src, lbl, tgt)
+            solver.step(*next_batch())
         torch.cuda.synchronize()
         mdist.barrier()
         torch.cuda.synchronize()
@@ -362,7 +379,7 @@ def main():
         default_cfg = (args.net, args.batch, args.height, args.width, args.input_ch) == ("drn_d_38", 16, 480, 640, 6)
         # dominant kernel = the one with the largest summed duration inside the timed region; launches run alone on the
         # stream, so the event pairs are clean
-        roofline = roofline_fwd = None
+        roofline = roofline_fwd = roofline_wg = None
         if kern:
             dom = max(kern, key=lambda n: kern[n]["ms"])
             roofline = kernel_roofline(dom, kern[dom], ops.CONV_MATH, pmc_traffic(dom) if default_cfg else None)
@@ -370,6 +387,10 @@ def main():
             if fwd:
                 fn = max(fwd, key=lambda n: fwd[n]["flops"])
                 roofline_fwd = kernel_roofline(fn, fwd[fn], ops.CONV_MATH, pmc_traffic(fn) if default_cfg else None)
+            wgk = {n: v for n, v in kern.items() if n.startswith("conv_wgrad")}
+            if wgk:
+                wn = max(wgk, key=lambda n: wgk[n]["flops"])
+                roofline_wg = kernel_roofline(wn, wgk[wn], ops.CONV_MATH, pmc_traffic(wn) if default_cfg else None)
         # whole-step accounting on the algorithmic work of SURVEY.md 8d (drn_d_38 @ 6x480x640 only)
         step_acc = None
         if args.net == "drn_d_38" and (args.height, args.width, args.input_ch) == (480, 640, 6):
@@ -406,9 +427,12 @@ def main():
                                        "running update applied twice) -- %d generator forwards + 5 backwards per step, bit-identical "
                                        "weights/statistics/losses to the literal 7-forward schedule (--no_forward_reuse runs that)"
                                        % 6 if solver.reuse_tgt else "; literal 7 generator forwards + 5 backwards per step")},
+            "value_literal_schedule": literal["value"] if literal else (round(value, 3) if not solver.reuse_tgt else None),
+            "ms_per_step_literal_schedule": literal["ms_per_step"] if literal else (round(ms_per_step, 2) if not solver.reuse_tgt else None),
             "literal_schedule": literal,
             "roofline": roofline,
             "roofline_forward": roofline_fwd,
+            "roofline_wgrad": roofline_wg,
             "step_accounting": step_acc,
             "kernels": {k: {"launches": v["launches"], "ms_total": round(v["ms"], 2), "avg_ms": round(v["avg_ms"], 4), "share": v["share"],
                             "tflops": round(v["tflops"], 2), "alg_gbs": round(v["gbs"], 1)}

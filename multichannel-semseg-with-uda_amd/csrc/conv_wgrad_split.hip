@@ -824,14 +824,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr64_kernel(WgradCbPa
 // which pre-split kernel runs: 0 = register-transposing (three-piece policy, or MCDSEG_WGRAD_TR=0), 1 = transposed-read
 // 128x128 tiles, 2 = transposed-read 256x128 tiles
 int mcdseg_internal_wgrad_cb_variant(const mcdseg_conv_desc* d, int math, int co_p, int ci_p, int splits) {
-  static const bool use_tr = [] {
-    const char* e = getenv("MCDSEG_WGRAD_TR");  // development knob: 0 = register-transposing kernel for the two-piece policy too
-    return e == nullptr || atoi(e) != 0;
-  }();
-  static const bool use_big = [] {
-    const char* e = getenv("MCDSEG_WGRAD_BIG");  // development knob: 0 = 128 x 128 tiles only
-    return e == nullptr || atoi(e) != 0;
-  }();
+  // development / test knobs, read per call (a getenv costs nothing next to a launch) so that a test can run one problem on
+  // both tile shapes: MCDSEG_WGRAD_TR=0 = register-transposing kernel for the two-piece policy too, MCDSEG_WGRAD_BIG=0 = 128 x 128
+  // tiles only
+  const char* e_tr = getenv("MCDSEG_WGRAD_TR");
+  const char* e_big = getenv("MCDSEG_WGRAD_BIG");
+  const bool use_tr = e_tr == nullptr || atoi(e_tr) != 0;
+  const bool use_big = e_big == nullptr || atoi(e_big) != 0;
   if (!(math == MCDSEG_MATH_F16X3 && use_tr)) return 0;
   // 256 x 128 tiles (16-pixel stages) for the layers whose padded Cout is a multiple of 256 -- the plan was made for 128-row
   // tiles, so the number of workgroups halves; taken only while that still fills the chip twice over

@@ -18,7 +18,7 @@ from torch.nn import Parameter
 from mcdseg import ops
 
 from . import drn
-from .drn import BatchNorm2d, Conv2d, FusedSequential
+from .drn import BatchNorm2d, Conv2d, FusedSequential, run_fused
 from .fusion import AddFusion, ConcatFusion, get_fusion_model
 
 
@@ -37,10 +37,13 @@ class Trunk(FusedSequential):
 
     def forward(self, x):
         mods = list(self.children())
+        if not mods:
+            return x
+        # the fusing walk of FusedSequential, so that the DRN-C stem (conv1, bn1, relu as top-level children, models/drn.py:118-121)
+        # runs as one fused group like everywhere else
         with ops.trunk_internal():
-            for m in mods[:-1]:
-                x = m(x)
-        return mods[-1](x) if mods else x
+            x = run_fused(mods[:-1], x)
+        return run_fused(mods[-1:], x)
 
 
 def _seg_head(cin, n_class):

@@ -53,18 +53,22 @@ class FusedSequential(nn.Sequential):
     (models/drn.py:195-205), the 1x1 projection shortcuts (:175-180) and the DRN-C stem (:118-121)."""
 
     def forward(self, x):
-        mods = list(self.children())
-        i = 0
-        while i < len(mods):
-            m = mods[i]
-            if isinstance(m, Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], BatchNorm2d):
-                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
-                x = ops.conv_bn_act(x, m, mods[i + 1], relu=relu)
-                i += 3 if relu else 2
-            else:
-                x = m(x)
-                i += 1
-        return x
+        return run_fused(list(self.children()), x)
+
+
+def run_fused(mods, x):
+    """the fusing walk over a list of modules: (Conv2d, BatchNorm2d[, ReLU]) runs become one fused group each"""
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], BatchNorm2d):
+            relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+            x = ops.conv_bn_act(x, m, mods[i + 1], relu=relu)
+            i += 3 if relu else 2
+        else:
+            x = m(x)
+            i += 1
+    return x
 
 
 ConvBNReLU = FusedSequential

@@ -48,12 +48,22 @@ def _detached(t):
     return d
 
 
+# generators whose forward is a pure function of (weights, batch) plus BatchNorm running-statistics updates that honour
+# ``ops.bn_running_updates``: the classes of models/dilated_fcn.py built on the fused conv+BN groups.  Anything else -- a user's
+# own generator, functional dropout / noise this module cannot see -- gets the reference's literal schedule.
+_REPEATABLE_GENERATORS = {"DRNSegBase", "MultiTaskEncoder"}
+
+
 def _forward_is_repeatable(modules):
-    """two forwards of these modules on one batch give the same features, and every BatchNorm in them honours
-    ``ops.bn_running_updates``: no dropout, and no BatchNorm that runs outside the fused conv+BN groups"""
+    """two forwards of these generators on one batch give the same features and the same running statistics as one forward whose
+    BatchNorm layers apply their update twice: a whitelisted generator class holding no active dropout and no BatchNorm outside
+    the fused groups.  Decided once, when the solver is built."""
     from models.drn import BatchNorm2d
     for g in modules:
-        for m in g.modules():
+        inner = getattr(g, "module", g) if type(g).__name__ == "DataParallel" else g
+        if type(inner).__name__ not in _REPEATABLE_GENERATORS or not type(inner).__module__.startswith("models."):
+            return False
+        for m in inner.modules():
             if isinstance(m, torch.nn.modules.dropout._DropoutNd) and m.p > 0:
                 return False
             if isinstance(m, torch.nn.modules.batchnorm._NormBase) and not isinstance(m, BatchNorm2d):
@@ -100,7 +110,8 @@ class MCDSolver:
             raise NotImplementedError("the fused solver implements d_loss='diff' (loss.py:93-100)")
         self.num_k = num_k
         self.mult = float(num_multiply_d_loss)
-        self.reuse_tgt = REUSE_TARGET_FORWARD  # step B's target forward doubles as step C's first (see the module docstring)
+        # step B's target forward doubles as step C's first (see the module docstring) -- for generator classes known to be repeatable
+        self.reuse_tgt = REUSE_TARGET_FORWARD and _forward_is_repeatable(self._generators())
         self.fused_up = (self.prob_criterion is None and ops.FUSED_UP_LOSS
                          and all(type(f).__name__ == "DRNSegPixelClassifier" and getattr(f, "ver", None) == "ver1"
                                  and type(getattr(f, "up", None)).__name__ == "Up8" for f in (model_f1, model_f2)))
@@ -170,7 +181,7 @@ class MCDSolver:
             feats = self._features(src_imgs)
         self._loss_backward(feats, src_lbls, ce_coef=1.0)
         taped = None
-        if self.reuse_tgt and self.num_k > 0 and _forward_is_repeatable(self._generators()):
+        if self.reuse_tgt and self.num_k > 0:
             with ops.bn_running_updates(2):  # this forward is also the first one of step C
                 taped = self._features(tgt_imgs)
             feats = tuple(_detached(f) for f in taped)
@@ -205,9 +216,9 @@ class MFNetMCDSolver(MCDSolver):
 
     def __init__(self, model_g_3ch, model_g_1ch, model_f1, model_f2, optimizer_g, optimizer_f, criterion, criterion_d,
                  num_k=4):
+        self.g_3ch, self.g_1ch = model_g_3ch, model_g_1ch  # (before the base constructor: it asks _generators())
         super().__init__(model_g_3ch, model_f1, model_f2, optimizer_g, optimizer_f, criterion, criterion_d, num_k=num_k,
                          num_multiply_d_loss=1)  # adapt_mfnet_trainer.py:226-235 applies no multiplier
-        self.g_3ch, self.g_1ch = model_g_3ch, model_g_1ch
 
     def _features(self, x):
         return self.g_3ch(x[:, :3, :, :]), self.g_1ch(x[:, 3:, :, :])
@@ -232,7 +243,7 @@ class MultiTaskMCDSolver:
         self.enc, self.dec = model_enc, model_dec
         self.opt_enc, self.opt_dec = optimizer_enc, optimizer_dec
         self.num_k, self.mult = num_k, num_multiply_d_loss
-        self.reuse_tgt = REUSE_TARGET_FORWARD
+        self.reuse_tgt = REUSE_TARGET_FORWARD and _forward_is_repeatable([model_enc])
 
     def step(self, src_imgs, src_gt_semseg, tgt_imgs):
         enc, dec = self.enc, self.dec
@@ -258,7 +269,7 @@ class MultiTaskMCDSolver:
             dec.semseg_forward(src_fet)
         src_semseg_loss, src_depth_loss = dec.get_loss(src_fet, src_gt_semseg, src_depths, separately_returning=True)
         taped = None
-        if self.reuse_tgt and self.num_k > 0 and _forward_is_repeatable([enc]):
+        if self.reuse_tgt and self.num_k > 0:
             with ops.bn_running_updates(2):  # this forward is also the first one of step C
                 taped = enc(tgt_rgbs)
             tgt_fet = _detached(taped)

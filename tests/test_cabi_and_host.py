@@ -243,3 +243,13 @@ def test_checkpoint_layout_roundtrips_with_torch_modules(golden, tmp_path):
     ref_opt.load_state_dict(ck["optimizer_g"])
     assert ref_opt.state_dict()["param_groups"][0]["momentum"] == 0.9
     og.load_state_dict(ref_opt.state_dict())
+
+
+def test_drn_c_generator_has_the_reference_state_dict_layout(golden):
+    """``--net drn_c_26``: conv1 / bn1 / relu are top-level children of the trunk (models/drn.py:118-121), so the keys are
+    base.0.weight, base.1.*, base.3.0.conv1.weight ... -- pinned to the reference's own key list (make_golden_drnc.py)"""
+    import json
+    from models.model_util import get_models
+    want = json.loads(str(golden.npz("drnc_small.npz")["keys"]))
+    g = get_models("drn_c_26", 6, 41)[0]
+    assert [[k, list(v.shape)] for k, v in g.state_dict().items()] == want

@@ -1104,6 +1104,38 @@ def test_conv_wgrad_presplit_operands(case, math, monkeypatch):
     assert e_cb <= max(2.0 * e_loop, 2e-6 * _maxerr(dw_loop, gw_ref)[1])
 
 
+@pytest.mark.parametrize("case", [(256, 512, 3, 1, 4, 30, 40, 6), (512, 512, 3, 1, 2, 24, 32, 6), (264, 512, 3, 1, 4, 29, 37, 6)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv_wgrad_large_tile_kernel(case, monkeypatch):
+    """``conv_wgrad_split_tr_kernel<SplitF16x3, 4, 2, 3>`` -- the 256 x 128 weight-gradient tile, 14 % of the benchmark step -- on
+    problems small enough for an fp64 reference but with enough split-K work that the launcher takes it (it was
+    only reached at the benchmark's size): named through ``mcdseg_conv_wgrad_variant == 13``, <= 2e-5 of the scale against fp64, and
+    bit for bit the 128 x 128 kernel's result (same stage tiles in the same order, same MFMA K order; MCDSEG_WGRAD_BIG=0 selects it)."""
+    dev = _dev()
+    import ctypes
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "CONV_MATH", "f16x3")
+    monkeypatch.delenv("MCDSEG_WGRAD_BIG", raising=False)
+    cin, cout, k, s, d, h, w, n = case
+    x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, s, d, h, w, n, False), 41)
+    desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
+    assert ops.lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), ops.MATH_ID["f16x3"], 1) == 13
+    x64, w64 = x.double(), wt.double().requires_grad_()
+    ref = F.conv2d(x64, w64, None, stride=s, padding=pad, dilation=d)
+    gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(42))
+    (gw_ref,) = torch.autograd.grad(ref, [w64], gy.double())
+    xg, gyg = x.to(dev), gy.to(dev)
+    x_cb, x_bound = ops.split_companion(xg)
+    gy_cb, gy_bound = ops.split_companion(gyg)
+    dw_big = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
+    _assert_close(dw_big, gw_ref, 2e-5, "wgrad (256 x 128 tiles)")
+    monkeypatch.setenv("MCDSEG_WGRAD_BIG", "0")
+    assert ops.lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), ops.MATH_ID["f16x3"], 1) == 12
+    dw_small = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
+    _assert_close(dw_small, gw_ref, 2e-5, "wgrad (128 x 128 tiles)")
+    assert torch.equal(dw_big, dw_small)
+
+
 @pytest.mark.parametrize("cin,h,w,n", [(6, 21, 45, 2), (3, 16, 64, 1), (1, 9, 33, 2)])
 def test_stem_wgrad_from_padded_companion(cin, h, w, n, monkeypatch):
     """7x7 stem weight gradient in the split arithmetic: the 6- (3-, 1-) channel input's zero-padded companion

@@ -336,6 +336,54 @@ def test_solver_target_forward_reuse_is_bitwise_the_literal_schedule(golden):
     g.add_module("drop", torch.nn.Dropout2d(0.1))
     assert not S._forward_is_repeatable([g])
 
+    class Wrapped(torch.nn.Module):  # an unknown generator class (it could hide functional dropout): literal schedule by default
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, x):
+            return self.inner(x)
+
+    g2 = Wrapped(_mcd_models(dev)[0])
+    assert not S._forward_is_repeatable([g2])
+    og = get_optimizer(g2.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    assert not S.MCDSolver(g2, f1, f2, og, of, CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff")).reuse_tgt
+
+
+@pytest.mark.parametrize("kind", ["mfnet", "drn_c"])
+def test_target_forward_reuse_is_bitwise_for_other_generators(kind):
+    """the reuse of step B's target forward (previous test) for the two-encoder MFNet solver and for a DRN-C generator: state and
+    logged losses after two iterations equal the literal schedule's bit for bit"""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, get_prob_distance_criterion
+    from models.model_util import get_models, get_optimizer
+    from solvers import solver as S
+    s, l, t = (v.to(dev) for v in make_batch(31, 2, 6, 64, 96, NC))
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    states, losses = [], []
+    for reuse in (True, False):
+        if kind == "mfnet":
+            ms = get_models("drn_d_22", 6, NC, method="MFNet-ScoreAddFusion")
+        else:
+            ms = get_models("drn_c_26", 6, NC)
+        for i, m in enumerate(ms):
+            fill_state_(m, 60 + i)
+            m.to(dev).train()
+        gens, heads = ms[:-2], ms[-2:]
+        og = get_optimizer([p for m in gens for p in m.parameters()], "sgd", 1e-3, 0.9, 2e-5)
+        of = get_optimizer([p for m in heads for p in m.parameters()], "sgd", 1e-3, 0.9, 2e-5)
+        crit, critd = CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff")
+        solver = (S.MFNetMCDSolver(ms[0], ms[1], ms[2], ms[3], og, of, crit, critd, num_k=2) if kind == "mfnet"
+                  else S.MCDSolver(ms[0], ms[1], ms[2], og, of, crit, critd, num_k=2))
+        assert solver.reuse_tgt  # whitelisted generator classes
+        solver.reuse_tgt = reuse
+        losses.append([tuple(float(v) for v in solver.step(s, l, t)) for _ in range(2)])
+        states.append({"%d.%s" % (i, k): v.clone() for i, m in enumerate(ms) for k, v in m.state_dict().items()})
+    assert losses[0] == losses[1]
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
+
 
 def test_training_on_a_fixed_batch_reduces_the_source_loss():
     """End-to-end sanity of the whole update path over many steps (weights, BN statistics and the per-tensor fp16 scales all
@@ -524,6 +572,10 @@ def test_cfg2_full_batch_vs_oracle():
     if ops.CONV_MATH != "f32":
         assert big in names, "the forward pass did not run %s: %s" % (big, sorted(set(names)))
         assert ops.gemm_kernel_name(512, 512, True, True, True, False, n * 60 * 80) in names, sorted(set(names))
+        if ops.CONV_MATH == "f16x3":  # ... and the weight gradients of those layers ran on the 256 x 128 / 128 x 128 / 64-channel tiles
+            for wg in ("conv_wgrad_split_tr_kernel<SplitF16x3, 4, 2, 3>", "conv_wgrad_split_tr_kernel<SplitF16x3, 2, 2, 3>",
+                       "conv_wgrad_split_tr64_kernel<SplitF16x3>", "conv_wgrad_thin_tr_kernel<SplitF16x3>"):
+                assert wg in names, "the backward pass did not run %s: %s" % (wg, sorted(set(names)))
     err = float((feat.detach().cpu() - ref_feat).abs().max())
     assert err <= 1e-3, "feat err %.3e" % err
     lerr = float((logits.detach()[:, :, ::8, ::8].cpu() - ref_logits).abs().max())
@@ -754,6 +806,40 @@ def test_model_variants_vs_oracle(net, method):
             if k.endswith("up.weight") or k.startswith("seg.") or k.endswith("up1.weight"):
                 ga, gb = pa[k].grad.cpu(), pb[k].grad
                 assert float((ga - gb).abs().max()) <= max(2e-3 * float(gb.abs().max()), 1e-7), k
+
+
+def test_drn_c_generator_vs_reference(golden):
+    """a DRN-C generator (stem = three top-level children of the trunk, BasicBlock stages 1 / 2 / 7 / 8, the last two without
+    residual) through the fused groups against vectors of the REAL reference: features within 1e-3 (north_star) and within 4x the
+    reference's own fp32-vs-fp64 spread, gradients within max(1e-3 of scale, 8x that spread) -- the bounds of
+    test_forward_small_vs_reference / test_backward_small_vs_reference.  (Trunk.forward had lost the fusing walk.)"""
+    dev = _dev()
+    from models.model_util import get_models
+    fx = golden.npz("drnc_small.npz")
+    g = get_models("drn_c_26", 6, NC)[0]
+    fill_state_(g, 21)
+    g.to(dev).train()
+    x, _, _ = make_batch(22, 2, 6, 32, 48, NC)
+    feat = g(x.to(dev))
+    feat.backward(torch.from_numpy(fx["gy"]).to(dev))
+    f32, f64 = torch.from_numpy(fx["feat_f32"]).double(), torch.from_numpy(fx["feat_f64"])
+    got = feat.detach().double().cpu()
+    scale = float(f64.abs().max())
+    assert float((got - f32).abs().max()) <= 1e-3
+    assert float((got - f64).abs().max()) <= max(4 * float((f32 - f64).abs().max()), 4e-5 * scale)
+    named = dict(g.named_parameters())
+    for key in fx.files:
+        if not key.startswith("grad_f64_"):
+            continue
+        name = key[len("grad_f64_"):]
+        g64 = torch.from_numpy(fx[key])
+        g32 = torch.from_numpy(fx["grad_f32_" + name]).double()
+        mine = named[name].grad[:4].double().cpu()
+        bound = max(1e-3 * max(float(g64.abs().max()), 1e-3), 8 * float((g32 - g64).abs().max()))
+        assert float((mine - g64).abs().max()) <= bound, (name, float((mine - g64).abs().max()), bound)
+    sd = g.state_dict()
+    assert int(sd["base.1.num_batches_tracked"]) == int(fx["nbt"]) == 1
+    np.testing.assert_allclose(sd["base.1.running_mean"].cpu().numpy(), fx["rm_f32"], rtol=2e-5, atol=1e-6)
 
 
 def test_rccl_path_world_size_one(golden):
