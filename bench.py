@@ -51,10 +51,13 @@ MATH = {
     "f32": (1.0, PEAK_FP32_TFLOPS, "v_mfma_f32_32x32x2_f32"),
     "bf16x6": (6.0, PEAK_16BIT_TFLOPS, "fp32 operands as 3-way bf16 split, 6 cross terms on v_mfma_f32_32x32x16_bf16"),
     "f16x3": (3.0, PEAK_16BIT_TFLOPS, "fp32 operands as scaled 2-way fp16 split, 3 cross terms on v_mfma_f32_32x32x16_f16"),
+    "f16x1": (1.0, PEAK_16BIT_TFLOPS, "operands rounded to one scaled fp16 piece, 1 term on v_mfma_f32_32x32x16_f16 (reduced precision)"),
 }
 DTYPE_LABEL = {"f32": "f32",
                "bf16x6": "f32 (operands split 3-way into bf16, 6 cross terms on the bf16 MFMA pipe, fp32 accumulate)",
                "f16x3": "f32 (operands split 2-way into scaled fp16, 3 cross terms on the fp16 MFMA pipe, fp32 accumulate)",
+               "f16x1": "f16 (operands rounded to one scaled fp16 piece, fp32 accumulate, fp32 BatchNorm / loss / optimizer) -- REDUCED precision, "
+                        "not the judged configuration",
                "mixed": "f32 (bf16x6 split for forward/dgrad, f32 MFMA for wgrad)"}
 TIMED_FAMILIES = {
     "all": ["conv_", "bn_", "up8_", "softmax_ce_l1", "sgd_", "loss_", "wgrad_", "split_", "pack_"],
@@ -229,7 +232,9 @@ def dry_run(args):
 def kernel_roofline(name, k, math, traffic):
     """roofline entry of one timed kernel family: MFMA-bound for the convolutions, HBM-bound for the streaming kernels"""
     if name.startswith("conv_") and k["flops"] > 0:
-        if "SplitF16x3" in name:
+        if "SplitF16x1" in name:
+            mult, peak, what = MATH["f16x1"]
+        elif "SplitF16x3" in name:
             mult, peak, what = MATH["f16x3"]
         elif "SplitBf16x6" in name or "x6" in name:
             mult, peak, what = MATH["bf16x6"]
@@ -280,6 +285,9 @@ def main():
     ap.add_argument("--no_forward_reuse", action="store_true",
                     help="literal schedule of adapt_trainer.py: step B's target forward and step C's first one run separately "
                          "(7 generator forwards per step instead of 6; same weights, statistics and losses bit for bit)")
+    ap.add_argument("--dtype", choices=["f32", "f16"], default="f32",
+                    help="f32 (default, the judged configuration): fp32-grade split arithmetic; f16: reduced precision, one fp16 term per product "
+                         "(MCDSEG_CONV_MATH=f16x1; BASELINE config 5's intent) -- reported with its own dtype label")
     ap.add_argument("--timer", choices=sorted(TIMED_FAMILIES), default="all", help="kernel families bracketed by HIP events")
     ap.add_argument("--timer_steps", type=int, default=2,
                     help="how many of the timed steps (the last ones) carry the per-launch HIP events: bracketing all ~1 500 launches "
@@ -295,6 +303,8 @@ def main():
     import torch
     from mcdseg import dist as mdist
     from mcdseg import ops
+    if args.dtype == "f16":
+        ops.CONV_MATH = "f16x1"
     rank, world, local = mdist.init_from_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))

@@ -27,7 +27,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: exactly the declarations below are exported */
 #pragma GCC visibility push(default)
 
-#define MCDSEG_VERSION 100
+#define MCDSEG_VERSION 101
 
 int mcdseg_version(void);
 const char* mcdseg_last_error(void);
@@ -71,9 +71,13 @@ int mcdseg_conv_dgrad(const mcdseg_conv_desc* d, const float* dy, const float* w
  * *_bound arguments (F16X3 only, NULL otherwise): one device float holding an UPPER BOUND of |tensor| -- written by the
  * producer of the tensor (mcdseg_bn_stats_finalize, mcdseg_bn_bwd_reduce, mcdseg_conv_split_pack_weights) or measured
  * with mcdseg_absmax; every kernel derives the scale 2^(ceil(log2 bound) - 15) from it, so no finite value overflows fp16.
- * Weight images are 16-bit, layout [k-step][piece][k-half 2][Mp][8]; sizes from *_packed_bytes. */
+ * Weight images are 16-bit, layout [k-step][piece][k-half 2][Mp][8]; sizes from *_packed_bytes.
+ *   MCDSEG_MATH_F16X1   reduced precision: F16X3's operands (same images, companions, bounds -- every producer treats it as
+ *                       F16X3) multiplied with the leading term only, h1 h1': one MFMA instead of three, operands rounded to
+ *                       fp16's 11 significant bits.  The thin full-resolution layers' window kernels keep three terms. */
 #define MCDSEG_MATH_F16X3 3
 #define MCDSEG_MATH_BF16X6 6
+#define MCDSEG_MATH_F16X1 1
 int mcdseg_conv_split_packed_bytes(const mcdseg_conv_desc* d, int32_t math, int64_t* fprop_bytes, int64_t* dgrad_bytes);
 /* 1 when the forward of this geometry runs as the direct (LDS-tiled) convolution of the network stem (7x7, stride 1,
  * pad 3, Cin <= 8, Cout <= 16; models/drn.py:126-131) -- the one case where the split path takes fewer than 16
@@ -89,6 +93,11 @@ int64_t mcdseg_conv_split_stat_rows(const mcdseg_conv_desc* d);
  * bias for such a geometry is rejected. */
 int64_t mcdseg_conv_split_stat_rows_for(const mcdseg_conv_desc* d, int32_t math, int32_t presplit);
 int32_t mcdseg_conv_split_window_ok(const mcdseg_conv_desc* d, int32_t math, int32_t presplit, int32_t dgrad);
+/* Workgroup tile mcdseg_conv_split_fprop / _dgrad take for M output rows (Cout forward, Cin for the data gradient) and P output
+ * pixels, as the decimal digits WM WN WAVES_M WAVES_N of conv_gemm_split_kernel<P, WM, WN, WAVES_M, WAVES_N, ...>: 4222 = 256 x 128,
+ * 4214 = 128 x 256, 2222 = 128 x 128, 2214 = 64 x 256, 1214 = 32 x 256 (rows x pixels).  For profilers and the benchmark's
+ * per-kernel accounting; never needed to call the operators. */
+int32_t mcdseg_conv_split_tile_config(int32_t M, int64_t P, int32_t presplit);
 /* bound[0] = max |x[i]| (exact, order-independent; non-finite data gives a non-finite bound) */
 int mcdseg_absmax(const float* x, int64_t n, float* bound, void* stream);
 /* w [Cout,Cin,KH,KW] -> fprop and/or dgrad image; F16X3 first measures w_bound = max |w| (device float, written here) */
@@ -134,7 +143,9 @@ int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy
  * fused with ReLU and the residual add of BasicBlock/Bottleneck (models/drn.py:43-59, 80-100)
  * ---------------------------------------------------------------------------------------------- */
 /* Merge the conv epilogue partials -> mean[C], rstd[C]; update running_mean/var (unbiased var) and
- * ++num_batches_tracked when those pointers are non-NULL.  workspace: 8-byte aligned scratch.
+ * num_batches_tracked when those pointers are non-NULL -- running_updates times (>= 1): one launch may stand for several identical
+ * forward passes of the reference's schedule (solvers/solver.py; each update is rounded to fp32 as a separate pass would).
+ * workspace: 8-byte aligned scratch.
  * y_bound (may be NULL): receives an upper bound of |y| for the tensor mcdseg_bn_apply(_cb) is about to write from these
  * statistics, y = act(gamma*xhat + beta (+ residual)): max_c(|gamma_c| sqrt(n-1) + |beta_c|) + res_bound[0], using
  * Samuelson's inequality |xhat| <= sqrt(n-1) for a batch of n values normalised by their own mean and biased variance
@@ -144,7 +155,7 @@ int mcdseg_bn_stats_finalize(const float* stat_partials, int64_t rows, int32_t C
                              float* mean, float* rstd, float* running_mean, float* running_var,
                              int64_t* num_batches_tracked, float momentum, float eps,
                              const float* gamma, const float* beta, const float* res_bound, float* y_bound,
-                             void* workspace, size_t workspace_bytes, void* stream);
+                             int32_t running_updates, void* workspace, size_t workspace_bytes, void* stream);
 /* eval mode: mean = running_mean, rstd = 1/sqrt(running_var+eps) */
 int mcdseg_bn_eval_stats(const float* running_mean, const float* running_var, int32_t C, float eps,
                          float* mean, float* rstd, void* stream);

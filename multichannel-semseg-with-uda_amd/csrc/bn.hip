@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
                                                                 float* __restrict__ running_var, int64_t* nbt,
                                                                 float momentum, float eps, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta,
-                                                                const float* __restrict__ res_bound, float* __restrict__ y_bound) {
-  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+                                                                const float* __restrict__ res_bound, float* __restrict__ y_bound, int updates) {
+  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += updates;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (c >= C) return;  // wave-uniform
@@ -91,8 +91,13 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
   rstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
   if (running_mean != nullptr) {
     const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
-    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
-    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    float rm = running_mean[c], rv = running_var[c];
+    for (int u = 0; u < updates; ++u) {  // one update per forward pass this launch stands for (rounded to fp32 each time, as separate launches would)
+      rm = (float)((1.0 - (double)momentum) * (double)rm + (double)momentum * mean);
+      rv = (float)((1.0 - (double)momentum) * (double)rv + (double)momentum * unbiased);
+    }
+    running_mean[c] = rm;
+    running_var[c] = rv;
   }
   if (y_bound != nullptr) {
     float bound = fabsf(gamma[c]) * (float)sqrt(n > 1.0 ? n - 1.0 : 1.0) * 1.0001f + fabsf(beta[c]);
@@ -790,8 +795,9 @@ extern "C" size_t mcdseg_bn_stats_workspace_bytes(int64_t rows, int32_t C) {
 extern "C" int mcdseg_bn_stats_finalize(const float* stat_partials, int64_t rows, int32_t C, int32_t Mp, float* mean, float* rstd,
                                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                                         float eps, const float* gamma, const float* beta, const float* res_bound, float* y_bound,
-                                        void* workspace, size_t workspace_bytes, void* stream) {
+                                        int32_t running_updates, void* workspace, size_t workspace_bytes, void* stream) {
   MCD_REQUIRE(stat_partials && mean && rstd && workspace, "bn_stats_finalize: null pointer");
+  MCD_REQUIRE(running_updates >= 1 && running_updates <= 64, "bn_stats_finalize: running_updates must be 1..64 (got %d)", running_updates);
   MCD_REQUIRE(rows > 0 && C > 0 && Mp >= C, "bn_stats_finalize: bad dims rows=%lld C=%d Mp=%d", (long long)rows, C, Mp);
   MCD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize: running stats must come in pairs");
   MCD_REQUIRE(y_bound == nullptr || (gamma && beta), "bn_stats_finalize: the output bound needs gamma and beta");
@@ -803,7 +809,7 @@ extern "C" int mcdseg_bn_stats_finalize(const float* stat_partials, int64_t rows
                      (double*)workspace, y_bound);
   MCD_LAUNCH_CHECK("bn_stats_partial");
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)workspace, S, C, mean,
-                     rstd, running_mean, running_var, num_batches_tracked, momentum, eps, gamma, beta, res_bound, y_bound);
+                     rstd, running_mean, running_var, num_batches_tracked, momentum, eps, gamma, beta, res_bound, y_bound, running_updates);
   MCD_LAUNCH_CHECK("bn_stats_finalize");
   return 0;
 }
@@ -852,6 +858,7 @@ static int cb_check(const char* who, int32_t math, const float* bound, int32_t N
 
 extern "C" int mcdseg_split_cb(const float* x, void* x_cb, const float* x_bound, int32_t math, int32_t N, int32_t C, int32_t HW,
                                void* stream) {
+  math = mcd_storage_math(math);  // F16X1 shares F16X3's storage
   MCD_REQUIRE(x && x_cb, "split_cb: null pointer");
   if (int rc = cb_check("split_cb", math, x_bound, N, C, HW)) return rc;
   const dim3 grid(ceil_div(HW, 256), N * (C / 8));
@@ -865,6 +872,7 @@ extern "C" int mcdseg_split_cb(const float* x, void* x_cb, const float* x_bound,
 
 extern "C" int mcdseg_split_cb_padded(const float* x, void* x_cb, const float* x_bound, int32_t math, int32_t N, int32_t C, int32_t HW,
                                       void* stream) {
+  math = mcd_storage_math(math);  // F16X1 shares F16X3's storage
   MCD_REQUIRE(x && x_cb, "split_cb_padded: null pointer");
   MCD_REQUIRE(math == MCDSEG_MATH_BF16X6 || math == MCDSEG_MATH_F16X3, "split_cb_padded: unknown math %d", math);
   MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || x_bound != nullptr, "split_cb_padded: the f16x3 split needs the bound scalar of the tensor");
@@ -890,6 +898,7 @@ static bool bn_v4_on() {
 extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                   const float* residual, const void* res_cb, const float* res_bound, float* y, void* y_cb,
                                   const float* y_bound, int32_t math, int32_t N, int32_t C, int32_t HW, int32_t relu, void* stream) {
+  math = mcd_storage_math(math);  // F16X1 shares F16X3's storage
   MCD_REQUIRE(z && mean && rstd && gamma && beta && y_cb, "bn_apply_cb: null pointer");
   MCD_REQUIRE(!(residual && res_cb), "bn_apply_cb: the residual comes either as fp32 or as its companion, not both");
   MCD_REQUIRE(res_cb == nullptr || math != MCDSEG_MATH_F16X3 || res_bound != nullptr, "bn_apply_cb: the residual companion needs its bound");
@@ -918,6 +927,7 @@ extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float
 
 extern "C" int mcdseg_unsplit_cb(const void* x_cb, const float* x_bound, int32_t math, int32_t N, int32_t C, int32_t HW, float* x,
                                  void* stream) {
+  math = mcd_storage_math(math);  // F16X1 shares F16X3's storage
   MCD_REQUIRE(x_cb && x, "unsplit_cb: null pointer");
   if (int rc = cb_check("unsplit_cb", math, x_bound, N, C, HW)) return rc;
   const dim3 grid(ceil_div(HW, 256), N * (C / 8));
@@ -948,6 +958,7 @@ extern "C" int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const voi
                                       const float* rstd, const float* gamma, const float* dgamma, const float* dbeta, float* dz,
                                       float* dres, void* dz_cb, const float* dz_bound, int32_t math, int32_t N, int32_t C, int32_t HW,
                                       int32_t relu, int32_t train, void* stream) {
+  math = mcd_storage_math(math);  // F16X1 shares F16X3's storage
   MCD_REQUIRE(dy && z && mean && rstd && gamma && dz_cb, "bn_bwd_apply_cb: null pointer");
   MCD_REQUIRE(!relu || y || y_cb, "bn_bwd_apply_cb: relu mask needs y or its companion");
   MCD_REQUIRE(!train || (dgamma && dbeta), "bn_bwd_apply_cb: train mode needs dgamma/dbeta");
@@ -974,6 +985,7 @@ extern "C" int mcdseg_bn_bwd_apply_cb_zmask(const float* dy, const float* z, con
                                             const float* beta, const float* dgamma, const float* dbeta, float* dz, void* dz_cb,
                                             const float* dz_bound, int32_t math, int32_t N, int32_t C, int32_t HW, int32_t train,
                                             void* stream) {
+  math = mcd_storage_math(math);  // F16X1 shares F16X3's storage
   MCD_REQUIRE(dy && z && mean && rstd && gamma && beta && dz_cb, "bn_bwd_apply_cb_zmask: null pointer");
   MCD_REQUIRE(!train || (dgamma && dbeta), "bn_bwd_apply_cb_zmask: train mode needs dgamma/dbeta");
   if (int rc = cb_check("bn_bwd_apply_cb_zmask", math, dz_bound, N, C, HW)) return rc;
@@ -1009,6 +1021,7 @@ extern "C" int mcdseg_bn_bwd_reduce(const float* dy, const float* y, const void*
                                     const float* rstd, float* dgamma, float* dbeta, const float* gamma, float* dz_bound, int32_t train,
                                     int32_t N, int32_t C, int32_t HW, int32_t relu, void* workspace, size_t workspace_bytes,
                                     void* stream) {
+  math = mcd_storage_math(math);  // F16X1 shares F16X3's storage
   MCD_REQUIRE(dy && workspace && (dgamma || dbeta), "bn_bwd_reduce: null pointer");
   MCD_REQUIRE(!relu || y || y_cb, "bn_bwd_reduce: relu mask needs y or its companion");
   MCD_REQUIRE(!z || (mean && rstd), "bn_bwd_reduce: z needs mean/rstd");

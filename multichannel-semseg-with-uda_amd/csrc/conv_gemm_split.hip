@@ -59,12 +59,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
   constexpr int A_ITERS = (A_CHUNKS + NT - 1) / NT;
   constexpr bool A_EXACT = (A_CHUNKS % NT) == 0;
   constexpr bool A_DMA = A_EXACT;                  // weight slab by LDS-DMA when it tiles the workgroup exactly
+  // ... of which only the pieces the policy multiplies are moved (piece-major slab) -- when those still tile the workgroup
+  // exactly (every wave must issue the same number of DMAs: the K loop's waits are counted)
+  constexpr int A_ITERS_DMA = ((2 * P::NPU * BM) % NT == 0) ? (2 * P::NPU * BM) / NT : A_ITERS;
   constexpr int A_BYTES = NQ * BM * 16, B_BYTES = NQ * BN * 16;
 
   // B_DMA: the pre-split operand also goes global -> LDS by DMA (see dma_b); that K loop keeps NSTAGE LDS stages: with three,
   // the DMAs of step s+2 are in flight while step s multiplies -- a K-step of the three-term arithmetic is only ~400-800
   // cycles, less than a round trip beyond the XCD's L2
-  constexpr bool B_DMA = PRESPLIT && A_DMA && B_ITEMS == 1;
+  constexpr bool B_DMA = PRESPLIT && A_DMA && (B_ITEMS == 1 || (BM == 128 && BN == 256));  // (the 128 x 256 tile: two k-halves per thread)
   constexpr int NSTAGE = (B_DMA && 3 * (A_BYTES + B_BYTES) <= 80 * 1024) ? 3 : 2;  // two workgroups per CU must still fit 160 KiB
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * (A_BYTES + B_BYTES)];
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
     unsigned char* adst = As + buf * A_BYTES + wave * 64 * 16;
 #if defined(__HIP_DEVICE_COMPILE__)  // the LDS address space does not exist in the host pass of this translation unit
 #pragma unroll
-    for (int i = 0; i < A_ITERS; ++i)
+    for (int i = 0; i < A_ITERS_DMA; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wp_rs, (__attribute__((address_space(3))) void*)(adst + i * NT * 16), 16, a_voff[i], a_soff, 0, 0);
 #else
     (void)a_soff;
@@ -341,21 +344,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
   // offset makes the DMA deposit zeros -- so the K loop issues six DMAs per thread and touches no vector register for
   // staging: no ds_write, no register prefetch sets.
   auto dma_b = [&](int buf) {
-    const int grp = (l_c0 >> 3) + bh0;
     const int wave_px = __builtin_amdgcn_readfirstlane(bj - lane);
-    unsigned char* bdst = Bs + buf * B_BYTES + (bh0 * BN + wave_px) * 16;
+#pragma unroll
+    for (int it = 0; it < B_ITEMS; ++it) {
+      const int h = (B_ITEMS == 1) ? bh0 : it;  // BN = 256: the thread's pixel in both k-halves
+      const int grp = (l_c0 >> 3) + h;
+      unsigned char* bdst = Bs + buf * B_BYTES + (h * BN + wave_px) * 16;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int pc = 0; pc < NP; ++pc) {
-      const int soff = grp < C8 ? (grp * HWs + pc * piece_stride) * 16 : 0x7FFFFFFF;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (__attribute__((address_space(3))) void*)(bdst + pc * 2 * BN * 16), 16, l_voff, soff, 0, 0);
-    }
+      for (int pc = 0; pc < P::NPU; ++pc) {
+        const int soff = grp < C8 ? (grp * HWs + pc * piece_stride) * 16 : 0x7FFFFFFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (__attribute__((address_space(3))) void*)(bdst + pc * 2 * BN * 16), 16, l_voff, soff, 0, 0);
+      }
 #else
-    (void)grp;
-    (void)bdst;
+      (void)grp;
+      (void)bdst;
 #endif
+    }
   };
-  constexpr int DMA_PER_STEP = A_ITERS + NP;  // LDS-DMA instructions one thread issues per K-step (B_DMA loop)
+  constexpr int DMA_PER_STEP = A_ITERS_DMA + P::NPU * B_ITEMS;  // LDS-DMA instructions one thread issues per K-step (B_DMA loop)
   if constexpr (B_DMA) {
     if (nsteps > 0) {
       dma_weights(0);
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
       unsigned char* adst = As + (CUR ^ 1) * A_BYTES + wave * 64 * 16;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-      for (int i = 0; i < A_ITERS; ++i)
+      for (int i = 0; i < A_ITERS_DMA; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wp_rs, (__attribute__((address_space(3))) void*)(adst + i * NT * 16), 16, a_voff[i], a_soff, 0, 0);
 #else
       (void)a_soff;
@@ -793,7 +800,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* 
 
 int split_check(const mcdseg_conv_desc* d, int math, const char* who, bool operands = true) {
   MCD_REQUIRE(d != nullptr, "%s: null descriptor", who);
-  MCD_REQUIRE(math == MCDSEG_MATH_BF16X6 || math == MCDSEG_MATH_F16X3, "%s: math must be MCDSEG_MATH_BF16X6 or MCDSEG_MATH_F16X3 (got %d)", who, math);
+  MCD_REQUIRE(mcd_math_known(math), "%s: math must be MCDSEG_MATH_BF16X6, MCDSEG_MATH_F16X3 or MCDSEG_MATH_F16X1 (got %d)", who, math);
   MCD_REQUIRE(d->N > 0 && d->Cin > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "%s: non-positive dims", who);
   MCD_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0, "%s: bad kernel geometry", who);
   const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
@@ -809,12 +816,9 @@ int64_t split_image_bytes(int math, int M, int K, int T) {
 }
 
 // development knob: number of tile slots from which the 256 x 128 tile is preferred (see launch<>)
-int big_tile_min_slots() {
-  static const int v = [] {
-    const char* e = getenv("MCDSEG_BIGTILE_MIN_SLOTS");
-    return e ? atoi(e) : 1024;
-  }();
-  return v;
+int big_tile_min_slots() {  // (read per call: a test runs one problem on several tiles)
+  const char* e = getenv("MCDSEG_BIGTILE_MIN_SLOTS");
+  return e ? atoi(e) : 1024;
 }
 
 template <class P, int WM, int WN, int WAVES_M, int WAVES_N, bool DGRAD>
@@ -841,26 +845,45 @@ void launch_cfg(const ConvSplitParams& p, hipStream_t st) {
     hipLaunchKernelGGL((conv_gemm_split_kernel<P, WM, WN, WAVES_M, WAVES_N, DGRAD, false>), grid, dim3(256), 0, st, q);
 }
 
+// development knob: number of 128 x 256 tiles from which that tile is preferred over 128 x 128 (see tile_config)
+int wide_tile_min_slots() {
+  const char* e = getenv("MCDSEG_WIDETILE_MIN_SLOTS");
+  return e ? atoi(e) : 1024;
+}
+
+// Workgroup tile of the implicit GEMM with M output rows (padded Mp) and P pixels, as WM WN WAVES_M WAVES_N packed into decimal
+// digits: 4222 = 256 x 128 (each wave 128 x 64), 4214 = 128 x 256 (each wave 128 x 64, four waves along the pixels), 2222 =
+// 128 x 128, 2214 = 64 x 256, 1214 = 32 x 256.  The two large tiles need the pre-split operand (all-DMA K loop).
+//   256 x 128: the gathered operand is fetched once per TWO row tiles and a K-step issues fewer fragment reads per MFMA -- worth
+//     +5 % on the 512-channel layers, but only while the grid still holds two full rounds of the 512 workgroup slots this tile
+//     leaves (256-channel layers and small batches lose);
+//   128 x 256: the same wave tile for the 128- and 256-channel layers -- the WEIGHT slab is fetched once per two pixel tiles.
+//     Results (outputs and BatchNorm partial rows, one per 64 pixels) are bit for bit those of the 128 x 128 tile.
+int tile_config(int M, int64_t P, bool presplit) {
+  const int bm = mcd_bm(M), mp = mcd_mp(M);
+  if (bm == 128 && presplit && (mp % 256) == 0 && ceil_div64(P, 128) * (mp / 256) >= big_tile_min_slots()) return 4222;
+  if (bm == 128 && presplit && ceil_div64(P, 256) * (mp / 128) >= wide_tile_min_slots()) return 4214;
+  if (bm == 128) return 2222;
+  return bm == 64 ? 2214 : 1214;
+}
+
 template <class P, bool DGRAD>
 void launch(const ConvSplitParams& p, hipStream_t st) {
-  const int bm = mcd_bm(p.M);
-  // 256 x 128 tile (each wave 128 x 64): the gathered operand is fetched once per TWO row tiles and a K-step issues fewer
-  // fragment reads per MFMA -- worth +5 % on the 512-channel layers, but only while the grid still holds two full rounds of
-  // the 512 workgroup slots this tile leaves (256-channel layers and small batches lose)
-  if (bm == 128 && p.src_cb != nullptr && (p.Mp % 256) == 0 && (int64_t)ceil_div(p.P, 128) * (p.Mp / 256) >= big_tile_min_slots())
-    launch_cfg<P, 4, 2, 2, 2, DGRAD>(p, st);
-  else if (bm == 128)
-    launch_cfg<P, 2, 2, 2, 2, DGRAD>(p, st);
-  else if (bm == 64)
-    launch_cfg<P, 2, 2, 1, 4, DGRAD>(p, st);
-  else
-    launch_cfg<P, 1, 2, 1, 4, DGRAD>(p, st);
+  switch (tile_config(p.M, p.P, p.src_cb != nullptr)) {
+    case 4222: launch_cfg<P, 4, 2, 2, 2, DGRAD>(p, st); break;
+    case 4214: launch_cfg<P, 4, 2, 1, 4, DGRAD>(p, st); break;
+    case 2222: launch_cfg<P, 2, 2, 2, 2, DGRAD>(p, st); break;
+    case 2214: launch_cfg<P, 2, 2, 1, 4, DGRAD>(p, st); break;
+    default: launch_cfg<P, 1, 2, 1, 4, DGRAD>(p, st); break;
+  }
 }
 
 template <bool DGRAD>
 void launch_math(int math, const ConvSplitParams& p, hipStream_t st) {
   if (math == MCDSEG_MATH_F16X3)
     launch<SplitF16x3, DGRAD>(p, st);
+  else if (math == MCDSEG_MATH_F16X1)
+    launch<SplitF16x1, DGRAD>(p, st);  // the same operands, one term
   else
     launch<SplitBf16x6, DGRAD>(p, st);
 }
@@ -889,23 +912,31 @@ static int64_t stem_image_offset(const mcdseg_conv_desc* d, int math) {
 
 extern "C" int32_t mcdseg_conv_split_direct_ok(const mcdseg_conv_desc* d) { return d != nullptr && mcdseg_internal_stem_ok(d) ? 1 : 0; }
 
-extern "C" int64_t mcdseg_conv_split_stat_rows(const mcdseg_conv_desc* d) {
-  if (d == nullptr) return -22;
-  if (mcdseg_internal_stem_ok(d)) return mcdseg_internal_stem_stat_rows(d);
-  const int bm = mcd_bm(d->Cout);
-  const int64_t bn = bm == 128 ? 128 : 256;  // pixel tile and column waves of launch<>
-  const int64_t waves_n = bm == 128 ? 2 : 4;
+static int64_t stat_rows_of(const mcdseg_conv_desc* d, bool presplit) {
+  const int cfg = tile_config(d->Cout, (int64_t)d->N * d->Ho * d->Wo, presplit);
+  const int64_t waves_n = cfg % 10, bn = 32 * ((cfg / 100) % 10) * waves_n;  // pixel tile and column waves of launch<>
   return ceil_div64((int64_t)d->N * d->Ho * d->Wo, bn) * waves_n;
 }
 
+extern "C" int64_t mcdseg_conv_split_stat_rows(const mcdseg_conv_desc* d) {
+  if (d == nullptr) return -22;
+  if (mcdseg_internal_stem_ok(d)) return mcdseg_internal_stem_stat_rows(d);
+  return stat_rows_of(d, false);
+}
+
 extern "C" int64_t mcdseg_conv_split_stat_rows_for(const mcdseg_conv_desc* d, int32_t math, int32_t presplit) {
+  math = mcd_storage_math(math);  // F16X1 shares F16X3's storage
   if (d == nullptr) return -22;
   if (math == MCDSEG_MATH_F16X3 && presplit && mcdseg_internal_thin_window_ok(d, 0)) return mcdseg_internal_thin_window_stat_rows(d);
-  return mcdseg_conv_split_stat_rows(d);
+  if (mcdseg_internal_stem_ok(d)) return mcdseg_internal_stem_stat_rows(d);
+  return stat_rows_of(d, presplit != 0);
 }
+
+extern "C" int32_t mcdseg_conv_split_tile_config(int32_t M, int64_t P, int32_t presplit) { return tile_config(M, P, presplit != 0); }
 
 // 1 when mcdseg_conv_split_fprop / _dgrad run this geometry on the LDS-window kernel (for profilers and the benchmark's accounting)
 extern "C" int32_t mcdseg_conv_split_window_ok(const mcdseg_conv_desc* d, int32_t math, int32_t presplit, int32_t dgrad) {
+  math = mcd_storage_math(math);  // F16X1 shares F16X3's storage
   return d != nullptr && math == MCDSEG_MATH_F16X3 && presplit && mcdseg_internal_thin_window_ok(d, dgrad) ? 1 : 0;
 }
 
@@ -921,6 +952,7 @@ extern "C" int mcdseg_absmax(const float* x, int64_t n, float* bound, void* stre
 }
 
 extern "C" int mcdseg_conv_split_packed_bytes(const mcdseg_conv_desc* d, int32_t math, int64_t* fprop_bytes, int64_t* dgrad_bytes) {
+  math = mcd_storage_math(math);  // F16X1 shares F16X3's storage
   MCD_REQUIRE(d != nullptr, "conv_split_packed_bytes: null descriptor");
   MCD_REQUIRE(math == MCDSEG_MATH_BF16X6 || math == MCDSEG_MATH_F16X3, "conv_split_packed_bytes: unknown math %d", math);
   const int T = d->KH * d->KW;
@@ -934,6 +966,7 @@ extern "C" int mcdseg_conv_split_packed_bytes(const mcdseg_conv_desc* d, int32_t
 
 extern "C" int mcdseg_conv_split_pack_weights(const mcdseg_conv_desc* d, int32_t math, const float* w, void* wp_fprop, void* wp_dgrad,
                                               float* w_bound, void* stream) {
+  math = mcd_storage_math(math);  // F16X1 shares F16X3's storage
   if (int rc = split_check(d, math, "conv_split_pack_weights", false)) return rc;  // weights only: any batch size
   MCD_REQUIRE(w != nullptr && (wp_fprop != nullptr || wp_dgrad != nullptr), "conv_split_pack_weights: null pointer");
   MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || w_bound != nullptr, "conv_split_pack_weights: the f16x3 images need the weight bound scalar");
@@ -963,6 +996,7 @@ extern "C" int mcdseg_conv_split_pack_weights(const mcdseg_conv_desc* d, int32_t
 
 extern "C" int mcdseg_conv_split_pack_weights_multi(const int64_t* ptrs, const int32_t* dims, int32_t n, int32_t math, float* bounds,
                                                     void* stream) {
+  math = mcd_storage_math(math);  // F16X1 shares F16X3's storage
   MCD_REQUIRE(ptrs && dims && n > 0 && n <= 32767, "conv_split_pack_weights_multi: bad table");
   MCD_REQUIRE(math == MCDSEG_MATH_BF16X6 || math == MCDSEG_MATH_F16X3, "conv_split_pack_weights_multi: unknown math %d", math);
   MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || bounds != nullptr, "conv_split_pack_weights_multi: f16x3 needs the bounds array");
@@ -999,15 +1033,16 @@ static int split_fprop_impl(const mcdseg_conv_desc* d, int math, const float* x,
   const bool stem = mcdseg_internal_stem_ok(d);
   // the stem with a (zero-padded, 8-channel) companion of the network input runs on the window kernel; its fp32 form (and every
   // bias / affine epilogue) on the direct bf16x6 kernel
-  const bool stem_window = stem && math == MCDSEG_MATH_F16X3 && x_cb != nullptr && bias == nullptr && ep_scale == nullptr &&
+  const int smath = mcd_storage_math(math);
+  const bool stem_window = stem && smath == MCDSEG_MATH_F16X3 && x_cb != nullptr && bias == nullptr && ep_scale == nullptr &&
                            mcdseg_internal_thin_window_ok(d, 0);
   if (stem && !stem_window) {
     MCD_REQUIRE(x != nullptr, "conv_split_fprop: the stem kernel reads the fp32 input");
     return mcdseg_internal_stem_fprop(d, x, (const char*)wp + stem_image_offset(d, math), bias, y, stats, ep_scale, ep_shift, ep_res,
                                       ep_relu, (hipStream_t)stream);
   }
-  MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || (x_bound && w_bound), "conv_split_fprop: f16x3 needs the operand and weight bound scalars");
-  if (math == MCDSEG_MATH_F16X3 && x_cb != nullptr && mcdseg_internal_thin_window_ok(d, 0)) {
+  MCD_REQUIRE(smath != MCDSEG_MATH_F16X3 || (x_bound && w_bound), "conv_split_fprop: f16x3 needs the operand and weight bound scalars");
+  if (smath == MCDSEG_MATH_F16X3 && x_cb != nullptr && mcdseg_internal_thin_window_ok(d, 0)) {
     // the window kernel has no bias / affine epilogue: those callers (conv+bias heads, folded-BN inference) have no companion
     MCD_REQUIRE(bias == nullptr && ep_scale == nullptr, "conv_split_fprop: the thin-layer window kernel takes no bias / affine epilogue");
     return mcdseg_internal_thin_window_launch(d, 0, x_cb, x_bound, wp, split_image_bytes(math, d->Cout, d->Cin, d->KH * d->KW), w_bound, y,
@@ -1052,8 +1087,9 @@ extern "C" int mcdseg_conv_split_dgrad(const mcdseg_conv_desc* d, int32_t math, 
                                        const void* wp_dgrad, const float* w_bound, float* dx, void* stream) {
   if (int rc = split_check(d, math, "conv_split_dgrad")) return rc;
   MCD_REQUIRE((dy || dy_cb) && wp_dgrad && dx, "conv_split_dgrad: null pointer");
-  MCD_REQUIRE(math != MCDSEG_MATH_F16X3 || (dy_bound && w_bound), "conv_split_dgrad: f16x3 needs the operand and weight bound scalars");
-  if (math == MCDSEG_MATH_F16X3 && dy_cb != nullptr && mcdseg_internal_thin_window_ok(d, 1))
+  const int smath = mcd_storage_math(math);
+  MCD_REQUIRE(smath != MCDSEG_MATH_F16X3 || (dy_bound && w_bound), "conv_split_dgrad: f16x3 needs the operand and weight bound scalars");
+  if (smath == MCDSEG_MATH_F16X3 && dy_cb != nullptr && mcdseg_internal_thin_window_ok(d, 1))
     return mcdseg_internal_thin_window_launch(d, 1, dy_cb, dy_bound, wp_dgrad, split_image_bytes(math, d->Cin, d->Cout, d->KH * d->KW),
                                               w_bound, dx, nullptr, (hipStream_t)stream);
   ConvSplitParams p;

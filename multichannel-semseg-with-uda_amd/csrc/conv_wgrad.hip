@@ -469,7 +469,7 @@ static bool thin_tr_applies(const mcdseg_conv_desc* d, int math, const void* x_c
     const char* e = getenv("MCDSEG_WGRAD_THIN_TR");
     return e == nullptr || atoi(e) != 0;
   }();
-  return on && math == MCDSEG_MATH_F16X3 && x_cb && dy_cb && mcdseg_internal_wgrad_thin_tr_ok(d);
+  return on && mcd_storage_math(math) == MCDSEG_MATH_F16X3 && x_cb && dy_cb && mcdseg_internal_wgrad_thin_tr_ok(d);
 }
 
 // the 64 x 64 plan (32 < min(Cin, Cout) <= 64) from both pre-split companions: f16x3 only (MCDSEG_WGRAD_TR64=0 turns it off)
@@ -478,7 +478,7 @@ static bool tr64_applies(const mcdseg_conv_desc* d, int math, const void* x_cb, 
     const char* e = getenv("MCDSEG_WGRAD_TR64");
     return e == nullptr || atoi(e) != 0;
   }();
-  return on && cfg == 1 && math == MCDSEG_MATH_F16X3 && x_cb && dy_cb && (d->Cin & 7) == 0 && (d->Cout & 7) == 0;
+  return on && cfg == 1 && mcd_storage_math(math) == MCDSEG_MATH_F16X3 && x_cb && dy_cb && (d->Cin & 7) == 0 && (d->Cout & 7) == 0;
 }
 
 static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
@@ -492,7 +492,7 @@ extern "C" int32_t mcdseg_conv_wgrad_variant(const mcdseg_conv_desc* d, int32_t 
   if (d == nullptr) return -22;
   const WgradPlan pl = make_plan(d);
   if (presplit && thin_tr_applies(d, math, d, d)) return 15;
-  if (pl.cfg == 1 && math == MCDSEG_MATH_F16X3 && presplit && tr64_applies(d, math, d, d, 1)) return 14;
+  if (pl.cfg == 1 && presplit && tr64_applies(d, math, d, d, 1)) return 14;
   if (pl.cfg != 0 || math == 0) return pl.cfg;
   if (!(presplit && (d->Cin & 7) == 0 && (d->Cout & 7) == 0)) return 10;
   return 11 + mcdseg_internal_wgrad_cb_variant(d, math, pl.co_p, pl.ci_p, pl.splits);
@@ -508,7 +508,7 @@ extern "C" int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, cons
 extern "C" int mcdseg_conv_split_wgrad(const mcdseg_conv_desc* d, int32_t math, const float* x, const void* x_cb, const float* x_bound,
                                        const float* dy, const void* dy_cb, const float* dy_bound, float* dw, void* workspace,
                                        size_t workspace_bytes, void* stream) {
-  MCD_REQUIRE(math == MCDSEG_MATH_BF16X6 || math == MCDSEG_MATH_F16X3, "conv_split_wgrad: unknown math %d", math);
+  MCD_REQUIRE(mcd_math_known(math), "conv_split_wgrad: unknown math %d", math);
   return wgrad_impl(d, x, dy, dw, workspace, workspace_bytes, math, x_cb, x_bound, dy_cb, dy_bound, stream);
 }
 
@@ -526,7 +526,7 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
   const bool tr64 = tr64_applies(d, math, x_cb, dy_cb, make_plan(d).cfg);
   const bool cb_path = tr64 || (math && x_cb && dy_cb && (d->Cin & 7) == 0 && (d->Cout & 7) == 0 && make_plan(d).cfg == 0);
   const bool split_plan = tr64 || (math && make_plan(d).cfg == 0);
-  MCD_REQUIRE(!(split_plan && math == MCDSEG_MATH_F16X3) || (x_bound && dy_bound), "conv_split_wgrad: f16x3 needs both bound scalars");
+  MCD_REQUIRE(!(split_plan && mcd_storage_math(math) == MCDSEG_MATH_F16X3) || (x_bound && dy_bound), "conv_split_wgrad: f16x3 needs both bound scalars");
   MCD_REQUIRE(cb_path || (x && dy), "conv_wgrad: x and dy may be NULL only when the pre-split 128x128 plan applies");
   MCD_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0, "conv_wgrad: bad dims");
   MCD_REQUIRE(((int64_t)d->N * d->Cin + 128) * d->H * d->W * 4 < (1ll << 31) && ((int64_t)d->N * d->Cout + 128) * d->Ho * d->Wo * 4 < (1ll << 31),
@@ -565,7 +565,7 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
     MCD_LAUNCH_CHECK("conv_wgrad_thin_reduce");
     return 0;
   }
-  const bool scaled = split_plan && math == MCDSEG_MATH_F16X3;
+  const bool scaled = split_plan && mcd_storage_math(math) == MCDSEG_MATH_F16X3;
   if (tr64) {
     if (int rc = mcdseg_internal_wgrad_split_tr64_launch(d, math, x_cb, dy_cb, (float*)workspace, pl.co_p, pl.ci_p, pl.chunks_per_img,
                                                          pl.splits, st))

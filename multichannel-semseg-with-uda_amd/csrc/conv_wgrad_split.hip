@@ -11,6 +11,8 @@
 // MFMA lanes read back as ds_read_b128 over 512 contiguous bytes per half-wave.  Slabs + fixed-order fp64 reduce
 // as in conv_wgrad.hip (same plan, same workspace).
 #include <cstdlib>
+#include <type_traits>
+
 #include "split.h"
 
 namespace {
@@ -383,6 +385,16 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_split_cb_kernel(WgradCbPara
 }
 
 
+// re-define registers filled by inline-assembly LDS reads behind the wait that completes them (no instruction; an ordering edge)
+template <class F, int A, int B>
+__device__ __forceinline__ void mcd_settle(F (&f)[A][B], int used) {
+#pragma unroll
+  for (int a = 0; a < A; ++a)
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+      if (a < used) asm volatile("" : "+v"(f[a][b]));
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Pre-split operands, all-DMA variant (two-piece policies): the register transposition above is replaced by gfx950's
 // transposing LDS read.  The operands stay in LDS exactly as they sit in memory -- 16-B units of 8 channels x 1 pixel --
@@ -506,7 +518,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr_kernel(WgradCbPara
 #endif
   };
   // number of DMA instructions this wave issues per stage (wave-uniform): the counted wait below leaves one stage in flight
-  const int dma_per_stage = NQD * nblk;
+  // (a wave whose role is a piece the policy never multiplies -- SplitF16x1's second -- moves nothing)
+  const bool dma_on = piece < P::NPU;
+  const int dma_per_stage = dma_on ? NQD * nblk : 0;
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -539,23 +553,67 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr_kernel(WgradCbPara
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(frag, v);
   };
-  frag fa[NP][WM], fb[NP][WN];
-  auto read_frags = [&](const unsigned char* st, int kk) {
-#pragma unroll
-    for (int pc = 0; pc < NP; ++pc) {
-#pragma unroll
-      for (int i = 0; i < WM; ++i) fa[pc][i] = load_frag(st + pc * A_UNIT, AB * QUAD, 4 * kk + 2 * lh, a_lane, i);
-#pragma unroll
-      for (int j = 0; j < WN; ++j) fb[pc][j] = load_frag(st + NP * A_UNIT + pc * B_UNIT, QUAD, 4 * kk + 2 * lh, b_lane, j);
-    }
+  // Two fragment sets: while the matrix instructions of tile s run on one, the transposing reads of tile s+1 fill the other
+  // (MCD_WGRAD_PIPE, default).  Without it a wave spends the LDS round trip of 24 reads at the head of every 16-pixel stage
+  // before its first MFMA -- measured through the one-term policy: with a third of the matrix work the 256 x 128 kernel only
+  // went from 0.98 to 0.78 ms, i.e. the stage's critical path was the read phase, not the matrix pipe.
+  //   LDS ring of three stages, tile s in registers: at the top of step s tile s+1 has landed, tile s+2 is in flight; the step
+  //   issues the DMAs of tile s+3 into the buffer tile s came from (every wave finished reading it before the last barrier),
+  //   reads tile s+1's fragments, multiplies tile s, then waits for tile s+2 and its own reads and meets the barrier.
+  static_assert(KK == 1, "one K = 16 block per stage");
+  frag fa[2][NP][WM], fb[2][NP][WN];
+  // The transposing reads are issued as inline assembly: for a compiler-visible LDS load the wait-count pass puts an
+  // s_waitcnt vmcnt(0) in front whenever an LDS-DMA may be pending (it cannot tell that the DMA targets another stage), which
+  // would drain the prefetch every step.  Their completion is the lgkmcnt(0) of the step's closing wait; `settle` then
+  // re-defines the registers behind that wait so that no consumer can be scheduled ahead of it.
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  auto tr_read_at = [&](unsigned base, auto off_c) -> s16x4 {
+    s16x4 v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(decltype(off_c)::value) : "memory");
+#else
+    (void)base;
+    v = s16x4{};
+#endif
+    return v;
   };
-  auto mfma_frags = [&]() {
+  auto read_frags = [&](int stage, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + (unsigned)(stage * STAGE);
+#else
+    const unsigned sbase = 0;
+#endif
+    const unsigned base_a = sbase + (unsigned)((2 * lh) * AB * QUAD + a_lane);
+    const unsigned base_b = sbase + (unsigned)(NP * A_UNIT + (2 * lh) * QUAD + b_lane);
+    auto frag_of = [&](unsigned base, auto lo_c, auto hi_c) -> frag {
+      const s16x4 lo = tr_read_at(base, lo_c);
+      const s16x4 hi = tr_read_at(base, hi_c);
+      const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(frag, v);
+    };
+    // (compile-time offsets: piece, 32-row block, second quad)
+#define MCD_A_FRAG(PC, I) \
+    if constexpr ((PC) < P::NPU && (I) < WM) \
+      fa[SET][PC][I] = frag_of(base_a, std::integral_constant<int, (PC) * A_UNIT + (I) * 256>{}, std::integral_constant<int, (PC) * A_UNIT + (I) * 256 + AB * QUAD>{});
+#define MCD_B_FRAG(PC, J) \
+    if constexpr ((PC) < P::NPU && (J) < WN) \
+      fb[SET][PC][J] = frag_of(base_b, std::integral_constant<int, (PC) * B_UNIT + (J) * 256>{}, std::integral_constant<int, (PC) * B_UNIT + (J) * 256 + QUAD>{});
+    MCD_A_FRAG(0, 0) MCD_A_FRAG(0, 1) MCD_A_FRAG(0, 2) MCD_A_FRAG(0, 3)
+    MCD_B_FRAG(0, 0) MCD_B_FRAG(0, 1)
+    MCD_A_FRAG(1, 0) MCD_A_FRAG(1, 1) MCD_A_FRAG(1, 2) MCD_A_FRAG(1, 3)
+    MCD_B_FRAG(1, 0) MCD_B_FRAG(1, 1)
+#undef MCD_A_FRAG
+#undef MCD_B_FRAG
+  };
+  auto mfma_frags = [&](auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int tm = 0; tm < P::NTERMS; ++tm) acc[i][j] = P::mfma(fa[P::TA[tm]][i], fb[P::TB[tm]][j], acc[i][j]);
+        for (int tm = 0; tm < P::NTERMS; ++tm) acc[i][j] = P::mfma(fa[SET][P::TA[tm]][i], fb[SET][P::TB[tm]][j], acc[i][j]);
   };
   // wait until at most `left` of this wave's DMAs are outstanding (left is wave-uniform: 0, NQD or NQD * AB), then barrier
   auto wait_barrier = [&](int left) {
@@ -563,38 +621,46 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr_kernel(WgradCbPara
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else if (left == NQD)
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NQD) : "memory");
-    else
+    else if (left == NQD * AB)
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NQD * AB) : "memory");
+    else if (left == 2 * NQD)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NQD) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NQD * AB) : "memory");
   };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  static_assert(NSTAGE == 3, "three LDS stages");
 
   const int nsteps = t_end - t_begin;
-  if (nsteps > 0) issue_dma(t_begin, 0);
-  if (NSTAGE == 3 && nsteps > 1) {
-    issue_dma(t_begin + 1, 1);
-    wait_barrier(dma_per_stage);
-  } else {
-    wait_barrier(0);
+  // prologue: tiles 0, 1, 2 on their way; tile 0 into registers; tile 1 landed
+  if (dma_on) {
+    if (nsteps > 0) issue_dma(t_begin, 0);
+    if (nsteps > 1) issue_dma(t_begin + 1, 1);
+    if (nsteps > 2) issue_dma(t_begin + 2, 2);
   }
-  int cur = 0, nxt = NSTAGE - 1;
-  for (int s = 0; s < nsteps; ++s) {
-    const unsigned char* st = smem + cur * STAGE;
-    const bool more = s + (NSTAGE - 1) < nsteps;
-    // k-block 0 fragments first (right behind the barrier), then the DMAs of the tile NSTAGE-1 ahead, then the matrix instructions
-    read_frags(st, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) issue_dma(t_begin + s + (NSTAGE - 1), nxt);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_frags();
-#pragma unroll
-    for (int kk = 1; kk < KK; ++kk) {
-      read_frags(st, kk);
-      mfma_frags();
-    }
-    // NSTAGE = 3: tile s+1 must have landed, the DMAs of tile s+2 (younger) stay in flight; NSTAGE = 2: everything
-    wait_barrier((NSTAGE == 3 && more) ? dma_per_stage : 0);
-    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
-    nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+  wait_barrier(nsteps > 2 ? 2 * dma_per_stage : (nsteps > 1 ? dma_per_stage : 0));  // tile 0 landed
+  if (nsteps > 0) read_frags(0, S0{});
+  wait_barrier(nsteps > 2 ? dma_per_stage : 0);  // tile 1 landed, tile 0 read by every wave
+  auto step = [&](int s, auto cur_c, auto nxt_c) {
+    const bool more3 = s + 3 < nsteps;
+    // (program order matters to the compiler's wait-count insertion: LDS reads placed behind an LDS-DMA issued in the same
+    // iteration get an s_waitcnt vmcnt(0) in front -- it cannot tell that the DMA targets another buffer -- which would drain the
+    // whole prefetch; reads first, then the DMAs, then the matrix instructions)
+    mcd_settle(fa[decltype(cur_c)::value], P::NPU);
+    mcd_settle(fb[decltype(cur_c)::value], P::NPU);
+    if (s + 1 < nsteps) read_frags((s + 1) % 3, nxt_c);
+    if (more3 && dma_on) issue_dma(t_begin + s + 3, s % 3);
+    mfma_frags(cur_c);
+    // tile s+2 must have landed (the DMAs of tile s+3, younger, stay in flight), this wave's reads of tile s+1 are complete
+    wait_barrier(more3 ? dma_per_stage : 0);
+  };
+  int s = 0;
+  for (; s + 1 < nsteps; s += 2) {
+    step(s, S0{}, S1{});
+    step(s + 1, S1{}, S0{});
   }
+  if (s < nsteps) step(s, S0{}, S1{});
 
   float* out = p.slab + ((size_t)split * T_ + tap) * p.co_p * p.ci_p;
 #pragma unroll
@@ -632,6 +698,8 @@ int mcdseg_internal_wgrad_split_launch(const mcdseg_conv_desc* d, int math, cons
   }
   if (math == MCDSEG_MATH_F16X3)
     hipLaunchKernelGGL(conv_wgrad_split_kernel<SplitF16x3>, dim3((unsigned)nwg), dim3(256), 0, st, p);
+  else if (math == MCDSEG_MATH_F16X1)
+    hipLaunchKernelGGL(conv_wgrad_split_kernel<SplitF16x1>, dim3((unsigned)nwg), dim3(256), 0, st, p);
   else
     hipLaunchKernelGGL(conv_wgrad_split_kernel<SplitBf16x6>, dim3((unsigned)nwg), dim3(256), 0, st, p);
   MCD_LAUNCH_CHECK("conv_wgrad_split");
@@ -831,7 +899,7 @@ int mcdseg_internal_wgrad_cb_variant(const mcdseg_conv_desc* d, int math, int co
   const char* e_big = getenv("MCDSEG_WGRAD_BIG");
   const bool use_tr = e_tr == nullptr || atoi(e_tr) != 0;
   const bool use_big = e_big == nullptr || atoi(e_big) != 0;
-  if (!(math == MCDSEG_MATH_F16X3 && use_tr)) return 0;
+  if (!(mcd_storage_math(math) == MCDSEG_MATH_F16X3 && use_tr)) return 0;
   // 256 x 128 tiles (16-pixel stages) for the layers whose padded Cout is a multiple of 256 -- the plan was made for 128-row
   // tiles, so the number of workgroups halves; taken only while that still fills the chip twice over
   const bool big = use_big && (co_p % 256) == 0 && (int64_t)(co_p / 256) * (ci_p / 128) * d->KH * d->KW * splits >= 1024;
@@ -867,10 +935,17 @@ int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, c
     mcdseg_set_error("conv_wgrad_split: grid too large");
     return -22;
   }
-  if (big)
+  const bool one = math == MCDSEG_MATH_F16X1;  // the same staging, one term
+  if (big && one)
+    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x1, 4, 2, 3>), dim3((unsigned)nwg), dim3(256), 0, st, p);
+  else if (big)
     hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x3, 4, 2, 3>), dim3((unsigned)nwg), dim3(256), 0, st, p);
+  else if (tr && one)
+    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x1, 2, 2, 3>), dim3((unsigned)nwg), dim3(256), 0, st, p);
   else if (tr)
     hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x3, 2, 2, 3>), dim3((unsigned)nwg), dim3(256), 0, st, p);
+  else if (one)
+    hipLaunchKernelGGL(conv_wgrad_split_cb_kernel<SplitF16x1>, dim3((unsigned)nwg), dim3(256), 0, st, p);
   else if (math == MCDSEG_MATH_F16X3)
     hipLaunchKernelGGL(conv_wgrad_split_cb_kernel<SplitF16x3>, dim3((unsigned)nwg), dim3(256), 0, st, p);
   else
@@ -892,7 +967,7 @@ int mcdseg_internal_wgrad_split_tr64_launch(const mcdseg_conv_desc* d, int math,
   p.tiles_per_chunk = ceil_div(p.tiles_x * p.tiles_y, chunks_per_img);
   const int64_t np = mcd_math_pieces(math);
   const int64_t xb = np * d->N * d->Cin * d->H * d->W * 2, yb = np * d->N * d->Cout * d->Ho * d->Wo * 2;
-  if (math != MCDSEG_MATH_F16X3 || (d->Cin & 7) || (d->Cout & 7) || (co_p & 63) || (ci_p & 63) || xb >= (1ll << 31) || yb >= (1ll << 31)) {
+  if (mcd_storage_math(math) != MCDSEG_MATH_F16X3 || (d->Cin & 7) || (d->Cout & 7) || (co_p & 63) || (ci_p & 63) || xb >= (1ll << 31) || yb >= (1ll << 31)) {
     mcdseg_set_error("conv_wgrad_split: the 64-tile pre-split plan needs f16x3, channel counts divisible by 8 and < 2 GiB per operand");
     return -22;
   }
@@ -904,7 +979,10 @@ int mcdseg_internal_wgrad_split_tr64_launch(const mcdseg_conv_desc* d, int math,
     mcdseg_set_error("conv_wgrad_split: grid too large");
     return -22;
   }
-  hipLaunchKernelGGL(conv_wgrad_split_tr64_kernel<SplitF16x3>, dim3((unsigned)nwg), dim3(256), 0, st, p);
+  if (math == MCDSEG_MATH_F16X1)
+    hipLaunchKernelGGL(conv_wgrad_split_tr64_kernel<SplitF16x1>, dim3((unsigned)nwg), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(conv_wgrad_split_tr64_kernel<SplitF16x3>, dim3((unsigned)nwg), dim3(256), 0, st, p);
   MCD_LAUNCH_CHECK("conv_wgrad_split_tr64");
   return 0;
 }

@@ -37,6 +37,7 @@ __host__ __device__ __forceinline__ float mcd_scale_of_bound(float bound) {
 
 struct SplitBf16x6 {
   static constexpr int NP = 3;
+  static constexpr int NPU = 3;  // pieces a kernel stages into LDS (all of them)
   static constexpr int NTERMS = 6;
   static constexpr bool SCALED = false;
   typedef __bf16 elem;
@@ -59,6 +60,7 @@ struct SplitBf16x6 {
 
 struct SplitF16x3 {
   static constexpr int NP = 2;
+  static constexpr int NPU = 2;
   static constexpr int NTERMS = 3;
   static constexpr bool SCALED = true;
   typedef _Float16 elem;
@@ -74,6 +76,16 @@ struct SplitF16x3 {
     p[0] = h;
     p[1] = (_Float16)(q - (float)h);
   }
+};
+
+// SplitF16x1: the REDUCED-PRECISION arithmetic (BASELINE config 5 "bf16"; bench.py --dtype f16): the operands are stored exactly
+// as SplitF16x3 stores them (two scaled fp16 pieces -- same companions, weight images, bounds, producers), but a product keeps
+// only the leading term h1 h1': one MFMA instead of three, operands rounded to fp16's 11 significant bits (bf16 would keep 8).
+struct SplitF16x1 : SplitF16x3 {
+  static constexpr int NPU = 1;  // pieces a kernel has to STAGE (the second piece is stored but never multiplied)
+  static constexpr int NTERMS = 1;
+  static constexpr int TA[1] = {0};
+  static constexpr int TB[1] = {0};
 };
 
 // split 8 values into NP fragments
@@ -95,4 +107,7 @@ __device__ __forceinline__ float operand_scale(const float* bound) {
   return 1.f;
 }
 
-static inline int mcd_math_pieces(int math) { return math == 3 ? 2 : 3; }  // MCDSEG_MATH_F16X3 : MCDSEG_MATH_BF16X6
+static inline int mcd_math_pieces(int math) { return (math == 3 || math == 1) ? 2 : 3; }  // MCDSEG_MATH_F16X3 / _F16X1 : MCDSEG_MATH_BF16X6
+// the arithmetic whose STORAGE (companions, weight images, bounds) a math shares: F16X1 multiplies F16X3's operands
+static inline int mcd_storage_math(int math) { return math == 1 ? 3 : math; }
+static inline bool mcd_math_known(int math) { return math == 1 || math == 3 || math == 6; }

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "mcdseg_conv_split_stat_rows_for": (c_i64, [_P(ConvDesc), c_i32, c_i32]),
     "mcdseg_conv_split_window_ok": (c_i32, [_P(ConvDesc), c_i32, c_i32, c_i32]),
     "mcdseg_conv_split_direct_ok": (c_i32, [_P(ConvDesc)]),
+    "mcdseg_conv_split_tile_config": (c_i32, [c_i32, c_i64, c_i32]),
     "mcdseg_conv_fprop": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcdseg_conv_fprop_affine": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p]),
     "mcdseg_bn_eval_affine": (c_int, [c_void_p] * 5 + [c_i32, c_float, c_void_p, c_void_p, c_void_p]),
@@ -60,7 +61,7 @@ _SIGNATURES = {
     "mcdseg_conv_wgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mcdseg_bn_stats_workspace_bytes": (c_size_t, [c_i64, c_i32]),
     "mcdseg_bn_stats_finalize": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                         c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                         c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_size_t, c_void_p]),
     "mcdseg_bn_eval_stats": (c_int, [c_void_p, c_void_p, c_i32, c_float, c_void_p, c_void_p, c_void_p]),
     "mcdseg_bn_apply": (c_int, [c_void_p] * 7 + [c_i32] * 4 + [c_void_p]),
     "mcdseg_bn_bwd_workspace_bytes": (c_size_t, [c_i32, c_i32, c_i32]),
@@ -219,7 +220,7 @@ def lib():
                     fn = getattr(handle, name)
                     fn.restype = res
                     fn.argtypes = args
-                if handle.mcdseg_version() != 100:
+                if handle.mcdseg_version() != 101:
                     raise RuntimeError("libmcdseg.so version mismatch: %d" % handle.mcdseg_version())
                 _lib = handle
     return _lib

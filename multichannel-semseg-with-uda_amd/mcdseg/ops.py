@@ -58,21 +58,20 @@ def conv_work(desc):
     return 2 * macs, byts
 
 
-POLICY = {"f16x3": "SplitF16x3", "bf16x6": "SplitBf16x6"}
+POLICY = {"f16x3": "SplitF16x3", "bf16x6": "SplitBf16x6", "f16x1": "SplitF16x1"}
 
 
 def gemm_kernel_name(m, k, dgrad, split=False, presplit=False, direct=False, pixels=0, math=None):
-    """Template instantiation conv_fprop / conv_dgrad dispatch to (same rule as csrc/common.h mcd_bm / mcd_bk); the
-    string equals the kernel name rocprofv3 prints, so profiles/*_pmc_traffic.json can be keyed by it."""
+    """Template instantiation conv_fprop / conv_dgrad dispatch to (the launcher's own rule through
+    ``mcdseg_conv_split_tile_config``; csrc/common.h mcd_bm / mcd_bk for the f32 kernels); the string equals the kernel name
+    rocprofv3 prints, so profiles/*_pmc_traffic.json can be keyed by it."""
     bm = 32 if m <= 32 else (64 if m <= 64 else 128)
     cfg = {128: "2, 2, 2, 2", 64: "2, 2, 1, 4", 32: "1, 2, 1, 4"}[bm]
     if split and direct:
         return "conv_stem_x6_kernel"
     if split:
-        mp = -(-m // 128) * 128
-        if bm == 128 and presplit and mp % 256 == 0 and -(-pixels // 128) * (mp // 256) >= BIGTILE_MIN_SLOTS:
-            cfg = "4, 2, 2, 2"  # the 256 x 128 tile (same rule as launch<> in csrc/conv_gemm_split.hip)
-        return "conv_gemm_split_kernel<%s, %s, %s, %s>" % (POLICY[math or CONV_MATH], cfg, "true" if dgrad else "false",
+        code = "%04d" % lib().mcdseg_conv_split_tile_config(int(m), int(pixels), int(bool(presplit)))
+        return "conv_gemm_split_kernel<%s, %s, %s, %s>" % (POLICY[math or CONV_MATH], ", ".join(code), "true" if dgrad else "false",
                                                            "true" if presplit else "false")
     return "conv_gemm_kernel<%s, %d, %s>" % (cfg, 8 if k <= 8 else 16, "true" if dgrad else "false")
 
@@ -123,14 +122,19 @@ def conv_desc(x_shape, w_shape, stride, pad, dil):
 #                       test as the other modes) at 5.3x the f32 matrix rate;
 #   "bf16x6"            three bf16 pieces, the six largest cross terms on v_mfma_f32_32x32x16_bf16 (2.67x the f32 rate);
 #   "f32"               v_mfma_f32_32x32x2_f32, the exact k-ordered fp32 FMA chain.
+#   "f16x1"             REDUCED precision (BASELINE config 5's "bf16"; trainers / bench: --dtype f16): f16x3's operands -- same
+#                       companions, weight images and bounds -- multiplied with the leading term only: one MFMA instead of three,
+#                       operands rounded to fp16's 11 significant bits (bf16 would keep 8); accumulation, BatchNorm, loss and
+#                       optimizer stay fp32.  NOT within north_star's 1e-3 of the fp32 reference: tests/test_model_gpu.py states
+#                       what it keeps.
 CONV_MATH = os.environ.get("MCDSEG_CONV_MATH", "f16x3")
 # producers (BN apply / BN backward apply) also emit the split of what they write, so the convolution that gathers it
 # does not re-split every activation inside its K loop (MCDSEG_PRESPLIT=0 turns this off)
 PRESPLIT = os.environ.get("MCDSEG_PRESPLIT", "1") != "0"
-if CONV_MATH not in ("f16x3", "bf16x6", "f32"):
-    raise ValueError("MCDSEG_CONV_MATH must be f16x3, bf16x6 or f32, got %r" % CONV_MATH)
-MATH_ID = {"f16x3": 3, "bf16x6": 6}   # MCDSEG_MATH_F16X3 / MCDSEG_MATH_BF16X6 of include/mcdseg.h
-PIECES = {"f16x3": 2, "bf16x6": 3}
+if CONV_MATH not in ("f16x3", "bf16x6", "f32", "f16x1"):
+    raise ValueError("MCDSEG_CONV_MATH must be f16x3, bf16x6, f32 or f16x1, got %r" % CONV_MATH)
+MATH_ID = {"f16x3": 3, "bf16x6": 6, "f16x1": 1}   # MCDSEG_MATH_F16X3 / _BF16X6 / _F16X1 of include/mcdseg.h
+PIECES = {"f16x3": 2, "bf16x6": 3, "f16x1": 2}    # (f16x1 stores what f16x3 stores)
 BIGTILE_MIN_SLOTS = int(os.environ.get("MCDSEG_BIGTILE_MIN_SLOTS", "1024"))  # launch<> rule of csrc/conv_gemm_split.hip
 
 
@@ -224,8 +228,8 @@ def _use_split(contraction_channels):
 
 
 def _scaled():
-    """the active arithmetic needs per-tensor bound scalars (f16x3)"""
-    return CONV_MATH == "f16x3"
+    """the active arithmetic needs per-tensor bound scalars (f16x3 and its one-term form f16x1)"""
+    return CONV_MATH in ("f16x3", "f16x1")
 
 
 def absmax(x):
@@ -661,15 +665,14 @@ class _ConvBNAct(torch.autograd.Function):
         if training:
             track = running_mean is not None
             ws = torch.empty(L.mcdseg_bn_stats_workspace_bytes(rows, c) // 8 + 1, dtype=torch.float64, device=z.device)
-            for _ in range(BN_RUNNING_REPEAT if track else 1):
-                with _timed("bn_stats_finalize", (0, 12 * rows * mpf)):
-                    check(L.mcdseg_bn_stats_finalize(_p(part), rows, c, mpf, _p(mean), _p(rstd), _p(running_mean) if track else None,
-                                                     _p(running_var) if track else None, _p(nbt) if track else None,
-                                                     float(momentum), float(eps), _p(gamma) if y_bound is not None else None,
-                                                     _p(beta) if y_bound is not None else None,
-                                                     _p(res_bound) if (y_bound is not None and has_res) else None, _p(y_bound),
-                                                     _p(ws), ctypes.c_size_t(ws.numel() * 8), _stream()),
-                          "bn_stats_finalize")
+            with _timed("bn_stats_finalize", (0, 12 * rows * mpf)):  # (one launch also when it stands for BN_RUNNING_REPEAT forward passes)
+                check(L.mcdseg_bn_stats_finalize(_p(part), rows, c, mpf, _p(mean), _p(rstd), _p(running_mean) if track else None,
+                                                 _p(running_var) if track else None, _p(nbt) if track else None,
+                                                 float(momentum), float(eps), _p(gamma) if y_bound is not None else None,
+                                                 _p(beta) if y_bound is not None else None,
+                                                 _p(res_bound) if (y_bound is not None and has_res) else None, _p(y_bound),
+                                                 int(BN_RUNNING_REPEAT if track else 1), _p(ws), ctypes.c_size_t(ws.numel() * 8), _stream()),
+                      "bn_stats_finalize")
         else:
             check(L.mcdseg_bn_eval_stats(_p(running_mean), _p(running_var), c, float(eps), _p(mean), _p(rstd), _stream()),
                   "bn_eval_stats")

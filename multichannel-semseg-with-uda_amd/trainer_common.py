@@ -18,6 +18,9 @@ class Run:
         torch.cuda.set_device(self.device)
         if getattr(args, "no_pretrained", False):
             os.environ["MCDSEG_PRETRAINED"] = "0"
+        if getattr(args, "dtype", "f32") == "f16":  # reduced-precision convolutions (mcdseg/ops.py CONV_MATH "f16x1")
+            from mcdseg import ops
+            ops.CONV_MATH = "f16x1"
         torch.manual_seed(getattr(args, "seed", 1234))
         self._log = None
         self._pipe = None

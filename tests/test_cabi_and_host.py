@@ -47,7 +47,7 @@ def test_library_exports_every_header_symbol():
         exported = set(re.findall(r"\b(mcdseg_[a-z0-9_]+)$", nm.stdout, re.M))
         internal = {n for n in exported if n.startswith("mcdseg_internal_") or n == "mcdseg_set_error"}
         assert exported - internal == declared, (exported - internal) ^ declared
-    assert L.mcdseg_version() == 100
+    assert L.mcdseg_version() == 101
     assert isinstance(L.mcdseg_last_error(), bytes)
     # every source is written for gfx950 directly: no CUDA shims / dual paths
     for src in _lib.sources():

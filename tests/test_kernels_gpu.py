@@ -570,6 +570,63 @@ def test_conv_split_accuracy(case, monkeypatch):
             assert es <= max(2.0 * e32, 2e-6 * errs["f32"][k][1]), "%s err %.3e vs f32-MFMA err %.3e" % (math, es, e32)
 
 
+def _round_like_f16x1(t, bound):
+    """what SplitF16x1 multiplies: the leading scaled fp16 piece, s * fp16(t / s), s = 2^(e - 15) with bound = m 2^e (csrc/split.h)"""
+    import math
+    b = float(bound)
+    scale = 2.0 ** (math.frexp(b)[1] - 15) if b > 0 else 1.0
+    return (t.double() / scale).to(torch.float16).double() * scale
+
+
+@pytest.mark.parametrize("case", [(128, 128, 3, 1, 2, 13, 19, 2), (64, 96, 3, 1, 1, 12, 16, 2), (256, 512, 3, 1, 4, 30, 40, 6), (16, 16, 3, 1, 1, 21, 45, 2),
+                                  (136, 200, 1, 1, 1, 11, 13, 3), (64, 128, 3, 2, 1, 15, 17, 2)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_reduced_precision_f16x1(case, monkeypatch):
+    """``MCDSEG_CONV_MATH=f16x1`` (--dtype f16; BASELINE config 5's reduced-precision intent): f16x3's operands, leading term only.
+    The kernels must compute EXACTLY that arithmetic: against an fp64 convolution of the operands rounded to their leading scaled
+    fp16 piece the result is as tight as every other kernel test (2e-5 of the scale) -- forward, data gradient and weight
+    gradient, from fp32 operands and from the companions (all tile shapes these cases select, the 256 x 128 weight-gradient tile
+    included).  Against the UNROUNDED fp64 result the deviation is the operands' 11-bit rounding: measured 2e-4 .. 6e-4 of the
+    scale, bounded here at 2e-3 (the thin 16-channel layers keep their three-term window kernels and stay at 2e-5)."""
+    dev = _dev()
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "CONV_MATH", "f16x1")
+    cin, cout, k, s, d, h, w, n = case
+    x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, s, d, h, w, n, False), 51)
+    desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
+    gy = torch.randn(n, cout, desc.Ho, desc.Wo, generator=torch.Generator().manual_seed(52))
+    xg, wg, gyg = x.to(dev), wt.to(dev), gy.to(dev)
+    pk = ops.PackedWeights()
+    wf, wd, mpf = pk.get(wg, desc)
+    x_cb, x_bound = ops.split_companion(xg)
+    gy_cb, gy_bound = ops.split_companion(gyg)
+    thin = cin <= 16  # the window kernels (three terms) take these from the companions
+    xr, wr, gr = _round_like_f16x1(x, x_bound), _round_like_f16x1(wt, pk.w_bound), _round_like_f16x1(gy, gy_bound)
+    ref_y = F.conv2d(xr, wr, None, s, pad, d)
+    x64, w64 = xr.clone().requires_grad_(), wr.clone().requires_grad_()
+    (gx_w,) = torch.autograd.grad(F.conv2d(x64, wr, None, s, pad, d), [x64], gr)      # dgrad: rounded dy, rounded w
+    (gw_x,) = torch.autograd.grad(F.conv2d(xr, w64, None, s, pad, d), [w64], gr)      # wgrad: rounded x, rounded dy
+    xe, we = x.double().requires_grad_(), wt.double().requires_grad_()
+    ye = F.conv2d(xe, we, None, s, pad, d)
+    gxe, gwe = torch.autograd.grad(ye, [xe, we], gy.double())
+    y0, _, _ = ops._conv_fprop(desc, xg, wf, None, True, mpf, None, x_bound, pk.w_bound)
+    dx0 = ops._conv_dgrad(desc, gyg, wd, None, gy_bound, pk.w_bound)
+    dw0 = ops._conv_wgrad(desc, xg, gyg, None, None, x_bound, gy_bound)
+    y1, _, _ = ops._conv_fprop(desc, xg, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)
+    dx1 = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound)
+    dw1 = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
+    if not thin:
+        for name, got, ref in (("fprop", y0, ref_y), ("dgrad", dx0, gx_w), ("fprop (companion)", y1, ref_y), ("dgrad (companion)", dx1, gx_w),
+                               ("wgrad (companion)", dw1, gw_x)):
+            _assert_close(got, ref, 2e-5, "f16x1 " + name + " vs the rounded-operand arithmetic")
+        if min(cin, cout) > 64:  # the split plan from fp32 operands (thinner layers take the f32 weight-gradient kernels there)
+            _assert_close(dw0, gw_x, 2e-5, "f16x1 wgrad vs the rounded-operand arithmetic")
+        assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    for name, got, ref in (("fprop", y1, ye.detach()), ("dgrad", dx1, gxe), ("wgrad", dw1, gwe)):
+        _assert_close(got, ref, 2e-5 if thin else 2e-3, "f16x1 " + name + " vs fp64")
+    if not thin:
+        assert _maxerr(y1, ye.detach())[0] > 2e-5 * _maxerr(y1, ye.detach())[1], "suspiciously exact: is the one-term arithmetic running?"
+
+
 def test_f16x3_scaling_covers_the_fp32_range(monkeypatch):
     """The per-tensor power-of-two scale makes the fp16 pieces independent of the operand's magnitude: tensors scaled by
     2^-40 ... 2^+40 give the correspondingly scaled result to the same relative accuracy (no overflow to inf, no flush to 0),
@@ -798,14 +855,71 @@ def test_conv_large_tile_kernels(case):
     ws = torch.empty(L.mcdseg_bn_stats_workspace_bytes(rows, cout) // 8 + 1, dtype=torch.float64, device=dev)
     gam, bet, yb = torch.full((cout,), 1.5, device=dev), torch.full((cout,), -0.25, device=dev), torch.empty(1, device=dev)
     ops.check(L.mcdseg_bn_stats_finalize(ops._p(part_cb), rows, cout, mpf, ops._p(mean), ops._p(rstd), None, None, None, 0.1, 1e-5,
-                                         ops._p(gam), ops._p(bet), None, ops._p(yb), ops._p(ws), ctypes.c_size_t(ws.numel() * 8),
+                                         ops._p(gam), ops._p(bet), None, ops._p(yb), 1, ops._p(ws), ctypes.c_size_t(ws.numel() * 8),
                                          ops._stream()), "bn_stats_finalize")
     npix = n * desc.Ho * desc.Wo  # Samuelson bound of the BN output: |gamma| sqrt(n-1) + |beta|
     assert abs(float(yb) - (1.5 * (npix - 1) ** 0.5 + 0.25)) <= 1e-3 * float(yb)
+    # one launch standing for two forward passes (solvers/solver.py: step B's target forward is step C's first): the running
+    # statistics receive the update twice, running = 0.81 old + 0.19 stat, and num_batches_tracked counts both
+    rm, rv = torch.full((cout,), 0.25, device=dev), torch.full((cout,), 1.5, device=dev)
+    nbt = torch.zeros(1, dtype=torch.int64, device=dev)
+    ops.check(L.mcdseg_bn_stats_finalize(ops._p(part_cb), rows, cout, mpf, ops._p(mean), ops._p(rstd), ops._p(rm), ops._p(rv), ops._p(nbt),
+                                         0.1, 1e-5, ops._p(gam), ops._p(bet), None, ops._p(yb), 2, ops._p(ws), ctypes.c_size_t(ws.numel() * 8),
+                                         ops._stream()), "bn_stats_finalize")
+    assert int(nbt) == 2 and float((rm - (0.81 * 0.25 + 0.19 * mean)).abs().max()) <= 1e-6
     r = ref.detach()
     merr = float((mean.double().cpu() - r.mean((0, 2, 3))).abs().max())
     assert merr <= 1e-5 * float(r.std()), "fused BN mean off by %.3e (output std %.3e)" % (merr, float(r.std()))
     _assert_close(rstd, (r.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt(), 1e-5, "fused BN rstd")
+
+
+@pytest.mark.parametrize("case", [(128, 128, 3, 1, 2, 45, 67), (128, 256, 3, 2, 2, 33, 40), (256, 128, 3, 2, 1, 47, 30), (136, 200, 1, 1, 3, 29, 31)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv_wide_tile_kernels(case, monkeypatch):
+    """The 128 x 256 tile (``conv_gemm_split_kernel<P, 4, 2, 1, 4, ...>``: the 128- and 256-channel layers at BASELINE batch sizes, all-DMA
+    K loop with two k-halves per thread) forced onto small problems with MCDSEG_WIDETILE_MIN_SLOTS: forward (+ fused BatchNorm partial
+    rows) and data gradient against fp64 and bit for bit against the 128 x 128 tile (same K order, same 64-pixel statistic rows)."""
+    dev = _dev()
+    from mcdseg import ops
+    if ops.CONV_MATH == "f32":
+        pytest.skip("split-precision kernels only")
+    cin, cout, k, d, n, h, w = case
+    x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, 1, d, h, w, n, False), 33)
+    desc = ops.conv_desc(x.shape, wt.shape, 1, pad, d)
+    pk = ops.PackedWeights()
+    wf, wd, mpf = pk.get(wt.to(dev), desc)
+    xg = x.to(dev)
+    gy = torch.randn(n, cout, desc.Ho, desc.Wo, generator=torch.Generator().manual_seed(34))
+    gyg = gy.to(dev)
+    x64, w64 = x.double().requires_grad_(), wt.double().requires_grad_()
+    ref = F.conv2d(x64, w64, None, 1, pad, d)
+    (gx_ref,) = torch.autograd.grad(ref, [x64], gy.double())
+    x_cb, x_bound = ops.split_companion(xg)
+    gy_cb, gy_bound = ops.split_companion(gyg)
+    outs = {}
+    for tag, slots in (("wide", "1"), ("square", "1000000000")):
+        monkeypatch.setenv("MCDSEG_WIDETILE_MIN_SLOTS", slots)
+        names = []
+
+        class _Names:
+            def wants(self, name):
+                names.append(name)
+                return False
+        prev, ops.LAUNCH_TIMER = ops.LAUNCH_TIMER, _Names()
+        try:
+            y, part, rows = ops._conv_fprop(desc, xg, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)
+            dx = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound)
+        finally:
+            ops.LAUNCH_TIMER = prev
+        want = "4, 2, 1, 4" if tag == "wide" else "2, 2, 2, 2"
+        assert len(names) == 2 and all(want in nm for nm in names), names
+        outs[tag] = (y, dx, part.view(rows, 3, mpf), rows)
+    _assert_close(outs["wide"][0], ref, 2e-5, "fprop (128 x 256 tile)")
+    _assert_close(outs["wide"][1], gx_ref, 2e-5, "dgrad (128 x 256 tile)")
+    assert torch.equal(outs["wide"][0], outs["square"][0]) and torch.equal(outs["wide"][1], outs["square"][1])
+    rw, rs = outs["wide"][3], outs["square"][3]
+    assert rw >= rs and torch.equal(outs["wide"][2][:rs, :, :cout], outs["square"][2][:, :, :cout])
+    assert float(outs["wide"][2][rs:, 0, :cout].abs().max()) == 0.0 if rw > rs else True  # rows past the last pixel count nothing
 
 
 @pytest.mark.parametrize("cout,stride,h,w,n", [(16, 1, 16, 64, 1), (16, 1, 21, 45, 2), (32, 2, 23, 70, 2), (32, 1, 9, 33, 1),
@@ -838,7 +952,7 @@ def test_thin_layer_window_kernels(cout, stride, h, w, n, monkeypatch):
     rstd = torch.empty(cout, device=dev)
     ws = torch.empty(L.mcdseg_bn_stats_workspace_bytes(rows, cout) // 8 + 1, dtype=torch.float64, device=dev)
     ops.check(L.mcdseg_bn_stats_finalize(ops._p(part), rows, cout, mpf, ops._p(mean), ops._p(rstd), None, None, None, 0.1, 1e-5,
-                                         None, None, None, None, ops._p(ws), ctypes.c_size_t(ws.numel() * 8), ops._stream()),
+                                         None, None, None, None, 1, ops._p(ws), ctypes.c_size_t(ws.numel() * 8), ops._stream()),
               "bn_stats_finalize")
     r = ref.detach()
     assert float((mean.double().cpu() - r.mean((0, 2, 3))).abs().max()) <= 1e-5 * float(r.std())
@@ -877,7 +991,7 @@ def test_stem_forward_on_the_window_kernel(cin, h, w, n, monkeypatch):
     rstd = torch.empty(16, device=dev)
     ws = torch.empty(L.mcdseg_bn_stats_workspace_bytes(rows, 16) // 8 + 1, dtype=torch.float64, device=dev)
     ops.check(L.mcdseg_bn_stats_finalize(ops._p(part), rows, 16, mpf, ops._p(mean), ops._p(rstd), None, None, None, 0.1, 1e-5,
-                                         None, None, None, None, ops._p(ws), ctypes.c_size_t(ws.numel() * 8), ops._stream()),
+                                         None, None, None, None, 1, ops._p(ws), ctypes.c_size_t(ws.numel() * 8), ops._stream()),
               "bn_stats_finalize")
     assert float((mean.double().cpu() - ref.mean((0, 2, 3))).abs().max()) <= 1e-5 * float(ref.std())
     _assert_close(rstd, (ref.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt(), 1e-5, "fused BN rstd (stem window kernel)")
