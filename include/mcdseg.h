@@ -41,6 +41,11 @@ typedef struct mcdseg_conv_desc {
   int32_t Cout, KH, KW;      /* weight [Cout,Cin,KH,KW]                 */
   int32_t stride, pad, dil;
   int32_t Ho, Wo;            /* output [N,Cout,Ho,Wo]                   */
+  int32_t Ncb;               /* split operators: batch size of the tensor the pre-split companions (x_cb / dy_cb) were WRITTEN for,
+                              * when this call covers only N of its images (a launch addresses < 2 GiB per operand piece, so larger
+                              * tensors are processed in slices along N): the companion layout is [piece][Ncb][C/8][H*W][8], the
+                              * pointer passed is that of the slice's first image in piece 0, and piece p of the slice lies
+                              * p * Ncb * (C/8) * H*W * 16 bytes behind it.  0 = N (the companion belongs to exactly this batch). */
 } mcdseg_conv_desc;
 
 /* Padded GEMM dims of the packed weight images: fprop image is [KH*KW][Kp_f][Mp_f] with M = Cout,

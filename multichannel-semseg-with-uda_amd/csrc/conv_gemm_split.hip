@@ -38,7 +38,8 @@ struct ConvSplitParams {
   int Mp, Kp;
   int KH, KW, stride, pad, dil;
   int P;
-  int src_bytes, wp_bytes, cb_bytes;
+  int src_bytes, wp_bytes, cb_bytes;  // cb_bytes: ONE piece of the companion (this call's images)
+  long long cb_piece_stride;          // bytes from piece p to piece p + 1 (the companion's own batch may be larger: mcdseg_conv_desc.Ncb)
   // stride-2 dgrad in parity classes: output pixels (y%2, x%2) = class receive only the taps of matching parity, so a
   // tile holds pixels of ONE class and its K loop visits that class's taps only (1, 2, 2, 4 of 9 for a 3x3 kernel)
   int sub;           // 1 when the class ordering is active
@@ -130,9 +131,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
   constexpr unsigned UNIT = PRESPLIT ? 16u : 4u;
   const __amdgpu_buffer_rsrc_t src_rs = PRESPLIT ? __builtin_amdgcn_make_buffer_rsrc((void*)p.src_cb, 0, p.cb_bytes, 0x00020000)
                                                  : __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  // one descriptor per piece of the companion (each below 2 GiB; the pieces of a batch slice are not adjacent)
+  __amdgpu_buffer_rsrc_t cb_rs[NP];
+#pragma unroll
+  for (int pc = 0; pc < NP; ++pc)
+    cb_rs[pc] = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.src_cb + pc * p.cb_piece_stride), 0, PRESPLIT ? p.cb_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t wp_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.wp_bytes, 0x00020000);
   const int C8 = p.Cs >> 3;
-  const int piece_stride = p.N * C8 * HWs;  // 16-B units between the pieces
   const float inv_src_scale = 1.f / operand_scale<P>(p.src_bound);  // in-loop split only
   const unsigned pix_base = PRESPLIT ? (unsigned)pn * (unsigned)C8 * (unsigned)HWs : (unsigned)pn * (unsigned)p.Cs * (unsigned)HWs;
   const bool ragged = p.Kp != p.Cs;
@@ -256,8 +261,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
         const int grp = (l_c0 >> 3) + h;
 #pragma unroll
         for (int pc = 0; pc < NP; ++pc) {
-          const int soff = grp < C8 ? (grp * HWs + pc * piece_stride) * 16 : 0x7FFFFFFF;
-          const auto q = __builtin_amdgcn_raw_buffer_load_b128(src_rs, l_voff, soff, 0);
+          const int soff = grp < C8 ? grp * HWs * 16 : 0x7FFFFFFF;
+          const auto q = __builtin_amdgcn_raw_buffer_load_b128(cb_rs[pc], l_voff, soff, 0);
           bsplit[SET][it][pc][0] = __uint_as_float(q[0]);
           bsplit[SET][it][pc][1] = __uint_as_float(q[1]);
           bsplit[SET][it][pc][2] = __uint_as_float(q[2]);
@@ -353,8 +358,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
       for (int pc = 0; pc < P::NPU; ++pc) {
-        const int soff = grp < C8 ? (grp * HWs + pc * piece_stride) * 16 : 0x7FFFFFFF;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rs, (__attribute__((address_space(3))) void*)(bdst + pc * 2 * BN * 16), 16, l_voff, soff, 0, 0);
+        const int soff = grp < C8 ? grp * HWs * 16 : 0x7FFFFFFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(cb_rs[pc], (__attribute__((address_space(3))) void*)(bdst + pc * 2 * BN * 16), 16, l_voff, soff, 0, 0);
       }
 #else
       (void)grp;
@@ -1015,13 +1020,17 @@ extern "C" int mcdseg_conv_split_pack_weights_multi(const int64_t* ptrs, const i
   return 0;
 }
 
-static int split_cb_bytes(int math, int N, int C, int HW, const void* cb, int* out) {
-  *out = 0;
+// one piece of the companion of this call's N images, and the distance between the pieces (the companion's own batch d->Ncb)
+static int split_cb_bytes(const mcdseg_conv_desc* d, int C, int HW, const void* cb, int* piece_bytes, long long* piece_stride) {
+  *piece_bytes = 0;
+  *piece_stride = 0;
   if (cb == nullptr) return 0;
   MCD_REQUIRE((C % 8) == 0, "conv_split: a pre-split operand needs a channel count divisible by 8 (got %d)", C);
-  const int64_t b = (int64_t)mcd_math_pieces(math) * N * C * HW * 2;
-  MCD_REQUIRE(b < (1ll << 31), "conv_split: pre-split operand exceeds 2 GiB; split the batch");
-  *out = (int)b;
+  MCD_REQUIRE(d->Ncb == 0 || d->Ncb >= d->N, "conv_split: Ncb (%d) must be 0 or at least N (%d)", d->Ncb, d->N);
+  const int64_t b = (int64_t)d->N * C * HW * 2;
+  MCD_REQUIRE(b < (1ll << 31), "conv_split: one piece of the pre-split operand exceeds 2 GiB; split the batch");
+  *piece_bytes = (int)b;
+  *piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * C * HW * 2;
   return 0;
 }
 
@@ -1049,7 +1058,7 @@ static int split_fprop_impl(const mcdseg_conv_desc* d, int math, const float* x,
                                               stats, (hipStream_t)stream);
   }
   ConvSplitParams p;
-  if (int rc = split_cb_bytes(math, d->N, d->Cin, d->H * d->W, x_cb, &p.cb_bytes)) return rc;
+  if (int rc = split_cb_bytes(d, d->Cin, d->H * d->W, x_cb, &p.cb_bytes, &p.cb_piece_stride)) return rc;
   p.src_cb = x_cb;
   p.src_bound = x_bound; p.w_bound = w_bound;
   p.src = x; p.wp = wp; p.bias = bias; p.dst = y; p.stats = stats;
@@ -1093,7 +1102,7 @@ extern "C" int mcdseg_conv_split_dgrad(const mcdseg_conv_desc* d, int32_t math, 
     return mcdseg_internal_thin_window_launch(d, 1, dy_cb, dy_bound, wp_dgrad, split_image_bytes(math, d->Cin, d->Cout, d->KH * d->KW),
                                               w_bound, dx, nullptr, (hipStream_t)stream);
   ConvSplitParams p;
-  if (int rc = split_cb_bytes(math, d->N, d->Cout, d->Ho * d->Wo, dy_cb, &p.cb_bytes)) return rc;
+  if (int rc = split_cb_bytes(d, d->Cout, d->Ho * d->Wo, dy_cb, &p.cb_bytes, &p.cb_piece_stride)) return rc;
   p.src_cb = dy_cb;
   p.src_bound = dy_bound; p.w_bound = w_bound;
   p.src = dy; p.wp = wp_dgrad; p.bias = nullptr; p.dst = dx; p.stats = nullptr;

@@ -261,6 +261,7 @@ struct ThinWinPlan {
 ThinWinPlan thin_win_plan(const mcdseg_conv_desc* d, bool dgrad) {
   ThinWinPlan pl{};
   pl.ok = false;
+  if (d->Ncb != 0 && d->Ncb != d->N) return pl;  // a batch slice of a larger companion: its pieces are not adjacent (implicit GEMM handles it)
   static const bool on = [] {
     const char* e = getenv("MCDSEG_THIN_WINDOW");  // development knob: 0 = the implicit-GEMM kernels for these layers too
     return e == nullptr || atoi(e) != 0;

@@ -215,7 +215,8 @@ struct WgradCbParams {
   int KH, KW, stride, pad, dil;
   int co_p, ci_p;
   int tiles_x, tiles_y, tiles_per_chunk, chunks_per_img, splits;
-  int x_cb_bytes, dy_cb_bytes;
+  int x_cb_bytes, dy_cb_bytes;            // ONE piece of each companion (this call's images)
+  long long x_piece_stride, dy_piece_stride;  // bytes between the pieces (the companions' own batch: mcdseg_conv_desc.Ncb)
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -275,11 +276,13 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_split_cb_kernel(WgradCbPara
   const int sC8 = (opnd ? p.Cin : p.Cout) >> 3;
   const int ctile = opnd ? tile_ci : tile_co;
   const int sHW = sH * sW;
-  const int pstride = p.N * sC8 * sHW;  // 16-B units between pieces
-  // the descriptor starts `bias` bytes below the tensor so that the SGPR offset (tile + tap shift) is never negative
+  // ONE descriptor over all pieces here (a wave of this kernel stages more than one piece; the launcher admits the kernel only
+  // while the pieces of the call -- their stride included -- stay below 2 GiB); it starts `bias` bytes below the tensor so that
+  // the SGPR offset (tile + tap shift) is never negative
+  const int pstride = (int)((opnd ? p.x_piece_stride : p.dy_piece_stride) >> 4);  // 16-B units between pieces
   const int bias = p.pad * 16 + 16;
   const char* sptr = (const char*)(opnd ? p.x_cb : p.dy_cb) - bias;
-  const int sbytes = (opnd ? p.x_cb_bytes : p.dy_cb_bytes) + bias;
+  const int sbytes = (int)((NP - 1) * (opnd ? p.x_piece_stride : p.dy_piece_stride)) + (opnd ? p.x_cb_bytes : p.dy_cb_bytes) + bias;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sptr, 0, sbytes, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   const unsigned vconst = (ctile * 16 + cg) < sC8 ? (unsigned)(cg * sHW + ps * sS) * 16u : OOB;
@@ -475,17 +478,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr_kernel(WgradCbPara
   const int cg0 = opnd ? tile_ci * 16 : tile_co * (16 * AB);  // first channel group of the tile
   const int nblk = opnd ? 1 : AB;                              // 128-channel blocks this wave moves per quad
   const int sHW = sH * sW;
-  const int pstride = p.N * sC8 * sHW;  // 16-B units between pieces
-  // the descriptor starts `bias` bytes below the tensor so that the SGPR offset (tile + tap shift) is never negative
+  // the descriptor covers this wave's PIECE and starts `bias` bytes below it so that the SGPR offset (tile + tap shift) is never negative
   const int bias = p.pad * 16 + 16;
-  const char* sptr = (const char*)(opnd ? p.x_cb : p.dy_cb) - bias;
+  const char* sptr = (const char*)(opnd ? p.x_cb : p.dy_cb) + piece * (opnd ? p.x_piece_stride : p.dy_piece_stride) - bias;
   const int sbytes = (opnd ? p.x_cb_bytes : p.dy_cb_bytes) + bias;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sptr, 0, sbytes, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   unsigned vconst[AB];
 #pragma unroll
   for (int b = 0; b < AB; ++b) vconst[b] = (cg0 + 16 * b + cg) < sC8 ? (unsigned)((16 * b + cg) * sHW + ps * sS) * 16u : OOB;
-  const int sbase = (n * sC8 + cg0) * sHW + piece * pstride;  // 16-B units
+  const int sbase = (n * sC8 + cg0) * sHW;  // 16-B units inside the piece
   const int lane_x = ps * sS;
   unsigned char* const unit_lds = smem + (opnd ? NP * A_UNIT + piece * B_UNIT : piece * A_UNIT);
 
@@ -771,13 +773,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr64_kernel(WgradCbPa
   const int sC8 = (opnd ? p.Cin : p.Cout) >> 3;
   const int cg0 = (opnd ? tile_ci : tile_co) * 8;
   const int sHW = sH * sW;
-  const int pstride = p.N * sC8 * sHW;
-  const char* sptr = (const char*)(opnd ? p.x_cb : p.dy_cb);
+  const char* sptr = (const char*)(opnd ? p.x_cb : p.dy_cb) + piece * (opnd ? p.x_piece_stride : p.dy_piece_stride);  // this wave's piece
   const int sbytes = opnd ? p.x_cb_bytes : p.dy_cb_bytes;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sptr, 0, sbytes, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   const bool cg_ok = (cg0 + cg) < sC8 && tap_ok;
-  const int lbase = ((n * sC8 + cg0 + cg) * sHW + piece * pstride);  // 16-B units, per lane
+  const int lbase = (n * sC8 + cg0 + cg) * sHW;  // 16-B units inside the piece, per lane
   unsigned char* const unit_lds = smem + (opnd ? NP * A_UNIT + piece * B_UNIT : piece * A_UNIT);
 
   auto issue_dma = [&](int tt, int stage) {
@@ -917,18 +918,29 @@ int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, c
   p.co_p = co_p; p.ci_p = ci_p; p.chunks_per_img = chunks_per_img; p.splits = splits;
   const int variant = mcdseg_internal_wgrad_cb_variant(d, math, co_p, ci_p, splits);
   const bool tr = variant >= 1, big = variant == 2;
+  {
+    const int64_t npc = mcd_math_pieces(math), nb = d->Ncb ? d->Ncb : d->N;
+    const int64_t xall = (npc - 1) * nb * d->Cin * d->H * d->W * 2 + (int64_t)d->N * d->Cin * d->H * d->W * 2;
+    const int64_t yall = (npc - 1) * nb * d->Cout * d->Ho * d->Wo * 2 + (int64_t)d->N * d->Cout * d->Ho * d->Wo * 2;
+    if (!tr && (xall + 4096 >= (1ll << 31) || yall + 4096 >= (1ll << 31))) {
+      mcdseg_set_error("conv_wgrad_split: the register-transposing kernel needs all pieces of an operand below 2 GiB; split the batch further");
+      return -22;
+    }
+  }
   const int rows = tr ? 2 : 4;  // pixel rows of a stage tile (the transposing-read kernels run 16-pixel stages)
   p.tiles_x = ceil_div(d->Wo, 8);
   p.tiles_y = ceil_div(d->Ho, rows);
   p.tiles_per_chunk = ceil_div(p.tiles_x * p.tiles_y, chunks_per_img);
-  const int64_t np = mcd_math_pieces(math);
-  const int64_t xb = np * d->N * d->Cin * d->H * d->W * 2, yb = np * d->N * d->Cout * d->Ho * d->Wo * 2;
-  if ((d->Cin & 7) || (d->Cout & 7) || xb + 4096 >= (1ll << 31) || yb + 4096 >= (1ll << 31) || d->pad > 128) {
-    mcdseg_set_error("conv_wgrad_split: pre-split operands need channel counts divisible by 8 and < 2 GiB per operand");
+  // per PIECE of this call's images (the pieces of a batch slice are not adjacent: mcdseg_conv_desc.Ncb)
+  const int64_t xb = (int64_t)d->N * d->Cin * d->H * d->W * 2, yb = (int64_t)d->N * d->Cout * d->Ho * d->Wo * 2;
+  if ((d->Cin & 7) || (d->Cout & 7) || xb + 4096 >= (1ll << 31) || yb + 4096 >= (1ll << 31) || d->pad > 128 || (d->Ncb != 0 && d->Ncb < d->N)) {
+    mcdseg_set_error("conv_wgrad_split: pre-split operands need channel counts divisible by 8, < 2 GiB per operand piece and Ncb >= N");
     return -22;
   }
   p.x_cb_bytes = (int)xb;
   p.dy_cb_bytes = (int)yb;
+  p.x_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cin * d->H * d->W * 2;
+  p.dy_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cout * d->Ho * d->Wo * 2;
   const int64_t per_split = (int64_t)(co_p / (big ? 256 : 128)) * (ci_p / 128) * d->KH * d->KW;
   const int64_t nwg = 8 * ceil_div64(splits, 8) * per_split;
   if (nwg >= (1ll << 31)) {
@@ -965,14 +977,16 @@ int mcdseg_internal_wgrad_split_tr64_launch(const mcdseg_conv_desc* d, int math,
   p.tiles_x = ceil_div(d->Wo, 8);
   p.tiles_y = ceil_div(d->Ho, 4);
   p.tiles_per_chunk = ceil_div(p.tiles_x * p.tiles_y, chunks_per_img);
-  const int64_t np = mcd_math_pieces(math);
-  const int64_t xb = np * d->N * d->Cin * d->H * d->W * 2, yb = np * d->N * d->Cout * d->Ho * d->Wo * 2;
-  if (mcd_storage_math(math) != MCDSEG_MATH_F16X3 || (d->Cin & 7) || (d->Cout & 7) || (co_p & 63) || (ci_p & 63) || xb >= (1ll << 31) || yb >= (1ll << 31)) {
-    mcdseg_set_error("conv_wgrad_split: the 64-tile pre-split plan needs f16x3, channel counts divisible by 8 and < 2 GiB per operand");
+  const int64_t xb = (int64_t)d->N * d->Cin * d->H * d->W * 2, yb = (int64_t)d->N * d->Cout * d->Ho * d->Wo * 2;  // per piece
+  if (mcd_storage_math(math) != MCDSEG_MATH_F16X3 || (d->Cin & 7) || (d->Cout & 7) || (co_p & 63) || (ci_p & 63) || xb >= (1ll << 31) || yb >= (1ll << 31) ||
+      (d->Ncb != 0 && d->Ncb < d->N)) {
+    mcdseg_set_error("conv_wgrad_split: the 64-tile pre-split plan needs f16x3, channel counts divisible by 8, < 2 GiB per operand piece and Ncb >= N");
     return -22;
   }
   p.x_cb_bytes = (int)xb;
   p.dy_cb_bytes = (int)yb;
+  p.x_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cin * d->H * d->W * 2;
+  p.dy_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cout * d->Ho * d->Wo * 2;
   const int64_t per_split = (int64_t)(co_p / 64) * (ci_p / 64) * ((d->KH * d->KW + 1) / 2);
   const int64_t nwg = 8 * ceil_div64(splits, 8) * per_split;
   if (nwg >= (1ll << 31)) {

@@ -260,6 +260,7 @@ ThinTrPlan thin_tr_plan(const mcdseg_conv_desc* d) {
   ThinTrPlan pl{};
   const int T = d->KH * d->KW;
   pl.ok = false;
+  if (d->Ncb != 0 && d->Ncb != d->N) return pl;  // a batch slice of a larger companion: its pieces are not adjacent
   // instantiated: <2,1,9,8> (16 -> 16, 3x3), <2,2,9,4> (16 -> 32, 3x3 stride 2), <1,1,25,8> (<= 8 -> 16, 7x7: the stem, whose
   // input companion is the padded one of mcdseg_split_cb_padded)
   if (d->Cin == 16 && T == 9 && d->Cout == 16 && d->stride == 1) {

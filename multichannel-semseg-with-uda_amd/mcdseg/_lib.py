@@ -19,7 +19,7 @@ c_void_p, c_int, c_i32, c_i64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_in
 
 class ConvDesc(ctypes.Structure):
     """mirror of ``mcdseg_conv_desc``"""
-    _fields_ = [(n, c_i32) for n in ("N", "Cin", "H", "W", "Cout", "KH", "KW", "stride", "pad", "dil", "Ho", "Wo")]
+    _fields_ = [(n, c_i32) for n in ("N", "Cin", "H", "W", "Cout", "KH", "KW", "stride", "pad", "dil", "Ho", "Wo", "Ncb")]
 
 
 _P = ctypes.POINTER

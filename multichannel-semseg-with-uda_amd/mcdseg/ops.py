@@ -387,16 +387,28 @@ def _is_split(w_image):
 MAX_CONV_BYTES = int(os.environ.get("MCDSEG_MAX_CONV_BYTES", str((1 << 31) - (1 << 26))))
 
 
-def _sub_desc(desc, n):
-    return ConvDesc(n, desc.Cin, desc.H, desc.W, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad, desc.dil, desc.Ho, desc.Wo)
+def _sub_desc(desc, n, ncb=0):
+    """descriptor of ``n`` images of the batch; ``ncb``: batch size of the tensor the companions were written for (Ncb of mcdseg.h)"""
+    return ConvDesc(n, desc.Cin, desc.H, desc.W, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad, desc.dil, desc.Ho, desc.Wo, ncb)
+
+
+def _cb_slice(cb, a, channels, hw):
+    """pointer to image ``a`` in piece 0 of a companion [piece][N][C/8][HW][8 x 16 bit] (None stays None)"""
+    return None if cb is None else ctypes.c_void_p(cb.data_ptr() + a * (channels // 8) * hw * 16)
 
 
 def _batch_pieces(desc):
-    # the C side requires (N*C + 128) * H*W * 4 < 2 GiB per operand: the 128-channel tile of slack is per LAUNCH, not
-    # per image (charging it per image cut the full-resolution 16-channel layers in two and lost their pre-split operands)
+    # the f32 kernels express padding and ragged channel tails as offsets the buffer range check rejects, up to a 128-channel tile
+    # past the tensor: (N*C + 128) * H*W * 4 < 2 GiB per operand -- the tile of slack is per LAUNCH, not per image (charging it per
+    # image cut the full-resolution 16-channel layers in two and lost their pre-split operands).  The split kernels mark such
+    # accesses with an explicit out-of-range offset instead, so a layer that runs on them forward, data- and weight-gradient
+    # (both channel counts multiples of 8, at least 16) needs no slack: BASELINE config 5's 16- and 32-channel layers at
+    # 32 x 720 x 1280 (1.89 GB per tensor) stay in one launch and keep their companions.
+    split_only = CONV_MATH in MATH_ID and desc.Cin % 8 == 0 and desc.Cout % 8 == 0 and min(desc.Cin, desc.Cout) >= 16
+    slack = 0 if split_only else 128
     step = desc.N
     for c, hw in ((desc.Cin, desc.H * desc.W), (desc.Cout, desc.Ho * desc.Wo)):
-        step = min(step, max(1, (MAX_CONV_BYTES - 4 * 128 * hw) // (4 * c * hw)))
+        step = min(step, max(1, (MAX_CONV_BYTES - 4 * slack * hw) // (4 * c * hw)))
     if step >= desc.N:
         return [(0, desc.N)]
     return [(i, min(i + step, desc.N)) for i in range(0, desc.N, step)]
@@ -406,9 +418,8 @@ def _conv_fprop(desc, x, wf, bias, want_stats, mpf, x_cb=None, x_bound=None, w_b
     L = lib()
     y = torch.empty((desc.N, desc.Cout, desc.Ho, desc.Wo), dtype=torch.float32, device=x.device)
     pieces = _batch_pieces(desc)
-    if len(pieces) > 1:
-        x_cb = None  # the piece-major split layout cannot be sliced along N
-    descs = [desc if len(pieces) == 1 else _sub_desc(desc, b - a) for a, b in pieces]
+    # a batch cut along N keeps its companion: piece p of a slice lies p * N * (C/8) * HW * 16 bytes behind its piece 0 (Ncb)
+    descs = [desc if len(pieces) == 1 else _sub_desc(desc, b - a, desc.N if x_cb is not None else 0) for a, b in pieces]
     split = _is_split(wf)
     part, rows, row_off = None, 0, [0]
     if want_stats:
@@ -425,8 +436,8 @@ def _conv_fprop(desc, x, wf, bias, want_stats, mpf, x_cb=None, x_bound=None, w_b
         with _timed((_window_name(d, x_cb is not None, False) if split else None)
                     or gemm_kernel_name(desc.Cout, desc.Cin, False, split, x_cb is not None, direct, d.N * d.Ho * d.Wo), conv_work(d)):
             if split:
-                check(L.mcdseg_conv_split_fprop(ctypes.byref(d), MATH_ID[CONV_MATH], _p(x[a:b]), _p(x_cb), _p(x_bound), _p(wf), _p(w_bound),
-                                                _p(bias), _p(y[a:b]), pp, _stream()), "conv_split_fprop")
+                check(L.mcdseg_conv_split_fprop(ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(x, a, b)), _cb_slice(x_cb, a, desc.Cin, desc.H * desc.W),
+                                                _p(x_bound), _p(wf), _p(w_bound), _p(bias), _p(y[a:b]), pp, _stream()), "conv_split_fprop")
             else:
                 check(L.mcdseg_conv_fprop(ctypes.byref(d), _p(x[a:b]), _p(wf), _p(bias), _p(y[a:b]), pp, _stream()), "conv_fprop")
     return y, part, rows
@@ -450,17 +461,16 @@ def _conv_dgrad(desc, dy, wd, dy_cb=None, dy_bound=None, w_bound=None):
     L = lib()
     dx = torch.empty((desc.N, desc.Cin, desc.H, desc.W), dtype=torch.float32, device=(dy if dy is not None else dy_cb).device)
     pieces = _batch_pieces(desc)
-    if len(pieces) > 1:
-        dy_cb = None
     split = _is_split(wd)
     if split and dy is not None:
         dy_bound = _bound_or_measure(dy, dy_bound)
     for a, b in pieces:
-        d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
+        d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a, desc.N if dy_cb is not None else 0)
         with _timed((_window_name(d, dy_cb is not None, True) if split else None)
                     or gemm_kernel_name(desc.Cin, desc.Cout, True, split, dy_cb is not None, False, d.N * d.H * d.W), conv_work(d)):
             if split:
-                check(L.mcdseg_conv_split_dgrad(ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(dy, a, b)), _p(dy_cb), _p(dy_bound), _p(wd),
+                check(L.mcdseg_conv_split_dgrad(ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(dy, a, b)),
+                                                _cb_slice(dy_cb, a, desc.Cout, desc.Ho * desc.Wo), _p(dy_bound), _p(wd),
                                                 _p(w_bound), _p(dx[a:b]), _stream()), "conv_split_dgrad")
             else:
                 check(L.mcdseg_conv_dgrad(ctypes.byref(d), _p(dy[a:b]), _p(wd), _p(dx[a:b]), _stream()), "conv_dgrad")
@@ -536,22 +546,22 @@ def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None, x_bound=None, dy_bound=None)
     L = lib()
     total = None
     pieces = _batch_pieces(desc)
-    if len(pieces) > 1 or x_cb is None or dy_cb is None:
-        x_cb = dy_cb = None  # the piece-major split layout cannot be sliced along N; both companions or none
+    if x_cb is None or dy_cb is None:
+        x_cb = dy_cb = None  # both companions or none
     split = _wgrad_split_plan(desc, x_cb is not None)
     if split and x_cb is None:
         x_bound, dy_bound = _bound_or_measure(x, x_bound), _bound_or_measure(dy, dy_bound)
     for a, b in pieces:
-        d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a)
+        d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a, desc.N if x_cb is not None else 0)
         ws = _ws(L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(d)), (x if x is not None else x_cb).device)
         dw = torch.empty((desc.Cout, desc.Cin, desc.KH, desc.KW), dtype=torch.float32, device=ws.device)
         name = _WGRAD_NAMES.get(L.mcdseg_conv_wgrad_variant(ctypes.byref(d), MATH_ID[CONV_MATH], int(x_cb is not None)), "conv_wgrad") \
             % POLICY[CONV_MATH] if split else wgrad_kernel_name(desc.Cout, desc.Cin, desc.KH * desc.KW)
         with _timed(name, conv_work(d)):
             if split:
-                check(L.mcdseg_conv_split_wgrad(ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(x, a, b)), _p(x_cb), _p(x_bound),
-                                                _p(_sl(dy, a, b)), _p(dy_cb), _p(dy_bound), _p(dw), _p(ws),
-                                                ctypes.c_size_t(ws.numel() * 4), _stream()), "conv_split_wgrad")
+                check(L.mcdseg_conv_split_wgrad(ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(x, a, b)), _cb_slice(x_cb, a, desc.Cin, desc.H * desc.W),
+                                                _p(x_bound), _p(_sl(dy, a, b)), _cb_slice(dy_cb, a, desc.Cout, desc.Ho * desc.Wo), _p(dy_bound),
+                                                _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()), "conv_split_wgrad")
             else:
                 check(L.mcdseg_conv_wgrad(ctypes.byref(d), _p(x[a:b]), _p(dy[a:b]), _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4),
                                           _stream()), "conv_wgrad")
@@ -628,7 +638,10 @@ class _ConvBNAct(torch.autograd.Function):
         wf, wd, mpf = packed.get(weight, desc)
         w_bound = packed.w_bound
         x_virtual = aux["x_virtual"]
-        if x_virtual and not (_is_split(wf) and x_cb is not None and len(_batch_pieces(desc)) == 1):
+        # (a batch cut along N keeps its companions -- the split kernels take slices, mcdseg.h Ncb -- except on the thin layers'
+        # window kernels, Cin <= 16)
+        uncut = len(_batch_pieces(desc)) == 1
+        if x_virtual and not (_is_split(wf) and x_cb is not None and (uncut or desc.Cin > 16)):
             x, x_virtual = materialize(x, x_cb, x_bound), False  # this consumer reads fp32
         if not x_virtual:
             x = _req(x, "conv input")
@@ -649,8 +662,8 @@ class _ConvBNAct(torch.autograd.Function):
         # give one (Samuelson), eval-mode running statistics do not (the consumer then measures y)
         want_cb = _cb_wanted(c) and desc.N * (c // 8) <= 65535 and (training or not _scaled())
         compact = aux["compact"] and want_cb and training
-        if compact and aux.get("single_piece_only") and (len(_batch_pieces(desc)) != 1 or c <= 32):
-            compact = False  # the consumer would cut the batch, or run its weight gradient on the f32 kernels, and read fp32
+        if compact and aux.get("single_piece_only") and c <= 32:
+            compact = False  # the consumer would run its weight gradient on the f32 kernels and read fp32
         res_cb = aux["res_cb"] if aux["res_virtual"] else None
         if aux["res_virtual"] and not want_cb:
             residual, res_cb = materialize(residual, aux["res_cb"], res_bound), None  # plain bn_apply reads fp32
@@ -736,7 +749,7 @@ class _ConvBNAct(torch.autograd.Function):
         dz_cb = None
         # the fp32 dz is skipped when every consumer reads the split companion: dgrad (pre-split gather) and wgrad
         # (pre-split plans); a conv bias gradient or any fallback path still needs it
-        single = single_piece = len(_batch_pieces(desc)) == 1
+        single = single_piece = len(_batch_pieces(desc)) == 1 or desc.Cin > 16  # (cut batches keep their companions, see forward)
         wgrad_cb = stem_tr or (x_cb is not None and use_cb and single_piece and _wgrad_split_plan(desc, True) and desc.Cin % 8 == 0
                                and desc.Cout % 8 == 0)
         skip_dz = (use_cb and single and not (ctx.has_bias and ctx.needs_input_grad[5])

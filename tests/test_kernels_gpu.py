@@ -476,31 +476,50 @@ def test_conv_bias_bn_relu():
 
 
 def test_conv_batch_split_for_large_operands(monkeypatch):
-    """Operands above the 2 GiB launch limit (cfg5) are cut along N on the host; exercised here with a tiny limit."""
+    """Operands above the 2 GiB launch limit (cfg5's 2048-channel layers at N = 32) are cut along N on the host; exercised here
+    with a tiny limit on a chain of two fused groups, so that the second group's forward, data gradient and weight gradient run in
+    slices WITH their companions (mcdseg_conv_desc.Ncb: the pieces of a slice are not adjacent) -- asserted by kernel name."""
     dev = _dev()
     from mcdseg import ops
     from models.drn import BatchNorm2d, Conv2d
     g = torch.Generator().manual_seed(2)
-    conv, bn = Conv2d(24, 40, 3, padding=2, dilation=2, bias=False).to(dev), BatchNorm2d(40).to(dev)
+    conv1, bn1 = Conv2d(24, 40, 3, padding=2, dilation=2, bias=False).to(dev), BatchNorm2d(40).to(dev)
+    conv2, bn2 = Conv2d(40, 136, 3, padding=1, bias=False).to(dev), BatchNorm2d(136).to(dev)
     x = torch.randn(5, 24, 12, 14, generator=g).to(dev).requires_grad_()
-    gy = torch.randn(5, 40, 12, 14, generator=g).to(dev)
+    gy = torch.randn(5, 136, 12, 14, generator=g).to(dev)
+    params = (conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight, bn2.bias)
 
     def run():
-        bn.running_mean.zero_(), bn.running_var.fill_(1), bn.num_batches_tracked.zero_()
-        for t in (x, conv.weight, bn.weight, bn.bias):
+        for bn in (bn1, bn2):
+            bn.running_mean.zero_(), bn.running_var.fill_(1), bn.num_batches_tracked.zero_()
+        for t in (x,) + params:
             t.grad = None
-        y = ops.conv_bn_act(x, conv, bn, relu=True)
-        y.backward(gy)
-        return [t.detach().clone() for t in (y, x.grad, conv.weight.grad, bn.weight.grad, bn.bias.grad, bn.running_var)]
+        names = []
 
-    whole = run()
+        class _Names:
+            def wants(self, name):
+                names.append(name)
+                return False
+        prev, ops.LAUNCH_TIMER = ops.LAUNCH_TIMER, _Names()
+        try:
+            y = ops.conv_bn_act(ops.conv_bn_act(x, conv1, bn1, relu=True), conv2, bn2, relu=True)
+            y.backward(gy)
+        finally:
+            ops.LAUNCH_TIMER = prev
+        return names, [t.detach().clone() for t in (y, x.grad) + tuple(p.grad for p in params) + (bn1.running_var, bn2.running_var)]
+
+    _, whole = run()
     hw = 12 * 14
-    monkeypatch.setattr(ops, "MAX_CONV_BYTES", 4 * 128 * hw + 2 * 4 * 40 * hw)  # tile slack + two images -> pieces of 2, 2, 1
-    desc = ops.conv_desc(x.shape, conv.weight.shape, 1, 2, 2)
+    monkeypatch.setattr(ops, "MAX_CONV_BYTES", 2 * 4 * 136 * hw)  # two images of the widest tensor -> pieces of 2, 2, 1
+    desc = ops.conv_desc((5, 40, 12, 14), conv2.weight.shape, 1, 1, 1)
     assert ops._batch_pieces(desc) == [(0, 2), (2, 4), (4, 5)]
-    split = run()
-    for name, a, b in zip(["y", "dx", "dw", "dgamma", "dbeta", "running_var"], split, whole):
-        _assert_close(a, b, 2e-6, name)
+    names, split = run()
+    if ops.CONV_MATH in ops.MATH_ID:  # the second group's three passes ran from the companions, slice by slice
+        pre = [nm for nm in names if nm.startswith("conv_gemm_split_kernel") and nm.endswith("true>")]
+        assert len(pre) >= 6, names
+        assert sum(nm.startswith("conv_wgrad_split_tr") for nm in names) >= 3, names
+    for name, a, b in zip(["y", "dx", "dw1", "dgamma1", "dbeta1", "dw2", "dgamma2", "dbeta2", "running_var1", "running_var2"], split, whole):
+        _assert_close(a, b, 5e-6, name)
 
 
 def test_folded_bn_inference_and_predict_tail():
@@ -568,6 +587,52 @@ def test_conv_split_accuracy(case, monkeypatch):
         for k in (0, 1, 2):
             e32, es = errs["f32"][k][0], errs[math][k][0]
             assert es <= max(2.0 * e32, 2e-6 * errs["f32"][k][1]), "%s err %.3e vs f32-MFMA err %.3e" % (math, es, e32)
+
+
+@pytest.mark.parametrize("cin,cout,stride", [(16, 16, 1), (16, 32, 2)])
+def test_full_resolution_layers_of_cfg5_in_one_launch(cin, cout, stride, monkeypatch):
+    """BASELINE config 5's thin layers at its stated batch -- 32 x 720 x 1280, 1.89 GB per 16-channel tensor, 3 % below the 2 GiB a
+    launch can address -- are no longer cut along N (ops._batch_pieces: the split kernels need no tile of slack), so they keep their
+    companions: forward, data gradient and weight gradient from the companions in ONE launch each.  Checked at that size:
+    the last images' forward / data-gradient values equal the same images processed alone bit for bit (different pixel tiles,
+    different offsets near the 2 GiB end), and the weight gradient equals the sum of the batch quarters' to fp32 rounding."""
+    dev = _dev()
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "CONV_MATH", "f16x3")
+    n, h, w = 32, 720, 1280
+    g = torch.Generator(device=dev).manual_seed(61)
+    x = torch.randn(n, cin, h, w, device=dev, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, device=dev, generator=g) * (2.0 / (9 * cout)) ** 0.5
+    desc = ops.conv_desc(x.shape, wt.shape, stride, 1, 1)
+    assert ops._batch_pieces(desc) == [(0, n)]
+    gy = torch.randn(n, cout, desc.Ho, desc.Wo, device=dev, generator=g)
+    pk = ops.PackedWeights()
+    wf, wd, mpf = pk.get(wt, desc)
+    x_cb, x_bound = ops.split_companion(x)
+    gy_cb, gy_bound = ops.split_companion(gy)
+    y, part, rows = ops._conv_fprop(desc, x, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)
+    dx = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound)
+    dw = ops._conv_wgrad(desc, x, gy, x_cb, gy_cb, x_bound, gy_bound)
+    assert bool(torch.isfinite(dw).all())
+    # the last three images alone (their own companions, the full tensors' bounds)
+    tail = slice(n - 3, n)
+    xs, gs = x[tail].contiguous(), gy[tail].contiguous()
+    ds = ops.conv_desc(xs.shape, wt.shape, stride, 1, 1)
+    xs_cb, _ = ops.split_companion(xs, x_bound)
+    gs_cb, _ = ops.split_companion(gs, gy_bound)
+    ys, _, _ = ops._conv_fprop(ds, xs, wf, None, True, mpf, xs_cb, x_bound, pk.w_bound)
+    dxs = ops._conv_dgrad(ds, None, wd, gs_cb, gy_bound, pk.w_bound)
+    assert torch.equal(y[tail], ys) and torch.equal(dx[tail], dxs)
+    del ys, dxs, xs_cb, gs_cb, y, dx
+    acc = torch.zeros_like(dw, dtype=torch.float64)
+    for q in range(4):
+        sl = slice(8 * q, 8 * q + 8)
+        xq, gq = x[sl].contiguous(), gy[sl].contiguous()
+        dq = ops.conv_desc(xq.shape, wt.shape, stride, 1, 1)
+        xq_cb, _ = ops.split_companion(xq, x_bound)
+        gq_cb, _ = ops.split_companion(gq, gy_bound)
+        acc += ops._conv_wgrad(dq, xq, gq, xq_cb, gq_cb, x_bound, gy_bound).double()
+    _assert_close(dw, acc, 1e-5, "weight gradient of the whole batch vs the sum over its quarters")
 
 
 def _round_like_f16x1(t, bound):

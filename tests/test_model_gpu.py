@@ -385,10 +385,14 @@ def test_target_forward_reuse_is_bitwise_for_other_generators(kind):
         assert torch.equal(states[0][k], states[1][k]), k
 
 
-def test_training_on_a_fixed_batch_reduces_the_source_loss():
+@pytest.mark.parametrize("math", ["f16x3", "f16x1"])
+def test_training_on_a_fixed_batch_reduces_the_source_loss(math, monkeypatch):
     """End-to-end sanity of the whole update path over many steps (weights, BN statistics and the per-tensor fp16 scales all
-    move): 40 MCD steps on one fixed batch drive the source cross-entropy down and keep every parameter finite."""
+    move): 40 MCD steps on one fixed batch drive the source cross-entropy down and keep every parameter finite -- in the default
+    arithmetic and in the reduced-precision one (--dtype f16)."""
     dev = _dev()
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "CONV_MATH", math)
     from loss import CrossEntropyLoss2d, get_prob_distance_criterion
     from models.model_util import get_models, get_optimizer
     from solvers.solver import MCDSolver
@@ -408,6 +412,79 @@ def test_training_on_a_fixed_batch_reduces_the_source_loss():
     for m in (g, f1, f2):
         for k, v in m.state_dict().items():
             assert bool(torch.isfinite(v.float()).all()), k
+
+
+def test_reduced_precision_f16x1_states_what_it_keeps(golden, monkeypatch):
+    """``--dtype f16`` (MCDSEG_CONV_MATH=f16x1; BASELINE config 5's reduced-precision intent): the convolutions multiply operands rounded
+    to 11 significant bits, so the result is NOT within north_star's 1e-3 of the fp32 reference -- this test states what the mode keeps,
+    against the same reference vectors as the fp32-grade tests (measured values in brackets, tools/f16x1_report.py):
+      * train-mode encoder features within 3e-2 of their scale [1.1e-2], logits within 3e-2 of theirs [1.2e-2];
+      * arg-max label maps identical wherever the reference's own top-1 / top-2 margin exceeds 5e-2 [largest margin of a flipped
+        pixel 2.2e-2], fewer than 3 % of all pixels flipped at random initialisation [1.1 %];
+      * the logged losses of the three-step trace: c_loss within 1e-4 [6e-6], d_loss within 5e-3 [5e-4] relative;
+      * every stored parameter update of that trace points the reference's way: cosine with its fp64 update >= 0.9 [0.937 .. 1.0]
+        (the fp32-grade default: >= 0.9994);
+      * 40 steps on a fixed batch still drive the source loss down (next test, parametrised)."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, get_prob_distance_criterion
+    from mcdseg import ops
+    from models.model_util import get_optimizer
+    from solvers.solver import MCDSolver
+    monkeypatch.setattr(ops, "CONV_MATH", "f16x1")
+    fx = golden.npz("fwd_small.npz")
+    g, f1, f2 = _mcd_models(dev)
+    src, _, _ = make_batch(21, 2, 6, 64, 96, NC)
+    names = []
+
+    class _Names:
+        def wants(self, name):
+            names.append(name)
+            return False
+    prev, ops.LAUNCH_TIMER = ops.LAUNCH_TIMER, _Names()
+    try:
+        with torch.no_grad():
+            feat = g(src.to(dev))
+            o1 = f1(feat)
+    finally:
+        ops.LAUNCH_TIMER = prev
+    assert any("SplitF16x1" in nm for nm in names) and not any("SplitF16x3" in nm for nm in names), sorted(set(names))
+    ref = fx["feat_train"]
+    assert np.abs(feat.cpu().numpy() - ref).max() <= 3e-2 * np.abs(ref).max()
+    lref = fx["logits1_sub_train"]
+    assert np.abs(o1[:, :, ::4, ::4].cpu().numpy() - lref).max() <= 3e-2 * np.abs(lref).max()
+    pred = o1[:, :NC - 1].argmax(1).cpu().numpy()
+    mism = pred != fx["argmax1_train"]
+    assert not (mism & (fx["margin1_train"] > 5e-2)).any() and mism.mean() < 0.03
+    # the three-step trace
+    tr = golden.json("traces.json")["mcd_small"]
+    dl = golden.npz("trace_deltas.npz")
+    g, f1, f2 = _mcd_models(dev)
+    flat = lambda: dict(list(g.state_dict().items()) + [("f1." + k, v) for k, v in f1.state_dict().items()] +  # noqa: E731
+                        [("f2." + k, v) for k, v in f2.state_dict().items()])
+    before = {k: v.detach().clone() for k, v in flat().items()}
+    n, ch, h, w = tr["shape"]
+    s, l, t = (v.to(dev) for v in make_batch(tr["seed_batch"], n, ch, h, w, NC))
+    og = get_optimizer(g.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    of = get_optimizer(list(f1.parameters()) + list(f2.parameters()), "sgd", 1e-3, 0.9, 2e-5)
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    solver = MCDSolver(g, f1, f2, og, of, CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff"), num_k=4)
+    for it in range(2):
+        c, d = solver.step(s, l, t)
+        assert abs(float(c) - tr["iters"][it]["c_loss"]) <= 1e-4 * tr["iters"][it]["c_loss"]
+        assert abs(float(d) - tr["iters"][it]["d_loss"]) <= 5e-3 * tr["iters"][it]["d_loss"]
+    after = flat()
+    seen = 0
+    for key in dl.files:
+        if not key.startswith("f64/delta/"):
+            continue
+        name = key[len("f64/delta/"):]
+        r = dl[key].ravel()
+        dd = _pick(after[name].double().cpu() - before[name].double().cpu()).numpy().ravel()
+        cos = float(np.dot(dd, r) / (np.linalg.norm(dd) * np.linalg.norm(r)))
+        assert cos >= 0.9, (name, cos)
+        seen += 1
+    assert seen >= 12
 
 
 def test_mfnet_vs_reference(golden):
