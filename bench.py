@@ -347,7 +347,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timer.enabled = False
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if mdist.is_distributed():
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(el)
     c_loss, d_loss = float(c_loss), float(d_loss)
@@ -367,7 +367,7 @@ def main():
         mdist.barrier()
         torch.cuda.synchronize()
         lt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        if world > 1:
+        if mdist.is_distributed():
             torch.distributed.all_reduce(lt, op=torch.distributed.ReduceOp.MAX)
         solver.reuse_tgt = True
         literal = {"steps": args.literal_steps, "ms_per_step": round(1e3 * float(lt) / args.literal_steps, 2),
@@ -429,6 +429,9 @@ def main():
             "config": {"workload": "adapt_trainer MCD early-fusion %s %d-ch, bs=%d/GPU synthetic %dx%d, full A+B+C step (num_k=4)"
                                    % (args.net, args.input_ch, args.batch, args.height, args.width),
                        "pairs_per_gpu": args.batch, "global_pairs": args.batch * world, "parallelism": "dp%d" % world,
+                       "collectives": ("none (single process)" if not mdist.is_distributed() else
+                                       ("rccl (forced, 1 rank)" if world == 1 else "rccl all-reduce of the flat gradient buffer over %d ranks, one rank "
+                                        "per GPU%s" % (world, ", bucketed during backward (MCDSEG_DP_OVERLAP=1)" if os.environ.get("MCDSEG_DP_OVERLAP") == "1" else ""))),
                        "n_class": args.n_class, "conv_math": ops.CONV_MATH, "c_loss": c_loss, "d_loss": d_loss, "timer": args.timer,
                        "timer_steps": min(args.steps, args.timer_steps),
                        "schedule": "the reference's A+B+C statements with the results-neutral elisions of solvers/solver.py: no generator "
@@ -454,7 +457,7 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     mdist.barrier()
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -13,8 +13,13 @@ import torch
 import torch.distributed as dist
 
 
+# MCDSEG_DIST_FORCE=1: join a process group even as the only rank and run every collective through it -- the RCCL path of a
+# one-GPU box (bench.py under torch.distributed.run with one rank: tests/test_trainers_gpu.py)
+FORCE = os.environ.get("MCDSEG_DIST_FORCE", "0") == "1"
+
+
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE)
 
 
 def world_size():
@@ -30,7 +35,7 @@ def init_from_env(backend=None):
     Returns (rank, world, local_rank); a no-op for single-process runs."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world <= 1:
+    if world <= 1 and not (FORCE and "MASTER_PORT" in os.environ):
         return 0, 1, local
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -50,6 +55,14 @@ def all_reduce_sum_(flat):
     if is_distributed():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
+
+
+def all_reduce_sum_async(flat):
+    """Start the in-place sum and return the work handle (None when not distributed); ``handle.wait()`` orders the caller's
+    stream behind it"""
+    if is_distributed():
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    return None
 
 
 def broadcast_(tensors, src=0):

@@ -10,12 +10,21 @@ of it); momentum lives in a second flat buffer and gradients are gathered into a
 the single payload of the data-parallel all-reduce (``mcdseg.dist``).  Parameters whose ``grad`` is
 None are skipped exactly as torch does (no weight decay, no momentum update).
 """
+import os
+
 import torch
 
 from . import dist as mdist
 from . import ops
 
 _ALIGN = 64  # floats; keeps every view 256-byte aligned for the float4 kernels
+# Data parallelism, optional: MCDSEG_DP_OVERLAP=1 all-reduces the flat gradient buffer in buckets of MCDSEG_DP_BUCKET_MB (default 25)
+# while the backward pass is still running -- a gradient is copied into its flat view by a post-accumulate hook, and once every
+# parameter of a bucket has arrived the bucket's slice is reduced asynchronously (RCCL's own stream).  OFF by default: the five
+# 104 MB all-reduces of an MCD step are ~2 % of its time on xGMI (DESIGN.md section 5); the switch exists so that a measured
+# scaling curve can be acted on without new code.  Results are those of the single all-reduce (sums of the same values).
+DP_OVERLAP = os.environ.get("MCDSEG_DP_OVERLAP", "0") == "1"
+DP_BUCKET_MB = float(os.environ.get("MCDSEG_DP_BUCKET_MB", "25"))
 
 
 class FlatSGD(torch.optim.Optimizer):
@@ -69,6 +78,53 @@ class FlatSGD(torch.optim.Optimizer):
             views[id(p)] = (o, n, vv, fg[o:o + n].view(p.shape))
         self._flat = dict(p=fp, v=fv, g=fg, params=params, offs=offs, views=views, total=total)
         ops.bump_weight_epoch()
+        self._setup_overlap()
+
+    # ------------------------------------------------------------------ bucketed all-reduce during backward (optional)
+    def _setup_overlap(self):
+        fl = self._flat
+        for h in getattr(self, "_hooks", []):
+            h.remove()
+        self._hooks, fl["buckets"], fl["bucket_of"] = [], [], {}
+        if not (DP_OVERLAP and mdist.is_distributed()):
+            return
+        limit = int(DP_BUCKET_MB * (1 << 20) / 4)
+        cur = None
+        # buckets in REVERSE parameter order: the backward pass produces the last layers' gradients first
+        for p, o in reversed(list(zip(fl["params"], fl["offs"]))):
+            n = p.numel()
+            if cur is None or cur["hi"] - o > limit:
+                cur = dict(lo=o, hi=o + n, ids=set(), arrived=0, work=None)
+                fl["buckets"].append(cur)
+            cur["lo"] = o
+            cur["ids"].add(id(p))
+            fl["bucket_of"][id(p)] = cur
+        for p in fl["params"]:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._grad_arrived))
+
+    def _grad_arrived(self, p):
+        fl = self._flat
+        if fl is None or id(p) not in fl["bucket_of"] or p.grad is None:
+            return
+        b = fl["bucket_of"][id(p)]
+        fl["views"][id(p)][3].copy_(p.grad)
+        b["arrived"] += 1
+        if b["arrived"] == len(b["ids"]) and b["work"] is None:
+            b["work"] = mdist.all_reduce_sum_async(fl["g"][b["lo"]:b["hi"]])
+
+    def _finish_overlap(self, ps):
+        """waits for the collectives the hooks started; True when every gradient of ``ps`` has been reduced that way (else the
+        caller copies and reduces the whole run again -- correct, merely redundant for the buckets that were complete)"""
+        fl = self._flat
+        buckets = {id(b): b for b in (fl["bucket_of"].get(id(p)) for p in ps) if b is not None}
+        for b in buckets.values():
+            if b["work"] is not None:
+                b["work"].wait()
+        return all(fl["bucket_of"].get(id(p)) is not None and fl["bucket_of"][id(p)]["work"] is not None for p in ps)
+
+    def _reset_overlap(self):
+        for b in (self._flat or {}).get("buckets", []):
+            b["arrived"], b["work"] = 0, None
 
     def _ensure_flat(self):
         if self._flat is None:
@@ -111,21 +167,29 @@ class FlatSGD(torch.optim.Optimizer):
         world = mdist.world_size()
         for run in runs:
             ps = run["params"]
-            gviews = [fl["views"][id(p)][3] for p in ps]
-            grads = [p.grad if p.grad.dtype == torch.float32 else p.grad.float() for p in ps]
-            torch._foreach_copy_(gviews, grads)
             o0 = fl["views"][id(ps[0])][0]
             o1, n1 = fl["views"][id(ps[-1])][0], fl["views"][id(ps[-1])][1]
             lo, hi = o0, o1 + n1
             gflat = fl["g"][lo:hi]
-            if world > 1:
-                mdist.all_reduce_sum_(gflat)
+            reduced = bool(fl.get("buckets")) and self._finish_overlap(ps)  # the hooks copied and reduced these during backward
+            if not reduced:
+                gviews = [fl["views"][id(p)][3] for p in ps]
+                grads = [p.grad if p.grad.dtype == torch.float32 else p.grad.float() for p in ps]
+                torch._foreach_copy_(gviews, grads)
+                if mdist.is_distributed():
+                    mdist.all_reduce_sum_(gflat)
             lr, mu, wd = run["key"]
             ops.sgd_momentum_flat_(fl["p"][lo:hi], gflat, fl["v"][lo:hi], lr, mu, wd, 1.0 / world)
             if mu != 0:
                 for p in ps:
                     self.state[p]["momentum_buffer"] = fl["views"][id(p)][2]
+        self._reset_overlap()
         return loss
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none=set_to_none)
+        if self._flat is not None:
+            self._reset_overlap()
 
     def state_dict(self):
         sd = super().state_dict()

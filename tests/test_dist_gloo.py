@@ -22,8 +22,10 @@ def _ref_sgd_(p, g, v, lr, mu, wd, gs=1.0):
     p.sub_(lr * v)
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, overlap=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if overlap:  # bucketed all-reduce from post-accumulate hooks: tiny buckets so that the three parameters fall into several
+        os.environ.update(MCDSEG_DP_OVERLAP="1", MCDSEG_DP_BUCKET_MB="0.0005")
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "multichannel-semseg-with-uda_amd"))
@@ -44,8 +46,14 @@ def _worker(rank, world, port, tmp):
         grads_all = [[torch.randn(s, generator=torch.Generator().manual_seed(100 * step + 10 * k + i)) for i, s in enumerate(shapes)]
                      for k in range(world)]
         opt.zero_grad()
-        for p, g in zip(params, grads_all[rank]):
-            p.grad = g.clone()
+        if overlap and step > 0:  # through autograd, so that the hooks see the gradients arrive (step 0: plain assignment -> fallback path)
+            loss = sum((p * g).sum() for p, g in zip(params, grads_all[rank]))
+            loss.backward()
+            fl = opt._flat
+            assert len(fl["buckets"]) >= 2 and all(b["work"] is not None for b in fl["buckets"])
+        else:
+            for p, g in zip(params, grads_all[rank]):
+                p.grad = g.clone()
         opt.step()
         for i in range(len(ref)):
             gavg = sum(grads_all[k][i] for k in range(world)) / world
@@ -69,6 +77,15 @@ def _worker(rank, world, port, tmp):
 def test_flat_sgd_data_parallel_gloo(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
+
+
+def test_flat_sgd_bucketed_overlap_gloo(tmp_path):
+    """MCDSEG_DP_OVERLAP=1: gradients copied into the flat buffer by post-accumulate hooks, buckets all-reduced asynchronously as they
+    complete during backward -- same parameters as the reference update of the averaged gradients (and the un-hooked first step
+    takes the one-collective path)"""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
     assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
 
 

@@ -314,3 +314,29 @@ def test_bench_with_two_ranks_on_one_gpu():
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["cpu_baseline"] is None
     assert abs(line["value"] - 2 * 2 / (line["ms_per_step"] * 1e-3)) <= 1e-2 * line["value"]
     assert line["config"]["global_pairs"] == 4 and line["config"]["parallelism"] == "dp2"
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_bench_with_one_rank_through_rccl(overlap):
+    """``bench.py`` under ``torch.distributed.run`` with ONE rank and MCDSEG_DIST_FORCE=1: the process group is RCCL ("nccl") and every
+    collective of the step -- the flat-gradient all-reduces (in one piece, or bucketed from the backward hooks with
+    MCDSEG_DP_OVERLAP=1), the cross-entropy normaliser, the MAX over ranks of the timing -- really goes through it on the GPU.
+    What a one-GPU box can prove of the multi-GPU path: same losses as the plain single-process run."""
+    _need_gpu()
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", "--height", "64", "--width", "96", "--no_cpu_baseline",
+            "--literal_steps", "0", "--batch_pool", "1"]
+    r = _run_ranks(1, os.path.join(root, "bench.py"), args, extra_env={"MCDSEG_DIST_BACKEND": "nccl", "MCDSEG_DIST_FORCE": "1", "MCDSEG_DP_OVERLAP": overlap,
+                                                                      "MCDSEG_DP_BUCKET_MB": "8"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    import subprocess
+    import sys
+    plain = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, MCDSEG_PRETRAINED="0"))
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    ref = json.loads([ln for ln in plain.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["parallelism"] == "dp1"
+    assert line["config"]["c_loss"] == ref["config"]["c_loss"] and line["config"]["d_loss"] == ref["config"]["d_loss"]
+    assert line["config"]["collectives"] == "rccl (forced, 1 rank)" and ref["config"]["collectives"] == "none (single process)"
