@@ -487,7 +487,7 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
 // Which kernel mcdseg_conv_wgrad / mcdseg_conv_split_wgrad launch for this geometry (math = 0 for mcdseg_conv_wgrad):
 // 0..3 the f32 plans (128x128, 64x64, 32x32 tiles, tap-packed thin), 10 split arithmetic from fp32 operands, 11 / 12 / 13 / 14 from
 // both pre-split companions: register-transposing, transposed-read 128x128, transposed-read 256x128, transposed-read 64-channel
-// tap pairs, 15 the thin-layer window kernel.  For profilers and the benchmark's per-kernel accounting; never needed to call the operators.
+// tap pairs, 15 the thin-layer window kernel, 16 transposed-read 128-channel tiles with two taps per workgroup.  For profilers and the benchmark's per-kernel accounting; never needed to call the operators.
 extern "C" int32_t mcdseg_conv_wgrad_variant(const mcdseg_conv_desc* d, int32_t math, int32_t presplit) {
   if (d == nullptr) return -22;
   const WgradPlan pl = make_plan(d);
@@ -495,7 +495,8 @@ extern "C" int32_t mcdseg_conv_wgrad_variant(const mcdseg_conv_desc* d, int32_t 
   if (pl.cfg == 1 && presplit && tr64_applies(d, math, d, d, 1)) return 14;
   if (pl.cfg != 0 || math == 0) return pl.cfg;
   if (!(presplit && (d->Cin & 7) == 0 && (d->Cout & 7) == 0)) return 10;
-  return 11 + mcdseg_internal_wgrad_cb_variant(d, math, pl.co_p, pl.ci_p, pl.splits);
+  const int v = mcdseg_internal_wgrad_cb_variant(d, math, pl.co_p, pl.ci_p, pl.splits);
+  return v == 3 ? 16 : 11 + v;  // 16: transposed-read 128-row tiles, two taps per workgroup
 }
 
 extern "C" int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,

@@ -418,9 +418,17 @@ __device__ __forceinline__ void mcd_settle(F (&f)[A][B], int used) {
 //   <WM = 4, R = 2, NSTAGE = 3>   256 (co) x 128 (ci) tile (each wave 128 x 64), 16-pixel stages of 24 KB, three stages: the
 //                                 DMAs of tile s+2 fly while tile s multiplies -- the structure of the forward kernel's
 //                                 256 x 128 configuration, for the layers with Cout a multiple of 256
-template <class P, int WM, int R, int NSTAGE>
+//   <WM = 4, R = 2, NSTAGE = 3, TWO = true>   the 128-channel layers, TWO TAPS per workgroup (round 3): the 128 x 128 tile is LDS-bound (8
+//                                 fragment reads per 12 MFMAs per wave), so the operand roles are swapped -- the "A" side is X
+//                                 at the shifts of taps 2 tp and 2 tp + 1 (two 128-channel blocks, exactly the big tile's two dY blocks),
+//                                 the "B" side the ONE staged dY tile both taps share -- and the workgroup computes the transposed tile
+//                                 [tap, ci][co] with the big tile's wave shape: 12 reads per 24 MFMAs, a quarter fewer DMA bytes.  The
+//                                 pieces of the cross terms are swapped with the roles, so every product and its order are those of the
+//                                 one-tap kernel: bit-identical slabs.
+template <class P, int WM, int R, int NSTAGE, bool TWO>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr_kernel(WgradCbParams p) {
   static_assert(P::NP == 2, "two-piece policies");
+  static_assert(!TWO || WM == 4, "two taps = two 128-row blocks");
   constexpr int WN = 2, WAVES_N = 2;
   constexpr int BM = 64 * WM, BN = 128;
   constexpr int NP = P::NP;
@@ -443,50 +451,62 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr_kernel(WgradCbPara
   const int l31 = lane & 31, lh = lane >> 5;
 
   const int ci_tiles = p.ci_p / BN;
-  const int co_tiles = p.co_p / BM;
+  const int co_tiles = TWO ? p.co_p / 128 : p.co_p / BM;
   const int T_ = p.KH * p.KW;
-  const int per_split = co_tiles * ci_tiles * T_;
+  const int TG = TWO ? (T_ + 1) >> 1 : T_;  // tap groups: pairs or single taps
+  const int per_split = co_tiles * ci_tiles * TG;
   const int xcd = blockIdx.x & 7;
   const int slot = blockIdx.x >> 3;
   const int split = (slot / per_split) * 8 + xcd;
   if (split >= p.splits) return;
   int rem = slot % per_split;
-  const int tap = rem % T_;
-  rem /= T_;
+  const int tg = rem % TG;
+  rem /= TG;
   const int tile_ci = rem % ci_tiles;
   const int tile_co = rem / ci_tiles;
   const int n = split / p.chunks_per_img;
   const int chunk_id = split - n * p.chunks_per_img;
-  const int ky = tap / p.KW;
-  const int kx = tap - ky * p.KW;
   const int ntiles = p.tiles_x * p.tiles_y;
   const int t_begin = chunk_id * p.tiles_per_chunk;
   int t_end = t_begin + p.tiles_per_chunk;
   if (t_end > ntiles) t_end = ntiles;
 
-  // ---- DMA role of this wave: (operand, piece), wave-uniform (operand 0 = dY rows, 1 = X rows)
+  // ---- DMA role of this wave: (operand side, piece), wave-uniform.  Side 0 = the "A" rows (AB blocks of 128: dY channel blocks, or
+  // with TWO the two taps of X), side 1 = the "B" rows (one block: X at the tap, or with TWO the dY tile)
   const int opnd = wave >> 1;
   const int piece = wave & 1;
+  const bool isx = TWO ? (opnd == 0) : (opnd == 1);  // this wave stages X (gathered through the conv geometry) rather than dY
   const int ps = lane & 3;
   const int cg = lane >> 2;
-  const int sH = opnd ? p.H : p.Ho;
-  const int sW = opnd ? p.W : p.Wo;
-  const int sS = opnd ? p.stride : 1;
-  const int shy = opnd ? ky * p.dil - p.pad : 0;
-  const int shx = opnd ? kx * p.dil - p.pad : 0;
-  const int sC8 = (opnd ? p.Cin : p.Cout) >> 3;
-  const int cg0 = opnd ? tile_ci * 16 : tile_co * (16 * AB);  // first channel group of the tile
-  const int nblk = opnd ? 1 : AB;                              // 128-channel blocks this wave moves per quad
+  const int sH = isx ? p.H : p.Ho;
+  const int sW = isx ? p.W : p.Wo;
+  const int sS = isx ? p.stride : 1;
+  int shy[AB], shx[AB];
+  bool blk_ok[AB];
+#pragma unroll
+  for (int b = 0; b < AB; ++b) {
+    const int tap_b = TWO ? 2 * tg + b : tg;
+    const int ky = tap_b / p.KW, kx = tap_b - ky * p.KW;
+    shy[b] = isx ? ky * p.dil - p.pad : 0;
+    shx[b] = isx ? kx * p.dil - p.pad : 0;
+    blk_ok[b] = tap_b < T_;
+  }
+  const int sC8 = (isx ? p.Cin : p.Cout) >> 3;
+  const int cg0 = isx ? tile_ci * 16 : tile_co * (TWO ? 16 : 16 * AB);  // first channel group of the tile
+  const int nblk = opnd ? 1 : AB;                                        // 128-row blocks this wave moves per quad
   const int sHW = sH * sW;
   // the descriptor covers this wave's PIECE and starts `bias` bytes below it so that the SGPR offset (tile + tap shift) is never negative
   const int bias = p.pad * 16 + 16;
-  const char* sptr = (const char*)(opnd ? p.x_cb : p.dy_cb) + piece * (opnd ? p.x_piece_stride : p.dy_piece_stride) - bias;
-  const int sbytes = (opnd ? p.x_cb_bytes : p.dy_cb_bytes) + bias;
+  const char* sptr = (const char*)(isx ? p.x_cb : p.dy_cb) + piece * (isx ? p.x_piece_stride : p.dy_piece_stride) - bias;
+  const int sbytes = (isx ? p.x_cb_bytes : p.dy_cb_bytes) + bias;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sptr, 0, sbytes, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   unsigned vconst[AB];
 #pragma unroll
-  for (int b = 0; b < AB; ++b) vconst[b] = (cg0 + 16 * b + cg) < sC8 ? (unsigned)((16 * b + cg) * sHW + ps * sS) * 16u : OOB;
+  for (int b = 0; b < AB; ++b) {
+    const int cb = TWO ? cg : 16 * b + cg;  // (two taps: both blocks are the same 128 channels)
+    vconst[b] = ((cg0 + cb) < sC8 && blk_ok[b]) ? (unsigned)(cb * sHW + ps * sS) * 16u : OOB;
+  }
   const int sbase = (n * sC8 + cg0) * sHW;  // 16-B units inside the piece
   const int lane_x = ps * sS;
   unsigned char* const unit_lds = smem + (opnd ? NP * A_UNIT + piece * B_UNIT : piece * A_UNIT);
@@ -494,25 +514,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr_kernel(WgradCbPara
   auto issue_dma = [&](int tt, int stage) {
     const int ty = tt / p.tiles_x;
     const int tx = tt - ty * p.tiles_x;
-    bool colok[2];
+    bool colok[2][AB];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int ux = (tx * 8 + 4 * h) * sS + shx;  // uniform
-      colok[h] = (unsigned)(ux + lane_x) < (unsigned)sW;
-    }
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int b = 0; b < AB; ++b) {
+        const int ux = (tx * 8 + 4 * h) * sS + shx[b];  // uniform
+        colok[h][b] = (unsigned)(ux + lane_x) < (unsigned)sW;
+      }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
     for (int j = 0; j < NQD; ++j) {  // quad j: row j % R of the tile, column half j / R
       const int h = j / R;
-      const int iy = (ty * R + (j % R)) * sS + shy;
-      const int ux = (tx * 8 + 4 * h) * sS + shx;
-      const int soff = ((unsigned)iy < (unsigned)sH) ? (sbase + iy * sW + ux) * 16 + bias : 0x7FFFFFFF;
 #pragma unroll
       for (int b = 0; b < AB; ++b)
-        if (b < nblk)
+        if (b < nblk) {
+          const int iy = (ty * R + (j % R)) * sS + shy[b];
+          const int ux = (tx * 8 + 4 * h) * sS + shx[b];
+          const int soff = ((unsigned)iy < (unsigned)sH) ? (sbase + iy * sW + ux) * 16 + bias : 0x7FFFFFFF;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(
               rs, (__attribute__((address_space(3))) void*)(unit_lds + stage * STAGE + (j * (opnd ? 1 : AB) + b) * QUAD), 16,
-              colok[h] ? vconst[b] : OOB, soff, 0, 0);
+              colok[h][b] ? vconst[b] : OOB, soff, 0, 0);
+        }
     }
 #else
     (void)colok;
@@ -615,7 +638,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr_kernel(WgradCbPara
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int tm = 0; tm < P::NTERMS; ++tm) acc[i][j] = P::mfma(fa[SET][P::TA[tm]][i], fb[SET][P::TB[tm]][j], acc[i][j]);
+        for (int tm = 0; tm < P::NTERMS; ++tm)  // (roles swapped with TWO: the A side carries X, so the pieces swap too -- same products, same order)
+          acc[i][j] = P::mfma(fa[SET][TWO ? P::TB[tm] : P::TA[tm]][i], fb[SET][TWO ? P::TA[tm] : P::TB[tm]][j], acc[i][j]);
   };
   // wait until at most `left` of this wave's DMAs are outstanding (left is wave-uniform: 0, NQD or NQD * AB), then barrier
   auto wait_barrier = [&](int left) {
@@ -664,7 +688,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr_kernel(WgradCbPara
   }
   if (s < nsteps) step(s, S0{}, S1{});
 
-  float* out = p.slab + ((size_t)split * T_ + tap) * p.co_p * p.ci_p;
+  if constexpr (TWO) {  // transposed tile: rows = (tap wm, ci), columns = co -- turned through a wave-private LDS image so that the
+    // slab, laid out [co][ci] like everyone else's, is written in 256-byte runs (the loop's last barrier released the stages)
+    const int my_tap = 2 * tg + wm;
+    constexpr int PITCH = 68;  // floats per co row of the image: 16-byte aligned rows, 64 ci + padding
+    static_assert(4 * 64 * PITCH * 4 <= NSTAGE * STAGE, "four wave images fit the stage ring");
+    float* img = reinterpret_cast<float*>(smem) + wave * 64 * PITCH;
+    float* out = p.slab + ((size_t)split * T_ + (my_tap < T_ ? my_tap : 0)) * p.co_p * p.ci_p;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {  // 64 ci at a time
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci_l = i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+          for (int j = 0; j < WN; ++j) img[(j * 32 + l31) * PITCH + ci_l] = acc[2 * hh + i2][j][r];
+        }
+      // (one wave: its LDS writes and reads are ordered by the LDS queue)
+      if (my_tap < T_) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int co_l = q * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+          const float4 v = *reinterpret_cast<const float4*>(img + co_l * PITCH + c4);
+          *reinterpret_cast<float4*>(out + (size_t)(tile_co * 128 + wn * 64 + co_l) * p.ci_p + tile_ci * BN + hh * 64 + c4) = v;
+        }
+      }
+    }
+    return;
+  }
+  float* out = p.slab + ((size_t)split * T_ + tg) * p.co_p * p.ci_p;
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -904,7 +957,12 @@ int mcdseg_internal_wgrad_cb_variant(const mcdseg_conv_desc* d, int math, int co
   // 256 x 128 tiles (16-pixel stages) for the layers whose padded Cout is a multiple of 256 -- the plan was made for 128-row
   // tiles, so the number of workgroups halves; taken only while that still fills the chip twice over
   const bool big = use_big && (co_p % 256) == 0 && (int64_t)(co_p / 256) * (ci_p / 128) * d->KH * d->KW * splits >= 1024;
-  return big ? 2 : 1;
+  if (big) return 2;
+  // the remaining 128-row layers with more than one tap: two taps per workgroup sharing the staged dY tile -- built, bit-identical,
+  // and SLOWER at the benchmark's sizes (256 -> 256 at N = 16: 0.309-0.349 ms against 0.286: an odd tap count idles a tenth of the waves,
+  // half as many workgroups, a transposed epilogue), so it runs only on request (MCDSEG_WGRAD_TWOTAP=1; tests)
+  const char* e_two = getenv("MCDSEG_WGRAD_TWOTAP");
+  return (d->KH * d->KW > 1 && e_two != nullptr && atoi(e_two) != 0) ? 3 : 1;
 }
 
 // pre-split operands (see conv_wgrad_split_cb_kernel); chunks_per_img / splits come from the shared plan, the pixel range
@@ -917,7 +975,7 @@ int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, c
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
   p.co_p = co_p; p.ci_p = ci_p; p.chunks_per_img = chunks_per_img; p.splits = splits;
   const int variant = mcdseg_internal_wgrad_cb_variant(d, math, co_p, ci_p, splits);
-  const bool tr = variant >= 1, big = variant == 2;
+  const bool tr = variant >= 1, big = variant == 2, two = variant == 3;
   {
     const int64_t npc = mcd_math_pieces(math), nb = d->Ncb ? d->Ncb : d->N;
     const int64_t xall = (npc - 1) * nb * d->Cin * d->H * d->W * 2 + (int64_t)d->N * d->Cin * d->H * d->W * 2;
@@ -941,7 +999,7 @@ int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, c
   p.dy_cb_bytes = (int)yb;
   p.x_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cin * d->H * d->W * 2;
   p.dy_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cout * d->Ho * d->Wo * 2;
-  const int64_t per_split = (int64_t)(co_p / (big ? 256 : 128)) * (ci_p / 128) * d->KH * d->KW;
+  const int64_t per_split = (int64_t)(co_p / (big ? 256 : 128)) * (ci_p / 128) * (two ? (d->KH * d->KW + 1) / 2 : d->KH * d->KW);
   const int64_t nwg = 8 * ceil_div64(splits, 8) * per_split;
   if (nwg >= (1ll << 31)) {
     mcdseg_set_error("conv_wgrad_split: grid too large");
@@ -949,13 +1007,17 @@ int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, c
   }
   const bool one = math == MCDSEG_MATH_F16X1;  // the same staging, one term
   if (big && one)
-    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x1, 4, 2, 3>), dim3((unsigned)nwg), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x1, 4, 2, 3, false>), dim3((unsigned)nwg), dim3(256), 0, st, p);
   else if (big)
-    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x3, 4, 2, 3>), dim3((unsigned)nwg), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x3, 4, 2, 3, false>), dim3((unsigned)nwg), dim3(256), 0, st, p);
+  else if (two && one)
+    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x1, 4, 2, 3, true>), dim3((unsigned)nwg), dim3(256), 0, st, p);
+  else if (two)
+    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x3, 4, 2, 3, true>), dim3((unsigned)nwg), dim3(256), 0, st, p);
   else if (tr && one)
-    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x1, 2, 2, 3>), dim3((unsigned)nwg), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x1, 2, 2, 3, false>), dim3((unsigned)nwg), dim3(256), 0, st, p);
   else if (tr)
-    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x3, 2, 2, 3>), dim3((unsigned)nwg), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_wgrad_split_tr_kernel<SplitF16x3, 2, 2, 3, false>), dim3((unsigned)nwg), dim3(256), 0, st, p);
   else if (one)
     hipLaunchKernelGGL(conv_wgrad_split_cb_kernel<SplitF16x1>, dim3((unsigned)nwg), dim3(256), 0, st, p);
   else if (math == MCDSEG_MATH_F16X3)

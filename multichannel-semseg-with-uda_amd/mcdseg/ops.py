@@ -517,9 +517,9 @@ def split_companion_padded(x, bound=None):
 
 
 # mcdseg_conv_wgrad_variant code -> the kernel name rocprofv3 prints
-_WGRAD_NAMES = {10: "conv_wgrad_split_kernel<%s>", 11: "conv_wgrad_split_cb_kernel<%s>", 12: "conv_wgrad_split_tr_kernel<%s, 2, 2, 3>",
-                13: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3>", 14: "conv_wgrad_split_tr64_kernel<%s>",
-                15: "conv_wgrad_thin_tr_kernel<%s>"}
+_WGRAD_NAMES = {10: "conv_wgrad_split_kernel<%s>", 11: "conv_wgrad_split_cb_kernel<%s>", 12: "conv_wgrad_split_tr_kernel<%s, 2, 2, 3, false>",
+                13: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3, false>", 14: "conv_wgrad_split_tr64_kernel<%s>",
+                15: "conv_wgrad_thin_tr_kernel<%s>", 16: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3, true>"}
 WGRAD_TR64 = os.environ.get("MCDSEG_WGRAD_TR64", "1") != "0"
 
 

@@ -1315,6 +1315,40 @@ def test_conv_wgrad_large_tile_kernel(case, monkeypatch):
     assert torch.equal(dw_big, dw_small)
 
 
+@pytest.mark.parametrize("case", [(128, 128, 3, 1, 1, 12, 16, 2), (136, 200, 3, 1, 2, 13, 19, 2), (256, 128, 3, 1, 4, 9, 10, 1), (128, 128, 3, 2, 1, 15, 17, 2),
+                                  (72, 80, 3, 1, 1, 8, 8, 3), (128, 256, 3, 1, 2, 30, 40, 4), (128, 136, 5, 1, 1, 9, 11, 1)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_wgrad_two_taps_per_workgroup(case, monkeypatch):
+    """``conv_wgrad_split_tr_kernel<SplitF16x3, 4, 2, 3, true>``: the 128-row weight-gradient layers with two taps per workgroup (X at both
+    tap shifts on the "A" side, one shared dY tile on the "B" side, transposed output tile; odd tap counts leave the last pair half empty):
+    named through ``mcdseg_conv_wgrad_variant == 16``, <= 2e-5 of the scale against fp64, and bit for bit the one-tap kernel
+    (MCDSEG_WGRAD_TWOTAP=0) -- the cross terms' pieces are swapped with the roles, so products and their order are the same."""
+    dev = _dev()
+    import ctypes
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "CONV_MATH", "f16x3")
+    monkeypatch.setenv("MCDSEG_WGRAD_TWOTAP", "1")  # (off by default: slower at the benchmark's sizes, DESIGN 4.1c)
+    cin, cout, k, s, d, h, w, n = case
+    x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, s, d, h, w, n, False), 43)
+    desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
+    if min(cin, cout) <= 64:  # (the 64-channel plan has its own two-tap kernel)
+        assert ops.lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), ops.MATH_ID["f16x3"], 1) == 14
+        return
+    assert ops.lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), ops.MATH_ID["f16x3"], 1) == 16
+    x64, w64 = x.double(), wt.double().requires_grad_()
+    ref = F.conv2d(x64, w64, None, stride=s, padding=pad, dilation=d)
+    gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(44))
+    (gw_ref,) = torch.autograd.grad(ref, [w64], gy.double())
+    xg, gyg = x.to(dev), gy.to(dev)
+    x_cb, x_bound = ops.split_companion(xg)
+    gy_cb, gy_bound = ops.split_companion(gyg)
+    dw2 = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
+    _assert_close(dw2, gw_ref, 2e-5, "wgrad (two taps per workgroup)")
+    monkeypatch.setenv("MCDSEG_WGRAD_TWOTAP", "0")
+    assert ops.lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), ops.MATH_ID["f16x3"], 1) == 12
+    dw1 = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
+    assert torch.equal(dw2, dw1)
+
+
 @pytest.mark.parametrize("cin,h,w,n", [(6, 21, 45, 2), (3, 16, 64, 1), (1, 9, 33, 2)])
 def test_stem_wgrad_from_padded_companion(cin, h, w, n, monkeypatch):
     """7x7 stem weight gradient in the split arithmetic: the 6- (3-, 1-) channel input's zero-padded companion

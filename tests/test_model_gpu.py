@@ -650,7 +650,7 @@ def test_cfg2_full_batch_vs_oracle():
         assert big in names, "the forward pass did not run %s: %s" % (big, sorted(set(names)))
         assert ops.gemm_kernel_name(512, 512, True, True, True, False, n * 60 * 80) in names, sorted(set(names))
         if ops.CONV_MATH == "f16x3":  # ... and the weight gradients of those layers ran on the 256 x 128 / 128 x 128 / 64-channel tiles
-            for wg in ("conv_wgrad_split_tr_kernel<SplitF16x3, 4, 2, 3>", "conv_wgrad_split_tr_kernel<SplitF16x3, 2, 2, 3>",
+            for wg in ("conv_wgrad_split_tr_kernel<SplitF16x3, 4, 2, 3, false>", "conv_wgrad_split_tr_kernel<SplitF16x3, 2, 2, 3, false>",
                        "conv_wgrad_split_tr64_kernel<SplitF16x3>", "conv_wgrad_thin_tr_kernel<SplitF16x3>"):
                 assert wg in names, "the backward pass did not run %s: %s" % (wg, sorted(set(names)))
     err = float((feat.detach().cpu() - ref_feat).abs().max())
