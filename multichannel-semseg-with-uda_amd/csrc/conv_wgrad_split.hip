@@ -418,8 +418,8 @@ __device__ __forceinline__ void mcd_settle(F (&f)[A][B], int used) {
 //   <WM = 4, R = 2, NSTAGE = 3>   256 (co) x 128 (ci) tile (each wave 128 x 64), 16-pixel stages of 24 KB, three stages: the
 //                                 DMAs of tile s+2 fly while tile s multiplies -- the structure of the forward kernel's
 //                                 256 x 128 configuration, for the layers with Cout a multiple of 256
-//   <WM = 4, R = 2, NSTAGE = 3, TWO = true>   the 128-channel layers, TWO TAPS per workgroup (round 3): the 128 x 128 tile is LDS-bound (8
-//                                 fragment reads per 12 MFMAs per wave), so the operand roles are swapped -- the "A" side is X
+//   <WM = 4, R = 2, NSTAGE = 3, TWO = true>   the 128-channel layers, TWO TAPS per workgroup (round 3; on request only, it measured slower --
+//                                 DESIGN 4.1c): the operand roles are swapped -- the "A" side is X
 //                                 at the shifts of taps 2 tp and 2 tp + 1 (two 128-channel blocks, exactly the big tile's two dY blocks),
 //                                 the "B" side the ONE staged dY tile both taps share -- and the workgroup computes the transposed tile
 //                                 [tap, ci][co] with the big tile's wave shape: 12 reads per 24 MFMAs, a quarter fewer DMA bytes.  The

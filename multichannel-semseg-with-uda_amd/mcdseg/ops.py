@@ -546,8 +546,8 @@ def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None, x_bound=None, dy_bound=None)
     L = lib()
     total = None
     pieces = _batch_pieces(desc)
-    if x_cb is None or dy_cb is None:
-        x_cb = dy_cb = None  # both companions or none
+    if x_cb is None or dy_cb is None or (len(pieces) > 1 and desc.Cin <= 16):
+        x_cb = dy_cb = None  # both companions or none; the thin layers' window kernel takes whole batches only
     split = _wgrad_split_plan(desc, x_cb is not None)
     if split and x_cb is None:
         x_bound, dy_bound = _bound_or_measure(x, x_bound), _bound_or_measure(dy, dy_bound)
@@ -555,7 +555,7 @@ def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None, x_bound=None, dy_bound=None)
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a, desc.N if x_cb is not None else 0)
         ws = _ws(L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(d)), (x if x is not None else x_cb).device)
         dw = torch.empty((desc.Cout, desc.Cin, desc.KH, desc.KW), dtype=torch.float32, device=ws.device)
-        name = _WGRAD_NAMES.get(L.mcdseg_conv_wgrad_variant(ctypes.byref(d), MATH_ID[CONV_MATH], int(x_cb is not None)), "conv_wgrad") \
+        name = _WGRAD_NAMES.get(L.mcdseg_conv_wgrad_variant(ctypes.byref(d), MATH_ID[CONV_MATH], int(x_cb is not None)), "conv_wgrad<%s>") \
             % POLICY[CONV_MATH] if split else wgrad_kernel_name(desc.Cout, desc.Cin, desc.KH * desc.KW)
         with _timed(name, conv_work(d)):
             if split:

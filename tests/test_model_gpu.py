@@ -666,6 +666,181 @@ def test_cfg2_full_batch_vs_oracle():
         assert rel <= 5e-2, "%s: relative L2 difference %.3e" % (k, rel)
 
 
+def _all_threads():
+    import os
+    prev = torch.get_num_threads()
+    torch.set_num_threads(max(prev, os.cpu_count() or 1))
+    return prev
+
+
+def test_cfg3_full_batch_vs_oracle():
+    """BASELINE config 3 at its stated per-GPU size -- MFNet-ScoreAddFusion, two drn_d_38 encoders (RGB / HHA), 16 x 6 x 480 x 640 --
+    against the CPU oracle: both encoders' score maps and the fused full-resolution logits (<= 1e-3, north_star), the two cross-entropy
+    values, the gradients of the four up-sampling kernels and the gradients handed back to the two encoders.  (The oracle's encoders
+    run forward only -- their backward at this size is the cfg2 test's subject and two minutes of CPU; everything behind the score
+    maps is differentiated on both sides.)  What only this size reaches: the two-input up-sampling kernel and the stored-logit loss
+    kernel on 16 x 41 x 480 x 640 tensors (806 MB each)."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d
+    from models.model_util import get_models
+    from oracle import ref_loss, ref_models
+    n = 16
+    hip = get_models("drn_d_38", 6, NC, method="MFNet-ScoreAddFusion")
+    ora = ref_models.get_models("drn_d_38", 6, NC, method="MFNet-ScoreAddFusion")
+    for i, (a, b) in enumerate(zip(hip, ora)):
+        fill_state_(a, 51 + i), fill_state_(b, 51 + i)
+        a.to(dev).train(), b.train()
+    src, lbl, _ = make_batch(79, n, 6, 480, 640, NC)
+    cw = ref_loss.class_weights(NC)
+    prev = _all_threads()
+    try:
+        with torch.no_grad():
+            ra, rb = ora[0](src[:, :3].contiguous()), ora[1](src[:, 3:].contiguous())
+        ra, rb = ra.requires_grad_(), rb.requires_grad_()
+        ro1, ro2 = ora[2](ra, rb), ora[3](ra, rb)
+        rcrit = ref_loss.CrossEntropyLoss2d(cw)
+        rl1, rl2 = rcrit(ro1, lbl), rcrit(ro2, lbl)
+        (rl1 + rl2).backward()
+    finally:
+        torch.set_num_threads(prev)
+    keys = [(2, "up1.weight"), (2, "up2.weight"), (3, "up1.weight"), (3, "up2.weight")]
+    ref_gs = {k: dict(ora[k[0]].named_parameters())[k[1]].grad.clone() for k in keys}
+    rga, rgb_ = ra.grad.clone(), rb.grad.clone()
+    ra, rb, ro1s = ra.detach(), rb.detach(), ro1.detach()[:, :, ::8, ::8].clone()
+    rl1, rl2 = float(rl1.detach()), float(rl2.detach())
+    del ora, ro1, ro2
+    s = src.to(dev)
+    a, b = hip[0](s[:, :3].contiguous()), hip[1](s[:, 3:].contiguous())
+    a.retain_grad(), b.retain_grad()
+    o1, o2 = hip[2](a, b), hip[3](a, b)
+    crit = CrossEntropyLoss2d(cw.to(dev))
+    l1, l2 = crit(o1, lbl.to(dev)), crit(o2, lbl.to(dev))
+    (l1 + l2).backward()
+    assert float((a.detach().cpu() - ra).abs().max()) <= 1e-3 and float((b.detach().cpu() - rb).abs().max()) <= 1e-3
+    assert float((o1.detach()[:, :, ::8, ::8].cpu() - ro1s).abs().max()) <= 1e-3
+    assert abs(float(l1.detach()) - rl1) <= 1e-5 * rl1 and abs(float(l2.detach()) - rl2) <= 1e-5 * rl2
+    for (i, name), rg in ref_gs.items():
+        got = dict(hip[i].named_parameters())[name].grad.cpu()
+        rel = float((got - rg).norm() / rg.norm())
+        assert rel <= 2e-3, "%d.%s: relative L2 difference %.3e" % (i, name, rel)
+    for got, rg, what in ((a.grad, rga, "d/d(RGB score map)"), (b.grad, rgb_, "d/d(HHA score map)")):
+        rel = float((got.cpu() - rg).norm() / rg.norm())
+        assert rel <= 2e-3, "%s: relative L2 difference %.3e" % (what, rel)
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in hip[0].parameters())  # ... and the encoders did back-propagate
+
+
+def test_cfg4_full_batch_vs_oracle():
+    """BASELINE config 4 at its stated per-GPU size -- multitask, 8 x 6 x 480 x 640: RGB encoder, two segmentation decoders and the HHA
+    regression decoder (conv + bias + BN + ReLU groups on 512 channels, bilinear x8 to 480 x 640, MSE, learned task weights) -- against
+    the CPU oracle: encoder features and the decoder outputs (<= 1e-3 of scale), the loss the trainer's step A forms (``get_loss``,
+    adapt_multitask_trainer.py:174-181), its gradients into the decoders' convolutions and the gradient handed back to the encoder
+    (the oracle's encoder runs forward only, as in the cfg3 test)."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, Diff2d
+    from models.model_util import get_multitask_models
+    from oracle import ref_loss, ref_multitask
+    n = 8
+    cw = ref_loss.class_weights(NC)
+    enc, dec = get_multitask_models("drn_d_38", 6, NC, CrossEntropyLoss2d(cw), Diff2d())
+    renc, rdec = ref_multitask.get_multitask_models("drn_d_38", 6, NC, ref_loss.CrossEntropyLoss2d(cw), ref_loss.Diff2d())
+    fill_state_(enc, 81), fill_state_(dec, 82), fill_state_(renc, 81), fill_state_(rdec, 82)
+    enc.to(dev).train(), dec.to(dev).train(), renc.train(), rdec.train()
+    src, lbl, _ = make_batch(80, n, 6, 480, 640, NC)
+    rgb, dep = src[:, :3].contiguous(), src[:, 3:].contiguous()
+    prev = _all_threads()
+    try:
+        with torch.no_grad():
+            rfet = renc(rgb)
+        rfet.requires_grad_()
+        rloss = rdec.get_loss(rfet, lbl, dep)
+        rloss.backward()
+    finally:
+        torch.set_num_threads(prev)
+    names = ["semsegcls_dec1.cbr1.conv.weight", "semsegcls_dec2.cbr1.conv.weight", "deprgr_dec.cbr1.conv.weight", "semsegcls_dec1.conv3.weight",
+             "deprgr_dec.cbr2.bn.weight"]
+    rpar = dict(rdec.named_parameters())
+    ref_gs = {k: rpar[k].grad.clone() for k in names}
+    rgf, rl = rfet.grad.clone(), float(rloss.detach())
+    rfet = rfet.detach()
+    del renc, rdec
+    fet = enc(rgb.to(dev))
+    fet.retain_grad()
+    loss = dec.get_loss(fet, lbl.to(dev), dep.to(dev))
+    loss.backward()
+    assert float((fet.detach().cpu() - rfet).abs().max()) <= 1e-3 * max(1.0, float(rfet.abs().max()))
+    assert abs(float(loss.detach()) - rl) <= 1e-4 * abs(rl)
+    par = dict(dec.named_parameters())
+    for k, rg in ref_gs.items():
+        rel = float((par[k].grad.cpu() - rg).norm() / rg.norm())
+        assert rel <= 2e-2, "%s: relative L2 difference %.3e" % (k, rel)
+    rel = float((fet.grad.cpu() - rgf).norm() / rgf.norm())
+    assert rel <= 2e-2, "d/d(encoder features): relative L2 difference %.3e" % rel
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in enc.parameters())
+
+
+def test_cfg5_cut_batches_keep_their_companions(monkeypatch):
+    """BASELINE config 5's 2048-channel maps exceed one launch's 2 GiB at N = 32 and are processed in slices along N WITH their
+    companions (mcdseg_conv_desc.Ncb).  The same code path at a size a test can afford: drn_d_105 at 2 x 6 x 720 x 1280 with the launch
+    limit lowered so that those layers (and the 1024-channel and full-resolution ones) are cut into single images -- a source step's
+    loss and every gradient against the uncut run.  Convolution outputs are bit-identical per image; BatchNorm merges its partial
+    rows in another grouping, and 105 train-mode BatchNorms over two images amplify that last-bit difference to per cents of the
+    gradients (1 % already at the last trunk convolution).  The yardstick is therefore the same network under another fp32-grade
+    arithmetic (bf16x6): over all parameters the cut run must sit closer to the uncut one than that does (measured 0.046 against 0.063),
+    and no single tensor further than 1.5x."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d
+    from mcdseg import ops
+    from models.model_util import get_models
+    s, l, _ = (v.to(dev) for v in make_batch(6, 2, 6, 720, 1280, NC))
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    outs = {}
+    whole = ops.MAX_CONV_BYTES
+    # cut: just below two images of a 1024-channel 90 x 160 map (= of a 16-channel 720 x 1280 one)
+    for tag, math, limit in (("uncut", "f16x3", whole), ("cut", "f16x3", 4 * 1024 * 90 * 160 * 2 - 1), ("yardstick", "bf16x6", whole)):
+        monkeypatch.setattr(ops, "CONV_MATH", math)
+        monkeypatch.setattr(ops, "MAX_CONV_BYTES", limit)
+        ops.bump_weight_epoch()
+        g, f1, f2 = get_models("drn_d_105", 6, NC)
+        for m, seed in ((g, 71), (f1, 72), (f2, 73)):
+            fill_state_(m, seed)
+            m.to(dev).train()
+        names = []
+
+        class _Names:
+            def wants(self, name):
+                names.append(name)
+                return False
+        prev, ops.LAUNCH_TIMER = ops.LAUNCH_TIMER, _Names()
+        try:
+            feat = g(s)
+            crit = CrossEntropyLoss2d(cw.to(dev))
+            loss = crit(f1(feat), l) + crit(f2(feat), l)
+            loss.backward()
+        finally:
+            ops.LAUNCH_TIMER = prev
+        outs[tag] = (float(loss.detach()), {k: p.grad.detach().clone() for k, p in g.named_parameters()}, names)
+        del g, f1, f2, feat, loss
+        torch.cuda.empty_cache()
+    (l0, g0, n0), (l1, g1, n1), (_, g2, _) = outs["uncut"], outs["cut"], outs["yardstick"]
+    assert len(n1) > len(n0) + 50, (len(n0), len(n1))                     # the cut layers ran slice by slice ...
+    assert not any(nm.endswith("false>") and "conv_gemm_split" in nm and ", 1, 2, 1, 4," not in nm for nm in n1 if nm not in n0), \
+        sorted(set(n1) - set(n0))                                           # ... and none of them fell back to the fp32-gather kernels
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+
+    def rel(a, k):
+        return float((a[k] - g0[k]).double().norm() / (g0[k].double().norm() + 1e-30))
+
+    worst = max((rel(g1, k) / max(rel(g2, k), 1e-6), k) for k in g0)
+    assert worst[0] <= 1.5, worst  # (single tensors scatter around the yardstick: measured worst 1.04)
+
+    def overall(a):
+        return (sum(float(((a[k] - g0[k]).double() ** 2).sum()) for k in g0) / sum(float((g0[k].double() ** 2).sum()) for k in g0)) ** 0.5
+
+    assert overall(g1) <= overall(g2), (overall(g1), overall(g2))  # measured 0.046 against 0.063
+    assert rel(g1, "seg.weight") <= 1e-4 and rel(g1, "base.8.1.weight") <= 1e-4
+
+
 @pytest.mark.parametrize("storage,k", [("fp32", 4.0), ("compact", 6.0)])
 def test_d105_bottleneck_vs_reference(golden, storage, k, monkeypatch):
     """drn_d_105 (Bottleneck blocks; BASELINE config 5 trunk) forward + CE backward.  105 BN layers amplify fp32
