@@ -511,10 +511,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
       mfma_frags();
 #endif
       // step s+1 must have landed before the next iteration; the DMAs of step s+2 (younger) stay in flight
+#if defined(MCD_ABLATE) && (MCD_ABLATE & 16)  // timing only: never wait for the DMAs (wrong results) -- what does their latency cost?
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#elif defined(MCD_ABLATE) && (MCD_ABLATE & 32)  // timing only: no workgroup barrier (wrong results) -- what does the barrier skew cost?
+      if (more2)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMA_PER_STEP) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
       if (more2)
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DMA_PER_STEP) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
       cur = cur == 2 ? 0 : cur + 1;
       nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
     }
