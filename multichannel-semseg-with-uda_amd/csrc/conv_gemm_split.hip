@@ -410,13 +410,24 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
 #if defined(MCD_SETPRIO)
     __builtin_amdgcn_s_setprio(1);
 #endif
-    // the policy's cross terms, smallest first
+    // the policy's cross terms, smallest first -- TERM-MAJOR: consecutive matrix instructions go to different accumulator tiles, so
+    // none has to wait for the one just issued (tile-major order chained three dependent MFMAs per tile; same sums, same order per
+    // tile, bit-identical results)
+#if defined(MCD_MFMA_TILE_MAJOR)
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
         for (int tm = 0; tm < P::NTERMS; ++tm) acc[i][j] = P::mfma(fa[P::TA[tm]][i], fb[P::TB[tm]][j], acc[i][j]);
+#else
+#pragma unroll
+    for (int tm = 0; tm < P::NTERMS; ++tm)
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = P::mfma(fa[P::TA[tm]][i], fb[P::TB[tm]][j], acc[i][j]);
+#endif
 #if defined(MCD_SETPRIO)
     __builtin_amdgcn_s_setprio(0);
 #endif

@@ -162,11 +162,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradSplitPara
       for (int j = 0; j < WN; ++j) b[pc][j] = *reinterpret_cast<const frag*>(b_base + (pc * 2 * BN + j * 32) * 16);
     }
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+    for (int tm = 0; tm < P::NTERMS; ++tm)  // term-major: consecutive matrix instructions go to different accumulator tiles
 #pragma unroll
-      for (int j = 0; j < WN; ++j)
+      for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int tm = 0; tm < P::NTERMS; ++tm) acc[i][j] = P::mfma(a[P::TA[tm]][i], b[P::TB[tm]][j], acc[i][j]);
+        for (int j = 0; j < WN; ++j) acc[i][j] = P::mfma(a[P::TA[tm]][i], b[P::TB[tm]][j], acc[i][j]);
     if (more) store_lds(cur ^ 1);
     __syncthreads();
   }
@@ -362,11 +362,11 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_split_cb_kernel(WgradCbPara
           b[pc][j] = *reinterpret_cast<const frag*>(b_base + (pc * PIECE + 2 * kk * PLANE + j * 32) * 16);
       }
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
+      for (int tm = 0; tm < P::NTERMS; ++tm)  // term-major
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-          for (int tm = 0; tm < P::NTERMS; ++tm) acc[i][j] = P::mfma(a[P::TA[tm]][i], b[P::TB[tm]][j], acc[i][j]);
+          for (int j = 0; j < WN; ++j) acc[i][j] = P::mfma(a[P::TA[tm]][i], b[P::TB[tm]][j], acc[i][j]);
     }
   }
 
@@ -633,12 +633,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr_kernel(WgradCbPara
   };
   auto mfma_frags = [&](auto set_c) {
     constexpr int SET = decltype(set_c)::value;
+    // term-major (see conv_gemm_split.hip): consecutive matrix instructions go to different accumulator tiles
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+    for (int tm = 0; tm < P::NTERMS; ++tm)  // (roles swapped with TWO: the A side carries X, so the pieces swap too -- same products, same order)
 #pragma unroll
-      for (int j = 0; j < WN; ++j)
+      for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int tm = 0; tm < P::NTERMS; ++tm)  // (roles swapped with TWO: the A side carries X, so the pieces swap too -- same products, same order)
+        for (int j = 0; j < WN; ++j)
           acc[i][j] = P::mfma(fa[SET][TWO ? P::TB[tm] : P::TA[tm]][i], fb[SET][TWO ? P::TA[tm] : P::TB[tm]][j], acc[i][j]);
   };
   // wait until at most `left` of this wave's DMAs are outstanding (left is wave-uniform: 0, NQD or NQD * AB), then barrier
@@ -905,9 +906,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr64_kernel(WgradCbPa
   };
   auto mfma_frags = [&]() {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int tm = 0; tm < P::NTERMS; ++tm)  // term-major: the two tiles alternate
 #pragma unroll
-      for (int tm = 0; tm < P::NTERMS; ++tm) acc[j] = P::mfma(fa[P::TA[tm]], fb[P::TB[tm]][j], acc[j]);
+      for (int j = 0; j < 2; ++j) acc[j] = P::mfma(fa[P::TA[tm]], fb[P::TB[tm]][j], acc[j]);
   };
 
   const int nsteps = t_end - t_begin;
