@@ -24,9 +24,15 @@ from ._lib import ConvDesc, check, lib
 WEIGHT_EPOCH = 0
 
 
-def bump_weight_epoch():
+def bump_weight_epoch(params=None):
+    """an in-place parameter update happened: of ``params`` (each carries its own counter, so that stepping one optimizer does not
+    invalidate the packed images of another's parameters), or -- None -- of anything"""
     global WEIGHT_EPOCH
-    WEIGHT_EPOCH += 1
+    if params is None:
+        WEIGHT_EPOCH += 1
+        return
+    for p in params:
+        p._mcd_epoch = getattr(p, "_mcd_epoch", 0) + 1
 
 
 # Optional launch timer (bench.py): an object with ``wants(name) -> bool`` and ``add(name, work, start, stop)``.
@@ -284,7 +290,7 @@ class PackedWeights:
 
     @staticmethod
     def _key_of(weight):
-        return (weight.data_ptr(), weight._version, WEIGHT_EPOCH, weight.device, CONV_MATH)
+        return (weight.data_ptr(), weight._version, WEIGHT_EPOCH, getattr(weight, "_mcd_epoch", 0), weight.device, CONV_MATH)
 
     def get(self, weight, desc, need_dgrad=True):
         key = self._key_of(weight)
@@ -704,6 +710,7 @@ class _ConvBNAct(torch.autograd.Function):
                                         _stream()), "bn_apply")
         ctx.desc, ctx.wd, ctx.relu, ctx.training, ctx.has_res = desc, wd, relu, training, has_res
         ctx.w_bound = w_bound
+        ctx.packed, ctx.pack_key = packed, packed.key  # the data-gradient image is shared and re-packed in place: see backward
         ctx.has_bias = conv_bias is not None
         ctx.x_cb, ctx.x_bound = x_cb, x_bound  # wgrad reads the input's split companion too (an input of this node: safe to hold)
         ctx.x_virtual, ctx.compact = x_virtual, compact
@@ -721,6 +728,11 @@ class _ConvBNAct(torch.autograd.Function):
             return (None,) * 19
         x, z, y, mean, rstd, gamma, y_cb, y_bound, beta = ctx.saved_tensors
         desc = ctx.desc
+        if ctx.packed.key != ctx.pack_key:
+            # the weight was updated in place (and its packed image re-packed) between this forward and its backward: the data gradient
+            # would use the NEW weights -- what torch reports for a saved tensor as "modified by an inplace operation"
+            raise RuntimeError("mcdseg: a convolution weight was modified between a forward pass and its backward pass "
+                               "(an optimizer stepped the generator while its graph was still alive)")
         dy = _req(dy, "grad_output")
         n, c, hw = desc.N, desc.Cout, desc.Ho * desc.Wo
         split_d = _is_split(ctx.wd)
@@ -878,12 +890,15 @@ class _Conv2dBias(torch.autograd.Function):
         y, _, _ = _conv_fprop(desc, x, wf, _req(bias, "conv bias"), False, mpf, x_cb, x_bound, packed.w_bound)
         ctx.desc, ctx.wd, ctx.has_bias, ctx.w_bound = desc, wd, bias is not None, packed.w_bound
         ctx.x_bound = x_bound
+        ctx.packed, ctx.pack_key = packed, packed.key
         ctx.save_for_backward(x)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
+        if ctx.packed.key != ctx.pack_key:
+            raise RuntimeError("mcdseg: a convolution weight was modified between a forward pass and its backward pass")
         dy = _req(dy, "grad_output")
         dx, dw = _conv_backward(ctx.desc, x, dy, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], None, None, None, ctx.x_bound,
                                 ctx.w_bound)
@@ -1352,11 +1367,12 @@ def diff2d(z1, z2):
 
 
 # ------------------------------------------------------------------------------------------------ optimizer kernel
-def sgd_momentum_flat_(p, g, v, lr, momentum, weight_decay, grad_scale=1.0):
+def sgd_momentum_flat_(p, g, v, lr, momentum, weight_decay, grad_scale=1.0, params=None):
+    """``params``: the parameter objects living in ``p`` (their packed images go stale); None = every packed image does"""
     for t, name in ((p, "params"), (g, "grads"), (v, "momentum")):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             raise RuntimeError("mcdseg: flat SGD needs contiguous fp32 GPU buffers (%s)" % name)
     with _timed("sgd_momentum_kernel", (0, 20 * p.numel())):
         check(lib().mcdseg_sgd_momentum_flat(_p(p), _p(g), _p(v), p.numel(), float(lr), float(momentum), float(weight_decay),
                                              float(grad_scale), _stream()), "sgd_momentum_flat")
-    bump_weight_epoch()
+    bump_weight_epoch(params)

@@ -179,7 +179,7 @@ class FlatSGD(torch.optim.Optimizer):
                 if mdist.is_distributed():
                     mdist.all_reduce_sum_(gflat)
             lr, mu, wd = run["key"]
-            ops.sgd_momentum_flat_(fl["p"][lo:hi], gflat, fl["v"][lo:hi], lr, mu, wd, 1.0 / world)
+            ops.sgd_momentum_flat_(fl["p"][lo:hi], gflat, fl["v"][lo:hi], lr, mu, wd, 1.0 / world, params=ps)
             if mu != 0:
                 for p in ps:
                     self.state[p]["momentum_buffer"] = fl["views"][id(p)][2]

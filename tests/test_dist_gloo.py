@@ -34,7 +34,7 @@ def _worker(rank, world, port, tmp, overlap=False):
     from mcdseg.optim import FlatSGD
     r, w, _ = mdist.init_from_env(backend="gloo")
     assert (r, w) == (rank, world) and mdist.is_distributed() and mdist.world_size() == world
-    ops.sgd_momentum_flat_ = lambda p, g, v, lr, mu, wd, gs=1.0: _ref_sgd_(p, g, v, lr, mu, wd, gs)
+    ops.sgd_momentum_flat_ = lambda p, g, v, lr, mu, wd, gs=1.0, params=None: _ref_sgd_(p, g, v, lr, mu, wd, gs)
     FlatSGD._require_gpu = False
     gen = torch.Generator().manual_seed(0)
     shapes = [(8, 3, 3, 3), (8,), (5, 7)]

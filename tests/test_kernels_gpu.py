@@ -475,6 +475,34 @@ def test_conv_bias_bn_relu():
     assert float(conv.bias.grad.abs().max()) <= 1e-4 * float(grads[1].abs().max()) * 120
 
 
+def test_weight_update_between_forward_and_backward_is_refused():
+    """The packed data-gradient image of a convolution is shared by every graph that used the weight and is re-packed in place after an
+    optimizer step (lazily, by the next forward): from then on a backward pass through a graph recorded BEFORE the step would silently
+    multiply by the new weights.  It raises instead -- torch's "modified by an inplace operation" for a saved tensor -- while stepping ANOTHER optimizer in between
+    (the reuse of step B's target forward: only the classifiers' optimizer steps) leaves the graph valid."""
+    dev = _dev()
+    from mcdseg import ops
+    from mcdseg.optim import FlatSGD
+    from models.drn import BatchNorm2d, Conv2d
+    g = torch.Generator().manual_seed(9)
+    conv, bn = Conv2d(32, 64, 3, padding=1, bias=False).to(dev), BatchNorm2d(64).to(dev)
+    other = Conv2d(16, 16, 3, padding=1, bias=False).to(dev)
+    x = torch.randn(2, 32, 10, 12, generator=g).to(dev).requires_grad_()
+    gy = torch.randn(2, 64, 10, 12, generator=g).to(dev)
+    opt = FlatSGD(list(conv.parameters()) + list(bn.parameters()), lr=0.1, momentum=0.9)
+    opt_other = FlatSGD(other.parameters(), lr=0.1, momentum=0.9)
+    ops.conv_bn_act(x, conv, bn, relu=True).backward(gy)     # gradients for the step below
+    other.weight.grad = torch.zeros_like(other.weight)
+    y = ops.conv_bn_act(x, conv, bn, relu=True)               # graph recorded with the current weights
+    opt_other.step()                                          # another optimizer: this graph stays valid
+    y.backward(gy, retain_graph=True)
+    opt.step()                                                # the graph's own weights move ...
+    y.backward(gy, retain_graph=True)                         # ... but the packed image still holds the recorded ones: still exact
+    ops.conv_bn_act(x.detach(), conv, bn, relu=True)          # the next forward re-packs the image in place
+    with pytest.raises(RuntimeError, match="modified between a forward pass and its backward"):
+        y.backward(gy)
+
+
 def test_conv_batch_split_for_large_operands(monkeypatch):
     """Operands above the 2 GiB launch limit (cfg5's 2048-channel layers at N = 32) are cut along N on the host; exercised here
     with a tiny limit on a chain of two fused groups, so that the second group's forward, data gradient and weight gradient run in
