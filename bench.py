@@ -289,9 +289,10 @@ def main():
                     help="f32 (default, the judged configuration): fp32-grade split arithmetic; f16: reduced precision, one fp16 term per product "
                          "(MCDSEG_CONV_MATH=f16x1; BASELINE config 5's intent) -- reported with its own dtype label")
     ap.add_argument("--timer", choices=sorted(TIMED_FAMILIES), default="all", help="kernel families bracketed by HIP events")
-    ap.add_argument("--timer_steps", type=int, default=2,
+    ap.add_argument("--timer_steps", type=int, default=1,
                     help="how many of the timed steps (the last ones) carry the per-launch HIP events: bracketing all ~1 500 launches "
-                         "of a step costs 3.6 %% of its time (measured, profiles/README.md), so by default only two steps pay it")
+                         "of a step costs 3.6 %% of its time (measured, profiles/README.md) and such a step runs its weight gradients on "
+                         "the main stream (every pair brackets a kernel running alone), another 3.4 %%; so by default one step pays it")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -387,8 +388,8 @@ def main():
             k["gbs"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
             k["share"] = round(k["ms"] / total_ms, 4)
         default_cfg = (args.net, args.batch, args.height, args.width, args.input_ch) == ("drn_d_38", 16, 480, 640, 6)
-        # dominant kernel = the one with the largest summed duration inside the timed region; launches run alone on the
-        # stream, so the event pairs are clean
+        # dominant kernel = the one with the largest summed duration inside the timed region; in the steps that carry the event
+        # pairs every launch runs alone (ops._conv_backward keeps the weight gradients on the main stream there)
         roofline = roofline_fwd = roofline_wg = None
         if kern:
             dom = max(kern, key=lambda n: kern[n]["ms"])
@@ -432,6 +433,9 @@ def main():
                        "collectives": ("none (single process)" if not mdist.is_distributed() else
                                        ("rccl (forced, 1 rank)" if world == 1 else "rccl all-reduce of the flat gradient buffer over %d ranks, one rank "
                                         "per GPU%s" % (world, ", bucketed during backward (MCDSEG_DP_OVERLAP=1)" if os.environ.get("MCDSEG_DP_OVERLAP") == "1" else ""))),
+                       "streams": {"0": "one stream", "1": "weight gradients on a side stream beside their data gradient",
+                                   "2": "weight gradients of the trunk on a side stream, joined when each backward pass ends (MCDSEG_OVERLAP_WGRAD=2); "
+                                        "the timer_steps run them on the main stream, so every HIP-event pair brackets a kernel running alone"}[ops.OVERLAP_WGRAD],
                        "n_class": args.n_class, "conv_math": ops.CONV_MATH, "c_loss": c_loss, "d_loss": d_loss, "timer": args.timer,
                        "timer_steps": min(args.steps, args.timer_steps),
                        "schedule": "the reference's A+B+C statements with the results-neutral elisions of solvers/solver.py: no generator "

@@ -575,33 +575,123 @@ def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None, x_bound=None, dy_bound=None)
     return total
 
 
-# dgrad and wgrad of one layer are independent: launching wgrad on a second HIP stream lets its workgroups fill
-# the CUs that idle in the last (partial) round of dgrad's tiles, and vice versa.
-OVERLAP_WGRAD = os.environ.get("MCDSEG_OVERLAP_WGRAD", "0") != "0"  # measured: -2 % when on (both kernels are MFMA-bound)
+# dgrad and wgrad of one layer are independent.  MCDSEG_OVERLAP_WGRAD:
+#   "0"  both on the current stream;
+#   "1"  wgrad on a second HIP stream, joined right behind dgrad (round 1; measured +1 %: both kernels are matrix-bound);
+#   "2"  (default) wgrad on the second stream and NOT joined until the backward pass is nearly over: the weight gradient of layer k
+#        then also runs beside the HBM-bound BatchNorm backward of layer k-1, which a power-metered matrix kernel hides
+#        (tools/probes/overlap_probe.py: 20 forward launches + 20 bn_apply passes take as long as the 20 forward launches alone;
+#        -4 % of the cfg2 step).  Correct by construction: a deferred gradient is handed to autograd through a ``_LateGrad``
+#        identity node that sits between the parameter and the convolution and makes the main stream wait for the side stream
+#        BEFORE it passes the gradient on -- nothing downstream (the engine's summation of several gradients of one weight,
+#        AccumulateGrad's in-place add, hooks, torch.autograd.grad's capture) ever sees an unfinished tensor.  WHEN the wait
+#        happens is a matter of the engine's ready queue (latest-created node first): ``late_weight_grads`` creates the identity
+#        nodes at the start of a trunk's forward pass, so they run at the end of its backward pass; a convolution called outside
+#        such a context gets no identity node and runs its weight gradient on the main stream.
+OVERLAP_WGRAD = os.environ.get("MCDSEG_OVERLAP_WGRAD", "2")
+if OVERLAP_WGRAD not in ("0", "1", "2"):
+    raise ValueError("MCDSEG_OVERLAP_WGRAD must be 0, 1 or 2, got %r" % OVERLAP_WGRAD)
 _SIDE = {}
+_PENDING = {}  # device index -> event behind the last weight gradient on the side stream that the main stream has not waited for
 
 
 def _side_stream(device):
+    # (a stream of HIP's lowest priority -- hipStreamCreateWithPriority through ctypes, wrapped as torch.cuda.ExternalStream -- was
+    # measured too: 235.1 vs 236.2 ms on one box, 236.1 / 234.6 vs 234.8 / 235.0 on another; within the noise, not kept)
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
 
 
-def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_bound=None, x_bound=None, w_bound=None):
-    if not (need_dx and need_dw and OVERLAP_WGRAD):
+def join_side_streams():
+    """the current stream of every device waits for the weight gradients still running on that device's side stream (the
+    ``_LateGrad`` nodes call it; also queued as a final callback of every backward pass that deferred one; safe at any time)"""
+    for key in list(_PENDING):
+        torch.cuda.current_stream(key).wait_event(_PENDING.pop(key))
+
+
+class _LateGrad(torch.autograd.Function):
+    """identity on a convolution weight; its backward makes the main stream wait for the side stream, then passes the gradient on"""
+
+    @staticmethod
+    def forward(ctx, w):
+        return w.view_as(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        join_side_streams()
+        return g
+
+
+class late_weight_grads:
+    """Context around the forward pass of a trunk (``root``: an nn.Module): one ``_LateGrad`` alias per convolution weight, created
+    NOW -- before every other node of this forward pass, hence executed after all of them in the backward pass -- and consumed by
+    the first ``conv_bn_act`` call on that convolution.  Nothing is prepared without grad mode, for weights that do not require a
+    gradient, for weights with post-accumulate hooks (FlatSGD's bucketed all-reduce wants its gradients DURING the pass) or when
+    MCDSEG_OVERLAP_WGRAD is not "2"."""
+
+    def __init__(self, root):
+        self.root, self.mods = root, []
+
+    def __enter__(self):
+        if OVERLAP_WGRAD == "2" and torch.is_grad_enabled():
+            for m in self.root.modules():
+                if isinstance(getattr(m, "_packed", None), PackedWeights) and getattr(m, "_w_late", None) is None:
+                    w = m.weight
+                    if w.is_cuda and w.requires_grad and not getattr(w, "_post_accumulate_grad_hooks", None):
+                        alias = _LateGrad.apply(w)
+                        alias._mcd_param = w  # (the packed images are keyed by the parameter, see PackedWeights._key_of)
+                        m._w_late = alias
+                        self.mods.append(m)
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.mods:
+            m._w_late = None
+
+
+def _take_late(conv):
+    """the weight tensor a fused group hands to autograd: the prepared ``_LateGrad`` alias (once), else the parameter itself"""
+    alias = getattr(conv, "_w_late", None)
+    if alias is None or not torch.is_grad_enabled():
+        return conv.weight
+    conv._w_late = None
+    return alias
+
+
+def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_bound=None, x_bound=None, w_bound=None, defer=False):
+    """(dx, dw).  ``defer``: dw goes to a ``_LateGrad`` node, so mode "2" may leave it on the side stream"""
+    mode = OVERLAP_WGRAD
+    if mode == "2" and not (defer and x_cb is not None and dy_cb is not None):
+        mode = "0"  # (without companions the weight gradient measures bounds and caches them on tensors the main stream reads)
+    if mode != "0" and LAUNCH_TIMER is not None and LAUNCH_TIMER.wants("conv_wgrad"):
+        mode = "0"  # a step whose launches are bracketed by HIP events runs every kernel alone, so that the pairs time kernels
+    if not (need_dx and need_dw and mode != "0"):
         return ((_conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound) if need_dx else None),
                 (_conv_wgrad(desc, x, dy, x_cb, dy_cb, x_bound, dy_bound) if need_dw else None))
     main = torch.cuda.current_stream()
     side = _side_stream(x.device)
     if _scaled() and dy is not None:
         dy_bound = _bound_or_measure(dy, dy_bound)  # measured once, on the main stream, for both consumers
+    # (launching wgrad only once dgrad has finished -- so that it would run beside the next BatchNorm backward from its first
+    # workgroup on -- is slower: 243 vs 237.6 ms per step; the weight gradient fills the data gradient's partial rounds as it is)
     side.wait_stream(main)
     with torch.cuda.stream(side):
         dw = _conv_wgrad(desc, x, dy, x_cb, dy_cb, x_bound, dy_bound)
     dx = _conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound)
-    main.wait_stream(side)
     dw.record_stream(main)
+    if mode == "1":
+        main.wait_stream(side)
+        return dx, dw
+    # the operands must outlive the side stream's use of them, whatever the tape frees in the meantime
+    for t in (x, dy, x_cb, dy_cb, x_bound, dy_bound):
+        if t is not None:
+            t.record_stream(side)
+    ev = torch.cuda.Event()
+    ev.record(side)
+    _PENDING[side.device.index] = ev
+    torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)  # (backstop; the _LateGrad node has waited by then)
     return dx, dw
 
 
@@ -641,7 +731,7 @@ class _ConvBNAct(torch.autograd.Function):
         L = lib()
         stride, pad, dil = geom
         desc = conv_desc(x.shape, weight.shape, stride, pad, dil)
-        wf, wd, mpf = packed.get(weight, desc)
+        wf, wd, mpf = packed.get(getattr(weight, "_mcd_param", weight), desc)
         w_bound = packed.w_bound
         x_virtual = aux["x_virtual"]
         # (a batch cut along N keeps its companions -- the split kernels take slices, mcdseg.h Ncb -- except on the thin layers'
@@ -711,6 +801,7 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.desc, ctx.wd, ctx.relu, ctx.training, ctx.has_res = desc, wd, relu, training, has_res
         ctx.w_bound = w_bound
         ctx.packed, ctx.pack_key = packed, packed.key  # the data-gradient image is shared and re-packed in place: see backward
+        ctx.defer_ok = hasattr(weight, "_mcd_param")  # the weight came through a _LateGrad alias (late_weight_grads)
         ctx.has_bias = conv_bias is not None
         ctx.x_cb, ctx.x_bound = x_cb, x_bound  # wgrad reads the input's split companion too (an input of this node: safe to hold)
         ctx.x_virtual, ctx.compact = x_virtual, compact
@@ -794,7 +885,7 @@ class _ConvBNAct(torch.autograd.Function):
             DEBUG_TAPE.append(dict(dy=dy, dz=dz, dz_cb=dz_cb, dz_bound=dz_bound, dgamma=dgamma, dbeta=dbeta, dres=dres, shape=(n, c, hw), z=z,
                                    y=y_mask, mean=mean, rstd=rstd, gamma=gamma, beta=beta, zmask=zmask))
         dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz_cb, x_cb, dz_bound,
-                                x_bound, ctx.w_bound)
+                                x_bound, ctx.w_bound, defer=ctx.defer_ok)
         dbias = None
         if ctx.has_bias and ctx.needs_input_grad[5]:
             # a bias in front of train-mode BN has zero gradient up to rounding (BN removes the channel mean);
@@ -848,7 +939,7 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, internal=False):
     skip_y = internal and INTERNAL_SKIP_Y and BN_ZMASK and relu and residual is None and _scaled()
     aux = dict(x_virtual=is_virtual(x), res_virtual=is_virtual(residual), res_cb=res_cb, compact=_compact_now() or skip_y,
                single_piece_only=skip_y and not _compact_now())
-    y, y_cb, y_bound = _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, residual, conv.bias, bn.running_mean if track else None,
+    y, y_cb, y_bound = _ConvBNAct.apply(x, _take_late(conv), bn.weight, bn.bias, residual, conv.bias, bn.running_mean if track else None,
                                         bn.running_var if track else None, bn.num_batches_tracked if track else None, conv._packed,
                                         geom, training, momentum, bn.eps, relu, x_cb, x_bound, res_bound, aux)
     if y_cb is not None or y_bound is not None:
@@ -884,7 +975,7 @@ class _Conv2dBias(torch.autograd.Function):
     def forward(ctx, x, weight, bias, packed, geom, x_cb, x_bound):
         x = _req(x, "conv input")
         desc = conv_desc(x.shape, weight.shape, *geom)
-        wf, wd, mpf = packed.get(weight, desc)
+        wf, wd, mpf = packed.get(getattr(weight, "_mcd_param", weight), desc)
         if _is_split(wf) and _scaled():
             x_bound = _bound_or_measure(x, x_bound)
         y, _, _ = _conv_fprop(desc, x, wf, _req(bias, "conv bias"), False, mpf, x_cb, x_bound, packed.w_bound)

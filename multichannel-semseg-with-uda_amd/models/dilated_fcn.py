@@ -41,9 +41,10 @@ class Trunk(FusedSequential):
             return x
         # the fusing walk of FusedSequential, so that the DRN-C stem (conv1, bn1, relu as top-level children, models/drn.py:118-121)
         # runs as one fused group like everywhere else
-        with ops.trunk_internal():
-            x = run_fused(mods[:-1], x)
-        return run_fused(mods[-1:], x)
+        with ops.late_weight_grads(self):  # (the weight gradients of these layers may stay on the side stream, mcdseg/ops.py)
+            with ops.trunk_internal():
+                x = run_fused(mods[:-1], x)
+            return run_fused(mods[-1:], x)
 
 
 def _seg_head(cin, n_class):

@@ -195,6 +195,10 @@ class DRN(nn.Module):
         return [m for name, m in self.named_children() if name not in ("avgpool", "fc")]
 
     def forward(self, x):
+        with ops.late_weight_grads(self):
+            return self._forward(x)
+
+    def _forward(self, x):
         feats = []
         if self.arch == "C":
             x = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True)

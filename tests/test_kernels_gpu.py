@@ -503,6 +503,88 @@ def test_weight_update_between_forward_and_backward_is_refused():
         y.backward(gy)
 
 
+def test_deferred_weight_gradients_equal_the_serial_schedule(monkeypatch):
+    """MCDSEG_OVERLAP_WGRAD=2 (the default): inside ``ops.late_weight_grads`` the weight gradient of a fused group runs on a
+    low-priority side stream and reaches autograd through a ``_LateGrad`` identity node that waits for that stream first.  Everything
+    that could read the gradient early must therefore still see the finished tensor: a weight used twice in one graph (the engine
+    sums the two gradients), a gradient already present (AccumulateGrad adds in place), a tensor hook, torch.autograd.grad.  All
+    bit-equal to the one-stream schedule -- with every kernel group on the side stream delayed by ~10 ms, so that a missing wait
+    shows at once instead of once in a thousand runs."""
+    dev = _dev()
+    from mcdseg import ops
+    from models.drn import BatchNorm2d, Conv2d
+    g = torch.Generator().manual_seed(31)
+    convs = torch.nn.ModuleList([Conv2d(64, 64, 3, padding=d, dilation=d, bias=False) for d in (1, 2, 1)]).to(dev)
+    bns = [BatchNorm2d(64).to(dev) for _ in convs]
+    with torch.no_grad():
+        for c in convs:
+            c.weight.copy_((torch.randn(c.weight.shape, generator=g) * 0.05).to(dev))
+    x = torch.randn(4, 64, 96, 128, generator=g).to(dev)
+    gy = torch.randn(4, 64, 96, 128, generator=g).to(dev)
+    params = [c.weight for c in convs] + [b.weight for b in bns] + [b.bias for b in bns]
+    seen, on_side = [], []
+
+    def chain(inp, twice):
+        with ops.late_weight_grads(convs):
+            h = inp
+            for k, (c, b) in enumerate(zip(convs, bns)):
+                h = ops.conv_bn_act(h, c, b, relu=True)
+                if twice == "middle" and k == 1:
+                    h = ops.conv_bn_act(h, c, b, relu=True)  # the same weight a second time in this graph (no alias left: main stream)
+            if twice == "first":
+                h = ops.conv_bn_act(h, convs[0], bns[0], relu=True)
+            return h
+
+    inner = ops._conv_wgrad
+
+    def lagging(*a, **kw):
+        if torch.cuda.current_stream() != torch.cuda.default_stream():
+            on_side.append(1)
+            torch.cuda._sleep(20_000_000)
+        return inner(*a, **kw)
+    monkeypatch.setattr(ops, "_conv_wgrad", lagging)
+
+    def run(mode, twice=None, accumulate=False, hook=False):
+        monkeypatch.setattr(ops, "OVERLAP_WGRAD", mode)
+        for p_ in params:
+            p_.grad = None
+        handle = convs[1].weight.register_hook(lambda gr: seen.append(float(gr.abs().sum())) or None) if hook else None
+        xin = x.clone().requires_grad_()
+        chain(xin, twice).backward(gy)
+        if accumulate:
+            chain(xin, twice).backward(gy)
+        if handle is not None:
+            handle.remove()
+        assert not ops._PENDING, "a backward pass ended with an unjoined weight gradient"
+        assert all(getattr(c, "_w_late", None) is None for c in convs)
+        return [xin.grad.clone()] + [p_.grad.clone() for p_ in params]
+
+    names = ["dx"] + ["dw%d" % k for k in range(3)] + ["dgamma%d" % k for k in range(3)] + ["dbeta%d" % k for k in range(3)]
+    for kw in (dict(), dict(twice="middle"), dict(twice="first"), dict(accumulate=True), dict(hook=True), dict(twice="first", accumulate=True)):
+        ref = run("0", **kw)
+        assert not on_side
+        del seen[:]
+        got = run("2", **kw)
+        assert len(on_side) >= 2, "the weight gradients of the groups with companions did not run on the side stream"
+        del on_side[:]
+        for name, a, b in zip(names, got, ref):
+            assert torch.equal(a, b), "%s differs between the deferred and the serial schedule (%s)" % (name, kw)
+        if kw.get("hook"):
+            assert len(seen) == 1 and seen[0] == float(ref[2].abs().sum()), "the hook saw an unfinished weight gradient"
+    # torch.autograd.grad (no AccumulateGrad at all), and a convolution outside the context (no alias: main stream)
+    monkeypatch.setattr(ops, "OVERLAP_WGRAD", "0")
+    xin = x.clone().requires_grad_()
+    ref = torch.autograd.grad(chain(xin, None), [xin] + params[:3], gy)
+    monkeypatch.setattr(ops, "OVERLAP_WGRAD", "2")
+    got = torch.autograd.grad(chain(xin, None), [xin] + params[:3], gy)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    del on_side[:]
+    h = ops.conv_bn_act(ops.conv_bn_act(xin, convs[0], bns[0], relu=True), convs[1], bns[1], relu=True)
+    h.backward(gy)
+    assert not on_side and not ops._PENDING
+
+
 def test_conv_batch_split_for_large_operands(monkeypatch):
     """Operands above the 2 GiB launch limit (cfg5's 2048-channel layers at N = 32) are cut along N on the host; exercised here
     with a tiny limit on a chain of two fused groups, so that the second group's forward, data gradient and weight gradient run in

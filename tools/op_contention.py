@@ -20,6 +20,14 @@ def worker(a):
     from mcdseg import ops
     from models.drn import BatchNorm2d, Conv2d
     dev = torch.device("cuda:0")
+    if a.side_lag:  # delay whatever runs on the side stream (the deferred weight gradients): exposes a missing wait at once
+        inner = ops._conv_wgrad
+
+        def lagging(*args, **kw):
+            if torch.cuda.current_stream() != torch.cuda.default_stream():
+                torch.cuda._sleep(a.side_lag)
+            return inner(*args, **kw)
+        ops._conv_wgrad = lagging
     n, c, h, w = (int(v) for v in a.shape.split(","))
     g = torch.Generator().manual_seed(5)
     convs, bns = [], []
@@ -126,10 +134,11 @@ def main():
     ap.add_argument("--shape", default="4,256,24,32")
     ap.add_argument("--dil", type=int, default=2)
     ap.add_argument("--worker", action="store_true")
+    ap.add_argument("--side_lag", type=int, default=0, help="spin cycles in front of every kernel group launched on the side stream")
     a = ap.parse_args()
     if a.worker or a.procs == 1:
         sys.exit(worker(a))
-    cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--iters", str(a.iters), "--shape", a.shape, "--dil", str(a.dil)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--iters", str(a.iters), "--shape", a.shape, "--dil", str(a.dil), "--side_lag", str(a.side_lag)]
     ps = [subprocess.Popen(cmd) for _ in range(a.procs)]
     rc = 0
     for p in ps:
