@@ -11,8 +11,10 @@ mirror the ATen call sites of the reference's hot path:
   diff2d           mean |softmax - softmax|                         loss.py:93-100
   mcd_losses       both of the above in one fused kernel            adapt_trainer.py:163-212
 """
+import collections
 import ctypes
 import os
+import threading
 import weakref
 
 import torch
@@ -93,8 +95,30 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+# the stream the next kernels are launched on when it is not torch's current one: the side stream while _conv_backward enqueues a
+# weight gradient there.  torch's CURRENT stream stays the main one meanwhile, so every tensor still comes from the main stream's
+# allocator pool, and whatever those kernels touch is collected in ``keep``: the caller holds the list until the main stream has
+# waited for the side stream, which makes the memory reusable at once.  (Tensor.record_stream instead would return it only when
+# the side stream has passed the point in WALL-CLOCK time; the host enqueues a whole backward pass ahead of the device, so the
+# allocator kept growing -- 27 -> 116 GB reserved for drn_d_105 at N = 8 -- and cfg5 at N = 32, 232 of 288 GB, fell into its
+# free-everything-and-retry path: 14-18 s per step instead of 3.8 s.)
+class _LaunchStream(threading.local):  # (per thread: the autograd engine runs backward nodes on one worker thread per device)
+    stream = None
+    keep = None
+
+
+_LAUNCH = _LaunchStream()
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    s = _LAUNCH.stream
+    return ctypes.c_void_p((s if s is not None else torch.cuda.current_stream()).cuda_stream)
+
+
+def _on_launch_stream(*tensors):
+    """tensors just handed to kernels on the launch stream: their memory must not be reused before those kernels have run"""
+    if _LAUNCH.stream is not None:
+        _LAUNCH.keep.extend(t for t in tensors if t is not None)
 
 
 def _req(t, name, dtype=torch.float32):
@@ -243,6 +267,7 @@ def absmax(x):
     x = _req(x, "tensor")
     b = torch.empty(1, dtype=torch.float32, device=x.device)
     check(lib().mcdseg_absmax(_p(x), x.numel(), _p(b), _stream()), "absmax")
+    _on_launch_stream(b)
     return b
 
 
@@ -571,7 +596,12 @@ def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None, x_bound=None, dy_bound=None)
             else:
                 check(L.mcdseg_conv_wgrad(ctypes.byref(d), _p(x[a:b]), _p(dy[a:b]), _p(dw), _p(ws), ctypes.c_size_t(ws.numel() * 4),
                                           _stream()), "conv_wgrad")
-        total = dw if total is None else total.add_(dw)
+        _on_launch_stream(ws, dw)
+        if total is None:
+            total = dw
+        else:
+            with torch.cuda.stream(_LAUNCH.stream or torch.cuda.current_stream()):
+                total.add_(dw)
     return total
 
 
@@ -609,6 +639,7 @@ def join_side_streams():
     ``_LateGrad`` nodes call it; also queued as a final callback of every backward pass that deferred one; safe at any time)"""
     for key in list(_PENDING):
         torch.cuda.current_stream(key).wait_event(_PENDING.pop(key))
+        _HELD.pop(key, None)  # (after the wait: the operands of the deferred launches go back to the allocator)
 
 
 class _LateGrad(torch.autograd.Function):
@@ -660,6 +691,24 @@ def _take_late(conv):
     return alias
 
 
+# What a deferred weight gradient reads and writes stays allocated until the main stream has waited for it.  At most MAX_LAG
+# launches are left behind: before the next one is enqueued the main stream waits for the oldest (the side stream is rarely more
+# than a layer or two behind, so this wait is almost always already satisfied) and its operands are released.  And nothing is
+# deferred while the allocator holds more than DEFER_MEM_FRACTION of the device's memory (cfg5 at N = 32: 232 of 288 GB).
+MAX_LAG = int(os.environ.get("MCDSEG_OVERLAP_WGRAD_LAG", "4"))
+DEFER_MEM_FRACTION = float(os.environ.get("MCDSEG_OVERLAP_WGRAD_MEM", "0.6"))
+WGRAD_STREAM_STATS = {"deferred": 0, "no_room": 0}  # launches left on the side stream / kept on the main stream for lack of memory
+_TOTAL_MEM = {}
+_HELD = {}  # device index -> deque of (event behind a deferred weight gradient, [tensors it uses])
+
+
+def _room_to_defer(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _TOTAL_MEM:
+        _TOTAL_MEM[key] = torch.cuda.get_device_properties(key).total_memory
+    return torch.cuda.memory_reserved(key) < DEFER_MEM_FRACTION * _TOTAL_MEM[key]
+
+
 def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_bound=None, x_bound=None, w_bound=None, defer=False):
     """(dx, dw).  ``defer``: dw goes to a ``_LateGrad`` node, so mode "2" may leave it on the side stream"""
     mode = OVERLAP_WGRAD
@@ -667,30 +716,37 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_
         mode = "0"  # (without companions the weight gradient measures bounds and caches them on tensors the main stream reads)
     if mode != "0" and LAUNCH_TIMER is not None and LAUNCH_TIMER.wants("conv_wgrad"):
         mode = "0"  # a step whose launches are bracketed by HIP events runs every kernel alone, so that the pairs time kernels
+    if mode == "2" and not _room_to_defer(x.device):
+        mode = "0"
+        WGRAD_STREAM_STATS["no_room"] += 1
     if not (need_dx and need_dw and mode != "0"):
         return ((_conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound) if need_dx else None),
                 (_conv_wgrad(desc, x, dy, x_cb, dy_cb, x_bound, dy_bound) if need_dw else None))
     main = torch.cuda.current_stream()
     side = _side_stream(x.device)
+    key = side.device.index
     if _scaled() and dy is not None:
         dy_bound = _bound_or_measure(dy, dy_bound)  # measured once, on the main stream, for both consumers
     # (launching wgrad only once dgrad has finished -- so that it would run beside the next BatchNorm backward from its first
     # workgroup on -- is slower: 243 vs 237.6 ms per step; the weight gradient fills the data gradient's partial rounds as it is)
     side.wait_stream(main)
-    with torch.cuda.stream(side):
+    _LAUNCH.stream, _LAUNCH.keep = side, [x, dy, x_cb, dy_cb, x_bound, dy_bound]
+    try:
         dw = _conv_wgrad(desc, x, dy, x_cb, dy_cb, x_bound, dy_bound)
+    finally:
+        keep, _LAUNCH.stream, _LAUNCH.keep = _LAUNCH.keep, None, None
     dx = _conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound)
-    dw.record_stream(main)
     if mode == "1":
         main.wait_stream(side)
         return dx, dw
-    # the operands must outlive the side stream's use of them, whatever the tape frees in the meantime
-    for t in (x, dy, x_cb, dy_cb, x_bound, dy_bound):
-        if t is not None:
-            t.record_stream(side)
+    WGRAD_STREAM_STATS["deferred"] += 1
     ev = torch.cuda.Event()
     ev.record(side)
-    _PENDING[side.device.index] = ev
+    _PENDING[key] = ev
+    held = _HELD.setdefault(key, collections.deque())
+    held.append((ev, keep))
+    while len(held) > MAX_LAG:
+        main.wait_event(held.popleft()[0])  # (its tensors are dropped with the tuple: the main stream is behind their last use now)
     torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)  # (backstop; the _LateGrad node has waited by then)
     return dx, dw
 

@@ -538,9 +538,10 @@ def test_deferred_weight_gradients_equal_the_serial_schedule(monkeypatch):
     inner = ops._conv_wgrad
 
     def lagging(*a, **kw):
-        if torch.cuda.current_stream() != torch.cuda.default_stream():
+        if ops._LAUNCH.stream is not None:
             on_side.append(1)
-            torch.cuda._sleep(20_000_000)
+            with torch.cuda.stream(ops._LAUNCH.stream):
+                torch.cuda._sleep(20_000_000)
         return inner(*a, **kw)
     monkeypatch.setattr(ops, "_conv_wgrad", lagging)
 
@@ -555,7 +556,7 @@ def test_deferred_weight_gradients_equal_the_serial_schedule(monkeypatch):
             chain(xin, twice).backward(gy)
         if handle is not None:
             handle.remove()
-        assert not ops._PENDING, "a backward pass ended with an unjoined weight gradient"
+        assert not ops._PENDING and not ops._HELD, "a backward pass ended with an unjoined weight gradient"
         assert all(getattr(c, "_w_late", None) is None for c in convs)
         return [xin.grad.clone()] + [p_.grad.clone() for p_ in params]
 
@@ -582,7 +583,7 @@ def test_deferred_weight_gradients_equal_the_serial_schedule(monkeypatch):
     del on_side[:]
     h = ops.conv_bn_act(ops.conv_bn_act(xin, convs[0], bns[0], relu=True), convs[1], bns[1], relu=True)
     h.backward(gy)
-    assert not on_side and not ops._PENDING
+    assert not on_side and not ops._PENDING and not ops._HELD
 
 
 def test_conv_batch_split_for_large_operands(monkeypatch):

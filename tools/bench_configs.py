@@ -82,6 +82,9 @@ def main():
         print("%s %-10s N=%-2d 6x%dx%d [%s, activations %s]: %.1f ms/step, %.2f pairs/s, peak %.1f GB  (c_loss %.4f, d_loss %.6f)" % (
             cfg, net, n, h, w, ops.CONV_MATH, ops.ACT_STORAGE, 1e3 * dt, n / dt, torch.cuda.max_memory_allocated() / 2 ** 30,
             float(out[0]), float(out[1])), flush=True)
+        print("      weight gradients on the side stream: %(deferred)d launches, kept on the main stream for lack of memory: %(no_room)d" % ops.WGRAD_STREAM_STATS
+              + "; reserved %.1f GB" % (torch.cuda.memory_reserved() / 2 ** 30), flush=True)
+        ops.WGRAD_STREAM_STATS.update(deferred=0, no_room=0)
         del solver, s, l, t
         torch.cuda.empty_cache()
 

@@ -24,8 +24,9 @@ def worker(a):
         inner = ops._conv_wgrad
 
         def lagging(*args, **kw):
-            if torch.cuda.current_stream() != torch.cuda.default_stream():
-                torch.cuda._sleep(a.side_lag)
+            if ops._LAUNCH.stream is not None:
+                with torch.cuda.stream(ops._LAUNCH.stream):
+                    torch.cuda._sleep(a.side_lag)
             return inner(*args, **kw)
         ops._conv_wgrad = lagging
     n, c, h, w = (int(v) for v in a.shape.split(","))
