@@ -376,6 +376,30 @@ def main():
                    "note": "same build with solver.reuse_tgt = False (7 generator forwards + 5 backwards per step), measured after the "
                            "timed region; identical weights, statistics and losses"}
 
+    # likewise outside the timed region: the same step with the weight gradients on the main stream, the same-box
+    # price of the second stream
+    one_stream = None
+    if ops.OVERLAP_WGRAD != "0" and args.literal_steps > 0:
+        mode, ops.OVERLAP_WGRAD = ops.OVERLAP_WGRAD, "0"
+        solver.step(*next_batch())
+        torch.cuda.synchronize()
+        mdist.barrier()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.literal_steps):
+            solver.step(*next_batch())
+        torch.cuda.synchronize()
+        mdist.barrier()
+        torch.cuda.synchronize()
+        ot = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device=dev)
+        if mdist.is_distributed():
+            torch.distributed.all_reduce(ot, op=torch.distributed.ReduceOp.MAX)
+        ops.OVERLAP_WGRAD = mode
+        one_stream = {"steps": args.literal_steps, "ms_per_step": round(1e3 * float(ot) / args.literal_steps, 2),
+                      "value": round(args.batch * world * args.literal_steps / float(ot), 3),
+                      "note": "same build with MCDSEG_OVERLAP_WGRAD=0 (every kernel on one stream), measured after the timed region; "
+                              "identical results bit for bit"}
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         pairs = args.batch * world * args.steps
@@ -447,6 +471,7 @@ def main():
             "value_literal_schedule": literal["value"] if literal else (round(value, 3) if not solver.reuse_tgt else None),
             "ms_per_step_literal_schedule": literal["ms_per_step"] if literal else (round(ms_per_step, 2) if not solver.reuse_tgt else None),
             "literal_schedule": literal,
+            "one_stream": one_stream,
             "roofline": roofline,
             "roofline_forward": roofline_fwd,
             "roofline_wgrad": roofline_wg,
