@@ -126,6 +126,18 @@ int mcdseg_conv_split_fprop_affine(const mcdseg_conv_desc* d, int32_t math, cons
                                    const float* residual, int32_t relu, float* y, void* stream);
 int mcdseg_conv_split_dgrad(const mcdseg_conv_desc* d, int32_t math, const float* dy, const void* dy_cb, const float* dy_bound,
                             const void* wp_dgrad, const float* w_bound, float* dx, void* stream);
+/* One convolution may run as TWO launches: whole rounds of 256 x 256 tiles (one per CU) on the 8-wave ping-pong kernel
+ * (csrc/conv_gemm_split_pp.hip), the remaining pixels on the 4-wave tiles.  mcdseg_conv_split_parts returns the number of output
+ * pixels (a multiple of 256, counted from pixel 0 of the flattened (n, y, x) order) the first launch takes -- 0 when the geometry
+ * runs as one launch.  The _part entry points are mcdseg_conv_split_fprop / _dgrad with `part` = 0 (the whole convolution, what
+ * those do), 1 (only the ping-pong launch) or 2 (only the rest); parts 1 + 2 write exactly what part 0 writes.  They exist so that
+ * a profiler or bench.py can bracket each kernel with its own HIP events.  Reference: nn.Conv2d, models/drn.py:21-23. */
+int64_t mcdseg_conv_split_parts(const mcdseg_conv_desc* d, int32_t math, int32_t presplit, int32_t dgrad);
+int mcdseg_conv_split_fprop_part(const mcdseg_conv_desc* d, int32_t math, const float* x, const void* x_cb, const float* x_bound,
+                                 const void* wp_fprop, const float* w_bound, const float* bias, float* y, float* stat_partials,
+                                 int32_t part, void* stream);
+int mcdseg_conv_split_dgrad_part(const mcdseg_conv_desc* d, int32_t math, const float* dy, const void* dy_cb, const float* dy_bound,
+                                 const void* wp_dgrad, const float* w_bound, float* dx, int32_t part, void* stream);
 /* same workspace as mcdseg_conv_wgrad; 128x128-tile layers run on the split path, thin layers on the f32 kernels.
  * x_cb / dy_cb (may be NULL; used only when BOTH are given): the pre-split companions of x and dy in the layout above --
  * the kernel then transposes 8x8 blocks of 16-bit pieces in registers instead of splitting fp32 values.  x / dy may be NULL
@@ -138,6 +150,11 @@ int mcdseg_conv_split_wgrad(const mcdseg_conv_desc* d, int32_t math, const float
  * pre-split companions (register-transposing, transposed-read 128x128, transposed-read 256x128).  For profilers and
  * bench.py's per-kernel accounting. */
 int32_t mcdseg_conv_wgrad_variant(const mcdseg_conv_desc* d, int32_t math, int32_t presplit);
+/* 1 when ONE launch of mcdseg_conv_wgrad (math = 0) / mcdseg_conv_split_wgrad (presplit: both companions are passed) can address
+ * this descriptor's operands with its 32-bit buffer offsets: (N*C + 128 channels of slack) planes below 2 GiB for the kernels that
+ * read the fp32 tensors, N*C planes for the plans that read the companions (variants 11..16).  The host cuts larger batches along
+ * N -- the reference has no such limit (nn.Conv2d, models/drn.py:21-23).  Host-side arithmetic, no launch. */
+int32_t mcdseg_conv_wgrad_fits(const mcdseg_conv_desc* d, int32_t math, int32_t presplit);
 /* dw = x (*) dy ; split over pixels into slabs in `workspace`, then reduced in a fixed order. */
 size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d);
 int mcdseg_conv_wgrad(const mcdseg_conv_desc* d, const float* x, const float* dy, float* dw,

@@ -15,36 +15,10 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "split.h"
+#include "conv_split_params.h"
 
 namespace {
 
-struct ConvSplitParams {
-  const float* src;
-  const void* src_cb;  // optional pre-split operand: [piece NP][N][Cs/8][Hs*Ws][8 x 16 bit] (PRESPLIT kernels)
-  const void* wp;      // packed 16-bit weight image
-  const float* src_bound;  // SplitF16x3: device scalars, upper bounds of |src| and |w| (scale = mcd_scale_of_bound)
-  const float* w_bound;
-  const float* bias;
-  float* dst;
-  float* stats;
-  const float* ep_scale;
-  const float* ep_shift;
-  const float* ep_res;
-  int ep_relu;
-  int N;
-  int Cs, Hs, Ws;
-  int M, Hd, Wd;
-  int Mp, Kp;
-  int KH, KW, stride, pad, dil;
-  int P;
-  int src_bytes, wp_bytes, cb_bytes;  // cb_bytes: ONE piece of the companion (this call's images)
-  long long cb_piece_stride;          // bytes from piece p to piece p + 1 (the companion's own batch may be larger: mcdseg_conv_desc.Ncb)
-  // stride-2 dgrad in parity classes: output pixels (y%2, x%2) = class receive only the taps of matching parity, so a
-  // tile holds pixels of ONE class and its K loop visits that class's taps only (1, 2, 2, 4 of 9 for a 3x3 kernel)
-  int sub;           // 1 when the class ordering is active
-  int cls_tile0[5];  // first tile of class c (c = 2*ry + rx), cls_tile0[4] = number of tiles
-};
 
 template <class P, int WM, int WN, int WAVES_M, int WAVES_N, bool DGRAD, bool PRESPLIT>
 __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams p) {
@@ -84,12 +58,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
 
   const int m_tiles = p.Mp / BM;
   const bool SUB = DGRAD && p.sub != 0;
-  const int n_tiles = SUB ? p.cls_tile0[4] : (p.P + BN - 1) / BN;
-  const int per_xcd = (n_tiles + 7) >> 3;
+  const int n_tiles = SUB ? p.cls_tile0[4] : p.tile_n1;  // (the tile window of this launch: tile_n0 .. tile_n1 - 1, never with SUB)
+  const int tile_n0 = SUB ? 0 : p.tile_n0;
+  const int per_xcd = (n_tiles - tile_n0 + 7) >> 3;
   const int xcd = blockIdx.x & 7;
   const int slot = blockIdx.x >> 3;
   const int tile_m = slot % m_tiles;
-  const int tile_n = xcd * per_xcd + slot / m_tiles;
+  const int tile_n = tile_n0 + xcd * per_xcd + slot / m_tiles;
   if (tile_n >= n_tiles) return;
 
   // ---- this thread's gather pixel (same pixel for both of its k-halves when BN = 256)
@@ -847,11 +822,14 @@ int big_tile_min_slots() {  // (read per call: a test runs one problem on severa
 }
 
 template <class P, int WM, int WN, int WAVES_M, int WAVES_N, bool DGRAD>
-void launch_cfg(const ConvSplitParams& p, hipStream_t st) {
+void launch_cfg(const ConvSplitParams& p, int64_t pix0, hipStream_t st) {
   constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
   ConvSplitParams q = p;
   q.sub = 0;
   int n_tiles = ceil_div(p.P, BN);
+  q.tile_n0 = (int)(pix0 / BN);  // (pix0: a multiple of 256, the pixels the ping-pong kernel has taken)
+  q.tile_n1 = n_tiles;
+  n_tiles -= q.tile_n0;
   if (DGRAD && p.stride == 2 && p.KH * p.KW <= 32) {  // parity classes: tiles never straddle a class
     q.sub = 1;
     int t0 = 0;
@@ -893,24 +871,38 @@ int tile_config(int M, int64_t P, bool presplit) {
 }
 
 template <class P, bool DGRAD>
-void launch(const ConvSplitParams& p, hipStream_t st) {
-  switch (tile_config(p.M, p.P, p.src_cb != nullptr)) {
-    case 4222: launch_cfg<P, 4, 2, 2, 2, DGRAD>(p, st); break;
-    case 4214: launch_cfg<P, 4, 2, 1, 4, DGRAD>(p, st); break;
-    case 2222: launch_cfg<P, 2, 2, 2, 2, DGRAD>(p, st); break;
-    case 2214: launch_cfg<P, 2, 2, 1, 4, DGRAD>(p, st); break;
-    default: launch_cfg<P, 1, 2, 1, 4, DGRAD>(p, st); break;
+void launch(const ConvSplitParams& p, int64_t pix0, hipStream_t st) {
+  switch (tile_config(p.M, p.P, p.src_cb != nullptr)) {  // (of the WHOLE problem, whatever the ping-pong kernel has taken: one row numbering)
+    case 4222: launch_cfg<P, 4, 2, 2, 2, DGRAD>(p, pix0, st); break;
+    case 4214: launch_cfg<P, 4, 2, 1, 4, DGRAD>(p, pix0, st); break;
+    case 2222: launch_cfg<P, 2, 2, 2, 2, DGRAD>(p, pix0, st); break;
+    case 2214: launch_cfg<P, 2, 2, 1, 4, DGRAD>(p, pix0, st); break;
+    default: launch_cfg<P, 1, 2, 1, 4, DGRAD>(p, pix0, st); break;
   }
 }
 
+}  // namespace
+
+// the 8-wave ping-pong tile (conv_gemm_split_pp.hip) takes whole rounds of 256 x 256 tiles, the kernels of this file the rest
+int64_t mcdseg_internal_conv_pp_pixels(const ConvSplitParams& p, int math, bool dgrad);
+int mcdseg_internal_conv_pp_launch(const ConvSplitParams& p, int math, bool dgrad, int64_t pixels, hipStream_t st);
+
+namespace {
+
+// part 0: the whole convolution; 1: only the pixels of the ping-pong kernel; 2: only the rest (mcdseg_conv_split_parts)
 template <bool DGRAD>
-void launch_math(int math, const ConvSplitParams& p, hipStream_t st) {
+int launch_math(int math, const ConvSplitParams& p, int part, hipStream_t st) {
+  const int64_t pp = mcdseg_internal_conv_pp_pixels(p, math, DGRAD);
+  if (pp > 0 && part != 2)
+    if (int rc = mcdseg_internal_conv_pp_launch(p, math, DGRAD, pp, st)) return rc;
+  if (pp >= p.P || part == 1) return 0;
   if (math == MCDSEG_MATH_F16X3)
-    launch<SplitF16x3, DGRAD>(p, st);
+    launch<SplitF16x3, DGRAD>(p, pp, st);
   else if (math == MCDSEG_MATH_F16X1)
-    launch<SplitF16x1, DGRAD>(p, st);  // the same operands, one term
+    launch<SplitF16x1, DGRAD>(p, pp, st);  // the same operands, one term
   else
-    launch<SplitBf16x6, DGRAD>(p, st);
+    launch<SplitBf16x6, DGRAD>(p, pp, st);
+  return 0;
 }
 
 }  // namespace
@@ -1054,9 +1046,11 @@ static int split_cb_bytes(const mcdseg_conv_desc* d, int C, int HW, const void* 
   return 0;
 }
 
+static int fill_fprop_params(const mcdseg_conv_desc* d, int math, const void* x_cb, ConvSplitParams& p);
+
 static int split_fprop_impl(const mcdseg_conv_desc* d, int math, const float* x, const void* x_cb, const float* x_bound, const void* wp,
                             const float* w_bound, const float* bias, float* y, float* stats, const float* ep_scale,
-                            const float* ep_shift, const float* ep_res, int ep_relu, void* stream) {
+                            const float* ep_shift, const float* ep_res, int ep_relu, void* stream, int part = 0) {
   if (int rc = split_check(d, math, "conv_split_fprop")) return rc;
   MCD_REQUIRE((x || x_cb) && wp && y, "conv_split_fprop: null pointer");
   const bool stem = mcdseg_internal_stem_ok(d);
@@ -1065,6 +1059,7 @@ static int split_fprop_impl(const mcdseg_conv_desc* d, int math, const float* x,
   const int smath = mcd_storage_math(math);
   const bool stem_window = stem && smath == MCDSEG_MATH_F16X3 && x_cb != nullptr && bias == nullptr && ep_scale == nullptr &&
                            mcdseg_internal_thin_window_ok(d, 0);
+  if (part == 1 && (stem || (smath == MCDSEG_MATH_F16X3 && x_cb != nullptr && mcdseg_internal_thin_window_ok(d, 0)))) return 0;  // (no ping-pong part)
   if (stem && !stem_window) {
     MCD_REQUIRE(x != nullptr, "conv_split_fprop: the stem kernel reads the fp32 input");
     return mcdseg_internal_stem_fprop(d, x, (const char*)wp + stem_image_offset(d, math), bias, y, stats, ep_scale, ep_shift, ep_res,
@@ -1078,11 +1073,19 @@ static int split_fprop_impl(const mcdseg_conv_desc* d, int math, const float* x,
                                               stats, (hipStream_t)stream);
   }
   ConvSplitParams p;
-  if (int rc = split_cb_bytes(d, d->Cin, d->H * d->W, x_cb, &p.cb_bytes, &p.cb_piece_stride)) return rc;
-  p.src_cb = x_cb;
+  if (int rc = fill_fprop_params(d, math, x_cb, p)) return rc;
   p.src_bound = x_bound; p.w_bound = w_bound;
   p.src = x; p.wp = wp; p.bias = bias; p.dst = y; p.stats = stats;
   p.ep_scale = ep_scale; p.ep_shift = ep_shift; p.ep_res = ep_res; p.ep_relu = ep_relu;
+  if (int rc = launch_math<false>(math, p, part, (hipStream_t)stream)) return rc;
+  MCD_LAUNCH_CHECK("conv_split_fprop");
+  return 0;
+}
+
+// geometry of the forward implicit GEMM (everything but the data pointers)
+static int fill_fprop_params(const mcdseg_conv_desc* d, int math, const void* x_cb, ConvSplitParams& p) {
+  if (int rc = split_cb_bytes(d, d->Cin, d->H * d->W, x_cb, &p.cb_bytes, &p.cb_piece_stride)) return rc;
+  p.src_cb = x_cb;
   p.N = d->N;
   p.Cs = d->Cin; p.Hs = d->H; p.Ws = d->W;
   p.M = d->Cout; p.Hd = d->Ho; p.Wd = d->Wo;
@@ -1094,8 +1097,7 @@ static int split_fprop_impl(const mcdseg_conv_desc* d, int math, const float* x,
   const int64_t wb = split_image_bytes(math, d->Cout, d->Cin, d->KH * d->KW);
   MCD_REQUIRE(wb < (1ll << 31), "conv_split_fprop: packed weights exceed 2 GiB");
   p.wp_bytes = (int)wb;
-  launch_math<false>(math, p, (hipStream_t)stream);
-  MCD_LAUNCH_CHECK("conv_split_fprop");
+  p.sub = 0; p.tile_n0 = 0; p.tile_n1 = 0;
   return 0;
 }
 
@@ -1112,21 +1114,9 @@ extern "C" int mcdseg_conv_split_fprop_affine(const mcdseg_conv_desc* d, int32_t
   return split_fprop_impl(d, math, x, x_cb, x_bound, wp_fprop, w_bound, nullptr, y, nullptr, scale, shift, residual, relu, stream);
 }
 
-extern "C" int mcdseg_conv_split_dgrad(const mcdseg_conv_desc* d, int32_t math, const float* dy, const void* dy_cb, const float* dy_bound,
-                                       const void* wp_dgrad, const float* w_bound, float* dx, void* stream) {
-  if (int rc = split_check(d, math, "conv_split_dgrad")) return rc;
-  MCD_REQUIRE((dy || dy_cb) && wp_dgrad && dx, "conv_split_dgrad: null pointer");
-  const int smath = mcd_storage_math(math);
-  MCD_REQUIRE(smath != MCDSEG_MATH_F16X3 || (dy_bound && w_bound), "conv_split_dgrad: f16x3 needs the operand and weight bound scalars");
-  if (smath == MCDSEG_MATH_F16X3 && dy_cb != nullptr && mcdseg_internal_thin_window_ok(d, 1))
-    return mcdseg_internal_thin_window_launch(d, 1, dy_cb, dy_bound, wp_dgrad, split_image_bytes(math, d->Cin, d->Cout, d->KH * d->KW),
-                                              w_bound, dx, nullptr, (hipStream_t)stream);
-  ConvSplitParams p;
+static int fill_dgrad_params(const mcdseg_conv_desc* d, int math, const void* dy_cb, ConvSplitParams& p) {
   if (int rc = split_cb_bytes(d, d->Cout, d->Ho * d->Wo, dy_cb, &p.cb_bytes, &p.cb_piece_stride)) return rc;
   p.src_cb = dy_cb;
-  p.src_bound = dy_bound; p.w_bound = w_bound;
-  p.src = dy; p.wp = wp_dgrad; p.bias = nullptr; p.dst = dx; p.stats = nullptr;
-  p.ep_scale = nullptr; p.ep_shift = nullptr; p.ep_res = nullptr; p.ep_relu = 0;
   p.N = d->N;
   p.Cs = d->Cout; p.Hs = d->Ho; p.Ws = d->Wo;
   p.M = d->Cin; p.Hd = d->H; p.Wd = d->W;
@@ -1138,7 +1128,55 @@ extern "C" int mcdseg_conv_split_dgrad(const mcdseg_conv_desc* d, int32_t math, 
   const int64_t wb = split_image_bytes(math, d->Cin, d->Cout, d->KH * d->KW);
   MCD_REQUIRE(wb < (1ll << 31), "conv_split_dgrad: packed weights exceed 2 GiB");
   p.wp_bytes = (int)wb;
-  launch_math<true>(math, p, (hipStream_t)stream);
+  p.sub = 0; p.tile_n0 = 0; p.tile_n1 = 0;
+  return 0;
+}
+
+static int split_dgrad_impl(const mcdseg_conv_desc* d, int32_t math, const float* dy, const void* dy_cb, const float* dy_bound,
+                            const void* wp_dgrad, const float* w_bound, float* dx, void* stream, int part) {
+  if (int rc = split_check(d, math, "conv_split_dgrad")) return rc;
+  MCD_REQUIRE((dy || dy_cb) && wp_dgrad && dx, "conv_split_dgrad: null pointer");
+  const int smath = mcd_storage_math(math);
+  MCD_REQUIRE(smath != MCDSEG_MATH_F16X3 || (dy_bound && w_bound), "conv_split_dgrad: f16x3 needs the operand and weight bound scalars");
+  if (smath == MCDSEG_MATH_F16X3 && dy_cb != nullptr && mcdseg_internal_thin_window_ok(d, 1))
+    return part == 1 ? 0
+                     : mcdseg_internal_thin_window_launch(d, 1, dy_cb, dy_bound, wp_dgrad, split_image_bytes(math, d->Cin, d->Cout, d->KH * d->KW),
+                                                          w_bound, dx, nullptr, (hipStream_t)stream);
+  ConvSplitParams p;
+  if (int rc = fill_dgrad_params(d, math, dy_cb, p)) return rc;
+  p.src_bound = dy_bound; p.w_bound = w_bound;
+  p.src = dy; p.wp = wp_dgrad; p.bias = nullptr; p.dst = dx; p.stats = nullptr;
+  p.ep_scale = nullptr; p.ep_shift = nullptr; p.ep_res = nullptr; p.ep_relu = 0;
+  if (int rc = launch_math<true>(math, p, part, (hipStream_t)stream)) return rc;
   MCD_LAUNCH_CHECK("conv_split_dgrad");
   return 0;
+}
+
+extern "C" int mcdseg_conv_split_dgrad(const mcdseg_conv_desc* d, int32_t math, const float* dy, const void* dy_cb, const float* dy_bound,
+                                       const void* wp_dgrad, const float* w_bound, float* dx, void* stream) {
+  return split_dgrad_impl(d, math, dy, dy_cb, dy_bound, wp_dgrad, w_bound, dx, stream, 0);
+}
+
+// ---- the two launches of one convolution, separately (profilers and bench.py's per-kernel HIP events; results are those of the whole call)
+extern "C" int64_t mcdseg_conv_split_parts(const mcdseg_conv_desc* d, int32_t math, int32_t presplit, int32_t dgrad) {
+  if (d == nullptr || !mcd_math_known(math) || !presplit) return 0;
+  const int smath = mcd_storage_math(math);
+  if (smath == MCDSEG_MATH_F16X3 && mcdseg_internal_thin_window_ok(d, dgrad ? 1 : 0)) return 0;
+  if (!dgrad && mcdseg_internal_stem_ok(d)) return 0;
+  ConvSplitParams p;
+  if (dgrad ? fill_dgrad_params(d, math, d, p) : fill_fprop_params(d, math, d, p)) return 0;
+  return mcdseg_internal_conv_pp_pixels(p, math, dgrad != 0);
+}
+
+extern "C" int mcdseg_conv_split_fprop_part(const mcdseg_conv_desc* d, int32_t math, const float* x, const void* x_cb, const float* x_bound,
+                                            const void* wp_fprop, const float* w_bound, const float* bias, float* y, float* stat_partials,
+                                            int32_t part, void* stream) {
+  MCD_REQUIRE(part >= 0 && part <= 2, "conv_split_fprop_part: part must be 0 (whole), 1 (ping-pong tiles) or 2 (the rest)");
+  return split_fprop_impl(d, math, x, x_cb, x_bound, wp_fprop, w_bound, bias, y, stat_partials, nullptr, nullptr, nullptr, 0, stream, part);
+}
+
+extern "C" int mcdseg_conv_split_dgrad_part(const mcdseg_conv_desc* d, int32_t math, const float* dy, const void* dy_cb, const float* dy_bound,
+                                            const void* wp_dgrad, const float* w_bound, float* dx, int32_t part, void* stream) {
+  MCD_REQUIRE(part >= 0 && part <= 2, "conv_split_dgrad_part: part must be 0 (whole), 1 (ping-pong tiles) or 2 (the rest)");
+  return split_dgrad_impl(d, math, dy, dy_cb, dy_bound, wp_dgrad, w_bound, dx, stream, part);
 }

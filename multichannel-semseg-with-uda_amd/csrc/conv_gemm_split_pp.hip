@@ -1,0 +1,360 @@
+// Implicit-GEMM convolution (forward and stride-1 data gradient) in the split arithmetic of conv_gemm_split.hip on a 256 x 256
+// tile owned by EIGHT waves that run as two groups half a K-step apart ("ping-pong"): what the reference computes with
+// nn.Conv2d (models/drn.py:21-23, 43-59).
+//
+// Why.  In conv_gemm_split_kernel a wave's K-step is a serial chain -- 12 fragment reads, 6 LDS-DMA issues with their scalar
+// bookkeeping, 24 matrix instructions, a counted wait, the workgroup barrier -- and the two waves that share a SIMD belong to
+// two independent workgroups, so nothing keeps one of them in its matrix phase while the other reads: measured matrix pipe
+// busy 0.61, 49 % of the wave cycles waiting to issue (profiles/r03zb_pmc_sq.json).  Here the SIMD partners are waves w and
+// w + 4 of ONE workgroup and the workgroup's barriers alternate their roles (MI355X_MICROARCH.md "Two waves per SIMD";
+// cdna_hip_programming.md, the 8-phase GEMM template): between two barriers group 0 (waves 0-3, output rows 0-127) multiplies
+// -- nothing but 24 MFMAs -- while group 1 (waves 4-7, rows 128-255) reads its fragments of the same K-step, issues its share
+// of the LDS-DMAs for the K-step after next and waits for the share it issued one step earlier; then they swap.  The matrix
+// pipe of every SIMD always has exactly one wave feeding it, and the read phase (12 x ds_read_b128, 4 DMAs) hides behind the
+// partner's 768 matrix cycles.  The 256 x 256 tile also moves a third fewer operand bytes through L2 and LDS-DMA per FLOP than
+// two 256 x 128 tiles.  tools/probes/pingpong.hip (512 -> 512, 3x3, dilation 4, N = 16, random data, two full rounds of
+// workgroups): 0.594 of 2.5 PFLOP/s against 0.527 for the 4-wave structure; without the stagger the same 8-wave tile gets 0.44.
+//
+// One workgroup per CU (96 KB of LDS: three stages of 16 + 16 KB), so a grid is worth whole rounds of 256 tiles only: the host
+// (conv_gemm_split.hip::launch) gives this kernel floor(tiles / CUs) * CUs tiles and the remaining pixels to the 4-wave tiles.
+// K order, term order and the epilogue are those of conv_gemm_split_kernel, so outputs and BatchNorm partial rows (one per 64
+// pixels) are bit for bit the same whichever kernel computes a pixel (tests/test_kernels_gpu.py::test_conv_pingpong_tile).
+//
+// LDS timeline (stage of step s = s mod 3; "interval" = the time between two consecutive workgroup barriers; group g reads
+// step s in interval 2s + g and multiplies it in interval 2s + g + 1):
+//   * a group issues its share of step s+2's DMAs in its read phase of step s -- into the stage step s-1 occupied, whose last
+//     readers (group 0 in interval 2s-2, group 1 in 2s-1) both waited lgkmcnt(0) before the barrier that closed their interval;
+//   * at the end of its read phase of step s a group waits vmcnt(share) -- everything but the share just issued -- so its share
+//     of step s+1 has landed before the barrier; group 1 passes that barrier at the end of interval 2s+1, and the first read of
+//     step s+1 is group 0's in interval 2s+2.
+#include <cstdlib>
+#include <type_traits>
+
+#include "conv_split_params.h"
+
+namespace {
+
+template <class P, bool DGRAD>
+__global__ __launch_bounds__(512) void conv_gemm_split_pp_kernel(ConvSplitParams p) {
+  constexpr int WM = 4, WN = 2, WAVES_N = 4;
+  constexpr int BM = 256, BN = 256, NT = 512, NS = 3;
+  constexpr int NP = P::NP;          // pieces per operand
+  constexpr int NPU = P::NPU;        // ... of which the policy multiplies (and the loop stages) the first NPU
+  constexpr int NQ = 2 * NP;         // (piece, k-half) planes per K-step
+  typedef typename P::frag frag;
+  constexpr int A_BYTES = NQ * BM * 16, B_BYTES = NQ * BN * 16;
+  constexpr int A_DMAS = 2 * NPU * BM / NT;       // weight-slab DMAs per thread and K-step (piece-major slab: the staged pieces are its head)
+  constexpr int DMA_PER_STEP = A_DMAS + NPU;      // + one 16-byte unit of the pixel operand per staged piece
+  static_assert((2 * NPU * BM) % NT == 0 && BN * 2 == NT, "every wave issues the same number of DMAs (the waits are counted)");
+  static_assert(NS * (A_BYTES + B_BYTES) <= 160 * 1024, "LDS");
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (A_BYTES + B_BYTES)];
+  unsigned char* As = smem;                   // [NS][piece][half][BM][16 B]
+  unsigned char* Bs = smem + NS * A_BYTES;    // [NS][piece][half][BN][16 B]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2;  // the group: SIMD partners are waves w and w + 4 (MI355X_MICROARCH.md item 9: split by wave >= 4, not by parity)
+  const int wn = wave & 3;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int m_tiles = p.Mp / BM;
+  const int n_tiles = p.tile_n1;  // this launch: pixel tiles 0 .. tile_n1 - 1, all of them full
+  const int per_xcd = (n_tiles + 7) >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int tile_m = slot % m_tiles;
+  const int tile_n = xcd * per_xcd + slot / m_tiles;
+  if (tile_n >= n_tiles) return;
+
+  // ---- this thread's gather pixel and k-half (the pixel never changes; waves 0-3 gather k-half 0, waves 4-7 k-half 1)
+  const int bj = t & (BN - 1);
+  const int bh = wave >> 2;
+  const int HWd = p.Hd * p.Wd;
+  const int HWs = p.Hs * p.Ws;
+  const int pix = tile_n * BN + bj;
+  const bool pv = pix < p.P;
+  int pn = 0, py = 0, px = 0;
+  if (pv) {
+    pn = pix / HWd;
+    const int rem = pix - pn * HWd;
+    py = rem / p.Wd;
+    px = rem - py * p.Wd;
+  }
+  constexpr unsigned OOB = 0x80000000u;
+  __amdgpu_buffer_rsrc_t cb_rs[NPU];  // one descriptor per piece of the companion (each below 2 GiB; the pieces of a batch slice are not adjacent)
+#pragma unroll
+  for (int pc = 0; pc < NPU; ++pc)
+    cb_rs[pc] = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.src_cb + pc * p.cb_piece_stride), 0, p.cb_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wp_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.wp_bytes, 0x00020000);
+  const int C8 = p.Cs >> 3;
+  const unsigned pix_base = (unsigned)pn * (unsigned)C8 * (unsigned)HWs;  // in 16-byte units
+  const int taps = p.KH * p.KW;  // <= 32 (host)
+  // whether tap q of this pixel falls into the zero padding is one bit of a per-thread mask; the tap's address offset is the same for
+  // every thread (scalar ALU): a K-step spends three vector instructions on addressing
+  unsigned valid_mask = 0;
+  for (int q = 0; q < taps; ++q) {
+    const int ky = q / p.KW, kx = q - ky * p.KW;
+    const int sy = DGRAD ? py + p.pad - ky * p.dil : py * p.stride + ky * p.dil - p.pad;
+    const int sx = DGRAD ? px + p.pad - kx * p.dil : px * p.stride + kx * p.dil - p.pad;
+    valid_mask |= (pv && sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws ? 1u : 0u) << q;
+  }
+  const unsigned vbase = DGRAD ? pix_base + (unsigned)(py * p.Ws + px) : pix_base + (unsigned)(py * p.stride * p.Ws + px * p.stride);
+
+  unsigned a_voff[A_DMAS];
+#pragma unroll
+  for (int i = 0; i < A_DMAS; ++i) {
+    const int id = t + i * NT;
+    const int plane = id / BM;
+    const int m = id - plane * BM;
+    a_voff[i] = ((unsigned)plane * (unsigned)p.Mp + (unsigned)m) * 16u;
+  }
+  const int wave_px = __builtin_amdgcn_readfirstlane(bj - lane);
+
+  // loader state: K order is channel-chunk outer, tap inner (the shifted re-reads of a 16-channel slab are back to back)
+  int l_tap = 0, l_c0 = 0, l_ky = 0, l_kx = 0, l_kstep = 0;
+  auto issue = [&](int buf) {  // this wave's share of one K-step: A_DMAS KB of the weight slab, NPU x 1 KB of gathered pixel units
+#if defined(__HIP_DEVICE_COMPILE__)  // the LDS address space does not exist in the host pass of this translation unit
+    const int a_soff = (l_kstep * NQ * p.Mp + tile_m * BM) * 16;
+    unsigned char* adst = As + buf * A_BYTES + wave * 64 * 16;
+#pragma unroll
+    for (int i = 0; i < A_DMAS; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wp_rs, (__attribute__((address_space(3))) void*)(adst + i * NT * 16), 16, a_voff[i], a_soff, 0, 0);
+    const int rel = DGRAD ? (p.pad - l_ky * p.dil) * p.Ws + (p.pad - l_kx * p.dil) : (l_ky * p.dil - p.pad) * p.Ws + (l_kx * p.dil - p.pad);
+    const unsigned voff = ((valid_mask >> l_tap) & 1u) ? (vbase + (unsigned)rel) * 16u : OOB;
+    const int grp = (l_c0 >> 3) + bh;
+    const int soff = grp < C8 ? grp * HWs * 16 : 0x7FFFFFFF;  // (a ragged last chunk: the range check deposits zeros)
+    unsigned char* bdst = Bs + buf * B_BYTES + (bh * BN + wave_px) * 16;
+#pragma unroll
+    for (int pc = 0; pc < NPU; ++pc)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(cb_rs[pc], (__attribute__((address_space(3))) void*)(bdst + pc * 2 * BN * 16), 16, voff, soff, 0, 0);
+#else
+    (void)buf;
+#endif
+  };
+  auto advance = [&]() {
+    ++l_kstep;
+    ++l_tap;
+    if (++l_kx == p.KW) {
+      l_kx = 0;
+      ++l_ky;
+    }
+    if (l_tap == taps) {
+      l_tap = 0;
+      l_kx = 0;
+      l_ky = 0;
+      l_c0 += 16;
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nsteps = taps * (p.Kp / 16);
+  issue(0);
+  if (nsteps > 1) {
+    advance();
+    issue(1);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1 runs one barrier behind group 0 from here to the end of the K loop
+
+  frag fa[NP][WM], fb[NP][WN];
+  int cur = 0, nxt2 = 2;
+  for (int s = 0; s < nsteps; ++s) {
+    // ---- read phase (the partner group multiplies meanwhile)
+    const unsigned char* a_base = As + cur * A_BYTES + (lh * BM + wm * (32 * WM) + l31) * 16;
+    const unsigned char* b_base = Bs + cur * B_BYTES + (lh * BN + wn * (32 * WN) + l31) * 16;
+#pragma unroll
+    for (int pc = 0; pc < NPU; ++pc) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) fa[pc][i] = *reinterpret_cast<const frag*>(a_base + (pc * 2 * BM + i * 32) * 16);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) fb[pc][j] = *reinterpret_cast<const frag*>(b_base + (pc * 2 * BN + j * 32) * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < nsteps) {
+      advance();
+      issue(nxt2);
+      // this wave's share of step s+1 has landed (the share of step s+2 stays in flight) and its fragment reads are back
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DMA_PER_STEP) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- matrix phase (the partner group reads meanwhile): the policy's cross terms, smallest first, term-major -- consecutive
+    // instructions go to different accumulator tiles; same sums in the same order per tile as conv_gemm_split_kernel
+#pragma unroll
+    for (int tm = 0; tm < P::NTERMS; ++tm)
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = P::mfma(fa[P::TA[tm]][i], fb[P::TB[tm]][j], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    cur = cur == 2 ? 0 : cur + 1;
+    nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's last matrix-phase barrier
+
+  // ---- epilogue (conv_gemm_split_kernel's, without the parity classes): acc[i][j][r] = D[row][col], row = (r&3) + 8*(r>>2) + 4*lh, col = l31
+  if constexpr (P::SCALED) {
+    const float osc = mcd_scale_of_bound(*p.src_bound) * mcd_scale_of_bound(*p.w_bound);  // exact power of two
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= osc;
+  }
+  const int m_wave = tile_m * BM + wm * (32 * WM);
+  const int p_wave = tile_n * BN + wn * (32 * WN);
+  if (!DGRAD && p.bias != nullptr) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float bv = (m < p.M) ? p.bias[m] : 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j][r] += bv;
+      }
+  }
+  if (!DGRAD && p.ep_scale != nullptr) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float sc = (m < p.M) ? p.ep_scale[m] : 0.f;
+        const float sh = (m < p.M) ? p.ep_shift[m] : 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j][r] = fmaf(acc[i][j][r], sc, sh);
+      }
+  }
+  bool colv[WN];
+  size_t dbase[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int pp = p_wave + j * 32 + l31;
+    colv[j] = pp < p.P;
+    int n = 0, rem = 0;
+    if (colv[j]) {
+      n = pp / HWd;
+      rem = pp - n * HWd;
+    }
+    dbase[j] = (size_t)n * p.M * HWd + rem;
+  }
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < p.M) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          if (colv[j]) {
+            float v = acc[i][j][r];
+            if (!DGRAD && p.ep_scale != nullptr) {
+              if (p.ep_res != nullptr) v += p.ep_res[dbase[j] + (size_t)m * HWd];
+              if (p.ep_relu) v = fmaxf(v, 0.f);
+            }
+            p.dst[dbase[j] + (size_t)m * HWd] = v;
+          }
+      }
+    }
+  if (!DGRAD && p.stats != nullptr) {
+    int cntw = p.P - p_wave;
+    cntw = cntw < 0 ? 0 : (cntw > 32 * WN ? 32 * WN : cntw);
+    const float inv = cntw > 0 ? 1.f / (float)cntw : 0.f;
+    const size_t srow = ((size_t)(tile_n * WAVES_N + wn) * 3) * p.Mp;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      float my_mean = 0.f, my_m2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) v += colv[j] ? acc[i][j][r] : 0.f;
+        const float mean = wave_half_sum(v) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const float d = acc[i][j][r] - mean;
+          q += colv[j] ? d * d : 0.f;
+        }
+        q = wave_half_sum(q);
+        if (l31 == r) {
+          my_mean = mean;
+          my_m2 = q;
+        }
+      }
+      if (l31 < 16) {
+        const int m = m_wave + i * 32 + (l31 & 3) + 8 * (l31 >> 2) + 4 * lh;
+        p.stats[srow + m] = (float)cntw;
+        p.stats[srow + p.Mp + m] = my_mean;
+        p.stats[srow + 2 * (size_t)p.Mp + m] = my_m2;
+      }
+    }
+  }
+}
+
+int compute_units() {  // one workgroup per CU: a launch is worth whole rounds of this many tiles
+  static const int n = [] {
+    const char* e = getenv("MCDSEG_PP_CUS");  // development knob
+    if (e && atoi(e) > 0) return atoi(e);
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;  // MI355X
+    return cus;
+  }();
+  return n;
+}
+
+bool pp_enabled() {  // (read per call: a test runs one problem with and without the kernel)
+  const char* e = getenv("MCDSEG_PINGPONG");
+  return e == nullptr || atoi(e) != 0;
+}
+
+}  // namespace
+
+// Pixels (a multiple of 256, counted from pixel 0) of this problem that the ping-pong kernel takes: whole rounds of one 256 x 256
+// tile per CU; 0 when the kernel does not apply (no pre-split operand, three-piece arithmetic, output rows not a multiple of 256,
+// strided data gradient, more than 32 taps, less than one round of tiles).
+int64_t mcdseg_internal_conv_pp_pixels(const ConvSplitParams& p, int math, bool dgrad) {
+  if (!pp_enabled() || p.src_cb == nullptr || mcd_math_pieces(math) != 2 || (p.Mp % 256) != 0) return 0;
+  if (p.KH * p.KW > 32 || (dgrad && p.stride != 1) || (p.Cs & 7) != 0) return 0;
+  const int64_t m_tiles = p.Mp / 256, n_full = p.P / 256, cus = compute_units();
+  const int64_t rounds = n_full * m_tiles / cus;
+  if (rounds < 1) return 0;
+  int64_t n_pp = rounds * cus / m_tiles;  // pixel tiles (all their row tiles) that make whole rounds
+  if (n_pp > n_full) n_pp = n_full;
+  return n_pp * 256;
+}
+
+int mcdseg_internal_conv_pp_launch(const ConvSplitParams& p, int math, bool dgrad, int64_t pixels, hipStream_t st) {
+  ConvSplitParams q = p;
+  q.sub = 0;
+  q.tile_n0 = 0;
+  q.tile_n1 = (int)(pixels / 256);
+  const dim3 grid((unsigned)(8 * ceil_div(q.tile_n1, 8) * (p.Mp / 256)));
+  if (math == MCDSEG_MATH_F16X1) {
+    if (dgrad)
+      hipLaunchKernelGGL((conv_gemm_split_pp_kernel<SplitF16x1, true>), grid, dim3(512), 0, st, q);
+    else
+      hipLaunchKernelGGL((conv_gemm_split_pp_kernel<SplitF16x1, false>), grid, dim3(512), 0, st, q);
+  } else {
+    if (dgrad)
+      hipLaunchKernelGGL((conv_gemm_split_pp_kernel<SplitF16x3, true>), grid, dim3(512), 0, st, q);
+    else
+      hipLaunchKernelGGL((conv_gemm_split_pp_kernel<SplitF16x3, false>), grid, dim3(512), 0, st, q);
+  }
+  MCD_LAUNCH_CHECK("conv_gemm_split_pp");
+  return 0;
+}

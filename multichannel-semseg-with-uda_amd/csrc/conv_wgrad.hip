@@ -513,6 +513,28 @@ extern "C" int mcdseg_conv_split_wgrad(const mcdseg_conv_desc* d, int32_t math, 
   return wgrad_impl(d, x, dy, dw, workspace, workspace_bytes, math, x_cb, x_bound, dy_cb, dy_bound, stream);
 }
 
+// One launch addresses an operand with 32-bit buffer offsets.  The kernels that read the fp32 tensors express padding and ragged
+// channel tails as offsets up to a 128-channel tile past the tensor, which the buffer range check must still reject: (N*C + 128)
+// planes below 2 GiB.  The plans that read both pre-split companions (variants 11..16) mark such accesses with an explicit
+// out-of-range offset and check their own limits (one piece of a companion below 2 GiB): no slack.
+static bool wgrad_reads_companions(const mcdseg_conv_desc* d, int math, bool have_cb) {
+  if (!math || !have_cb) return false;
+  if (thin_tr_applies(d, math, d, d)) return true;
+  const int cfg = make_plan(d).cfg;
+  return tr64_applies(d, math, d, d, cfg) || ((d->Cin & 7) == 0 && (d->Cout & 7) == 0 && cfg == 0);
+}
+static bool wgrad_operands_fit(const mcdseg_conv_desc* d, int math, bool have_cb) {
+  const int64_t slack = wgrad_reads_companions(d, math, have_cb) ? 0 : 128;
+  return ((int64_t)d->N * d->Cin + slack) * d->H * d->W * 4 < (1ll << 31) && ((int64_t)d->N * d->Cout + slack) * d->Ho * d->Wo * 4 < (1ll << 31);
+}
+
+// 1 when ONE launch of mcdseg_conv_wgrad (math = 0) / mcdseg_conv_split_wgrad can address this descriptor's operands (presplit:
+// both companions are passed); the host cuts larger batches along N (mcdseg/ops.py::_batch_pieces).  Host-side arithmetic only.
+extern "C" int32_t mcdseg_conv_wgrad_fits(const mcdseg_conv_desc* d, int32_t math, int32_t presplit) {
+  if (d == nullptr || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
+  return wgrad_operands_fit(d, math, presplit != 0) ? 1 : 0;
+}
+
 extern "C" size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d) {
   if (d == nullptr) return 0;
   const size_t a = (size_t)make_plan(d).slab_floats * sizeof(float), b = mcdseg_internal_wgrad_thin_tr_ws(d);
@@ -530,8 +552,9 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
   MCD_REQUIRE(!(split_plan && mcd_storage_math(math) == MCDSEG_MATH_F16X3) || (x_bound && dy_bound), "conv_split_wgrad: f16x3 needs both bound scalars");
   MCD_REQUIRE(cb_path || (x && dy), "conv_wgrad: x and dy may be NULL only when the pre-split 128x128 plan applies");
   MCD_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0, "conv_wgrad: bad dims");
-  MCD_REQUIRE(((int64_t)d->N * d->Cin + 128) * d->H * d->W * 4 < (1ll << 31) && ((int64_t)d->N * d->Cout + 128) * d->Ho * d->Wo * 4 < (1ll << 31),
-              "conv_wgrad: activation tensor must stay below 2 GiB (32-bit buffer offsets); split the batch");
+  MCD_REQUIRE(wgrad_operands_fit(d, math, x_cb && dy_cb),
+              "conv_wgrad: activation tensor must stay below 2 GiB (32-bit buffer offsets, plus a 128-channel tile of slack for the kernels "
+              "that read the fp32 operands); split the batch (mcdseg_conv_wgrad_fits)");
   const WgradPlan pl = make_plan(d);
   MCD_REQUIRE(workspace_bytes >= (size_t)pl.slab_floats * sizeof(float), "conv_wgrad: workspace too small (%zu < %zu)",
               workspace_bytes, (size_t)pl.slab_floats * sizeof(float));

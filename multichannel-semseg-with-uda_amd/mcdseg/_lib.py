@@ -47,6 +47,9 @@ _SIGNATURES = {
     "mcdseg_conv_split_fprop": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 9),
     "mcdseg_conv_split_fprop_affine": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 8 + [c_i32, c_void_p, c_void_p]),
     "mcdseg_conv_split_dgrad": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 7),
+    "mcdseg_conv_split_parts": (c_i64, [_P(ConvDesc), c_i32, c_i32, c_i32]),
+    "mcdseg_conv_split_fprop_part": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 8 + [c_i32, c_void_p]),
+    "mcdseg_conv_split_dgrad_part": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 6 + [c_i32, c_void_p]),
     "mcdseg_split_cb": (c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "mcdseg_split_cb_padded": (c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "mcdseg_unsplit_cb": (c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
@@ -57,6 +60,7 @@ _SIGNATURES = {
     "mcdseg_conv_split_wgrad": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "mcdseg_conv_dgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcdseg_conv_wgrad_variant": (c_i32, [_P(ConvDesc), c_i32, c_i32]),
+    "mcdseg_conv_wgrad_fits": (c_i32, [_P(ConvDesc), c_i32, c_i32]),
     "mcdseg_conv_wgrad_workspace_bytes": (c_size_t, [_P(ConvDesc)]),
     "mcdseg_conv_wgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mcdseg_bn_stats_workspace_bytes": (c_size_t, [c_i64, c_i32]),

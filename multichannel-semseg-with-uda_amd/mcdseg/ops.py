@@ -84,6 +84,26 @@ def gemm_kernel_name(m, k, dgrad, split=False, presplit=False, direct=False, pix
     return "conv_gemm_kernel<%s, %d, %s>" % (cfg, 8 if k <= 8 else 16, "true" if dgrad else "false")
 
 
+def pingpong_kernel_name(dgrad, math=None):
+    """rocprofv3's name of the 8-wave ping-pong tile (csrc/conv_gemm_split_pp.hip)"""
+    return "conv_gemm_split_pp_kernel<%s, %s>" % (POLICY[math or CONV_MATH], "true" if dgrad else "false")
+
+
+def _split_launches(d, presplit, dgrad, name, call):
+    """One split-arithmetic convolution as the library would launch it, each kernel bracketed by its own timer: the pixels
+    ``mcdseg_conv_split_parts`` gives to the ping-pong kernel (part 1) and the rest on the 4-wave tiles (part 2); ``call(part)``
+    invokes the ``_part`` entry point.  Work is shared out by pixels."""
+    pixels = d.N * (d.H * d.W if dgrad else d.Ho * d.Wo)
+    pp = lib().mcdseg_conv_split_parts(ctypes.byref(d), MATH_ID[CONV_MATH], int(presplit), int(dgrad)) if presplit else 0
+    flops, byts = conv_work(d)
+    if pp > 0:
+        with _timed(pingpong_kernel_name(dgrad), (flops * pp / pixels, byts * pp / pixels)):
+            call(1)
+    if pp < pixels:
+        with _timed(name, (flops * (pixels - pp) / pixels, byts * (pixels - pp) / pixels)):
+            call(2 if pp > 0 else 0)
+
+
 def wgrad_kernel_name(cout, cin, taps=9):
     if cin <= 16 and taps > 1:
         return "conv_wgrad_thin_kernel<%d, %s>" % (8 if cin <= 8 else 16, "true" if cout <= 16 else "false")
@@ -428,18 +448,28 @@ def _cb_slice(cb, a, channels, hw):
     return None if cb is None else ctypes.c_void_p(cb.data_ptr() + a * (channels // 8) * hw * 16)
 
 
-def _batch_pieces(desc):
+def _batch_pieces(desc, wgrad_cb=None):
+    """[(first image, end)] of the launches a convolution's batch is cut into.  ``wgrad_cb``: None for the forward pass and the data
+    gradient; for the weight gradient, whether both pre-split companions will be passed."""
     # the f32 kernels express padding and ragged channel tails as offsets the buffer range check rejects, up to a 128-channel tile
     # past the tensor: (N*C + 128) * H*W * 4 < 2 GiB per operand -- the tile of slack is per LAUNCH, not per image (charging it per
     # image cut the full-resolution 16-channel layers in two and lost their pre-split operands).  The split kernels mark such
-    # accesses with an explicit out-of-range offset instead, so a layer that runs on them forward, data- and weight-gradient
-    # (both channel counts multiples of 8, at least 16) needs no slack: BASELINE config 5's 16- and 32-channel layers at
-    # 32 x 720 x 1280 (1.89 GB per tensor) stay in one launch and keep their companions.
+    # accesses with an explicit out-of-range offset instead, so the forward pass and the data gradient of a layer that runs on them
+    # (both channel counts multiples of 8, at least 16) need no slack: BASELINE config 5's 16- and 32-channel layers at
+    # 32 x 720 x 1280 (1.89 GB per tensor) stay in one launch and keep their companions.  The WEIGHT gradient is slack-free only on
+    # the plans that read both companions (mcdseg_conv_wgrad_fits states the library's own rule): the f32 plans of thin layers, the
+    # split plan without companions and bf16x6's thin layers still gather fp32 values with the slack.
     split_only = CONV_MATH in MATH_ID and desc.Cin % 8 == 0 and desc.Cout % 8 == 0 and min(desc.Cin, desc.Cout) >= 16
+    if wgrad_cb is not None:
+        math = MATH_ID.get(CONV_MATH, 0)
+        split_only = split_only and bool(wgrad_cb) and lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), math, 1) >= 11
     slack = 0 if split_only else 128
     step = desc.N
     for c, hw in ((desc.Cin, desc.H * desc.W), (desc.Cout, desc.Ho * desc.Wo)):
         step = min(step, max(1, (MAX_CONV_BYTES - 4 * slack * hw) // (4 * c * hw)))
+    if wgrad_cb is not None:  # (the variant can change with N: hold every piece to the library's rule)
+        while step > 1 and not lib().mcdseg_conv_wgrad_fits(ctypes.byref(_sub_desc(desc, step, desc.N if wgrad_cb else 0)), math, int(wgrad_cb)):
+            step -= 1
     if step >= desc.N:
         return [(0, desc.N)]
     return [(i, min(i + step, desc.N)) for i in range(0, desc.N, step)]
@@ -464,12 +494,14 @@ def _conv_fprop(desc, x, wf, bias, want_stats, mpf, x_cb=None, x_bound=None, w_b
         x_bound = _bound_or_measure(x, x_bound)
     for i, ((a, b), d) in enumerate(zip(pieces, descs)):
         pp = None if part is None else ctypes.c_void_p(part.data_ptr() + 4 * row_off[i] * 3 * mpf)
-        with _timed((_window_name(d, x_cb is not None, False) if split else None)
-                    or gemm_kernel_name(desc.Cout, desc.Cin, False, split, x_cb is not None, direct, d.N * d.Ho * d.Wo), conv_work(d)):
-            if split:
-                check(L.mcdseg_conv_split_fprop(ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(x, a, b)), _cb_slice(x_cb, a, desc.Cin, desc.H * desc.W),
-                                                _p(x_bound), _p(wf), _p(w_bound), _p(bias), _p(y[a:b]), pp, _stream()), "conv_split_fprop")
-            else:
+        name = (_window_name(d, x_cb is not None, False) if split else None) \
+            or gemm_kernel_name(desc.Cout, desc.Cin, False, split, x_cb is not None, direct, d.N * d.Ho * d.Wo)
+        if split:
+            _split_launches(d, x_cb is not None, False, name, lambda part: check(L.mcdseg_conv_split_fprop_part(
+                ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(x, a, b)), _cb_slice(x_cb, a, desc.Cin, desc.H * desc.W), _p(x_bound), _p(wf),
+                _p(w_bound), _p(bias), _p(y[a:b]), pp, part, _stream()), "conv_split_fprop"))
+        else:
+            with _timed(name, conv_work(d)):
                 check(L.mcdseg_conv_fprop(ctypes.byref(d), _p(x[a:b]), _p(wf), _p(bias), _p(y[a:b]), pp, _stream()), "conv_fprop")
     return y, part, rows
 
@@ -497,13 +529,14 @@ def _conv_dgrad(desc, dy, wd, dy_cb=None, dy_bound=None, w_bound=None):
         dy_bound = _bound_or_measure(dy, dy_bound)
     for a, b in pieces:
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a, desc.N if dy_cb is not None else 0)
-        with _timed((_window_name(d, dy_cb is not None, True) if split else None)
-                    or gemm_kernel_name(desc.Cin, desc.Cout, True, split, dy_cb is not None, False, d.N * d.H * d.W), conv_work(d)):
-            if split:
-                check(L.mcdseg_conv_split_dgrad(ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(dy, a, b)),
-                                                _cb_slice(dy_cb, a, desc.Cout, desc.Ho * desc.Wo), _p(dy_bound), _p(wd),
-                                                _p(w_bound), _p(dx[a:b]), _stream()), "conv_split_dgrad")
-            else:
+        name = (_window_name(d, dy_cb is not None, True) if split else None) \
+            or gemm_kernel_name(desc.Cin, desc.Cout, True, split, dy_cb is not None, False, d.N * d.H * d.W)
+        if split:
+            _split_launches(d, dy_cb is not None, True, name, lambda part: check(L.mcdseg_conv_split_dgrad_part(
+                ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(dy, a, b)), _cb_slice(dy_cb, a, desc.Cout, desc.Ho * desc.Wo), _p(dy_bound),
+                _p(wd), _p(w_bound), _p(dx[a:b]), part, _stream()), "conv_split_dgrad"))
+        else:
+            with _timed(name, conv_work(d)):
                 check(L.mcdseg_conv_dgrad(ctypes.byref(d), _p(dy[a:b]), _p(wd), _p(dx[a:b]), _stream()), "conv_dgrad")
     return dx
 
@@ -576,9 +609,12 @@ def _wgrad_split_plan(desc, have_cb=False):
 def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None, x_bound=None, dy_bound=None):
     L = lib()
     total = None
-    pieces = _batch_pieces(desc)
-    if x_cb is None or dy_cb is None or (len(pieces) > 1 and desc.Cin <= 16):
-        x_cb = dy_cb = None  # both companions or none; the thin layers' window kernel takes whole batches only
+    if x_cb is None or dy_cb is None:
+        x_cb = dy_cb = None  # both companions or none
+    pieces = _batch_pieces(desc, wgrad_cb=x_cb is not None)
+    if x_cb is not None and len(pieces) > 1 and desc.Cin <= 16:
+        x_cb = dy_cb = None  # the thin layers' window kernel takes whole batches only: the cut batch gathers fp32 values (with the slack)
+        pieces = _batch_pieces(desc, wgrad_cb=False)
     split = _wgrad_split_plan(desc, x_cb is not None)
     if split and x_cb is None:
         x_bound, dy_bound = _bound_or_measure(x, x_bound), _bound_or_measure(dy, dy_bound)

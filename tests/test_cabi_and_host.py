@@ -55,6 +55,53 @@ def test_library_exports_every_header_symbol():
         assert "__HIP_PLATFORM" not in text and "cuda_runtime" not in text and "hipify" not in text.lower()
 
 
+@pytest.mark.parametrize("math", ["f16x3", "bf16x6"])
+def test_weight_gradient_batch_pieces_respect_the_library_limit(monkeypatch, math):
+    """every piece ``ops._batch_pieces`` hands to the weight gradient must pass the library's own operand-range rule
+    (mcdseg_conv_wgrad_fits = the check inside mcdseg_conv_wgrad / mcdseg_conv_split_wgrad) -- also where the weight gradient still
+    gathers fp32 values with a 128-channel tile of slack although forward and data gradient run slack-free: thin 16-channel
+    layers cut along N (companions dropped), bf16x6's thin layers, 1x1 shortcuts.  Host arithmetic only."""
+    import ctypes
+    import mcdseg
+    from mcdseg import ops
+    mcdseg.build()
+    monkeypatch.setattr(ops, "CONV_MATH", math)
+    L, mid = mcdseg.lib(), ops.MATH_ID[math]
+    cases = [  # (N, Cin, H, W, Cout, k, stride, dil)
+        (40, 16, 720, 1280, 16, 3, 1, 1),    # cfg5's full-resolution 16 -> 16 layer past one launch: pieces lose their companions
+        (36, 16, 720, 1280, 16, 3, 1, 1),    # 35-image pieces of it failed the (N*C + 128) rule in round 3
+        (32, 16, 720, 1280, 32, 3, 2, 1),    # 16 -> 32 stride 2
+        (64, 16, 720, 1280, 32, 1, 2, 1),    # DRN-C's 1x1 stride-2 shortcut
+        (32, 2048, 90, 160, 512, 3, 1, 2),   # cfg5's widest tensor (3.8 GB): cut with companions
+        (32, 256, 180, 320, 256, 3, 1, 1),
+        (16, 512, 60, 80, 512, 3, 1, 4),     # cfg2: one launch
+    ]
+    for n, cin, h, w, cout, k, stride, dil in cases:
+        pad = dil * (k // 2)
+        desc = ops.conv_desc((n, cin, h, w), (cout, cin, k, k), stride, pad, dil)
+        for have_cb in (True, False):
+            pieces = ops._batch_pieces(desc, wgrad_cb=have_cb)
+            if have_cb and len(pieces) > 1 and cin <= 16:  # (what ops._conv_wgrad does: the thin window kernel takes whole batches only)
+                have_cb, pieces = False, ops._batch_pieces(desc, wgrad_cb=False)
+            assert pieces[0][0] == 0 and pieces[-1][1] == n and all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+            for a, b in pieces:
+                d = desc if (a, b) == (0, n) else ops._sub_desc(desc, b - a, n if have_cb else 0)
+                assert L.mcdseg_conv_wgrad_fits(ctypes.byref(d), mid, int(have_cb)) == 1, (math, n, cin, cout, h, w, have_cb, a, b)
+    # the rule itself: fp32-gathering plans need the tile of slack, companion-reading plans do not
+    d = ops.conv_desc((35, 16, 720, 1280), (16, 16, 3, 3), 1, 1, 1)
+    assert (35 * 16 + 128) * 720 * 1280 * 4 >= 2 ** 31 > 35 * 16 * 720 * 1280 * 4
+    assert L.mcdseg_conv_wgrad_fits(ctypes.byref(d), mid, 0) == 0
+    assert L.mcdseg_conv_wgrad_fits(ctypes.byref(d), 0, 0) == 0
+    if math == "f16x3":
+        assert L.mcdseg_conv_wgrad_variant(ctypes.byref(d), mid, 1) == 15 and L.mcdseg_conv_wgrad_fits(ctypes.byref(d), mid, 1) == 1
+    else:
+        assert L.mcdseg_conv_wgrad_fits(ctypes.byref(d), mid, 1) == 0  # (bf16x6 has no thin window kernel)
+    # a small limit still cuts (the GPU tests force pieces that way)
+    monkeypatch.setattr(ops, "MAX_CONV_BYTES", 2 * 4 * 128 * 32 * 32)
+    d = ops.conv_desc((5, 128, 32, 32), (128, 128, 3, 3), 1, 1, 1)
+    assert ops._batch_pieces(d, wgrad_cb=True) == ops._batch_pieces(d) == [(0, 2), (2, 4), (4, 5)]
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "multichannel-semseg-with-uda_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -1016,7 +1016,7 @@ def test_conv_large_tile_kernels(case):
         dx = ops._conv_dgrad(desc, gyg, wd, None, gy_bound, pk.w_bound)
     finally:
         ops.LAUNCH_TIMER = prev
-    big = [nm for nm in names if "4, 2, 2, 2" in nm or "4, 4, 2, 2" in nm]
+    big = [nm for nm in names if "4, 2, 2, 2" in nm or "4, 4, 2, 2" in nm or "conv_gemm_split_pp_kernel" in nm]
     assert big, "no large-tile kernel ran: %s" % names
     _assert_close(y_cb, ref, 2e-5, "fprop (large tile)")
     _assert_close(dx_cb, gx_ref, 2e-5, "dgrad (large tile)")
@@ -1047,6 +1047,84 @@ def test_conv_large_tile_kernels(case):
     merr = float((mean.double().cpu() - r.mean((0, 2, 3))).abs().max())
     assert merr <= 1e-5 * float(r.std()), "fused BN mean off by %.3e (output std %.3e)" % (merr, float(r.std()))
     _assert_close(rstd, (r.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt(), 1e-5, "fused BN rstd")
+
+
+# (Cin, Cout, k, stride, dil, N, H, W, math): one or two rounds of 256 x 256 tiles for the 8-wave ping-pong kernel plus a ragged rest
+PINGPONG_CASES = [
+    (64, 512, 3, 1, 2, 2, 160, 131, "f16x3"),   # forward M = 512: 326 tiles -> one round (128 pixel tiles) + 9 152 ragged pixels on 256 x 128
+    (512, 64, 3, 1, 4, 2, 160, 131, "f16x3"),   # its mirror: the DATA gradient has M = Cin = 512
+    (64, 256, 3, 1, 1, 3, 150, 160, "f16x3"),   # M = 256 (one row tile): 256 of 281 pixel tiles, the rest on 128 x 128
+    (48, 256, 1, 1, 1, 4, 128, 129, "f16x3"),   # 1x1: three K-steps (prologue and tail of the K loop only); 258 full tiles
+    (24, 256, 3, 2, 1, 1, 512, 514, "f16x3"),   # stride-2 forward, ragged contraction (24 channels = 1.5 K-steps per tap)
+    (64, 512, 3, 1, 2, 2, 160, 131, "f16x1"),   # the reduced-precision arithmetic (one term, one staged piece)
+]
+
+
+@pytest.mark.parametrize("case", PINGPONG_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_pingpong_tile(case, monkeypatch):
+    """``conv_gemm_split_pp_kernel`` (csrc/conv_gemm_split_pp.hip: 256 x 256 tile, eight waves in two groups half a K-step apart) takes
+    whole rounds of one tile per CU, the 4-wave tiles the remaining pixels.  Forward (+ fused BatchNorm partial rows) and data
+    gradient of such a two-launch convolution against fp64, and BIT FOR BIT against the same convolution with the kernel switched off
+    (MCDSEG_PINGPONG=0: same K order, same term order, same 64-pixel statistic rows); the parts API writes what the whole call writes."""
+    dev = _dev()
+    import ctypes
+    from mcdseg import ops
+    cin, cout, k, stride, d, n, h, w, math = case
+    monkeypatch.setattr(ops, "CONV_MATH", math)
+    x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, stride, d, h, w, n, False), 41)
+    desc = ops.conv_desc(x.shape, wt.shape, stride, pad, d)
+    pk = ops.PackedWeights()
+    wf, wd, mpf = pk.get(wt.to(dev), desc)
+    xg = x.to(dev)
+    gy = torch.randn(n, cout, desc.Ho, desc.Wo, generator=torch.Generator().manual_seed(42))
+    gyg = gy.to(dev)
+    x_cb, x_bound = ops.split_companion(xg)
+    gy_cb, gy_bound = ops.split_companion(gyg)
+    L, mid = ops.lib(), ops.MATH_ID[math]
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    outs = {}
+    for tag in ("pp", "off"):
+        monkeypatch.setenv("MCDSEG_PINGPONG", "1" if tag == "pp" else "0")
+        names = []
+
+        class _Names:
+            def wants(self, name):
+                names.append(name)
+                return False
+        prev, ops.LAUNCH_TIMER = ops.LAUNCH_TIMER, _Names()
+        try:
+            y, part, rows = ops._conv_fprop(desc, xg, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)
+            dx = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound) if stride == 1 else None
+        finally:
+            ops.LAUNCH_TIMER = prev
+        outs[tag] = (y, dx, part, rows, names)
+        for dgrad, m, pix in ((0, cout, n * desc.Ho * desc.Wo), (1, cin, n * h * w)):
+            pp = L.mcdseg_conv_split_parts(ctypes.byref(desc), mid, 1, dgrad)
+            tiles = (pix // 256) * (m // 256) if m % 256 == 0 and (dgrad == 0 or stride == 1) else 0
+            want = (tiles // cus) * cus // max(1, m // 256) * 256 if tag == "pp" else 0
+            assert pp == min(want, pix // 256 * 256), (tag, dgrad, pp, want)
+    y, dx, part, rows, names = outs["pp"]
+    assert any(nm in (ops.pingpong_kernel_name(False), ops.pingpong_kernel_name(True)) for nm in names), names
+    assert not any("conv_gemm_split_pp_kernel" in nm for nm in outs["off"][4]), outs["off"][4]
+    assert torch.equal(y, outs["off"][0]), "forward differs from the 4-wave tiles (max %.3e)" % float((y - outs["off"][0]).abs().max())
+    assert rows == outs["off"][3] and torch.equal(part, outs["off"][2]), "fused BatchNorm partial rows differ"
+    if dx is not None:
+        assert torch.equal(dx, outs["off"][1]), "data gradient differs from the 4-wave tiles"
+    if math == "f16x3":
+        x64, w64 = x.double().requires_grad_(), wt.double()
+        ref = F.conv2d(x64, w64, None, stride, pad, d)
+        _assert_close(y, ref, 2e-5, "forward (ping-pong + rest)")
+        if dx is not None:
+            (gx_ref,) = torch.autograd.grad(ref, [x64], gy.double())
+            _assert_close(dx, gx_ref, 2e-5, "data gradient (ping-pong + rest)")
+    # parts 1 + 2 of the C ABI write exactly what part 0 writes (poisoned output, two calls)
+    monkeypatch.setenv("MCDSEG_PINGPONG", "1")
+    y2 = torch.full_like(y, float("nan"))
+    part2 = torch.full_like(part, float("nan"))
+    for prt in (2, 1):
+        ops.check(L.mcdseg_conv_split_fprop_part(ctypes.byref(desc), mid, None, ops._p(x_cb), ops._p(x_bound), ops._p(wf), ops._p(pk.w_bound), None,
+                                                 ops._p(y2), ops._p(part2), prt, ops._stream()), "conv_split_fprop_part")
+    assert torch.equal(y2, y) and torch.equal(part2, part)
 
 
 @pytest.mark.parametrize("case", [(128, 128, 3, 1, 2, 45, 67), (128, 256, 3, 2, 2, 33, 40), (256, 128, 3, 2, 1, 47, 30), (136, 200, 1, 1, 3, 29, 31)],
