@@ -21,7 +21,9 @@ bytes per launch / its average launch duration, against the MFMA peak of the ari
 ``roofline_forward`` / ``roofline_wgrad`` are the same for the forward / weight-gradient convolution carrying the most FLOPs.  The pass is matrix-rate bound,
 not HBM bound: ``step_accounting`` says so next to the raw HBM fraction the metric asks for.
 ``cpu_baseline`` times the CPU oracle (plain PyTorch restatement of the reference) on a bounded sample of the same
-workload on the host cores (rank 0, N = 1 only).
+workload on the host cores (rank 0, N = 1 only).  ``other_configs`` (N = 1 only, after the timed region): full A+B+C steps of BASELINE
+configs 3-5 at their stated per-GPU sizes -- parity-tested configurations, timed here so that the driver sees them; they never enter
+``value``.  ``collective_ms_per_step`` (N > 1): the time the compute stream stands still for the gradient exchange.
 """
 import argparse
 import json
@@ -119,6 +121,73 @@ def build_hip(args, dev):
     if args.no_forward_reuse:
         solver.reuse_tgt = False
     return solver, (g, f1, f2)
+
+
+def other_config(tag, dev, steps, n_class=41):
+    """One of BASELINE's other configurations on synthetic device-resident batches: 1 warm-up + ``steps`` timed full A+B+C steps
+    (adapt_mfnet_trainer.py:174-244, adapt_multitask_trainer.py:166-239, adapt_trainer.py:155-220 on drn_d_105)."""
+    import torch
+    from loss import CrossEntropyLoss2d, Diff2d, get_prob_distance_criterion
+    from mcdseg import ops
+    from models.model_util import get_models, get_multitask_models, get_optimizer
+    from solvers.solver import MCDSolver, MFNetMCDSolver, MultiTaskMCDSolver
+    n, h, w, net, math, storage = {"cfg3": (16, 480, 640, "drn_d_38", None, "fp32"), "cfg4": (8, 480, 640, "drn_d_38", None, "fp32"),
+                                   "cfg5": (32, 720, 1280, "drn_d_105", None, "compact"),
+                                   "cfg5_f16": (32, 720, 1280, "drn_d_105", "f16x1", "compact")}[tag]
+    prev = (ops.CONV_MATH, ops.ACT_STORAGE)
+    ops.CONV_MATH, ops.ACT_STORAGE = math or prev[0], storage
+    try:
+        def opt(params):
+            return get_optimizer(params, "sgd", 1e-3, 0.9, 2e-5)
+        cw = torch.ones(n_class)
+        cw[n_class - 1] = 0
+        crit, crit_d = CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff")
+        torch.manual_seed(0)
+        if tag == "cfg3":
+            g3, g1, f1, f2 = get_models(net, 6, n_class, method="MFNet-ScoreAddFusion")
+            for m in (g3, g1, f1, f2):
+                m.to(dev).train()
+            solver = MFNetMCDSolver(g3, g1, f1, f2, opt(list(g3.parameters()) + list(g1.parameters())),
+                                    opt(list(f1.parameters()) + list(f2.parameters())), crit, crit_d, num_k=4)
+            what = "adapt_mfnet_trainer MFNet-ScoreAddFusion, two drn_d_38 encoders"
+        elif tag == "cfg4":
+            enc, dec = get_multitask_models(net, 6, n_class, CrossEntropyLoss2d(cw), Diff2d())
+            enc.to(dev).train(), dec.to(dev).train()
+            solver = MultiTaskMCDSolver(enc, dec, opt(enc.parameters()), opt(dec.parameters()), num_k=4)
+            what = "adapt_multitask_trainer seg + HHA-regression decoders, drn_d_38 RGB encoder"
+        else:
+            g, f1, f2 = get_models(net, 6, n_class, method="MCD")
+            for m in (g, f1, f2):
+                m.to(dev).train()
+            solver = MCDSolver(g, f1, f2, opt(g.parameters()), opt(list(f1.parameters()) + list(f2.parameters())), crit, crit_d, num_k=4)
+            what = "adapt_trainer MCD drn_d_105, activations kept as 2 x fp16 companions (MCDSEG_ACT_STORAGE=compact)"
+        gen = torch.Generator(device=dev).manual_seed(1234)
+        src = torch.randn(n, 6, h, w, generator=gen, device=dev)
+        lbl = torch.randint(0, n_class, (n, h, w), generator=gen, device=dev, dtype=torch.int64)
+        tgt = torch.randn(n, 6, h, w, generator=gen, device=dev)
+        torch.cuda.reset_peak_memory_stats(dev)
+        ops.WGRAD_STREAM_STATS.update(deferred=0, no_room=0)
+        out = solver.step(src, lbl, tgt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = solver.step(src, lbl, tgt)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res = {"workload": "%s, bs=%d/GPU synthetic 6x%dx%d, full A+B+C step (num_k=4)" % (what, n, h, w), "conv_math": ops.CONV_MATH,
+               "steps": steps, "ms_per_step": round(1e3 * dt, 1), "pairs_per_s": round(n / dt, 3),
+               "peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1), "c_loss": float(out[0]), "d_loss": float(out[1]),
+               "wgrad_stream": dict(ops.WGRAD_STREAM_STATS)}
+        del solver, src, lbl, tgt
+        return res
+    finally:
+        ops.CONV_MATH, ops.ACT_STORAGE = prev
+        torch.cuda.empty_cache()
+
+
+def is_forward_conv(name):
+    """conv_gemm*<..., DGRAD, PRESPLIT> / conv_gemm_split_pp_kernel<P, DGRAD>: the instantiations with DGRAD = false"""
+    return name.startswith("conv_gemm") and (", false, " in name or name.endswith(", false>"))
 
 
 def host_cpu():
@@ -288,6 +357,10 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f16"], default="f32",
                     help="f32 (default, the judged configuration): fp32-grade split arithmetic; f16: reduced precision, one fp16 term per product "
                          "(MCDSEG_CONV_MATH=f16x1; BASELINE config 5's intent) -- reported with its own dtype label")
+    ap.add_argument("--other_configs", default="cfg3,cfg4,cfg5,cfg5_f16",
+                    help="BASELINE configs 3-5 timed after the judged region (N = 1 only; '' = skip): cfg3 MFNet N=16, cfg4 multitask N=8, "
+                         "cfg5 drn_d_105 N=32 at 720x1280 with compact activation storage, cfg5_f16 the same in the reduced-precision arithmetic")
+    ap.add_argument("--other_steps", type=int, default=3)
     ap.add_argument("--timer", choices=sorted(TIMED_FAMILIES), default="all", help="kernel families bracketed by HIP events")
     ap.add_argument("--timer_steps", type=int, default=1,
                     help="how many of the timed steps (the last ones) carry the per-launch HIP events: bracketing all ~1 500 launches "
@@ -338,6 +411,8 @@ def main():
     torch.cuda.synchronize()
     mdist.barrier()
     torch.cuda.synchronize()
+    ops.WGRAD_STREAM_STATS.update(deferred=0, no_room=0)
+    mdist.COLLECTIVE_EVENTS = [] if mdist.is_distributed() else None
     t0 = time.perf_counter()
     for i in range(args.steps):
         timer.enabled = i >= args.steps - args.timer_steps
@@ -347,6 +422,18 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    wgrad_stream = dict(ops.WGRAD_STREAM_STATS)
+    collectives, mdist.COLLECTIVE_EVENTS = mdist.COLLECTIVE_EVENTS, None
+    coll = None
+    if collectives is not None:
+        ms = [a.elapsed_time(b) for _, a, b in collectives]
+        big = [(nb, m) for (nb, _, _), m in zip(collectives, ms) if nb >= (1 << 20)]
+        coll = {"collective_ms_per_step": round(sum(ms) / args.steps, 3), "collectives_per_step": round(len(ms) / args.steps, 1),
+                "bytes_per_step": int(sum(nb for nb, _, _ in collectives) / args.steps),
+                "large_all_reduce_avg_ms": round(sum(m for _, m in big) / len(big), 3) if big else None,
+                "large_all_reduce_avg_mb": round(sum(nb for nb, _ in big) / len(big) / 1e6, 1) if big else None,
+                "note": "HIP events on the compute stream around every all-reduce (or around the wait for a bucketed one): the time that "
+                        "stream stands still for the exchange, rank 0"}
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if mdist.is_distributed():
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
@@ -400,11 +487,29 @@ def main():
                       "note": "same build with MCDSEG_OVERLAP_WGRAD=0 (every kernel on one stream), measured after the timed region; "
                               "identical results bit for bit"}
 
+    others = None
+    if world == 1 and args.other_configs.strip():
+        # free the judged configuration first: cfg5 at N = 32 takes 232 of the 288 GB
+        kern_summary = timer.summary()
+        reuse_tgt = solver.reuse_tgt
+        ops.LAUNCH_TIMER = None
+        del solver, models, pool
+        torch.cuda.empty_cache()
+        others = {}
+        for tag in [t.strip() for t in args.other_configs.split(",") if t.strip()]:
+            try:
+                others[tag] = other_config(tag, dev, max(1, args.other_steps), args.n_class)
+            except Exception as e:  # (a configuration that does not fit or fails must not take the judged line down)
+                others[tag] = {"error": "%s: %s" % (type(e).__name__, e)}
+                torch.cuda.empty_cache()
+    else:
+        kern_summary, reuse_tgt = timer.summary(), solver.reuse_tgt
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         pairs = args.batch * world * args.steps
         value = pairs / elapsed
-        kern = timer.summary()
+        kern = kern_summary
         total_ms = sum(k["ms"] for k in kern.values()) or 1.0
         for k in kern.values():
             k["avg_ms"] = k["ms"] / max(k["launches"], 1)
@@ -418,7 +523,7 @@ def main():
         if kern:
             dom = max(kern, key=lambda n: kern[n]["ms"])
             roofline = kernel_roofline(dom, kern[dom], ops.CONV_MATH, pmc_traffic(dom) if default_cfg else None)
-            fwd = {n: v for n, v in kern.items() if n.startswith("conv_gemm") and ", false, " in n}
+            fwd = {n: v for n, v in kern.items() if is_forward_conv(n)}
             if fwd:
                 fn = max(fwd, key=lambda n: fwd[n]["flops"])
                 roofline_fwd = kernel_roofline(fn, fwd[fn], ops.CONV_MATH, pmc_traffic(fn) if default_cfg else None)
@@ -430,7 +535,7 @@ def main():
         step_acc = None
         if args.net == "drn_d_38" and (args.height, args.width, args.input_ch) == (480, 640, 6):
             # passes actually executed per pair: step B's two generator backward passes elided; its target forward is step C's first
-            fwd_p, bwd_p = (6 if solver.reuse_tgt else 7), 5
+            fwd_p, bwd_p = (6 if reuse_tgt else 7), 5
             gf = GF_FWD_PER_IMG * (fwd_p + 2 * bwd_p)
             gb = GB_FWD_PER_IMG * fwd_p + GB_BWD_PER_IMG * bwd_p
             t_pair = elapsed / (args.batch * args.steps)
@@ -467,11 +572,14 @@ def main():
                                        "; step B's target forward doubles as step C's first (generator unchanged in between; BatchNorm "
                                        "running update applied twice) -- %d generator forwards + 5 backwards per step, bit-identical "
                                        "weights/statistics/losses to the literal 7-forward schedule (--no_forward_reuse runs that)"
-                                       % 6 if solver.reuse_tgt else "; literal 7 generator forwards + 5 backwards per step")},
-            "value_literal_schedule": literal["value"] if literal else (round(value, 3) if not solver.reuse_tgt else None),
-            "ms_per_step_literal_schedule": literal["ms_per_step"] if literal else (round(ms_per_step, 2) if not solver.reuse_tgt else None),
+                                       % 6 if reuse_tgt else "; literal 7 generator forwards + 5 backwards per step")},
+            "value_literal_schedule": literal["value"] if literal else (round(value, 3) if not reuse_tgt else None),
+            "ms_per_step_literal_schedule": literal["ms_per_step"] if literal else (round(ms_per_step, 2) if not reuse_tgt else None),
             "literal_schedule": literal,
             "one_stream": one_stream,
+            "wgrad_stream": wgrad_stream,
+            "collectives": coll,
+            "other_configs": others,
             "roofline": roofline,
             "roofline_forward": roofline_fwd,
             "roofline_wgrad": roofline_wg,

@@ -133,6 +133,9 @@ int mcdseg_conv_split_dgrad(const mcdseg_conv_desc* d, int32_t math, const float
  * those do), 1 (only the ping-pong launch) or 2 (only the rest); parts 1 + 2 write exactly what part 0 writes.  They exist so that
  * a profiler or bench.py can bracket each kernel with its own HIP events.  Reference: nn.Conv2d, models/drn.py:21-23. */
 int64_t mcdseg_conv_split_parts(const mcdseg_conv_desc* d, int32_t math, int32_t presplit, int32_t dgrad);
+/* 1 when "the rest" (part 2; the whole convolution when mcdseg_conv_split_parts returns 0) runs on the ping-pong kernel's 256 x 128
+ * tile, 0 when it runs on the 4-wave tiles -- the kernel name a profiler will see. */
+int32_t mcdseg_conv_split_rest_pingpong(const mcdseg_conv_desc* d, int32_t math, int32_t presplit, int32_t dgrad);
 int mcdseg_conv_split_fprop_part(const mcdseg_conv_desc* d, int32_t math, const float* x, const void* x_cb, const float* x_bound,
                                  const void* wp_fprop, const float* w_bound, const float* bias, float* y, float* stat_partials,
                                  int32_t part, void* stream);

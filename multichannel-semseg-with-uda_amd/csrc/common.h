@@ -41,13 +41,24 @@ static inline int mcd_kp(int K) { return round_up(K, mcd_bk(K)); }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Butterfly steps of the wave reductions without the LDS crossbar: v + (v of lane ^ 1, 2, 4, 8) as DPP row operations -- quad
+// permutes for 1 and 2; for 4 and 8 the half-row / row mirror, which pairs a lane with one that already holds the same value as
+// lane ^ 4 / lane ^ 8 (after the earlier steps the sums are uniform within groups of 4 / 8 lanes, bit for bit: IEEE addition
+// commutes) -- and one ds_swizzle for lane ^ 16.  Same sums in the same order as five __shfl_xor steps, i.e. the same bits; but
+// __shfl_xor is a ds_bpermute (an LDS-crossbar round trip of ~100 cycles), and five DEPENDENT ones per sum made the fused
+// BatchNorm statistics of a 256 x 256 convolution tile (128 sums per wave) cost 67 000 cycles -- 17 % of a 256-channel layer's kernel.
+template <int CTRL>
+__device__ __forceinline__ float mcd_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 __device__ __forceinline__ float wave_half_sum(float v) {
   // sum over the 32 lanes that share (lane >> 5); every lane of the half ends with the total
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 16);
+  v += mcd_dpp<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+  v += mcd_dpp<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+  v += mcd_dpp<0x141>(v);  // row_half_mirror: lane -> 7 - lane (the other quad of the 8)
+  v += mcd_dpp<0x140>(v);  // row_mirror: lane -> 15 - lane (the other 8 of the 16)
+  v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // bit mode, xor 0x10: lane ^ 16
   return v;
 }
 

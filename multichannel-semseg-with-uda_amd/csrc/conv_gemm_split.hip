@@ -886,6 +886,8 @@ void launch(const ConvSplitParams& p, int64_t pix0, hipStream_t st) {
 // the 8-wave ping-pong tile (conv_gemm_split_pp.hip) takes whole rounds of 256 x 256 tiles, the kernels of this file the rest
 int64_t mcdseg_internal_conv_pp_pixels(const ConvSplitParams& p, int math, bool dgrad);
 int mcdseg_internal_conv_pp_launch(const ConvSplitParams& p, int math, bool dgrad, int64_t pixels, hipStream_t st);
+int mcdseg_internal_conv_pp_rest(const ConvSplitParams& p, int math, bool dgrad);
+int mcdseg_internal_conv_pp_rest_launch(const ConvSplitParams& p, int math, bool dgrad, int64_t pix0, hipStream_t st);
 
 namespace {
 
@@ -896,6 +898,7 @@ int launch_math(int math, const ConvSplitParams& p, int part, hipStream_t st) {
   if (pp > 0 && part != 2)
     if (int rc = mcdseg_internal_conv_pp_launch(p, math, DGRAD, pp, st)) return rc;
   if (pp >= p.P || part == 1) return 0;
+  if (mcdseg_internal_conv_pp_rest(p, math, DGRAD)) return mcdseg_internal_conv_pp_rest_launch(p, math, DGRAD, pp, st);
   if (math == MCDSEG_MATH_F16X3)
     launch<SplitF16x3, DGRAD>(p, pp, st);
   else if (math == MCDSEG_MATH_F16X1)
@@ -1166,6 +1169,18 @@ extern "C" int64_t mcdseg_conv_split_parts(const mcdseg_conv_desc* d, int32_t ma
   ConvSplitParams p;
   if (dgrad ? fill_dgrad_params(d, math, d, p) : fill_fprop_params(d, math, d, p)) return 0;
   return mcdseg_internal_conv_pp_pixels(p, math, dgrad != 0);
+}
+
+// 1 when the launch that `part` 2 stands for (every pixel mcdseg_conv_split_parts does not give to the 256 x 256 tile) runs on the
+// 256 x 128 ping-pong tile, 0 when it runs on the 4-wave tiles (kernel names for profilers / bench.py)
+extern "C" int32_t mcdseg_conv_split_rest_pingpong(const mcdseg_conv_desc* d, int32_t math, int32_t presplit, int32_t dgrad) {
+  if (d == nullptr || !mcd_math_known(math) || !presplit) return 0;
+  const int smath = mcd_storage_math(math);
+  if (smath == MCDSEG_MATH_F16X3 && mcdseg_internal_thin_window_ok(d, dgrad ? 1 : 0)) return 0;
+  if (!dgrad && mcdseg_internal_stem_ok(d)) return 0;
+  ConvSplitParams p;
+  if (dgrad ? fill_dgrad_params(d, math, d, p) : fill_fprop_params(d, math, d, p)) return 0;
+  return mcdseg_internal_conv_pp_rest(p, math, dgrad != 0);
 }
 
 extern "C" int mcdseg_conv_split_fprop_part(const mcdseg_conv_desc* d, int32_t math, const float* x, const void* x_cb, const float* x_bound,

@@ -34,18 +34,26 @@
 
 namespace {
 
-template <class P, bool DGRAD>
-__global__ __launch_bounds__(512) void conv_gemm_split_pp_kernel(ConvSplitParams p) {
-  constexpr int WM = 4, WN = 2, WAVES_N = 4;
-  constexpr int BM = 256, BN = 256, NT = 512, NS = 3;
+// WM x WN: 32 x 32 accumulator tiles per wave; QM x QN: the four waves of a group; the two groups split the rows.  Two shapes are built:
+//   <4, 2, 1, 4>  256 x 256, waves of 128 x 64, ONE workgroup per CU (96 KB of LDS): the fewest operand bytes per FLOP;
+//   <2, 2, 2, 2>  256 x 128, waves of 64 x 64 (<= 128 VGPRs), TWO workgroups per CU (2 x 72 KB): half the tile, so a partial last
+//                 round of workgroups costs half as much, and one workgroup's epilogue hides behind the other's K loop.
+template <class P, bool DGRAD, int WM, int WN, int QM, int QN>
+__global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_pp_kernel(ConvSplitParams p) {
+  static_assert(QM * QN == 4, "four waves per group");
+  constexpr int WAVES_N = QN;
+  constexpr int BM = 2 * QM * WM * 32, BN = QN * WN * 32, NT = 512, NS = 3;
   constexpr int NP = P::NP;          // pieces per operand
   constexpr int NPU = P::NPU;        // ... of which the policy multiplies (and the loop stages) the first NPU
   constexpr int NQ = 2 * NP;         // (piece, k-half) planes per K-step
   typedef typename P::frag frag;
   constexpr int A_BYTES = NQ * BM * 16, B_BYTES = NQ * BN * 16;
-  constexpr int A_DMAS = 2 * NPU * BM / NT;       // weight-slab DMAs per thread and K-step (piece-major slab: the staged pieces are its head)
-  constexpr int DMA_PER_STEP = A_DMAS + NPU;      // + one 16-byte unit of the pixel operand per staged piece
-  static_assert((2 * NPU * BM) % NT == 0 && BN * 2 == NT, "every wave issues the same number of DMAs (the waits are counted)");
+  constexpr int A_DMAS = 2 * NPU * BM / NT;        // weight-slab DMAs per thread and K-step (piece-major slab: the staged pieces are its head)
+  constexpr int B_UNITS = 2 * NPU * BN;            // 16-byte units of the pixel operand per K-step: [piece][k-half][pixel]
+  constexpr int B_DMAS = (B_UNITS + NT - 1) / NT;  // per thread (units past B_UNITS: an out-of-range DMA that deposits zeros in an unused plane)
+  constexpr int DMA_PER_STEP = A_DMAS + B_DMAS;
+  static_assert((2 * NPU * BM) % NT == 0 && NT % BN == 0 && BN >= 64, "every wave issues the same number of DMAs (the waits are counted)");
+  static_assert(B_DMAS * NT <= NQ * BN, "the zero-filled units stay inside the stage");
   static_assert(NS * (A_BYTES + B_BYTES) <= 160 * 1024, "LDS");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (A_BYTES + B_BYTES)];
@@ -55,22 +63,23 @@ __global__ __launch_bounds__(512) void conv_gemm_split_pp_kernel(ConvSplitParams
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 2;  // the group: SIMD partners are waves w and w + 4 (MI355X_MICROARCH.md item 9: split by wave >= 4, not by parity)
-  const int wn = wave & 3;
+  const int grp_id = wave >> 2;  // the group: SIMD partners are waves w and w + 4 (MI355X_MICROARCH.md item 9: split by wave >= 4, not by parity)
+  const int wm = grp_id * QM + (wave & 3) / QN;  // wave row / column inside the tile
+  const int wn = (wave & 3) % QN;
   const int l31 = lane & 31, lh = lane >> 5;
 
   const int m_tiles = p.Mp / BM;
-  const int n_tiles = p.tile_n1;  // this launch: pixel tiles 0 .. tile_n1 - 1, all of them full
-  const int per_xcd = (n_tiles + 7) >> 3;
+  const int n_tiles = p.tile_n1;  // this launch: pixel tiles tile_n0 .. tile_n1 - 1
+  const int per_xcd = (n_tiles - p.tile_n0 + 7) >> 3;
   const int xcd = blockIdx.x & 7;
   const int slot = blockIdx.x >> 3;
   const int tile_m = slot % m_tiles;
-  const int tile_n = xcd * per_xcd + slot / m_tiles;
+  const int tile_n = p.tile_n0 + xcd * per_xcd + slot / m_tiles;
   if (tile_n >= n_tiles) return;
 
-  // ---- this thread's gather pixel and k-half (the pixel never changes; waves 0-3 gather k-half 0, waves 4-7 k-half 1)
+  // ---- this thread's gather pixel (it never changes); unit i of the thread is plane (t + i NT) / BN = piece * 2 + k-half of that pixel
   const int bj = t & (BN - 1);
-  const int bh = wave >> 2;
+  const int plane0 = wave * 64 / BN;  // wave-uniform
   const int HWd = p.Hd * p.Wd;
   const int HWs = p.Hs * p.Ws;
   const int pix = tile_n * BN + bj;
@@ -123,12 +132,16 @@ __global__ __launch_bounds__(512) void conv_gemm_split_pp_kernel(ConvSplitParams
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wp_rs, (__attribute__((address_space(3))) void*)(adst + i * NT * 16), 16, a_voff[i], a_soff, 0, 0);
     const int rel = DGRAD ? (p.pad - l_ky * p.dil) * p.Ws + (p.pad - l_kx * p.dil) : (l_ky * p.dil - p.pad) * p.Ws + (l_kx * p.dil - p.pad);
     const unsigned voff = ((valid_mask >> l_tap) & 1u) ? (vbase + (unsigned)rel) * 16u : OOB;
-    const int grp = (l_c0 >> 3) + bh;
-    const int soff = grp < C8 ? grp * HWs * 16 : 0x7FFFFFFF;  // (a ragged last chunk: the range check deposits zeros)
-    unsigned char* bdst = Bs + buf * B_BYTES + (bh * BN + wave_px) * 16;
 #pragma unroll
-    for (int pc = 0; pc < NPU; ++pc)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(cb_rs[pc], (__attribute__((address_space(3))) void*)(bdst + pc * 2 * BN * 16), 16, voff, soff, 0, 0);
+    for (int i = 0; i < B_DMAS; ++i) {
+      const int plane = plane0 + i * (NT / BN);  // wave-uniform: piece = plane / 2, k-half = plane % 2
+      const int grp = (l_c0 >> 3) + (plane & 1);
+      // (a ragged last chunk, or a unit past the staged pieces: the range check deposits zeros)
+      const int soff = (grp < C8 && plane < 2 * NPU) ? grp * HWs * 16 : 0x7FFFFFFF;
+      unsigned char* bdst = Bs + buf * B_BYTES + (plane * BN + wave_px) * 16;
+      const __amdgpu_buffer_rsrc_t rs = (NPU > 1 && plane >= 2) ? cb_rs[NPU - 1] : cb_rs[0];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)bdst, 16, voff, soff, 0, 0);
+    }
 #else
     (void)buf;
 #endif
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(512) void conv_gemm_split_pp_kernel(ConvSplitParams
     issue(1);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  if (wm == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1 runs one barrier behind group 0 from here to the end of the K loop
+  if (grp_id == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1 runs one barrier behind group 0 from here to the end of the K loop
 
   frag fa[NP][WM], fb[NP][WN];
   int cur = 0, nxt2 = 2;
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(512) void conv_gemm_split_pp_kernel(ConvSplitParams
     cur = cur == 2 ? 0 : cur + 1;
     nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
   }
-  if (wm == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's last matrix-phase barrier
+  if (grp_id == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's last matrix-phase barrier
 
   // ---- epilogue (conv_gemm_split_kernel's, without the parity classes): acc[i][j][r] = D[row][col], row = (r&3) + 8*(r>>2) + 4*lh, col = l31
   if constexpr (P::SCALED) {
@@ -305,6 +318,15 @@ __global__ __launch_bounds__(512) void conv_gemm_split_pp_kernel(ConvSplitParams
   }
 }
 
+// Fewest whole rounds of 256 x 256 tiles for which the ping-pong kernels take a convolution.  Measured at BASELINE config 2's sizes
+// (N = 16, 60 x 80, same box, ms forward / data gradient, 4-wave tiles -> ping-pong): 512 -> 512 (600 tiles = 2.3 rounds) 0.892 / 0.894 ->
+// 0.816 / 0.800, 256 -> 512 0.476 / 0.477 -> 0.434 / 0.469; but 256 -> 256 (300 tiles = 1.2 rounds) 0.249 / 0.255 -> 0.253 / 0.246 and
+// 128 -> 256 0.135 -> 0.145: with one round the 15 % of the tiles left over take a third of the time.  (Read per call: tests lower it.)
+int pp_min_rounds() {
+  const char* e = getenv("MCDSEG_PP_MIN_ROUNDS");
+  return e ? atoi(e) : 2;
+}
+
 int compute_units() {  // one workgroup per CU: a launch is worth whole rounds of this many tiles
   static const int n = [] {
     const char* e = getenv("MCDSEG_PP_CUS");  // development knob
@@ -317,25 +339,64 @@ int compute_units() {  // one workgroup per CU: a launch is worth whole rounds o
   return n;
 }
 
-bool pp_enabled() {  // (read per call: a test runs one problem with and without the kernel)
+// MCDSEG_PINGPONG (development knob, read per call: a test runs one problem several ways): 0 the 4-wave tiles only; 1 whole rounds of
+// 256 x 256 tiles + the rest on the 4-wave tiles; 2 the 256 x 128 ping-pong tile for everything; 3 (default) whole rounds of 256 x 256
+// tiles + the rest on the 256 x 128 ping-pong tile
+int pp_mode() {
   const char* e = getenv("MCDSEG_PINGPONG");
-  return e == nullptr || atoi(e) != 0;
+  return e == nullptr ? 3 : atoi(e);
+}
+
+bool pp_applies(const ConvSplitParams& p, int math, bool dgrad) {
+  if (p.src_cb == nullptr || mcd_math_pieces(math) != 2 || (p.Mp % 256) != 0) return false;
+  return p.KH * p.KW <= 32 && !(dgrad && p.stride != 1) && (p.Cs & 7) == 0;
+}
+
+template <class P, bool DGRAD, int WM, int WN, int QM, int QN>
+void launch_tile(const ConvSplitParams& q, hipStream_t st) {
+  constexpr int BM = 2 * QM * WM * 32;
+  const dim3 grid((unsigned)(8 * ceil_div(q.tile_n1 - q.tile_n0, 8) * (q.Mp / BM)));
+  hipLaunchKernelGGL((conv_gemm_split_pp_kernel<P, DGRAD, WM, WN, QM, QN>), grid, dim3(512), 0, st, q);
+}
+
+template <int WM, int WN, int QM, int QN>
+void launch_math(const ConvSplitParams& q, int math, bool dgrad, hipStream_t st) {
+  if (math == MCDSEG_MATH_F16X1) {
+    if (dgrad)
+      launch_tile<SplitF16x1, true, WM, WN, QM, QN>(q, st);
+    else
+      launch_tile<SplitF16x1, false, WM, WN, QM, QN>(q, st);
+  } else {
+    if (dgrad)
+      launch_tile<SplitF16x3, true, WM, WN, QM, QN>(q, st);
+    else
+      launch_tile<SplitF16x3, false, WM, WN, QM, QN>(q, st);
+  }
 }
 
 }  // namespace
 
-// Pixels (a multiple of 256, counted from pixel 0) of this problem that the ping-pong kernel takes: whole rounds of one 256 x 256
-// tile per CU; 0 when the kernel does not apply (no pre-split operand, three-piece arithmetic, output rows not a multiple of 256,
-// strided data gradient, more than 32 taps, less than one round of tiles).
+// Pixels (a multiple of 256, counted from pixel 0) of this problem that the 256 x 256 ping-pong tile takes: whole rounds of one tile
+// per CU; 0 when it does not apply (no pre-split operand, three-piece arithmetic, output rows not a multiple of 256, strided data
+// gradient, more than 32 taps, less than one round of tiles).
 int64_t mcdseg_internal_conv_pp_pixels(const ConvSplitParams& p, int math, bool dgrad) {
-  if (!pp_enabled() || p.src_cb == nullptr || mcd_math_pieces(math) != 2 || (p.Mp % 256) != 0) return 0;
-  if (p.KH * p.KW > 32 || (dgrad && p.stride != 1) || (p.Cs & 7) != 0) return 0;
+  const int mode = pp_mode();
+  if ((mode != 1 && mode != 3) || !pp_applies(p, math, dgrad)) return 0;
   const int64_t m_tiles = p.Mp / 256, n_full = p.P / 256, cus = compute_units();
   const int64_t rounds = n_full * m_tiles / cus;
-  if (rounds < 1) return 0;
+  if (rounds < 1 || rounds < pp_min_rounds()) return 0;
   int64_t n_pp = rounds * cus / m_tiles;  // pixel tiles (all their row tiles) that make whole rounds
   if (n_pp > n_full) n_pp = n_full;
   return n_pp * 256;
+}
+
+// 1 when the pixels the 256 x 256 tile leaves (all of them when it takes none) run on the 256 x 128 ping-pong tile rather than on the
+// 4-wave tiles of conv_gemm_split.hip
+int mcdseg_internal_conv_pp_rest(const ConvSplitParams& p, int math, bool dgrad) {
+  const int mode = pp_mode();
+  if (!pp_applies(p, math, dgrad)) return 0;
+  if (mode == 2) return 1;
+  return mode == 3 && (p.P / 256) * (p.Mp / 256) / compute_units() >= (pp_min_rounds() > 1 ? pp_min_rounds() : 1) ? 1 : 0;
 }
 
 int mcdseg_internal_conv_pp_launch(const ConvSplitParams& p, int math, bool dgrad, int64_t pixels, hipStream_t st) {
@@ -343,18 +404,18 @@ int mcdseg_internal_conv_pp_launch(const ConvSplitParams& p, int math, bool dgra
   q.sub = 0;
   q.tile_n0 = 0;
   q.tile_n1 = (int)(pixels / 256);
-  const dim3 grid((unsigned)(8 * ceil_div(q.tile_n1, 8) * (p.Mp / 256)));
-  if (math == MCDSEG_MATH_F16X1) {
-    if (dgrad)
-      hipLaunchKernelGGL((conv_gemm_split_pp_kernel<SplitF16x1, true>), grid, dim3(512), 0, st, q);
-    else
-      hipLaunchKernelGGL((conv_gemm_split_pp_kernel<SplitF16x1, false>), grid, dim3(512), 0, st, q);
-  } else {
-    if (dgrad)
-      hipLaunchKernelGGL((conv_gemm_split_pp_kernel<SplitF16x3, true>), grid, dim3(512), 0, st, q);
-    else
-      hipLaunchKernelGGL((conv_gemm_split_pp_kernel<SplitF16x3, false>), grid, dim3(512), 0, st, q);
-  }
+  launch_math<4, 2, 1, 4>(q, math, dgrad, st);
   MCD_LAUNCH_CHECK("conv_gemm_split_pp");
+  return 0;
+}
+
+// the pixels from pix0 (a multiple of 256) to the end on the 256 x 128 ping-pong tile
+int mcdseg_internal_conv_pp_rest_launch(const ConvSplitParams& p, int math, bool dgrad, int64_t pix0, hipStream_t st) {
+  ConvSplitParams q = p;
+  q.sub = 0;
+  q.tile_n0 = (int)(pix0 / 128);
+  q.tile_n1 = ceil_div(p.P, 128);
+  launch_math<2, 2, 2, 2>(q, math, dgrad, st);
+  MCD_LAUNCH_CHECK("conv_gemm_split_pp (256 x 128)");
   return 0;
 }

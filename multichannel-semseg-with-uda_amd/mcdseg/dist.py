@@ -50,18 +50,52 @@ def init_from_env(backend=None):
     return dist.get_rank(), dist.get_world_size(), local
 
 
+# bench.py --gpus N: a list to which every collective on a GPU tensor appends (bytes, start event, end event) -- HIP events on the
+# caller's stream around the blocking all-reduce, or around the wait for an asynchronous one (the time the compute stream
+# stands still for the exchange; what overlapped with the backward pass does not show).  None: nothing is recorded.
+COLLECTIVE_EVENTS = None
+
+
+class _timed_collective:
+    def __init__(self, flat):
+        self.on = COLLECTIVE_EVENTS is not None and flat.is_cuda
+        self.nbytes = flat.numel() * flat.element_size()
+
+    def __enter__(self):
+        if self.on:
+            self.t0, self.t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.t0.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.t1.record()
+            COLLECTIVE_EVENTS.append((self.nbytes, self.t0, self.t1))
+
+
 def all_reduce_sum_(flat):
     """In-place sum of a flat buffer over all ranks (no-op when not distributed)."""
     if is_distributed():
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        with _timed_collective(flat):
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 
+class _AsyncSum:
+    """work handle of an asynchronous all-reduce; ``wait()`` orders the caller's stream behind it"""
+
+    def __init__(self, flat):
+        self.flat = flat
+        self.work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def wait(self):
+        with _timed_collective(self.flat):
+            self.work.wait()
+
+
 def all_reduce_sum_async(flat):
-    """Start the in-place sum and return the work handle (None when not distributed); ``handle.wait()`` orders the caller's
-    stream behind it"""
+    """Start the in-place sum and return a handle (None when not distributed); ``handle.wait()`` orders the caller's stream behind it"""
     if is_distributed():
-        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        return _AsyncSum(flat)
     return None
 
 

@@ -84,9 +84,10 @@ def gemm_kernel_name(m, k, dgrad, split=False, presplit=False, direct=False, pix
     return "conv_gemm_kernel<%s, %d, %s>" % (cfg, 8 if k <= 8 else 16, "true" if dgrad else "false")
 
 
-def pingpong_kernel_name(dgrad, math=None):
-    """rocprofv3's name of the 8-wave ping-pong tile (csrc/conv_gemm_split_pp.hip)"""
-    return "conv_gemm_split_pp_kernel<%s, %s>" % (POLICY[math or CONV_MATH], "true" if dgrad else "false")
+def pingpong_kernel_name(dgrad, math=None, small=False):
+    """rocprofv3's name of the 8-wave ping-pong kernel (csrc/conv_gemm_split_pp.hip): its 256 x 256 tile, or the 256 x 128 one"""
+    return "conv_gemm_split_pp_kernel<%s, %s, %s>" % (POLICY[math or CONV_MATH], "true" if dgrad else "false",
+                                                      "2, 2, 2, 2" if small else "4, 2, 1, 4")
 
 
 def _split_launches(d, presplit, dgrad, name, call):
@@ -100,6 +101,8 @@ def _split_launches(d, presplit, dgrad, name, call):
         with _timed(pingpong_kernel_name(dgrad), (flops * pp / pixels, byts * pp / pixels)):
             call(1)
     if pp < pixels:
+        if presplit and lib().mcdseg_conv_split_rest_pingpong(ctypes.byref(d), MATH_ID[CONV_MATH], 1, int(dgrad)):
+            name = pingpong_kernel_name(dgrad, small=True)
         with _timed(name, (flops * (pixels - pp) / pixels, byts * (pixels - pp) / pixels)):
             call(2 if pp > 0 else 0)
 
@@ -658,7 +661,7 @@ OVERLAP_WGRAD = os.environ.get("MCDSEG_OVERLAP_WGRAD", "2")
 if OVERLAP_WGRAD not in ("0", "1", "2"):
     raise ValueError("MCDSEG_OVERLAP_WGRAD must be 0, 1 or 2, got %r" % OVERLAP_WGRAD)
 _SIDE = {}
-_PENDING = {}  # device index -> event behind the last weight gradient on the side stream that the main stream has not waited for
+_PENDING = {}  # device index -> (event behind the last weight gradient on the side stream, the stream that has to wait for it)
 
 
 def _side_stream(device):
@@ -670,12 +673,16 @@ def _side_stream(device):
     return _SIDE[key]
 
 
-def join_side_streams():
-    """the current stream of every device waits for the weight gradients still running on that device's side stream (the
-    ``_LateGrad`` nodes call it; also queued as a final callback of every backward pass that deferred one; safe at any time)"""
-    for key in list(_PENDING):
-        torch.cuda.current_stream(key).wait_event(_PENDING.pop(key))
-        _HELD.pop(key, None)  # (after the wait: the operands of the deferred launches go back to the allocator)
+def join_side_streams(device_index=None):
+    """The consumer stream of a device -- the stream its backward pass ran on when the weight gradients were deferred, recorded with
+    the event -- waits for the weight gradients still running on that device's side stream.  A ``_LateGrad`` node joins its own
+    device only (under nn.DataParallel every device has its own autograd thread, whose current stream says nothing about another
+    device's); the final callback of a backward pass that deferred one joins all of them.  Safe at any time."""
+    for key in ([device_index] if device_index is not None else list(_PENDING)):
+        rec = _PENDING.pop(key, None)
+        if rec is not None:
+            rec[1].wait_event(rec[0])
+            _HELD.pop(key, None)  # (after the wait: the operands of the deferred launches go back to the allocator)
 
 
 class _LateGrad(torch.autograd.Function):
@@ -687,7 +694,7 @@ class _LateGrad(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        join_side_streams()
+        join_side_streams(g.device.index)
         return g
 
 
@@ -742,7 +749,8 @@ def _room_to_defer(device):
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _TOTAL_MEM:
         _TOTAL_MEM[key] = torch.cuda.get_device_properties(key).total_memory
-    return torch.cuda.memory_reserved(key) < DEFER_MEM_FRACTION * _TOTAL_MEM[key]
+    # (memory IN USE, not memory_reserved: cached-but-free blocks left by one large pass would latch deferral off for the rest of the run)
+    return torch.cuda.memory_allocated(key) < DEFER_MEM_FRACTION * _TOTAL_MEM[key]
 
 
 def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_bound=None, x_bound=None, w_bound=None, defer=False):
@@ -778,7 +786,7 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_
     WGRAD_STREAM_STATS["deferred"] += 1
     ev = torch.cuda.Event()
     ev.record(side)
-    _PENDING[key] = ev
+    _PENDING[key] = (ev, main)
     held = _HELD.setdefault(key, collections.deque())
     held.append((ev, keep))
     while len(held) > MAX_LAG:

@@ -94,7 +94,7 @@ class FlatSGD(torch.optim.Optimizer):
         for p, o in reversed(list(zip(fl["params"], fl["offs"]))):
             n = p.numel()
             if cur is None or cur["hi"] - o > limit:
-                cur = dict(lo=o, hi=o + n, ids=set(), arrived=0, work=None)
+                cur = dict(lo=o, hi=o + n, ids=set(), arrived=0, work=None, dirty=False)
                 fl["buckets"].append(cur)
             cur["lo"] = o
             cur["ids"].add(id(p))
@@ -107,9 +107,19 @@ class FlatSGD(torch.optim.Optimizer):
         if fl is None or id(p) not in fl["bucket_of"] or p.grad is None:
             return
         b = fl["bucket_of"][id(p)]
+        if b["work"] is not None or b["dirty"] or b["arrived"] >= len(b["ids"]):
+            # A SECOND backward pass before step() (MCDSolver's step B: two loss.backward() calls, then optimizer_f.step()): p.grad
+            # now holds the accumulated local gradient, while the bucket's slice is being -- or has been -- summed over the ranks
+            # from the first pass alone.  Wait for the collective in flight (the copy below must not race it), and leave the
+            # bucket to step()'s copy-and-reduce path, which reads the accumulated p.grad of every parameter.
+            if b["work"] is not None:
+                b["work"].wait()
+                b["work"] = None
+            b["dirty"] = True
+            return
         fl["views"][id(p)][3].copy_(p.grad)
         b["arrived"] += 1
-        if b["arrived"] == len(b["ids"]) and b["work"] is None:
+        if b["arrived"] == len(b["ids"]):
             b["work"] = mdist.all_reduce_sum_async(fl["g"][b["lo"]:b["hi"]])
 
     def _finish_overlap(self, ps):
@@ -120,11 +130,14 @@ class FlatSGD(torch.optim.Optimizer):
         for b in buckets.values():
             if b["work"] is not None:
                 b["work"].wait()
-        return all(fl["bucket_of"].get(id(p)) is not None and fl["bucket_of"][id(p)]["work"] is not None for p in ps)
+        return all(fl["bucket_of"].get(id(p)) is not None and fl["bucket_of"][id(p)]["work"] is not None and
+                   not fl["bucket_of"][id(p)]["dirty"] for p in ps)
 
     def _reset_overlap(self):
         for b in (self._flat or {}).get("buckets", []):
-            b["arrived"], b["work"] = 0, None
+            if b["work"] is not None:  # (zero_grad() without step(): the reference's literal loop computes G's gradients in step B and
+                b["work"].wait()       # never applies them -- the next pass's copies must not race a collective still in flight)
+            b["arrived"], b["work"], b["dirty"] = 0, None, False
 
     def _ensure_flat(self):
         if self._flat is None:

@@ -46,7 +46,22 @@ def _worker(rank, world, port, tmp, overlap=False):
         grads_all = [[torch.randn(s, generator=torch.Generator().manual_seed(100 * step + 10 * k + i)) for i, s in enumerate(shapes)]
                      for k in range(world)]
         opt.zero_grad()
-        if overlap and step > 0:  # through autograd, so that the hooks see the gradients arrive (step 0: plain assignment -> fallback path)
+        if overlap == "twice" and step > 0:
+            # TWO backward passes before one step() (MCDSolver's step B) -- the second pass finds the buckets' collectives
+            # started by the first; the update must use the ACCUMULATED gradient averaged over the ranks.  And before that a pass whose
+            # gradients are dropped by zero_grad() without a step (the reference's literal loop): its collectives must not leak.
+            junk = sum((p * 7.0).sum() for p in params)
+            junk.backward()
+            assert all(b["work"] is not None for b in opt._flat["buckets"])
+            opt.zero_grad()
+            assert all(b["work"] is None and b["arrived"] == 0 for b in opt._flat["buckets"])
+            extra = [[torch.randn(s, generator=torch.Generator().manual_seed(5000 + 100 * step + 10 * k + i)) for i, s in enumerate(shapes)]
+                     for k in range(world)]
+            sum((p * g).sum() for p, g in zip(params, grads_all[rank])).backward()
+            sum((p * g).sum() for p, g in zip(params, extra[rank])).backward()
+            assert all(b["dirty"] and b["work"] is None for b in opt._flat["buckets"])
+            grads_all = [[a + b for a, b in zip(grads_all[k], extra[k])] for k in range(world)]
+        elif overlap and step > 0:  # through autograd, so that the hooks see the gradients arrive (step 0: plain assignment -> fallback path)
             loss = sum((p * g).sum() for p, g in zip(params, grads_all[rank]))
             loss.backward()
             fl = opt._flat
@@ -86,6 +101,14 @@ def test_flat_sgd_bucketed_overlap_gloo(tmp_path):
     takes the one-collective path)"""
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
+    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
+
+
+def test_flat_sgd_bucketed_overlap_two_backward_passes_gloo(tmp_path):
+    """MCDSEG_DP_OVERLAP=1 with two backward passes before one step() and with a zero_grad() that drops a pass: the
+    accumulated gradient is averaged over the ranks, nothing of the dropped pass survives"""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "twice"), nprocs=world, join=True)
     assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
 
 

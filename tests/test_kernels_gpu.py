@@ -626,7 +626,7 @@ def test_conv_batch_split_for_large_operands(monkeypatch):
     assert ops._batch_pieces(desc) == [(0, 2), (2, 4), (4, 5)]
     names, split = run()
     if ops.CONV_MATH in ops.MATH_ID:  # the second group's three passes ran from the companions, slice by slice
-        pre = [nm for nm in names if nm.startswith("conv_gemm_split_kernel") and nm.endswith("true>")]
+        pre = [nm for nm in names if (nm.startswith("conv_gemm_split_kernel") and nm.endswith("true>")) or nm.startswith("conv_gemm_split_pp_kernel")]
         assert len(pre) >= 6, names
         assert sum(nm.startswith("conv_wgrad_split_tr") for nm in names) >= 3, names
     for name, a, b in zip(["y", "dx", "dw1", "dgamma1", "dbeta1", "dw2", "dgamma2", "dbeta2", "running_var1", "running_var2"], split, whole):
@@ -1062,15 +1062,17 @@ PINGPONG_CASES = [
 
 @pytest.mark.parametrize("case", PINGPONG_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_pingpong_tile(case, monkeypatch):
-    """``conv_gemm_split_pp_kernel`` (csrc/conv_gemm_split_pp.hip: 256 x 256 tile, eight waves in two groups half a K-step apart) takes
-    whole rounds of one tile per CU, the 4-wave tiles the remaining pixels.  Forward (+ fused BatchNorm partial rows) and data
-    gradient of such a two-launch convolution against fp64, and BIT FOR BIT against the same convolution with the kernel switched off
-    (MCDSEG_PINGPONG=0: same K order, same term order, same 64-pixel statistic rows); the parts API writes what the whole call writes."""
+    """``conv_gemm_split_pp_kernel`` (csrc/conv_gemm_split_pp.hip: eight waves in two groups half a K-step apart) takes whole rounds of
+    one 256 x 256 tile per CU and, with its 256 x 128 tile, the remaining pixels.  Forward (+ fused BatchNorm partial rows) and data
+    gradient of such a two-launch convolution against fp64, and BIT FOR BIT against the same convolution on the 4-wave tiles
+    (MCDSEG_PINGPONG=0: same K order, same term order, same 64-pixel statistic rows), on the 256 x 128 tile alone and with the 4-wave
+    tiles for the rest; the parts API writes what the whole call writes."""
     dev = _dev()
     import ctypes
     from mcdseg import ops
     cin, cout, k, stride, d, n, h, w, math = case
     monkeypatch.setattr(ops, "CONV_MATH", math)
+    monkeypatch.setenv("MCDSEG_PP_MIN_ROUNDS", "1")  # (by default the kernels take a convolution from two whole rounds of tiles on)
     x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, stride, d, h, w, n, False), 41)
     desc = ops.conv_desc(x.shape, wt.shape, stride, pad, d)
     pk = ops.PackedWeights()
@@ -1084,7 +1086,7 @@ def test_conv_pingpong_tile(case, monkeypatch):
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
     outs = {}
     for tag in ("pp", "off"):
-        monkeypatch.setenv("MCDSEG_PINGPONG", "1" if tag == "pp" else "0")
+        monkeypatch.setenv("MCDSEG_PINGPONG", "3" if tag == "pp" else "0")
         names = []
 
         class _Names:
@@ -1105,6 +1107,7 @@ def test_conv_pingpong_tile(case, monkeypatch):
             assert pp == min(want, pix // 256 * 256), (tag, dgrad, pp, want)
     y, dx, part, rows, names = outs["pp"]
     assert any(nm in (ops.pingpong_kernel_name(False), ops.pingpong_kernel_name(True)) for nm in names), names
+    assert any(nm in (ops.pingpong_kernel_name(False, small=True), ops.pingpong_kernel_name(True, small=True)) for nm in names), names
     assert not any("conv_gemm_split_pp_kernel" in nm for nm in outs["off"][4]), outs["off"][4]
     assert torch.equal(y, outs["off"][0]), "forward differs from the 4-wave tiles (max %.3e)" % float((y - outs["off"][0]).abs().max())
     assert rows == outs["off"][3] and torch.equal(part, outs["off"][2]), "fused BatchNorm partial rows differ"
@@ -1117,8 +1120,15 @@ def test_conv_pingpong_tile(case, monkeypatch):
         if dx is not None:
             (gx_ref,) = torch.autograd.grad(ref, [x64], gy.double())
             _assert_close(dx, gx_ref, 2e-5, "data gradient (ping-pong + rest)")
+    # the 256 x 128 ping-pong tile alone (mode 2) and the 256 x 256 tile with the 4-wave tiles for the rest (mode 1): the same bits
+    for mode in ("2", "1"):
+        monkeypatch.setenv("MCDSEG_PINGPONG", mode)
+        y_m, part_m, rows_m = ops._conv_fprop(desc, xg, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)
+        assert torch.equal(y_m, y) and rows_m == rows and torch.equal(part_m, part), "mode %s differs" % mode
+        if dx is not None:
+            assert torch.equal(ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound), dx), "data gradient, mode %s" % mode
     # parts 1 + 2 of the C ABI write exactly what part 0 writes (poisoned output, two calls)
-    monkeypatch.setenv("MCDSEG_PINGPONG", "1")
+    monkeypatch.setenv("MCDSEG_PINGPONG", "3")
     y2 = torch.full_like(y, float("nan"))
     part2 = torch.full_like(part, float("nan"))
     for prt in (2, 1):
