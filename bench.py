@@ -488,7 +488,8 @@ def main():
                               "identical results bit for bit"}
 
     others = None
-    if world == 1 and args.other_configs.strip():
+    judged_cfg = (args.net, args.batch, args.height, args.width, args.input_ch) == ("drn_d_38", 16, 480, 640, 6)
+    if world == 1 and not mdist.is_distributed() and judged_cfg and args.other_configs.strip():
         # free the judged configuration first: cfg5 at N = 32 takes 232 of the 288 GB
         kern_summary = timer.summary()
         reuse_tgt = solver.reuse_tgt

@@ -150,8 +150,9 @@ int mcdseg_conv_split_wgrad(const mcdseg_conv_desc* d, int32_t math, const float
                             size_t workspace_bytes, void* stream);
 /* which kernel the two weight-gradient entry points launch for a geometry (math = 0: mcdseg_conv_wgrad): 0..3 the f32 plans
  * (128x128, 64x64, 32x32 tiles, tap-packed thin inputs), 10 split arithmetic from fp32 operands, 11 / 12 / 13 from both
- * pre-split companions (register-transposing, transposed-read 128x128, transposed-read 256x128).  For profilers and
- * bench.py's per-kernel accounting. */
+ * pre-split companions (register-transposing, transposed-read 128x128, transposed-read 256x128), 14 the 64-channel tap pairs,
+ * 15 the thin-layer window kernel, 16 two taps per workgroup, 17 the eight-wave ping-pong kernel over a stream-K decomposition
+ * (256-channel blocks on both sides; csrc/conv_wgrad_split_pp.hip).  For profilers and bench.py's per-kernel accounting. */
 int32_t mcdseg_conv_wgrad_variant(const mcdseg_conv_desc* d, int32_t math, int32_t presplit);
 /* 1 when ONE launch of mcdseg_conv_wgrad (math = 0) / mcdseg_conv_split_wgrad (presplit: both companions are passed) can address
  * this descriptor's operands with its 32-bit buffer offsets: (N*C + 128 channels of slack) planes below 2 GiB for the kernels that

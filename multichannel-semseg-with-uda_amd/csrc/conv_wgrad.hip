@@ -464,6 +464,10 @@ int mcdseg_internal_wgrad_thin_tr_ok(const mcdseg_conv_desc* d);
 size_t mcdseg_internal_wgrad_thin_tr_ws(const mcdseg_conv_desc* d);
 int mcdseg_internal_wgrad_thin_tr_launch(const mcdseg_conv_desc* d, const void* x_cb, const float* x_bound, const void* dy_cb,
                                          const float* dy_bound, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
+// the 256-channel-and-wider layers from both companions: eight-wave ping-pong kernel over a stream-K decomposition (conv_wgrad_split_pp.hip)
+int mcdseg_internal_wgrad_pp_plan(const mcdseg_conv_desc* d, int math, int* L, size_t* slab_floats);
+int mcdseg_internal_wgrad_pp_launch(const mcdseg_conv_desc* d, int math, const void* x_cb, const float* x_bound, const void* dy_cb,
+                                    const float* dy_bound, float* dw, float* slab, hipStream_t st);
 static bool thin_tr_applies(const mcdseg_conv_desc* d, int math, const void* x_cb, const void* dy_cb) {
   static const bool on = [] {
     const char* e = getenv("MCDSEG_WGRAD_THIN_TR");
@@ -492,6 +496,7 @@ extern "C" int32_t mcdseg_conv_wgrad_variant(const mcdseg_conv_desc* d, int32_t 
   if (d == nullptr) return -22;
   const WgradPlan pl = make_plan(d);
   if (presplit && thin_tr_applies(d, math, d, d)) return 15;
+  if (presplit && math && pl.cfg == 0 && mcdseg_internal_wgrad_pp_plan(d, math, nullptr, nullptr) > 0) return 17;
   if (pl.cfg == 1 && presplit && tr64_applies(d, math, d, d, 1)) return 14;
   if (pl.cfg != 0 || math == 0) return pl.cfg;
   if (!(presplit && (d->Cin & 7) == 0 && (d->Cout & 7) == 0)) return 10;
@@ -537,7 +542,9 @@ extern "C" int32_t mcdseg_conv_wgrad_fits(const mcdseg_conv_desc* d, int32_t mat
 
 extern "C" size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d) {
   if (d == nullptr) return 0;
-  const size_t a = (size_t)make_plan(d).slab_floats * sizeof(float), b = mcdseg_internal_wgrad_thin_tr_ws(d);
+  size_t a = (size_t)make_plan(d).slab_floats * sizeof(float), c = 0;
+  const size_t b = mcdseg_internal_wgrad_thin_tr_ws(d);
+  if (mcdseg_internal_wgrad_pp_plan(d, MCDSEG_MATH_F16X3, nullptr, &c) > 0 && c * sizeof(float) > a) a = c * sizeof(float);
   return a > b ? a : b;
 }
 
@@ -546,6 +553,13 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
   MCD_REQUIRE(d && dw && workspace, "conv_wgrad: null pointer");
   if (thin_tr_applies(d, math, x_cb, dy_cb) && x_bound && dy_bound)
     return mcdseg_internal_wgrad_thin_tr_launch(d, x_cb, x_bound, dy_cb, dy_bound, dw, workspace, workspace_bytes, (hipStream_t)stream);
+  if (math && x_cb && dy_cb && x_bound && dy_bound && make_plan(d).cfg == 0) {
+    size_t sf = 0;
+    if (mcdseg_internal_wgrad_pp_plan(d, math, nullptr, &sf) > 0) {
+      MCD_REQUIRE(workspace_bytes >= sf * sizeof(float), "conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, sf * sizeof(float));
+      return mcdseg_internal_wgrad_pp_launch(d, math, x_cb, x_bound, dy_cb, dy_bound, dw, (float*)workspace, (hipStream_t)stream);
+    }
+  }
   const bool tr64 = tr64_applies(d, math, x_cb, dy_cb, make_plan(d).cfg);
   const bool cb_path = tr64 || (math && x_cb && dy_cb && (d->Cin & 7) == 0 && (d->Cout & 7) == 0 && make_plan(d).cfg == 0);
   const bool split_plan = tr64 || (math && make_plan(d).cfg == 0);

@@ -1,0 +1,367 @@
+// Weight gradient of the 256-channel-and-wider convolutions from both pre-split companions, as an eight-wave PING-PONG kernel
+// (the structure of conv_gemm_split_pp.hip) over a STREAM-K decomposition: what the reference gets from autograd for nn.Conv2d
+// (models/drn.py:21-23; adapt_trainer.py:170-176).
+//
+// dW[tap][co][ci] = sum over pixels of dZ[co][pixel] * X[ci][pixel + shift(tap)].  A TILE is 256 (co) x 256 (ci) of one tap; its K
+// dimension are the 16-pixel stages (8 x 2 output pixels) of all images: KT = N * tiles_x * tiles_y K-steps.  The operands sit in
+// LDS exactly as in memory -- 16-byte units of 8 channels x 1 pixel, deposited by LDS-DMA -- and ds_read_b64_tr_b16 forms the MFMA
+// fragments (8 pixels of one channel per lane), as in conv_wgrad_split_tr_kernel (conv_wgrad_split.hip), whose LDS image this is.
+//
+// Ping-pong: waves 0-3 (co rows 0-127) and 4-7 (rows 128-255) are SIMD partners half a K-step apart; between two workgroup
+// barriers one group multiplies (24 MFMAs) while the other issues its 24 transposing reads of the same stage and its 4 LDS-DMAs
+// for the stage after next.  One workgroup per CU (three stages of 32 KB).
+//
+// Stream-K: the weight gradient is summed over split slabs anyway, so the work need not be cut along tile borders.  The (tile, K-step)
+// pairs, tile-major with the tap fastest (the nine taps of a channel block share their operands through L2), form one range that is cut
+// into nwg equal pieces of L K-steps -- one workgroup per CU, every CU the same work, whatever the layer's tile count (conv_wgrad_split_tr
+// at cfg2: 1 152 workgroups on 512 slots = 2.25 rounds).  A piece spans one or two tiles; each SEGMENT (piece x tile) writes its raw
+// 256 x 256 accumulators to slab number  g / L + g / KT  (g = the segment's first flattened K-step; the numbers of a tile's segments
+// are consecutive), and wgrad_reduce_sk_kernel sums a tile's slabs in K order in fp64 -- a fixed order, so the result is reproducible --
+// and applies scale(x) * scale(dz).
+#include <cstdlib>
+#include <type_traits>
+
+#include "split.h"
+
+namespace {
+
+struct WgradPpParams {
+  const void* x_cb;
+  const void* dy_cb;
+  float* slab;
+  int N, Cin, H, W, Cout, Ho, Wo;
+  int KH, KW, stride, pad, dil;
+  int co_tiles, ci_tiles;  // 256-channel tiles
+  int tiles_x, tiles_y;    // 8 x 2 pixel tiles of one image
+  int kt;                  // K-steps of one tile: N * tiles_x * tiles_y
+  int L, nwg;              // K-steps per workgroup, workgroups
+  int x_cb_bytes, dy_cb_bytes;                // ONE piece of each companion (this call's images)
+  long long x_piece_stride, dy_piece_stride;  // bytes between the pieces (the companions' own batch: mcdseg_conv_desc.Ncb)
+};
+
+template <class P>
+__global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams p) {
+  static_assert(P::NP == 2, "two-piece policies");
+  constexpr int WM = 4, WN = 2;
+  constexpr int NP = P::NP;
+  constexpr int R = 2;                  // pixel rows of a stage
+  constexpr int NQD = 2 * R;            // quads of 4 consecutive pixels per stage
+  constexpr int NBLK = 2;               // 128-channel blocks per operand
+  typedef typename P::frag frag;
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  constexpr int QUAD = 1024;            // bytes one DMA instruction deposits: [cg 16][pixel 4][16 B]
+  constexpr int QSTR = NBLK * QUAD;     // one quad of one (operand, piece): [block][cg 16][pixel 4][16 B]
+  constexpr int UNIT = NQD * QSTR;      // one piece of one operand: 8 KB
+  constexpr int STAGE = 2 * NP * UNIT;  // [operand: dZ, X][piece]
+  constexpr int NS = 3;
+  static_assert(NS * STAGE <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp_id = wave >> 2;  // SIMD partners are waves w and w + 4
+  const int wm = grp_id, wn = wave & 3;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int T_ = p.KH * p.KW;
+
+  // fragments that share a tile on one XCD when the count allows (speed only)
+  const int w_id = (p.nwg & 7) == 0 ? (blockIdx.x & 7) * (p.nwg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  if (w_id >= p.nwg) return;
+  const long long total = (long long)p.co_tiles * p.ci_tiles * T_ * p.kt;
+  long long g_next = (long long)w_id * p.L;
+  long long g_end = g_next + p.L;
+  if (g_end > total) g_end = total;
+
+  // ---- DMA role of this wave (wave-uniform): operand side (0 = dZ, the "A" rows; 1 = X, the "B" rows), piece, 128-channel block
+  const int opnd = wave >> 2;
+  const int piece = (wave >> 1) & 1;
+  const int blk = wave & 1;
+  const bool isx = opnd == 1;
+  const int ps = lane & 3;
+  const int cg = lane >> 2;
+  const int sH = isx ? p.H : p.Ho;
+  const int sW = isx ? p.W : p.Wo;
+  const int sS = isx ? p.stride : 1;
+  const int sC8 = (isx ? p.Cin : p.Cout) >> 3;
+  const int sHW = sH * sW;
+  // the descriptor covers this wave's PIECE and starts `bias` bytes below it so that the SGPR offset (tile + tap shift) is never negative
+  const int bias = p.pad * 16 + 16;
+  const char* sptr = (const char*)(isx ? p.x_cb : p.dy_cb) + piece * (isx ? p.x_piece_stride : p.dy_piece_stride) - bias;
+  const int sbytes = (isx ? p.x_cb_bytes : p.dy_cb_bytes) + bias;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sptr, 0, sbytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  const int lane_x = ps * sS;
+  unsigned char* const unit_lds = smem + (opnd * NP + piece) * UNIT + blk * QUAD;
+  const bool dma_on = piece < P::NPU;  // (a piece the policy never multiplies -- SplitF16x1's second -- is not moved)
+  const int ntiles = p.tiles_x * p.tiles_y;
+
+  // transposed-read address of this lane inside a (piece, quad) image, for the 32-row block i of the wave's rows: 16-lane group
+  // g = lane >> 4 covers rows 16 (g & 1) .. +15; lane 4q + pp of the group supplies pixel q, channels 4 pp .. 4 pp + 3
+  const int gl = lane & 15;
+  const int tq = gl >> 2, tpp = gl & 3;
+  const int trow = ((((lane >> 4) & 1) * 2 + (tpp >> 1)) * 4 + tq) * 16 + 8 * (tpp & 1);
+  const int a_lane = (2 * lh) * QSTR + wm * QUAD + trow;                                       // the wave's 128 dZ channels = block wm
+  const int b_lane = (2 * lh) * QSTR + (wn >> 1) * QUAD + (wn & 1) * 512 + trow;               // its 64 X channels = half of block wn >> 1
+
+  // The transposing reads are issued as inline assembly: for a compiler-visible one the wait-count pass puts an s_waitcnt vmcnt(0) in
+  // front whenever an LDS-DMA may be pending (it cannot tell that the DMA targets another stage), which would drain the prefetch at the
+  // head of every read phase.  They complete at the lgkmcnt(0) of the wait that closes the read phase; `settle` re-defines the registers
+  // behind that wait so that no matrix instruction can be scheduled ahead of it.
+  auto tr_read_at = [&](unsigned base, auto off_c) -> s16x4 {
+    s16x4 v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(decltype(off_c)::value) : "memory");
+#else
+    (void)base;
+    v = s16x4{};
+#endif
+    return v;
+  };
+  auto frag_of = [&](unsigned base, auto lo_c, auto hi_c) -> frag {  // k slots 0-3 from this lane's first quad, 4-7 from its second
+    const s16x4 lo = tr_read_at(base, lo_c);
+    const s16x4 hi = tr_read_at(base, hi_c);
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(frag, v);
+  };
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+#else
+  const unsigned smem_lds = 0;
+#endif
+
+  while (g_next < g_end) {  // the segments of this workgroup's piece: the rest of the current tile's K range, at most
+    const int tile = (int)(g_next / p.kt);
+    const int k0 = (int)(g_next - (long long)tile * p.kt);
+    const int k1 = (g_end - (long long)tile * p.kt < p.kt) ? (int)(g_end - (long long)tile * p.kt) : p.kt;
+    const int slab_id = (int)(g_next / p.L) + tile;
+    g_next += k1 - k0;
+    const int tap = tile % T_;
+    const int tile_ci = (tile / T_) % p.ci_tiles;
+    const int tile_co = tile / (T_ * p.ci_tiles);
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int shy = isx ? ky * p.dil - p.pad : 0;
+    const int shx = isx ? kx * p.dil - p.pad : 0;
+    const int cg0 = (isx ? tile_ci : tile_co) * 32 + blk * 16;  // first channel group of this wave's block
+    const unsigned vconst = (cg0 + cg) < sC8 ? (unsigned)(cg * sHW + ps * sS) * 16u : OOB;
+
+    // loader state: K-step -> (image, tile row, tile column), advanced incrementally
+    int l_n = k0 / ntiles;
+    int l_ty = (k0 - l_n * ntiles) / p.tiles_x;
+    int l_tx = k0 - l_n * ntiles - l_ty * p.tiles_x;
+    auto issue = [&](int stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (dma_on) {
+        const int sbase = (l_n * sC8 + cg0) * sHW;  // 16-byte units inside the piece
+#pragma unroll
+        for (int j = 0; j < NQD; ++j) {  // quad j: row j % R of the tile, column half j / R
+          const int h = j / R;
+          const int iy = (l_ty * R + (j % R)) * sS + shy;
+          const int ux = (l_tx * 8 + 4 * h) * sS + shx;
+          const bool colok = (unsigned)(ux + lane_x) < (unsigned)sW;
+          const int soff = ((unsigned)iy < (unsigned)sH) ? (sbase + iy * sW + ux) * 16 + bias : 0x7FFFFFFF;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(unit_lds + stage * STAGE + j * QSTR), 16,
+                                                   colok ? vconst : OOB, soff, 0, 0);
+        }
+      }
+#else
+      (void)stage;
+#endif
+    };
+    auto advance = [&]() {
+      if (++l_tx == p.tiles_x) {
+        l_tx = 0;
+        if (++l_ty == p.tiles_y) {
+          l_ty = 0;
+          ++l_n;
+        }
+      }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nsteps = k1 - k0;
+    issue(0);
+    if (nsteps > 1) {
+      advance();
+      issue(1);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (grp_id == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1 runs one barrier behind group 0 to the end of the K loop
+
+    frag fa[NP][WM], fb[NP][WN];
+    int cur = 0, nxt2 = 2;
+    for (int s = 0; s < nsteps; ++s) {
+      // ---- read phase (the partner group multiplies meanwhile)
+      const unsigned base_a = smem_lds + (unsigned)(cur * STAGE + a_lane), base_b = smem_lds + (unsigned)(cur * STAGE + b_lane);
+      // (compile-time offsets: operand, piece, 32-row block, second quad)
+#define MCD_A_FRAG(PC, I) \
+      if constexpr ((PC) < P::NPU) \
+        fa[PC][I] = frag_of(base_a, std::integral_constant<int, (PC) * UNIT + (I) * 256>{}, std::integral_constant<int, (PC) * UNIT + (I) * 256 + QSTR>{});
+#define MCD_B_FRAG(PC, J) \
+      if constexpr ((PC) < P::NPU) \
+        fb[PC][J] = frag_of(base_b, std::integral_constant<int, (NP + (PC)) * UNIT + (J) * 256>{}, std::integral_constant<int, (NP + (PC)) * UNIT + (J) * 256 + QSTR>{});
+      MCD_A_FRAG(0, 0) MCD_A_FRAG(0, 1) MCD_A_FRAG(0, 2) MCD_A_FRAG(0, 3) MCD_B_FRAG(0, 0) MCD_B_FRAG(0, 1)
+      MCD_A_FRAG(1, 0) MCD_A_FRAG(1, 1) MCD_A_FRAG(1, 2) MCD_A_FRAG(1, 3) MCD_B_FRAG(1, 0) MCD_B_FRAG(1, 1)
+#undef MCD_A_FRAG
+#undef MCD_B_FRAG
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < nsteps) {
+        advance();
+        issue(nxt2);
+        // this wave's share of stage s+1 has landed (the share of stage s+2 stays in flight) and its fragment reads are back
+        if (dma_on)
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NQD) : "memory");
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      // (the reads above have completed: re-define their registers behind the wait)
+#pragma unroll
+      for (int pc = 0; pc < P::NPU; ++pc) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) asm volatile("" : "+v"(fa[pc][i]));
+#pragma unroll
+        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(fb[pc][j]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- matrix phase (the partner group reads meanwhile): term-major, the sums and their order per tile of conv_wgrad_split_tr_kernel
+#pragma unroll
+      for (int tm = 0; tm < P::NTERMS; ++tm)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[i][j] = P::mfma(fa[P::TA[tm]][i], fb[P::TB[tm]][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" ::: "memory");
+      cur = cur == 2 ? 0 : cur + 1;
+      nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+    }
+    if (grp_id == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's last matrix-phase barrier: the groups are level again
+
+    // ---- the segment's raw sums (scaled units): slab[slab_id][co 256][ci 256]
+    float* out = p.slab + (size_t)slab_id * (256 * 256);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) out[row * 256 + wn * 64 + j * 32 + l31] = acc[i][j][r];
+      }
+  }
+}
+
+// dw[co][ci][tap] = scale * sum over the tile's slabs (in K order, fp64).  A block owns 64 consecutive ci of one co for all taps:
+// slab reads are coalesced along ci, the T values of a (co, ci) pair leave through LDS as one contiguous run of dw [Cout][Cin][T].
+__global__ __launch_bounds__(64) void wgrad_reduce_sk_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int T,
+                                                             int ci_tiles, int kt, int L, const float* __restrict__ x_bound,
+                                                             const float* __restrict__ dy_bound) {
+  __shared__ float stage[64 * 33];
+  const int co = blockIdx.y;
+  const int ci0 = blockIdx.x * 64;
+  const int ci = ci0 + threadIdx.x;
+  const double sc = x_bound != nullptr ? (double)mcd_scale_of_bound(*x_bound) * (double)mcd_scale_of_bound(*dy_bound) : 1.0;
+  const int nci = Cin - ci0 < 64 ? Cin - ci0 : 64;
+  for (int tap = 0; tap < T; ++tap) {
+    const int tile = ((co >> 8) * ci_tiles + (ci0 >> 8)) * T + tap;
+    const long long g0 = (long long)tile * kt;
+    const int s0 = (int)(g0 / L) + tile, s1 = (int)((g0 + kt - 1) / L) + tile;
+    double s = 0.0;
+    if (ci < Cin) {
+      const float* src = slab + ((size_t)s0 * 256 + (co & 255)) * 256 + (ci & 255);
+      constexpr size_t SL = 256 * 256;
+      int k = s0;
+      for (; k + 3 <= s1; k += 4, src += 4 * SL) {  // four loads in flight, added in slab order
+        const float v0 = src[0], v1 = src[SL], v2 = src[2 * SL], v3 = src[3 * SL];
+        s += (double)v0;
+        s += (double)v1;
+        s += (double)v2;
+        s += (double)v3;
+      }
+      for (; k <= s1; ++k, src += SL) s += (double)*src;
+    }
+    stage[threadIdx.x * T + tap] = (float)(s * sc);
+  }
+  __syncthreads();
+  float* out = dw + ((size_t)co * Cin + ci0) * T;
+  for (int i = threadIdx.x; i < nci * T; i += 64) out[i] = stage[i];
+}
+
+int pp_compute_units() {
+  static const int n = [] {
+    const char* e = getenv("MCDSEG_PP_CUS");  // development knob (shared with conv_gemm_split_pp.hip)
+    if (e && atoi(e) > 0) return atoi(e);
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;  // MI355X
+    return cus;
+  }();
+  return n;
+}
+
+}  // namespace
+
+// The stream-K plan of this geometry: workgroups and K-steps per workgroup; 0 workgroups when the kernel does not apply (two-piece
+// arithmetic on both companions, 256-channel blocks on both sides, at most 32 taps, and enough K-steps that a workgroup's piece
+// spans at most two tiles and is worth a launch).  MCDSEG_WGRAD_PP=0 turns it off (read per call: tests).
+int mcdseg_internal_wgrad_pp_plan(const mcdseg_conv_desc* d, int math, int* L, size_t* slab_floats) {
+  const char* e = getenv("MCDSEG_WGRAD_PP");
+  if (e != nullptr && atoi(e) == 0) return 0;
+  if (mcd_storage_math(math) != MCDSEG_MATH_F16X3 || (d->Cin & 7) || (d->Cout & 7) || d->Cin < 129 || d->Cout < 129) return 0;
+  const int T = d->KH * d->KW;
+  if (T > 32 || d->pad > 128) return 0;
+  const int64_t co_tiles = ceil_div(d->Cout, 256), ci_tiles = ceil_div(d->Cin, 256);
+  if (co_tiles * 256 - d->Cout >= 128 || ci_tiles * 256 - d->Cin >= 128) return 0;  // (a half-empty tile: the 128-channel kernels are better)
+  const int64_t kt = (int64_t)d->N * ceil_div(d->Wo, 8) * ceil_div(d->Ho, 2);
+  const int64_t tiles = co_tiles * ci_tiles * T, total = tiles * kt;
+  int64_t nwg = pp_compute_units();
+  if (total < nwg * 32) return 0;  // (less than 32 K-steps per CU: the launch is all prologue and slab traffic)
+  const int64_t l = ceil_div64(total, nwg);
+  if (l > kt) return 0;  // (a piece would span more than two tiles)
+  nwg = ceil_div64(total, l);
+  if (L) *L = (int)l;
+  if (slab_floats) *slab_floats = (size_t)(nwg + tiles + 1) * 256 * 256;
+  return (int)nwg;
+}
+
+int mcdseg_internal_wgrad_pp_launch(const mcdseg_conv_desc* d, int math, const void* x_cb, const float* x_bound, const void* dy_cb,
+                                    const float* dy_bound, float* dw, float* slab, hipStream_t st) {
+  WgradPpParams p;
+  int L = 0;
+  const int nwg = mcdseg_internal_wgrad_pp_plan(d, math, &L, nullptr);
+  MCD_REQUIRE(nwg > 0, "conv_wgrad_split_pp: the geometry has no stream-K plan");
+  const int64_t xb = (int64_t)d->N * d->Cin * d->H * d->W * 2, yb = (int64_t)d->N * d->Cout * d->Ho * d->Wo * 2;
+  MCD_REQUIRE(xb + 4096 < (1ll << 31) && yb + 4096 < (1ll << 31) && (d->Ncb == 0 || d->Ncb >= d->N),
+              "conv_wgrad_split_pp: pre-split operands need < 2 GiB per operand piece and Ncb >= N");
+  p.x_cb = x_cb; p.dy_cb = dy_cb; p.slab = slab;
+  p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+  p.co_tiles = ceil_div(d->Cout, 256); p.ci_tiles = ceil_div(d->Cin, 256);
+  p.tiles_x = ceil_div(d->Wo, 8); p.tiles_y = ceil_div(d->Ho, 2);
+  p.kt = d->N * p.tiles_x * p.tiles_y;
+  p.L = L; p.nwg = nwg;
+  p.x_cb_bytes = (int)xb; p.dy_cb_bytes = (int)yb;
+  p.x_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cin * d->H * d->W * 2;
+  p.dy_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cout * d->Ho * d->Wo * 2;
+  const dim3 grid((unsigned)(8 * ceil_div(nwg, 8)));
+  if (math == MCDSEG_MATH_F16X1)
+    hipLaunchKernelGGL(conv_wgrad_split_pp_kernel<SplitF16x1>, grid, dim3(512), 0, st, p);
+  else
+    hipLaunchKernelGGL(conv_wgrad_split_pp_kernel<SplitF16x3>, grid, dim3(512), 0, st, p);
+  MCD_LAUNCH_CHECK("conv_wgrad_split_pp");
+  const int T = d->KH * d->KW;
+  MCD_REQUIRE(T <= 33, "conv_wgrad_split_pp: more than 33 taps");
+  hipLaunchKernelGGL(wgrad_reduce_sk_kernel, dim3((unsigned)ceil_div(d->Cin, 64), (unsigned)d->Cout), dim3(64), 0, st, (const float*)slab, dw, d->Cout,
+                     d->Cin, T, p.ci_tiles, p.kt, L, x_bound, dy_bound);
+  MCD_LAUNCH_CHECK("wgrad_reduce_sk");
+  return 0;
+}

@@ -586,7 +586,8 @@ def split_companion_padded(x, bound=None):
 # mcdseg_conv_wgrad_variant code -> the kernel name rocprofv3 prints
 _WGRAD_NAMES = {10: "conv_wgrad_split_kernel<%s>", 11: "conv_wgrad_split_cb_kernel<%s>", 12: "conv_wgrad_split_tr_kernel<%s, 2, 2, 3, false>",
                 13: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3, false>", 14: "conv_wgrad_split_tr64_kernel<%s>",
-                15: "conv_wgrad_thin_tr_kernel<%s>", 16: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3, true>"}
+                15: "conv_wgrad_thin_tr_kernel<%s>", 16: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3, true>",
+                17: "conv_wgrad_split_pp_kernel<%s>"}
 WGRAD_TR64 = os.environ.get("MCDSEG_WGRAD_TR64", "1") != "0"
 
 
@@ -702,8 +703,8 @@ class late_weight_grads:
     """Context around the forward pass of a trunk (``root``: an nn.Module): one ``_LateGrad`` alias per convolution weight, created
     NOW -- before every other node of this forward pass, hence executed after all of them in the backward pass -- and consumed by
     the first ``conv_bn_act`` call on that convolution.  Nothing is prepared without grad mode, for weights that do not require a
-    gradient, for weights with post-accumulate hooks (FlatSGD's bucketed all-reduce wants its gradients DURING the pass) or when
-    MCDSEG_OVERLAP_WGRAD is not "2"."""
+    gradient, for weights with foreign post-accumulate hooks (they want their gradients DURING the pass; FlatSGD's bucketed
+    all-reduce takes deferred gradients through its ``_mcd_grad_sink`` instead) or when MCDSEG_OVERLAP_WGRAD is not "2"."""
 
     def __init__(self, root):
         self.root, self.mods = root, []
@@ -713,7 +714,10 @@ class late_weight_grads:
             for m in self.root.modules():
                 if isinstance(getattr(m, "_packed", None), PackedWeights) and getattr(m, "_w_late", None) is None:
                     w = m.weight
-                    if w.is_cuda and w.requires_grad and not getattr(w, "_post_accumulate_grad_hooks", None):
+                    # (a weight with post-accumulate hooks wants its gradient DURING the pass -- unless the hook's owner also left a
+                    # ``_mcd_grad_sink`` on it, which receives a deferred gradient on the side stream: _conv_backward)
+                    if w.is_cuda and w.requires_grad and (not getattr(w, "_post_accumulate_grad_hooks", None) or
+                                                          getattr(w, "_mcd_grad_sink", None) is not None):
                         alias = _LateGrad.apply(w)
                         alias._mcd_param = w  # (the packed images are keyed by the parameter, see PackedWeights._key_of)
                         m._w_late = alias
@@ -753,8 +757,11 @@ def _room_to_defer(device):
     return torch.cuda.memory_allocated(key) < DEFER_MEM_FRACTION * _TOTAL_MEM[key]
 
 
-def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_bound=None, x_bound=None, w_bound=None, defer=False):
-    """(dx, dw).  ``defer``: dw goes to a ``_LateGrad`` node, so mode "2" may leave it on the side stream"""
+def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_bound=None, x_bound=None, w_bound=None, defer=False, param=None):
+    """(dx, dw).  ``defer``: dw goes to a ``_LateGrad`` node, so mode "2" may leave it on the side stream.  ``param``: the parameter
+    behind that node; when its optimizer has left a ``_mcd_grad_sink`` on it (FlatSGD's bucketed all-reduce, MCDSEG_DP_OVERLAP=1) a
+    deferred gradient is handed to the sink ON THE SIDE STREAM, right behind its kernels -- the exchange of a bucket then starts when
+    its last weight gradient has been enqueued, long before the ``_LateGrad`` nodes pass the gradients on at the end of the pass."""
     mode = OVERLAP_WGRAD
     if mode == "2" and not (defer and x_cb is not None and dy_cb is not None):
         mode = "0"  # (without companions the weight gradient measures bounds and caches them on tensors the main stream reads)
@@ -783,6 +790,10 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_
     if mode == "1":
         main.wait_stream(side)
         return dx, dw
+    sink = getattr(param, "_mcd_grad_sink", None) if param is not None else None
+    if sink is not None:
+        with torch.cuda.stream(side):
+            sink(param, dw)
     WGRAD_STREAM_STATS["deferred"] += 1
     ev = torch.cuda.Event()
     ev.record(side)
@@ -902,6 +913,7 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.w_bound = w_bound
         ctx.packed, ctx.pack_key = packed, packed.key  # the data-gradient image is shared and re-packed in place: see backward
         ctx.defer_ok = hasattr(weight, "_mcd_param")  # the weight came through a _LateGrad alias (late_weight_grads)
+        ctx.w_param = getattr(weight, "_mcd_param", None)
         ctx.has_bias = conv_bias is not None
         ctx.x_cb, ctx.x_bound = x_cb, x_bound  # wgrad reads the input's split companion too (an input of this node: safe to hold)
         ctx.x_virtual, ctx.compact = x_virtual, compact
@@ -985,7 +997,7 @@ class _ConvBNAct(torch.autograd.Function):
             DEBUG_TAPE.append(dict(dy=dy, dz=dz, dz_cb=dz_cb, dz_bound=dz_bound, dgamma=dgamma, dbeta=dbeta, dres=dres, shape=(n, c, hw), z=z,
                                    y=y_mask, mean=mean, rstd=rstd, gamma=gamma, beta=beta, zmask=zmask))
         dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz_cb, x_cb, dz_bound,
-                                x_bound, ctx.w_bound, defer=ctx.defer_ok)
+                                x_bound, ctx.w_bound, defer=ctx.defer_ok, param=ctx.w_param)
         dbias = None
         if ctx.has_bias and ctx.needs_input_grad[5]:
             # a bias in front of train-mode BN has zero gradient up to rounding (BN removes the channel mean);

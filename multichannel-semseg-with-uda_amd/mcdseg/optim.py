@@ -85,6 +85,9 @@ class FlatSGD(torch.optim.Optimizer):
         fl = self._flat
         for h in getattr(self, "_hooks", []):
             h.remove()
+        for p in fl["params"]:
+            if getattr(p, "_mcd_grad_sink", None) is not None:
+                del p._mcd_grad_sink
         self._hooks, fl["buckets"], fl["bucket_of"] = [], [], {}
         if not (DP_OVERLAP and mdist.is_distributed()):
             return
@@ -94,19 +97,60 @@ class FlatSGD(torch.optim.Optimizer):
         for p, o in reversed(list(zip(fl["params"], fl["offs"]))):
             n = p.numel()
             if cur is None or cur["hi"] - o > limit:
-                cur = dict(lo=o, hi=o + n, ids=set(), arrived=0, work=None, dirty=False)
+                cur = dict(lo=o, hi=o + n, ids=set(), arrived=0, work=None, dirty=False, early=set(), early_seen={})
                 fl["buckets"].append(cur)
             cur["lo"] = o
             cur["ids"].add(id(p))
             fl["bucket_of"][id(p)] = cur
         for p in fl["params"]:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._grad_arrived))
+            p._mcd_grad_sink = self._early_grad  # (ops._conv_backward: a weight gradient left on the side stream arrives here first)
+
+    def _early_grad(self, p, dw):
+        """A weight gradient whose kernels have just been enqueued on the side stream (ops._conv_backward, MCDSEG_OVERLAP_WGRAD=2);
+        the CURRENT stream is that side stream.  Copy it into the flat view there and, when it completes its bucket, start the
+        bucket's all-reduce from there -- RCCL's stream then waits for the side stream only, and the main stream's backward pass goes
+        on.  The gradient reaches ``p.grad`` through its ``_LateGrad`` node at the end of the pass; ``_grad_arrived`` then finds the
+        parameter in ``early`` and has nothing left to do.  Anything but "first gradient of this parameter since the last step / zero_grad,
+        nothing accumulated yet" leaves the bucket to step()'s copy-and-reduce path."""
+        fl = self._flat
+        b = fl["bucket_of"].get(id(p)) if fl is not None else None
+        if b is None:
+            return
+        if b["work"] is not None or b["dirty"] or id(p) in b["early"] or p.grad is not None or b["arrived"] >= len(b["ids"]):
+            if b["work"] is not None:
+                b["work"].wait()
+                b["work"] = None
+            b["dirty"] = True
+            return
+        fl["views"][id(p)][3].copy_(dw)
+        b["early"].add(id(p))
+        b["arrived"] += 1
+        if b["arrived"] == len(b["ids"]):
+            self._launch_reduce(b)
+
+    def _launch_reduce(self, b):
+        """every gradient of the bucket sits in its flat view: start the all-reduce of the slice.  When some of them were copied on the
+        side stream (``_early_grad``) the exchange is started FROM the side stream, behind those copies and behind the current stream's
+        own: RCCL's stream then waits for the side stream, and the stream running the backward pass waits for nobody."""
+        fl = self._flat
+        flat = fl["g"][b["lo"]:b["hi"]]
+        if b["early"] and flat.is_cuda:
+            side = ops._side_stream(flat.device)
+            side.wait_stream(torch.cuda.current_stream())  # (a no-op when the side stream is the current one)
+            with torch.cuda.stream(side):
+                b["work"] = mdist.all_reduce_sum_async(flat)
+        else:
+            b["work"] = mdist.all_reduce_sum_async(flat)
 
     def _grad_arrived(self, p):
         fl = self._flat
         if fl is None or id(p) not in fl["bucket_of"] or p.grad is None:
             return
         b = fl["bucket_of"][id(p)]
+        if id(p) in b["early"] and not b["dirty"] and p.grad is not None and b["early_seen"].get(id(p), 0) == 0:
+            b["early_seen"][id(p)] = 1  # the gradient the side stream delivered (``_early_grad``) has now reached p.grad: nothing to do
+            return
         if b["work"] is not None or b["dirty"] or b["arrived"] >= len(b["ids"]):
             # A SECOND backward pass before step() (MCDSolver's step B: two loss.backward() calls, then optimizer_f.step()): p.grad
             # now holds the accumulated local gradient, while the bucket's slice is being -- or has been -- summed over the ranks
@@ -120,7 +164,7 @@ class FlatSGD(torch.optim.Optimizer):
         fl["views"][id(p)][3].copy_(p.grad)
         b["arrived"] += 1
         if b["arrived"] == len(b["ids"]):
-            b["work"] = mdist.all_reduce_sum_async(fl["g"][b["lo"]:b["hi"]])
+            self._launch_reduce(b)
 
     def _finish_overlap(self, ps):
         """waits for the collectives the hooks started; True when every gradient of ``ps`` has been reduced that way (else the
@@ -138,6 +182,7 @@ class FlatSGD(torch.optim.Optimizer):
             if b["work"] is not None:  # (zero_grad() without step(): the reference's literal loop computes G's gradients in step B and
                 b["work"].wait()       # never applies them -- the next pass's copies must not race a collective still in flight)
             b["arrived"], b["work"], b["dirty"] = 0, None, False
+            b["early"].clear(), b["early_seen"].clear()
 
     def _ensure_flat(self):
         if self._flat is None:

@@ -42,7 +42,8 @@ def test_fused_groups_are_bitwise_next_to_a_computing_neighbour(shape, dil, iter
     assert len(done) == 2 and all("done: 0 of" in ln for ln in done), r.stdout[-6000:]
 
 
-@pytest.mark.parametrize("mode,reps", [("grads", 5), ("step", 3)])
+@pytest.mark.parametrize("mode,reps", [("grads", 3), ("step", 2)])  # (round 3 ran 5 / 3 repetitions: 90 s of the suite; the offending
+# instruction has since been banned from the library by a CPU disassembly test, so this is a regression guard, not a soak)
 def test_model_step_is_bitwise_with_two_ranks_and_a_copy_loop_on_the_device(mode, reps):
     """drn_d_38 at 4 x 6 x 192 x 256 (round 2's failure showed in 6 of 10 such runs): two ranks on the one device, and two ranks next
     to a process streaming 1 GB device copies -- full tensors (every gradient / every parameter and buffer after the step) against the

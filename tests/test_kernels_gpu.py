@@ -1494,6 +1494,7 @@ def test_conv_wgrad_large_tile_kernel(case, monkeypatch):
     from mcdseg import ops
     monkeypatch.setattr(ops, "CONV_MATH", "f16x3")
     monkeypatch.delenv("MCDSEG_WGRAD_BIG", raising=False)
+    monkeypatch.setenv("MCDSEG_WGRAD_PP", "0")  # (the ping-pong / stream-K kernel takes these layers when the problem is large enough: next test)
     cin, cout, k, s, d, h, w, n = case
     x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, s, d, h, w, n, False), 41)
     desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
@@ -1512,6 +1513,64 @@ def test_conv_wgrad_large_tile_kernel(case, monkeypatch):
     dw_small = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
     _assert_close(dw_small, gw_ref, 2e-5, "wgrad (128 x 128 tiles)")
     assert torch.equal(dw_big, dw_small)
+
+
+# (Cin, Cout, k, stride, dil, H, W, N, math): enough 16-pixel K-steps for the stream-K plan (>= 32 per CU)
+WGRAD_PP_CASES = [
+    (512, 512, 3, 1, 2, 24, 32, 6, "f16x3"),   # 36 tiles x 288 K-steps: pieces of 41 K-steps, most of them inside one tile
+    (256, 256, 3, 1, 2, 60, 80, 4, "f16x3"),   # 9 tiles x 1 200: a 256-channel layer of the benchmark (N = 4)
+    (392, 504, 3, 1, 4, 29, 37, 8, "f16x3"),   # ragged channel groups on both sides (two tiles each way, the second partly empty), ragged pixel tiles
+    (256, 512, 1, 1, 1, 61, 83, 16, "f16x3"),  # 1x1: two tiles, pieces far shorter than a tile
+    (256, 400, 3, 2, 1, 63, 81, 6, "f16x3"),   # stride 2: X is gathered through the convolution geometry
+    (512, 512, 3, 1, 2, 24, 32, 6, "f16x1"),   # the reduced-precision arithmetic (the piece-1 waves move nothing)
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_PP_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_wgrad_pingpong_stream_k(case, monkeypatch):
+    """``conv_wgrad_split_pp_kernel`` (csrc/conv_wgrad_split_pp.hip): the weight gradient of the 256-channel-and-wider layers on
+    256 x 256 tiles, eight waves in two groups half a K-step apart, over a stream-K decomposition (one equal piece of the flattened
+    (tile, K-step) range per CU, a slab per (piece, tile) segment, summed in K order in fp64).  Named through
+    ``mcdseg_conv_wgrad_variant == 17``; within 2e-5 of fp64; two runs agree bit for bit; and it equals the 4-wave transposed-read
+    kernels (MCDSEG_WGRAD_PP=0) to the last bits -- the same products, only grouped into other partial sums."""
+    dev = _dev()
+    import ctypes
+    from mcdseg import ops
+    cin, cout, k, s, d, h, w, n, math = case
+    monkeypatch.setattr(ops, "CONV_MATH", math)
+    monkeypatch.delenv("MCDSEG_WGRAD_PP", raising=False)
+    x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, s, d, h, w, n, False), 43)
+    desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
+    L, mid = ops.lib(), ops.MATH_ID[math]
+    assert L.mcdseg_conv_wgrad_variant(ctypes.byref(desc), mid, 1) == 17
+    gy = torch.randn(n, cout, desc.Ho, desc.Wo, generator=torch.Generator().manual_seed(44))
+    xg, gyg = x.to(dev), gy.to(dev)
+    x_cb, x_bound = ops.split_companion(xg)
+    gy_cb, gy_bound = ops.split_companion(gyg)
+    names = []
+
+    class _Names:
+        def wants(self, name):
+            names.append(name)
+            return False
+    prev, ops.LAUNCH_TIMER = ops.LAUNCH_TIMER, _Names()
+    try:
+        dw = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
+    finally:
+        ops.LAUNCH_TIMER = prev
+    assert names == ["conv_wgrad_split_pp_kernel<%s>" % ops.POLICY[math]], names
+    dw_b = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
+    assert torch.equal(dw, dw_b), "two runs differ"
+    monkeypatch.setenv("MCDSEG_WGRAD_PP", "0")
+    assert L.mcdseg_conv_wgrad_variant(ctypes.byref(desc), mid, 1) in (12, 13)
+    dw_tr = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
+    scale = float(dw_tr.abs().max())
+    assert float((dw - dw_tr).abs().max()) <= 2e-6 * scale, float((dw - dw_tr).abs().max()) / scale
+    if math == "f16x3":
+        x64, w64 = x.double(), wt.double().requires_grad_()
+        ref = F.conv2d(x64, w64, None, stride=s, padding=pad, dilation=d)
+        (gw_ref,) = torch.autograd.grad(ref, [w64], gy.double())
+        _assert_close(dw, gw_ref, 2e-5, "wgrad (ping-pong, stream-K)")
 
 
 @pytest.mark.parametrize("case", [(128, 128, 3, 1, 1, 12, 16, 2), (136, 200, 3, 1, 2, 13, 19, 2), (256, 128, 3, 1, 4, 9, 10, 1), (128, 128, 3, 2, 1, 15, 17, 2),

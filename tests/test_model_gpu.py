@@ -601,9 +601,9 @@ def test_full_resolution_vs_oracle_and_properties():
 
 def test_cfg2_full_batch_vs_oracle():
     """BASELINE config 2 at its stated size -- 16 x 6 x 480 x 640, train-mode BatchNorm, with a tape -- so that the kernels the
-    benchmark times (the large-tile pre-split convolutions, selected only at this batch) are the ones compared: encoder
+    benchmark times (the ping-pong and large-tile pre-split convolutions, selected only at this batch) are the ones compared: encoder
     features and logits against the CPU oracle's N = 16 train-mode forward (<= 1e-3, north_star), then the cross-entropy
-    gradients of ``seg.weight`` and ``base.8.0.weight`` against the oracle's backward (adapt_trainer.py:163-185)."""
+    gradient of EVERY parameter against the oracle's backward (adapt_trainer.py:163-185): per tensor and over all of them."""
     dev = _dev()
     import os
     from loss import CrossEntropyLoss2d
@@ -628,7 +628,8 @@ def test_cfg2_full_batch_vs_oracle():
         (rcrit(ref_logits, lbl) + rcrit(of2(ref_feat), lbl)).backward()
     finally:
         torch.set_num_threads(threads)
-    ref_gs = {k: dict(og.named_parameters())[k].grad.clone() for k in ("seg.weight", "base.8.0.weight")}
+    ref_gs = {k: v.grad.clone() for k, v in og.named_parameters()}
+    ref_fgs = [m.up.weight.grad.clone() for m in (of1, of2)]
     ref_feat, ref_logits = ref_feat.detach(), ref_logits.detach()[:, :, ::8, ::8].clone()
     del og, of1, of2
     names = []
@@ -647,8 +648,14 @@ def test_cfg2_full_batch_vs_oracle():
     finally:
         ops.LAUNCH_TIMER = timer_prev
     if ops.CONV_MATH != "f32":
-        assert big in names, "the forward pass did not run %s: %s" % (big, sorted(set(names)))
-        assert ops.gemm_kernel_name(512, 512, True, True, True, False, n * 60 * 80) in names, sorted(set(names))
+        if ops.PIECES[ops.CONV_MATH] == 2:  # whole rounds of 256 x 256 ping-pong tiles, the rest on the 256 x 128 ping-pong tile
+            for nm in (ops.pingpong_kernel_name(False), ops.pingpong_kernel_name(True), ops.pingpong_kernel_name(False, small=True),
+                       ops.pingpong_kernel_name(True, small=True)):
+                assert nm in names, "the pass did not run %s: %s" % (nm, sorted(set(names)))
+        else:
+            assert big in names, "the forward pass did not run %s: %s" % (big, sorted(set(names)))
+            assert ops.gemm_kernel_name(512, 512, True, True, True, False, n * 60 * 80) in names, sorted(set(names))
+        assert ops.gemm_kernel_name(256, 256, False, True, True, False, n * 60 * 80) in names, sorted(set(names))  # the 128 x 128 family
         if ops.CONV_MATH == "f16x3":  # ... and the weight gradients of those layers ran on the 256 x 128 / 128 x 128 / 64-channel tiles
             for wg in ("conv_wgrad_split_tr_kernel<SplitF16x3, 4, 2, 3, false>", "conv_wgrad_split_tr_kernel<SplitF16x3, 2, 2, 3, false>",
                        "conv_wgrad_split_tr64_kernel<SplitF16x3>", "conv_wgrad_thin_tr_kernel<SplitF16x3>"):
@@ -657,13 +664,78 @@ def test_cfg2_full_batch_vs_oracle():
     assert err <= 1e-3, "feat err %.3e" % err
     lerr = float((logits.detach()[:, :, ::8, ::8].cpu() - ref_logits).abs().max())
     assert lerr <= 1e-3, "logit err %.3e" % lerr
+    # EVERY parameter gradient of the benchmarked pass against the oracle's backward.  Both sides are fp32 through 41 train-mode
+    # BatchNorms: the oracle's own fp32 noise on a single tensor is 1-3 % of its scale, so a tensor may be
+    # 5e-2 off in relative L2; summed over all 26 M parameters the noise averages out, and the overall bound is tight enough to see a
+    # wrong factor of a few per cent in any one layer of the benchmarked tile families (an overall 2e-3 = one 512 x 512 x 3 x 3
+    # tensor off by ~1 %).
     named = dict(g.named_parameters())
+    assert set(named) == set(ref_gs)
+    num = den = 0.0
+    worst = (0.0, None)
     for k, rg in ref_gs.items():
-        # both sides are fp32 through 41 train-mode BatchNorms: the oracle's own fp32 noise on these gradients is 1-3 %
-        # of their scale; direction and size must agree to that
         got = named[k].grad.cpu()
-        rel = float((got - rg).norm() / rg.norm())
-        assert rel <= 5e-2, "%s: relative L2 difference %.3e" % (k, rel)
+        dn, rn = float((got - rg).double().norm()), float(rg.double().norm())
+        num, den = num + dn * dn, den + rn * rn
+        worst = max(worst, (dn / rn, k))
+    assert worst[0] <= 5e-2, "%s: relative L2 difference %.3e" % (worst[1], worst[0])
+    overall = (num / den) ** 0.5
+    assert overall <= 2e-3, "all generator gradients: relative L2 difference %.3e (worst tensor %s %.3e)" % (overall, worst[1], worst[0])
+    for m, rg in zip((f1, f2), ref_fgs):
+        rel = float((m.up.weight.grad.cpu() - rg).norm() / rg.norm())
+        assert rel <= 2e-3, "up.weight: relative L2 difference %.3e" % rel
+
+
+def test_full_step_480x640_vs_oracle():
+    """One full A+B+C update (``MCDSolver.step``: 6 generator forwards, 5 backwards, 7 optimizer steps) at BASELINE's image size --
+    2 x 6 x 480 x 640 -- against ``oracle.ref_mcd.mcd_step`` running the reference's literal statements (adapt_trainer.py:155-220)
+    from the same weights: both logged losses, and the UPDATE every tensor received (after - before) with the smoke test's metric --
+    a missing or wrong-direction step is an error of order 1 there.  The single tensors carry the fp32 noise of 41 train-mode
+    BatchNorms (1-5 % on a delta, tests/golden/make_golden_deltas.py); over all parameters it averages out."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, get_prob_distance_criterion
+    from models.model_util import get_optimizer
+    from oracle import ref_loss, ref_mcd, ref_models
+    from solvers.solver import MCDSolver
+    hip = _mcd_models(dev)
+    ora = ref_models.get_models("drn_d_38", 6, NC)
+    for m, seed in zip(ora, (11, 12, 13)):
+        fill_state_(m, seed)
+        m.train()
+    src, lbl, tgt = make_batch(91, 2, 6, 480, 640, NC)
+    cw = ref_loss.class_weights(NC)
+    before = [{k: v.detach().clone().double() for k, v in m.state_dict().items()} for m in ora]
+    og = get_optimizer(hip[0].parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    of = get_optimizer(list(hip[1].parameters()) + list(hip[2].parameters()), "sgd", 1e-3, 0.9, 2e-5)
+    solver = MCDSolver(hip[0], hip[1], hip[2], og, of, CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff"))
+    c, d = solver.step(src.to(dev), lbl.to(dev), tgt.to(dev))
+    rog = ref_models.get_optimizer(ora[0].parameters(), "sgd", 1e-3, 0.9, 2e-5)
+    rof = ref_models.get_optimizer(list(ora[1].parameters()) + list(ora[2].parameters()), "sgd", 1e-3, 0.9, 2e-5)
+    prev = _all_threads()
+    try:
+        rc, rd = ref_mcd.mcd_step(ora[0], ora[1], ora[2], rog, rof, ref_loss.CrossEntropyLoss2d(cw), ref_loss.Diff2d(), src, lbl, tgt)
+    finally:
+        torch.set_num_threads(prev)
+    assert abs(float(c) - rc) <= 1e-4 * abs(rc), ("c_loss", float(c), rc)
+    assert abs(float(d) - rd) <= 2e-3 * abs(rd), ("d_loss", float(d), rd)
+    worst, num, den = (0.0, None), 0.0, 0.0
+    for i in range(3):
+        hsd, osd = hip[i].state_dict(), ora[i].state_dict()
+        assert list(hsd.keys()) == list(osd.keys())
+        for k, b in osd.items():
+            if not b.dtype.is_floating_point:
+                assert int(hsd[k]) == int(b) == 7, (k, int(hsd[k]), int(b))
+                continue
+            d_ref = b.double() - before[i][k]
+            d_hip = hsd[k].double().cpu() - before[i][k]
+            if float(d_ref.norm()) < 1e-12:
+                assert float(d_hip.norm()) < 1e-9, (k, float(d_hip.norm()))
+                continue
+            rel = float((d_hip - d_ref).norm() / d_ref.norm())
+            num, den = num + float((d_hip - d_ref).norm() ** 2), den + float(d_ref.norm() ** 2)
+            worst = max(worst, (rel, k))
+    assert worst[0] <= 0.15, ("parameter update differs from the oracle's", worst)
+    assert (num / den) ** 0.5 <= 2e-3, ("parameter updates differ from the oracle's", (num / den) ** 0.5, worst)
 
 
 def _all_threads():
@@ -841,15 +913,23 @@ def test_cfg5_cut_batches_keep_their_companions(monkeypatch):
     assert rel(g1, "seg.weight") <= 1e-4 and rel(g1, "base.8.1.weight") <= 1e-4
 
 
-@pytest.mark.parametrize("storage,k", [("fp32", 4.0), ("compact", 6.0)])
+@pytest.mark.parametrize("storage,k", [("fp32", 4.0), ("compact", 6.0), ("compact-f16x1", None)])
 def test_d105_bottleneck_vs_reference(golden, storage, k, monkeypatch):
     """drn_d_105 (Bottleneck blocks; BASELINE config 5 trunk) forward + CE backward.  105 BN layers amplify fp32
     re-association noise well beyond drn_d_38's, so the yardstick is the reference's own fp32 noise floor: the
     CPU oracle (pinned to the reference's d105 fixture) is run in fp32 and fp64 and our error against fp64 has to
     stay within a small multiple k of the fp32 oracle's.  "compact" is the storage mode cfg5 runs in at its stated batch
-    (trunk activations kept only as their 2 x fp16 companions, MCDSEG_ACT_STORAGE=compact)."""
+    (trunk activations kept only as their 2 x fp16 companions, MCDSEG_ACT_STORAGE=compact).
+    "compact-f16x1": BASELINE config 5 as stated ("drn_d_105 ... bf16") -- the REDUCED-precision arithmetic (``bench.py --dtype f16``,
+    operands rounded to fp16's 11 significant bits; bf16 would keep 8) on this network, whose 105 BatchNorms are where a short operand is
+    most likely to misbehave.  Not within north_star's 1e-3 and never the judged configuration; the test states what it keeps
+    against the fp64 oracle [measured]: features within 6e-2 of their scale, the loss within 2e-3 relative, and the gradients of the
+    three probed convolutions (first, deepest Bottleneck, head) pointing the fp64 way: cosine >= 0.9."""
     dev = _dev()
     from mcdseg import ops
+    if storage.endswith("f16x1"):
+        monkeypatch.setattr(ops, "CONV_MATH", "f16x1")
+        storage = "compact"
     monkeypatch.setattr(ops, "ACT_STORAGE", storage)
     from loss import CrossEntropyLoss2d
     from models.model_util import get_models
@@ -890,6 +970,15 @@ def test_d105_bottleneck_vs_reference(golden, storage, k, monkeypatch):
     scale = float(f64.abs().max())
     noise = float((f32 - f64).abs().max())
     err = float((feat.detach().double().cpu() - f64).abs().max())
+    if k is None:  # the reduced-precision arithmetic: stated deviations instead of the fp32 noise floor
+        named = dict(g.named_parameters())
+        cos = {nm: float(torch.dot(named[nm].grad.double().cpu().flatten(), g64[nm].flatten()) /
+                         (named[nm].grad.double().cpu().norm() * g64[nm].norm())) for nm in g64}
+        print("f16x1 on drn_d_105: feat err %.3e of scale %.3e, loss %.6f vs %.6f, gradient cosines %s" % (err, scale, float(loss), l64, cos))
+        assert err <= 6e-2 * scale, "feat err %.3e, scale %.3e" % (err, scale)
+        assert abs(float(loss) - l64) <= 2e-3 * abs(l64)
+        assert min(cos.values()) >= 0.9, cos
+        return
     assert err <= max(k * noise, 2e-5 * scale), "feat err %.3e, fp32-oracle noise %.3e, scale %.3e" % (err, noise, scale)
     assert abs(float(loss) - l64) <= max(k * abs(l32 - l64), 1e-5 * abs(l64))
     named = dict(g.named_parameters())
