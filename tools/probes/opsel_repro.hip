@@ -62,6 +62,7 @@ int main(int argc, char** argv) {
   const int seconds = argc > 1 ? atoi(argv[1]) : 20;
   const int mode = argc > 2 ? atoi(argv[2]) : 0;
   const char* tag = argc > 3 ? argv[3] : "solo";
+  const int iters = argc > 4 ? atoi(argv[4]) : 4;  // passes over the data per launch: 4 = 0.15 ms launches, 200 = 7 ms (longer than a time slice)
   const int n = 1 << 22;  // 32 MB of (g0, g1) pairs: streamed from memory every iteration
   const float k_lo = 3.0f, k_hi = 0.4375f;
   std::vector<v2f> hg(n), hw(n);
@@ -91,11 +92,11 @@ int main(int argc, char** argv) {
   int launches = 0;
   while (elapsed < seconds) {
     (void)hipEventRecord(e0);
-    for (int l = 0; l < 20; ++l) {
+    for (int l = 0; l < (iters > 16 ? 2 : 20); ++l) {
       if (mode == 0)
-        hipLaunchKernelGGL(probe<0>, dim3(2048), dim3(256), 0, 0, g, want, out, k_lo, k_hi, n, 4, checked, bad, log, log_cap);
+        hipLaunchKernelGGL(probe<0>, dim3(2048), dim3(256), 0, 0, g, want, out, k_lo, k_hi, n, iters, checked, bad, log, log_cap);
       else
-        hipLaunchKernelGGL(probe<1>, dim3(2048), dim3(256), 0, 0, g, want, out, k_lo, k_hi, n, 4, checked, bad, log, log_cap);
+        hipLaunchKernelGGL(probe<1>, dim3(2048), dim3(256), 0, 0, g, want, out, k_lo, k_hi, n, iters, checked, bad, log, log_cap);
       ++launches;
     }
     (void)hipEventRecord(e1);

@@ -8,3 +8,5 @@ S=${1:-20}
 ./opsel_repro "$S" 0 solo
 ./opsel_repro "$S" 0 duo-a & ./opsel_repro "$S" 0 duo-b & wait
 ./opsel_repro "$S" 1 control-a & ./opsel_repro "$S" 1 control-b & wait
+# long launches (7 ms: a process switch now falls INSIDE a kernel, wave state is saved and restored)
+./opsel_repro "$S" 0 long-a 200 & ./opsel_repro "$S" 0 long-b 200 & wait
