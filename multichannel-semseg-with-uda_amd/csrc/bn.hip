@@ -477,10 +477,13 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_apply_cb_v4_kernel(const float* _
                                                              const typename P::elem* __restrict__ res_cb,
                                                              const float* __restrict__ res_bound, float* __restrict__ y,
                                                              typename P::elem* __restrict__ cb, const float* __restrict__ y_bound, int N,
-                                                             int C, int HW, int relu) {
+                                                             int C, int HW, int relu, int rev) {
   __shared__ typename P::frag lds[BN_V4_NT / 64][256];
   const int C8 = C >> 3;
-  const int ng = blockIdx.y;  // n * C8 + g
+  // rev: walk the tensor from its END -- the convolution that has just written z did so front to back, so the tail is what the
+  // Infinity Cache still holds
+  const int ng = rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;  // n * C8 + g
+  const int bx = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
   const int g = ng % C8;
   const int n = ng / C8;
   const float inv_scale = 1.f / operand_scale<P>(y_bound);
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_apply_cb_v4_kernel(const float* _
     cbeta[e] = beta[c] - mean[c] * ca[e];
   }
   const int wave = threadIdx.x >> 6;
-  const int pix_wave = (blockIdx.x * BN_V4_NT + 64 * wave) * 4;  // first pixel of this wave's 256
+  const int pix_wave = (bx * BN_V4_NT + 64 * wave) * 4;  // first pixel of this wave's 256
   const int pix = pix_wave + 4 * (threadIdx.x & 63);
   float v[4][8];
   if (pix < HW) {
@@ -589,10 +592,13 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_bwd_apply_cb_v4_kernel(const floa
                                                                  float* __restrict__ dz, float* __restrict__ dres,
                                                                  typename P::elem* __restrict__ cb, const float* __restrict__ dz_bound,
                                                                  const typename P::elem* __restrict__ y_cb, int N, int C, int HW,
-                                                                 int relu, int train, const float* __restrict__ mbeta) {
+                                                                 int relu, int train, const float* __restrict__ mbeta, int rev) {
   __shared__ typename P::frag lds[BN_V4_NT / 64][256];
   const int C8 = C >> 3;
-  const int ng = blockIdx.y;
+  // rev: walk the tensor from its END -- the reduce pass that ran just before read dy and z front to back, so their tails are what the
+  // Infinity Cache still holds (MI355X_MICROARCH.md: a line survives while everything touched since fits in ~256 MB)
+  const int ng = rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+  const int bx = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
   const int g = ng % C8;
   const int n = ng / C8;
   const float inv_scale = 1.f / operand_scale<P>(dz_bound);
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_bwd_apply_cb_v4_kernel(const floa
     k2[e] = train ? dgamma[c] * inv_n : 0.f;
   }
   const int wave = threadIdx.x >> 6;
-  const int pix_wave = (blockIdx.x * BN_V4_NT + 64 * wave) * 4;
+  const int pix_wave = (bx * BN_V4_NT + 64 * wave) * 4;
   const int pix = pix_wave + 4 * (threadIdx.x & 63);
   float v[4][8];
   if (pix < HW) {
@@ -785,6 +791,12 @@ int plane_chunks(int HW, bool vec) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// the four-pixel apply kernels walk their tensors back to front (see the kernels); MCDSEG_BN_REVERSE=0: front to back (development knob)
+int bn_reverse_walk() {
+  const char* e = getenv("MCDSEG_BN_REVERSE");
+  return e ? atoi(e) : 1;
+}
+
 }  // namespace
 
 extern "C" size_t mcdseg_bn_stats_workspace_bytes(int64_t rows, int32_t C) {
@@ -905,12 +917,13 @@ extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float
   if (int rc = cb_check("bn_apply_cb", math, y_bound, N, C, HW)) return rc;
   if (bn_v4_on() && (HW & 3) == 0 && (((uintptr_t)z | (uintptr_t)y | (uintptr_t)residual) & 15) == 0) {
     const dim3 grid4(ceil_div(HW, 4 * BN_V4_NT), N * (C / 8));
+    const int rev = bn_reverse_walk();
     if (math == MCDSEG_MATH_F16X3)
       hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitF16x3>, grid4, dim3(BN_V4_NT), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
-                         (const _Float16*)res_cb, res_bound, y, (_Float16*)y_cb, y_bound, N, C, HW, relu);
+                         (const _Float16*)res_cb, res_bound, y, (_Float16*)y_cb, y_bound, N, C, HW, relu, rev);
     else
       hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitBf16x6>, grid4, dim3(BN_V4_NT), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
-                         (const __bf16*)res_cb, res_bound, y, (__bf16*)y_cb, y_bound, N, C, HW, relu);
+                         (const __bf16*)res_cb, res_bound, y, (__bf16*)y_cb, y_bound, N, C, HW, relu, rev);
     MCD_LAUNCH_CHECK("bn_apply_cb");
     return 0;
   }
@@ -945,12 +958,13 @@ static bool bwd_apply_v4(const float* dy, const float* y, const void* y_cb, cons
   if (!bn_v4_on() || (HW & 3) != 0) return false;
   if ((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)dres) & 15) != 0) return false;
   const dim3 grid(ceil_div(HW, 4 * BN_V4_NT), N * (C / 8));
+  const int rev = bn_reverse_walk();
   if (math == MCDSEG_MATH_F16X3)
     hipLaunchKernelGGL(bn_bwd_apply_cb_v4_kernel<SplitF16x3>, grid, dim3(BN_V4_NT), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres,
-                       (_Float16*)dz_cb, dz_bound, (const _Float16*)y_cb, N, C, HW, relu, train, mbeta);
+                       (_Float16*)dz_cb, dz_bound, (const _Float16*)y_cb, N, C, HW, relu, train, mbeta, rev);
   else
     hipLaunchKernelGGL(bn_bwd_apply_cb_v4_kernel<SplitBf16x6>, grid, dim3(BN_V4_NT), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres,
-                       (__bf16*)dz_cb, dz_bound, (const __bf16*)y_cb, N, C, HW, relu, train, mbeta);
+                       (__bf16*)dz_cb, dz_bound, (const __bf16*)y_cb, N, C, HW, relu, train, mbeta, rev);
   return true;
 }
 

@@ -3,9 +3,14 @@
 // (models/drn.py:21-23; adapt_trainer.py:170-176).
 //
 // dW[tap][co][ci] = sum over pixels of dZ[co][pixel] * X[ci][pixel + shift(tap)].  A TILE is 256 (co) x 256 (ci) of one tap; its K
-// dimension are the 16-pixel stages (8 x 2 output pixels) of all images: KT = N * tiles_x * tiles_y K-steps.  The operands sit in
-// LDS exactly as in memory -- 16-byte units of 8 channels x 1 pixel, deposited by LDS-DMA -- and ds_read_b64_tr_b16 forms the MFMA
-// fragments (8 pixels of one channel per lane), as in conv_wgrad_split_tr_kernel (conv_wgrad_split.hip), whose LDS image this is.
+// dimension are the 16-pixel stages (16 consecutive pixels of one output row) of all images: KT = N * tiles_x * Ho K-steps.  The
+// operands sit in LDS as in memory -- 16-byte units of 8 channels x 1 pixel, deposited by LDS-DMA -- and ds_read_b64_tr_b16 forms the
+// MFMA fragments (8 pixels of one channel per lane), as in conv_wgrad_split_tr_kernel (conv_wgrad_split.hip).  What differs from that
+// kernel's LDS image is the shape of a DMA: there one instruction moves 4 pixels of 16 channel groups (16 runs of 64 bytes); here it
+// moves 16 PIXELS of 4 channel groups (lane = group * 16 + pixel): 4 runs of 256 contiguous bytes, a quarter of the memory requests
+// for the same kilobyte.  The four groups of one instruction are four apart (d, d+4, d+8, d+12), and instruction d of a 128-channel block
+// lands at d * (1 KB + 64 B): the four consecutive groups a transposing read touches then sit in four different instructions'
+// images, 64 bytes apart modulo the 256-byte bank row -- conflict-free.
 //
 // Ping-pong: waves 0-3 (co rows 0-127) and 4-7 (rows 128-255) are SIMD partners half a K-step apart; between two workgroup
 // barriers one group multiplies (24 MFMAs) while the other issues its 24 transposing reads of the same stage and its 4 LDS-DMAs
@@ -32,7 +37,7 @@ struct WgradPpParams {
   int N, Cin, H, W, Cout, Ho, Wo;
   int KH, KW, stride, pad, dil;
   int co_tiles, ci_tiles;  // 256-channel tiles
-  int tiles_x, tiles_y;    // 8 x 2 pixel tiles of one image
+  int tiles_x, tiles_y;    // 16 x 1 pixel stages of one image: ceil(Wo / 16) per row, Ho rows
   int kt;                  // K-steps of one tile: N * tiles_x * tiles_y
   int L, nwg;              // K-steps per workgroup, workgroups
   int x_cb_bytes, dy_cb_bytes;                // ONE piece of each companion (this call's images)
@@ -44,15 +49,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams 
   static_assert(P::NP == 2, "two-piece policies");
   constexpr int WM = 4, WN = 2;
   constexpr int NP = P::NP;
-  constexpr int R = 2;                  // pixel rows of a stage
-  constexpr int NQD = 2 * R;            // quads of 4 consecutive pixels per stage
   constexpr int NBLK = 2;               // 128-channel blocks per operand
   typedef typename P::frag frag;
   typedef short s16x4 __attribute__((ext_vector_type(4)));
   typedef short s16x8 __attribute__((ext_vector_type(8)));
-  constexpr int QUAD = 1024;            // bytes one DMA instruction deposits: [cg 16][pixel 4][16 B]
-  constexpr int QSTR = NBLK * QUAD;     // one quad of one (operand, piece): [block][cg 16][pixel 4][16 B]
-  constexpr int UNIT = NQD * QSTR;      // one piece of one operand: 8 KB
+  constexpr int NDMA = 4;               // DMA instructions per (operand, piece, block) and stage: 4 channel groups x 16 pixels each
+  constexpr int DSTR = 1024 + 64;       // bytes from one instruction's image [group 4][pixel 16][16 B] to the next (64 B: the bank offset)
+  constexpr int BLKB = NDMA * DSTR;     // one 128-channel block of one piece
+  constexpr int UNIT = NBLK * BLKB;     // one piece of one operand
   constexpr int STAGE = 2 * NP * UNIT;  // [operand: dZ, X][piece]
   constexpr int NS = 3;
   static_assert(NS * STAGE <= 160 * 1024, "LDS");
@@ -79,8 +83,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams 
   const int piece = (wave >> 1) & 1;
   const int blk = wave & 1;
   const bool isx = opnd == 1;
-  const int ps = lane & 3;
-  const int cg = lane >> 2;
+  const int px = lane & 15;   // pixel of the stage
+  const int cgl = lane >> 4;  // channel group d + 4 cgl of the wave's block, for DMA instruction d
   const int sH = isx ? p.H : p.Ho;
   const int sW = isx ? p.W : p.Wo;
   const int sS = isx ? p.stride : 1;
@@ -92,18 +96,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams 
   const int sbytes = (isx ? p.x_cb_bytes : p.dy_cb_bytes) + bias;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sptr, 0, sbytes, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
-  const int lane_x = ps * sS;
-  unsigned char* const unit_lds = smem + (opnd * NP + piece) * UNIT + blk * QUAD;
+  const int lane_x = px * sS;
+  unsigned char* const unit_lds = smem + (opnd * NP + piece) * UNIT + blk * BLKB;
   const bool dma_on = piece < P::NPU;  // (a piece the policy never multiplies -- SplitF16x1's second -- is not moved)
   const int ntiles = p.tiles_x * p.tiles_y;
 
-  // transposed-read address of this lane inside a (piece, quad) image, for the 32-row block i of the wave's rows: 16-lane group
-  // g = lane >> 4 covers rows 16 (g & 1) .. +15; lane 4q + pp of the group supplies pixel q, channels 4 pp .. 4 pp + 3
+  // transposed-read address of this lane for the 32-row block i (channel groups 4i .. 4i+3) of a 128-channel block: 16-lane group
+  // g = lane >> 4 covers rows 16 (g & 1) .. +15; lane 4q + pp of the group supplies pixel q of the quad, channels 4 pp .. 4 pp + 3 --
+  // i.e. channel group j = 2 (g & 1) + (pp >> 1) of the four, which is row i of instruction j's image
   const int gl = lane & 15;
   const int tq = gl >> 2, tpp = gl & 3;
-  const int trow = ((((lane >> 4) & 1) * 2 + (tpp >> 1)) * 4 + tq) * 16 + 8 * (tpp & 1);
-  const int a_lane = (2 * lh) * QSTR + wm * QUAD + trow;                                       // the wave's 128 dZ channels = block wm
-  const int b_lane = (2 * lh) * QSTR + (wn >> 1) * QUAD + (wn & 1) * 512 + trow;               // its 64 X channels = half of block wn >> 1
+  const int trow = ((((lane >> 4) & 1) * 2 + (tpp >> 1)) * DSTR) + tq * 16 + 8 * (tpp & 1) + (2 * lh) * 64;  // (+ the k-half's first quad)
+  const int a_lane = wm * BLKB + trow;                          // the wave's 128 dZ channels = block wm
+  const int b_lane = (wn >> 1) * BLKB + (wn & 1) * 512 + trow;  // its 64 X channels = rows 2 (wn & 1), 2 (wn & 1) + 1 of block wn >> 1
 
   // The transposing reads are issued as inline assembly: for a compiler-visible one the wait-count pass puts an s_waitcnt vmcnt(0) in
   // front whenever an LDS-DMA may be pending (it cannot tell that the DMA targets another stage), which would drain the prefetch at the
@@ -144,9 +149,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams 
     const int shy = isx ? ky * p.dil - p.pad : 0;
     const int shx = isx ? kx * p.dil - p.pad : 0;
     const int cg0 = (isx ? tile_ci : tile_co) * 32 + blk * 16;  // first channel group of this wave's block
-    const unsigned vconst = (cg0 + cg) < sC8 ? (unsigned)(cg * sHW + ps * sS) * 16u : OOB;
+    unsigned vconst[NDMA];
+#pragma unroll
+    for (int d = 0; d < NDMA; ++d) vconst[d] = (cg0 + d + 4 * cgl) < sC8 ? (unsigned)((d + 4 * cgl) * sHW + px * sS) * 16u : OOB;
 
-    // loader state: K-step -> (image, tile row, tile column), advanced incrementally
+    // loader state: K-step -> (image, output row, 16-pixel column block), advanced incrementally
     int l_n = k0 / ntiles;
     int l_ty = (k0 - l_n * ntiles) / p.tiles_x;
     int l_tx = k0 - l_n * ntiles - l_ty * p.tiles_x;
@@ -154,16 +161,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams 
 #if defined(__HIP_DEVICE_COMPILE__)
       if (dma_on) {
         const int sbase = (l_n * sC8 + cg0) * sHW;  // 16-byte units inside the piece
+        const int iy = l_ty * sS + shy;
+        const int ux = l_tx * 16 * sS + shx;
+        const bool colok = (unsigned)(ux + lane_x) < (unsigned)sW;
+        const int soff = ((unsigned)iy < (unsigned)sH) ? (sbase + iy * sW + ux) * 16 + bias : 0x7FFFFFFF;
 #pragma unroll
-        for (int j = 0; j < NQD; ++j) {  // quad j: row j % R of the tile, column half j / R
-          const int h = j / R;
-          const int iy = (l_ty * R + (j % R)) * sS + shy;
-          const int ux = (l_tx * 8 + 4 * h) * sS + shx;
-          const bool colok = (unsigned)(ux + lane_x) < (unsigned)sW;
-          const int soff = ((unsigned)iy < (unsigned)sH) ? (sbase + iy * sW + ux) * 16 + bias : 0x7FFFFFFF;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(unit_lds + stage * STAGE + j * QSTR), 16,
-                                                   colok ? vconst : OOB, soff, 0, 0);
-        }
+        for (int d = 0; d < NDMA; ++d)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(unit_lds + stage * STAGE + d * DSTR), 16,
+                                                   colok ? vconst[d] : OOB, soff, 0, 0);
       }
 #else
       (void)stage;
@@ -204,10 +209,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams 
       // (compile-time offsets: operand, piece, 32-row block, second quad)
 #define MCD_A_FRAG(PC, I) \
       if constexpr ((PC) < P::NPU) \
-        fa[PC][I] = frag_of(base_a, std::integral_constant<int, (PC) * UNIT + (I) * 256>{}, std::integral_constant<int, (PC) * UNIT + (I) * 256 + QSTR>{});
+        fa[PC][I] = frag_of(base_a, std::integral_constant<int, (PC) * UNIT + (I) * 256>{}, std::integral_constant<int, (PC) * UNIT + (I) * 256 + 64>{});
 #define MCD_B_FRAG(PC, J) \
       if constexpr ((PC) < P::NPU) \
-        fb[PC][J] = frag_of(base_b, std::integral_constant<int, (NP + (PC)) * UNIT + (J) * 256>{}, std::integral_constant<int, (NP + (PC)) * UNIT + (J) * 256 + QSTR>{});
+        fb[PC][J] = frag_of(base_b, std::integral_constant<int, (NP + (PC)) * UNIT + (J) * 256>{}, std::integral_constant<int, (NP + (PC)) * UNIT + (J) * 256 + 64>{});
       MCD_A_FRAG(0, 0) MCD_A_FRAG(0, 1) MCD_A_FRAG(0, 2) MCD_A_FRAG(0, 3) MCD_B_FRAG(0, 0) MCD_B_FRAG(0, 1)
       MCD_A_FRAG(1, 0) MCD_A_FRAG(1, 1) MCD_A_FRAG(1, 2) MCD_A_FRAG(1, 3) MCD_B_FRAG(1, 0) MCD_B_FRAG(1, 1)
 #undef MCD_A_FRAG
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams 
         issue(nxt2);
         // this wave's share of stage s+1 has landed (the share of stage s+2 stays in flight) and its fragment reads are back
         if (dma_on)
-          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NQD) : "memory");
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA) : "memory");
         else
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       } else {
@@ -321,7 +326,7 @@ int mcdseg_internal_wgrad_pp_plan(const mcdseg_conv_desc* d, int math, int* L, s
   if (T > 32 || d->pad > 128) return 0;
   const int64_t co_tiles = ceil_div(d->Cout, 256), ci_tiles = ceil_div(d->Cin, 256);
   if (co_tiles * 256 - d->Cout >= 128 || ci_tiles * 256 - d->Cin >= 128) return 0;  // (a half-empty tile: the 128-channel kernels are better)
-  const int64_t kt = (int64_t)d->N * ceil_div(d->Wo, 8) * ceil_div(d->Ho, 2);
+  const int64_t kt = (int64_t)d->N * ceil_div(d->Wo, 16) * d->Ho;
   const int64_t tiles = co_tiles * ci_tiles * T, total = tiles * kt;
   int64_t nwg = pp_compute_units();
   if (total < nwg * 32) return 0;  // (less than 32 K-steps per CU: the launch is all prologue and slab traffic)
@@ -346,7 +351,7 @@ int mcdseg_internal_wgrad_pp_launch(const mcdseg_conv_desc* d, int math, const v
   p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.Ho = d->Ho; p.Wo = d->Wo;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
   p.co_tiles = ceil_div(d->Cout, 256); p.ci_tiles = ceil_div(d->Cin, 256);
-  p.tiles_x = ceil_div(d->Wo, 8); p.tiles_y = ceil_div(d->Ho, 2);
+  p.tiles_x = ceil_div(d->Wo, 16); p.tiles_y = d->Ho;
   p.kt = d->N * p.tiles_x * p.tiles_y;
   p.L = L; p.nwg = nwg;
   p.x_cb_bytes = (int)xb; p.dy_cb_bytes = (int)yb;
