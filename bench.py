@@ -187,7 +187,12 @@ def other_config(tag, dev, steps, n_class=41):
 
 def is_forward_conv(name):
     """conv_gemm*<..., DGRAD, PRESPLIT> / conv_gemm_split_pp_kernel<P, DGRAD>: the instantiations with DGRAD = false"""
-    return name.startswith("conv_gemm") and (", false, " in name or name.endswith(", false>"))
+    if not name.startswith("conv_gemm") or "<" not in name:
+        return False
+    args = [a.strip() for a in name[name.index("<") + 1:name.rindex(">")].split(",")]
+    if name.startswith("conv_gemm_split_pp_kernel"):
+        return args[1] == "false"
+    return (args[-2] if name.startswith("conv_gemm_split_kernel") else args[-1]) == "false"
 
 
 def host_cpu():

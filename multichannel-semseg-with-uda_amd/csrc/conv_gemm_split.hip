@@ -887,6 +887,7 @@ void launch(const ConvSplitParams& p, int64_t pix0, hipStream_t st) {
 int64_t mcdseg_internal_conv_pp_pixels(const ConvSplitParams& p, int math, bool dgrad);
 int mcdseg_internal_conv_pp_launch(const ConvSplitParams& p, int math, bool dgrad, int64_t pixels, hipStream_t st);
 int mcdseg_internal_conv_pp_rest(const ConvSplitParams& p, int math, bool dgrad);
+int mcdseg_internal_conv_pp_wide(const ConvSplitParams& p, int math, bool dgrad);
 int mcdseg_internal_conv_pp_rest_launch(const ConvSplitParams& p, int math, bool dgrad, int64_t pix0, hipStream_t st);
 
 namespace {
@@ -944,11 +945,18 @@ extern "C" int64_t mcdseg_conv_split_stat_rows(const mcdseg_conv_desc* d) {
   return stat_rows_of(d, false);
 }
 
+static int fill_fprop_params(const mcdseg_conv_desc* d, int math, const void* x_cb, ConvSplitParams& p);
+
 extern "C" int64_t mcdseg_conv_split_stat_rows_for(const mcdseg_conv_desc* d, int32_t math, int32_t presplit) {
   math = mcd_storage_math(math);  // F16X1 shares F16X3's storage
   if (d == nullptr) return -22;
   if (math == MCDSEG_MATH_F16X3 && presplit && mcdseg_internal_thin_window_ok(d, 0)) return mcdseg_internal_thin_window_stat_rows(d);
   if (mcdseg_internal_stem_ok(d)) return mcdseg_internal_stem_stat_rows(d);
+  if (presplit) {  // the 256 x 320 ping-pong tile: one row per wave column of 160 pixels
+    ConvSplitParams p;
+    if (fill_fprop_params(d, math, d, p) == 0 && mcdseg_internal_conv_pp_wide(p, math, false))
+      return 2 * ceil_div64((int64_t)d->N * d->Ho * d->Wo, 320);
+  }
   return stat_rows_of(d, presplit != 0);
 }
 
@@ -1181,6 +1189,17 @@ extern "C" int32_t mcdseg_conv_split_rest_pingpong(const mcdseg_conv_desc* d, in
   ConvSplitParams p;
   if (dgrad ? fill_dgrad_params(d, math, d, p) : fill_fprop_params(d, math, d, p)) return 0;
   return mcdseg_internal_conv_pp_rest(p, math, dgrad != 0);
+}
+
+// 1 when the whole convolution runs on the 256 x 320 ping-pong tile (mcdseg_conv_split_parts then returns every pixel)
+extern "C" int32_t mcdseg_conv_split_wide_pingpong(const mcdseg_conv_desc* d, int32_t math, int32_t presplit, int32_t dgrad) {
+  if (d == nullptr || !mcd_math_known(math) || !presplit) return 0;
+  const int smath = mcd_storage_math(math);
+  if (smath == MCDSEG_MATH_F16X3 && mcdseg_internal_thin_window_ok(d, dgrad ? 1 : 0)) return 0;
+  if (!dgrad && mcdseg_internal_stem_ok(d)) return 0;
+  ConvSplitParams p;
+  if (dgrad ? fill_dgrad_params(d, math, d, p) : fill_fprop_params(d, math, d, p)) return 0;
+  return mcdseg_internal_conv_pp_wide(p, math, dgrad != 0);
 }
 
 extern "C" int mcdseg_conv_split_fprop_part(const mcdseg_conv_desc* d, int32_t math, const float* x, const void* x_cb, const float* x_bound,

@@ -38,6 +38,9 @@ namespace {
 //   <4, 2, 1, 4>  256 x 256, waves of 128 x 64, ONE workgroup per CU (96 KB of LDS): the fewest operand bytes per FLOP;
 //   <2, 2, 2, 2>  256 x 128, waves of 64 x 64 (<= 128 VGPRs), TWO workgroups per CU (2 x 72 KB): half the tile, so a partial last
 //                 round of workgroups costs half as much, and one workgroup's epilogue hides behind the other's K loop.
+//   <2, 5, 2, 2>  256 x 320, waves of 64 x 160, one workgroup per CU (120 KB): the tile WIDTH is the knob against round quantisation --
+//                 76800 pixels (BASELINE config 2, 1/8 resolution) are 300 tiles of 256 (1.17 rounds of 256 CUs: the last 44 tiles
+//                 cost a whole round) but 240 tiles of 320 (0.94 of ONE round).  A wave's 160 pixels are one BatchNorm partial row.
 template <class P, bool DGRAD, int WM, int WN, int QM, int QN>
 __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_pp_kernel(ConvSplitParams p) {
   static_assert(QM * QN == 4, "four waves per group");
@@ -47,13 +50,15 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
   constexpr int NPU = P::NPU;        // ... of which the policy multiplies (and the loop stages) the first NPU
   constexpr int NQ = 2 * NP;         // (piece, k-half) planes per K-step
   typedef typename P::frag frag;
-  constexpr int A_BYTES = NQ * BM * 16, B_BYTES = NQ * BN * 16;
   constexpr int A_DMAS = 2 * NPU * BM / NT;        // weight-slab DMAs per thread and K-step (piece-major slab: the staged pieces are its head)
   constexpr int B_UNITS = 2 * NPU * BN;            // 16-byte units of the pixel operand per K-step: [piece][k-half][pixel]
-  constexpr int B_DMAS = (B_UNITS + NT - 1) / NT;  // per thread (units past B_UNITS: an out-of-range DMA that deposits zeros in an unused plane)
+  constexpr int B_DMAS = (B_UNITS + NT - 1) / NT;  // per thread (units past B_UNITS: an out-of-range DMA that deposits zeros past the planes)
   constexpr int DMA_PER_STEP = A_DMAS + B_DMAS;
-  static_assert((2 * NPU * BM) % NT == 0 && NT % BN == 0 && BN >= 64, "every wave issues the same number of DMAs (the waits are counted)");
-  static_assert(B_DMAS * NT <= NQ * BN, "the zero-filled units stay inside the stage");
+  constexpr int A_BYTES = NQ * BM * 16, B_BYTES = (NQ * BN > B_DMAS * NT ? NQ * BN : B_DMAS * NT) * 16;
+  // a pixel tile that divides the workgroup gives every thread ONE gather pixel for all its units; otherwise (320) one per unit
+  constexpr bool SAMEPX = (NT % BN) == 0;
+  constexpr int NPX = SAMEPX ? 1 : B_DMAS;
+  static_assert((2 * NPU * BM) % NT == 0 && BN % 64 == 0, "every wave issues the same number of DMAs (the waits are counted); a wave's units share a plane");
   static_assert(NS * (A_BYTES + B_BYTES) <= 160 * 1024, "LDS");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (A_BYTES + B_BYTES)];
@@ -77,20 +82,10 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
   const int tile_n = p.tile_n0 + xcd * per_xcd + slot / m_tiles;
   if (tile_n >= n_tiles) return;
 
-  // ---- this thread's gather pixel (it never changes); unit i of the thread is plane (t + i NT) / BN = piece * 2 + k-half of that pixel
-  const int bj = t & (BN - 1);
-  const int plane0 = wave * 64 / BN;  // wave-uniform
+  // ---- this thread's gather pixels (they never change): unit i of the thread is unit t + i NT of the stage, plane (t + i NT) / BN =
+  // piece * 2 + k-half, pixel (t + i NT) % BN of the tile -- plane and the wave's first pixel are wave-uniform (BN % 64 == 0)
   const int HWd = p.Hd * p.Wd;
   const int HWs = p.Hs * p.Ws;
-  const int pix = tile_n * BN + bj;
-  const bool pv = pix < p.P;
-  int pn = 0, py = 0, px = 0;
-  if (pv) {
-    pn = pix / HWd;
-    const int rem = pix - pn * HWd;
-    py = rem / p.Wd;
-    px = rem - py * p.Wd;
-  }
   constexpr unsigned OOB = 0x80000000u;
   __amdgpu_buffer_rsrc_t cb_rs[NPU];  // one descriptor per piece of the companion (each below 2 GiB; the pieces of a batch slice are not adjacent)
 #pragma unroll
@@ -98,18 +93,33 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
     cb_rs[pc] = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.src_cb + pc * p.cb_piece_stride), 0, p.cb_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wp_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.wp_bytes, 0x00020000);
   const int C8 = p.Cs >> 3;
-  const unsigned pix_base = (unsigned)pn * (unsigned)C8 * (unsigned)HWs;  // in 16-byte units
   const int taps = p.KH * p.KW;  // <= 32 (host)
-  // whether tap q of this pixel falls into the zero padding is one bit of a per-thread mask; the tap's address offset is the same for
-  // every thread (scalar ALU): a K-step spends three vector instructions on addressing
-  unsigned valid_mask = 0;
-  for (int q = 0; q < taps; ++q) {
-    const int ky = q / p.KW, kx = q - ky * p.KW;
-    const int sy = DGRAD ? py + p.pad - ky * p.dil : py * p.stride + ky * p.dil - p.pad;
-    const int sx = DGRAD ? px + p.pad - kx * p.dil : px * p.stride + kx * p.dil - p.pad;
-    valid_mask |= (pv && sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws ? 1u : 0u) << q;
+  // whether tap q of a pixel falls into the zero padding is one bit of a per-thread mask; the tap's address offset is the same for
+  // every thread (scalar ALU): a K-step spends three vector instructions per gather pixel on addressing
+  unsigned valid_mask[NPX], vbase[NPX];
+#pragma unroll
+  for (int x = 0; x < NPX; ++x) {
+    const int bj = (t + x * NT) % BN;
+    const int pix = tile_n * BN + bj;
+    const bool pv = pix < p.P;
+    int pn = 0, py = 0, px = 0;
+    if (pv) {
+      pn = pix / HWd;
+      const int rem = pix - pn * HWd;
+      py = rem / p.Wd;
+      px = rem - py * p.Wd;
+    }
+    const unsigned pix_base = (unsigned)pn * (unsigned)C8 * (unsigned)HWs;  // in 16-byte units
+    unsigned vm = 0;
+    for (int q = 0; q < taps; ++q) {
+      const int ky = q / p.KW, kx = q - ky * p.KW;
+      const int sy = DGRAD ? py + p.pad - ky * p.dil : py * p.stride + ky * p.dil - p.pad;
+      const int sx = DGRAD ? px + p.pad - kx * p.dil : px * p.stride + kx * p.dil - p.pad;
+      vm |= (pv && sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws ? 1u : 0u) << q;
+    }
+    valid_mask[x] = vm;
+    vbase[x] = DGRAD ? pix_base + (unsigned)(py * p.Ws + px) : pix_base + (unsigned)(py * p.stride * p.Ws + px * p.stride);
   }
-  const unsigned vbase = DGRAD ? pix_base + (unsigned)(py * p.Ws + px) : pix_base + (unsigned)(py * p.stride * p.Ws + px * p.stride);
 
   unsigned a_voff[A_DMAS];
 #pragma unroll
@@ -119,7 +129,6 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
     const int m = id - plane * BM;
     a_voff[i] = ((unsigned)plane * (unsigned)p.Mp + (unsigned)m) * 16u;
   }
-  const int wave_px = __builtin_amdgcn_readfirstlane(bj - lane);
 
   // loader state: K order is channel-chunk outer, tap inner (the shifted re-reads of a 16-channel slab are back to back)
   int l_tap = 0, l_c0 = 0, l_ky = 0, l_kx = 0, l_kstep = 0;
@@ -131,16 +140,19 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
     for (int i = 0; i < A_DMAS; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wp_rs, (__attribute__((address_space(3))) void*)(adst + i * NT * 16), 16, a_voff[i], a_soff, 0, 0);
     const int rel = DGRAD ? (p.pad - l_ky * p.dil) * p.Ws + (p.pad - l_kx * p.dil) : (l_ky * p.dil - p.pad) * p.Ws + (l_kx * p.dil - p.pad);
-    const unsigned voff = ((valid_mask >> l_tap) & 1u) ? (vbase + (unsigned)rel) * 16u : OOB;
+    unsigned voff[NPX];
+#pragma unroll
+    for (int x = 0; x < NPX; ++x) voff[x] = ((valid_mask[x] >> l_tap) & 1u) ? (vbase[x] + (unsigned)rel) * 16u : OOB;
 #pragma unroll
     for (int i = 0; i < B_DMAS; ++i) {
-      const int plane = plane0 + i * (NT / BN);  // wave-uniform: piece = plane / 2, k-half = plane % 2
+      const int unit0 = wave * 64 + i * NT;  // this wave's first unit of the stage: wave-uniform, and so is its plane
+      const int plane = unit0 / BN;          // piece = plane / 2, k-half = plane % 2
       const int grp = (l_c0 >> 3) + (plane & 1);
       // (a ragged last chunk, or a unit past the staged pieces: the range check deposits zeros)
       const int soff = (grp < C8 && plane < 2 * NPU) ? grp * HWs * 16 : 0x7FFFFFFF;
-      unsigned char* bdst = Bs + buf * B_BYTES + (plane * BN + wave_px) * 16;
+      unsigned char* bdst = Bs + buf * B_BYTES + unit0 * 16;
       const __amdgpu_buffer_rsrc_t rs = (NPU > 1 && plane >= 2) ? cb_rs[NPU - 1] : cb_rs[0];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)bdst, 16, voff, soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)bdst, 16, voff[SAMEPX ? 0 : i], soff, 0, 0);
     }
 #else
     (void)buf;
@@ -374,13 +386,44 @@ void launch_math(const ConvSplitParams& q, int math, bool dgrad, hipStream_t st)
   }
 }
 
+// The 256 x 320 tile takes a WHOLE convolution when that is the cheaper plan.  Costs in units of one 256 x 256 tile's time on a CU:
+//   hybrid  = whole rounds of 256 x 256 tiles + the rest on 256 x 128 tiles (half a unit per workgroup, two per CU side by side)
+//   wide    = ceil(tiles320 / CUs) rounds of 1.25
+// and the hybrid plan exists only from pp_min_rounds() whole rounds on; without it the wide tile must fill its rounds to 80 %
+// (MCDSEG_PP_WIDE_FILL, per cent; above 100 = never) to beat the 4-wave tiles.  Measured at BASELINE config 2 (76800 pixels, same
+// box, ms forward / data gradient): 256 -> 256 (240 wide tiles = 0.94 round; 4-wave tiles 0.246 / 0.246) 0.205 / 0.200;
+// 512 -> 512 (480 wide tiles, cost 2.5; hybrid cost 2.5, 0.793 / 0.773) 0.757 / 0.750 -- ties go to the single launch.
+// MCDSEG_PINGPONG = 4 forces the wide tile wherever the kernel applies.
+bool pp_wide(const ConvSplitParams& p, int math, bool dgrad) {
+  const int mode = pp_mode();
+  if ((mode != 3 && mode != 4) || !pp_applies(p, math, dgrad)) return false;
+  if (mode == 4) return true;
+  const char* e = getenv("MCDSEG_PP_WIDE_FILL");
+  const int64_t fill = e ? atoi(e) : 80;
+  if (fill > 100) return false;
+  const int64_t cus = compute_units(), m_tiles = p.Mp / 256;
+  const int64_t tiles = ceil_div64(p.P, 320) * m_tiles, rounds_w = ceil_div64(tiles, cus);
+  const int min_rounds = pp_min_rounds() > 1 ? pp_min_rounds() : 1;
+  const int64_t rounds = (p.P / 256) * m_tiles / cus;
+  if (rounds < min_rounds) return tiles * 100 >= fill * rounds_w * cus;  // against the 4-wave tiles
+  int64_t n_pp = rounds * cus / m_tiles;  // (mcdseg_internal_conv_pp_pixels)
+  if (n_pp > p.P / 256) n_pp = p.P / 256;
+  const int64_t rest = ceil_div64(p.P - n_pp * 256, 128) * m_tiles;  // 256 x 128 workgroups
+  // 4 x cost: hybrid = 4 rounds + 2 ceil(rest / CUs); wide = 5 rounds_w
+  return 5 * rounds_w <= 4 * rounds + 2 * ceil_div64(rest, cus);
+}
+
 }  // namespace
+
+// 1 when the whole convolution runs on the 256 x 320 ping-pong tile (BatchNorm partial rows of 160 pixels)
+int mcdseg_internal_conv_pp_wide(const ConvSplitParams& p, int math, bool dgrad) { return pp_wide(p, math, dgrad) ? 1 : 0; }
 
 // Pixels (a multiple of 256, counted from pixel 0) of this problem that the 256 x 256 ping-pong tile takes: whole rounds of one tile
 // per CU; 0 when it does not apply (no pre-split operand, three-piece arithmetic, output rows not a multiple of 256, strided data
 // gradient, more than 32 taps, less than one round of tiles).
 int64_t mcdseg_internal_conv_pp_pixels(const ConvSplitParams& p, int math, bool dgrad) {
   const int mode = pp_mode();
+  if (pp_wide(p, math, dgrad)) return p.P;  // (everything, on the 256 x 320 tile)
   if ((mode != 1 && mode != 3) || !pp_applies(p, math, dgrad)) return 0;
   const int64_t m_tiles = p.Mp / 256, n_full = p.P / 256, cus = compute_units();
   const int64_t rounds = n_full * m_tiles / cus;
@@ -403,6 +446,12 @@ int mcdseg_internal_conv_pp_launch(const ConvSplitParams& p, int math, bool dgra
   ConvSplitParams q = p;
   q.sub = 0;
   q.tile_n0 = 0;
+  if (pp_wide(p, math, dgrad)) {
+    q.tile_n1 = ceil_div(p.P, 320);
+    launch_math<2, 5, 2, 2>(q, math, dgrad, st);
+    MCD_LAUNCH_CHECK("conv_gemm_split_pp (256 x 320)");
+    return 0;
+  }
   q.tile_n1 = (int)(pixels / 256);
   launch_math<4, 2, 1, 4>(q, math, dgrad, st);
   MCD_LAUNCH_CHECK("conv_gemm_split_pp");

@@ -84,10 +84,11 @@ def gemm_kernel_name(m, k, dgrad, split=False, presplit=False, direct=False, pix
     return "conv_gemm_kernel<%s, %d, %s>" % (cfg, 8 if k <= 8 else 16, "true" if dgrad else "false")
 
 
-def pingpong_kernel_name(dgrad, math=None, small=False):
-    """rocprofv3's name of the 8-wave ping-pong kernel (csrc/conv_gemm_split_pp.hip): its 256 x 256 tile, or the 256 x 128 one"""
+def pingpong_kernel_name(dgrad, math=None, small=False, wide=False):
+    """rocprofv3's name of the 8-wave ping-pong kernel (csrc/conv_gemm_split_pp.hip): its 256 x 256 tile, the 256 x 128 one
+    (``small``) or the 256 x 320 one (``wide``)"""
     return "conv_gemm_split_pp_kernel<%s, %s, %s>" % (POLICY[math or CONV_MATH], "true" if dgrad else "false",
-                                                      "2, 2, 2, 2" if small else "4, 2, 1, 4")
+                                                      "2, 5, 2, 2" if wide else ("2, 2, 2, 2" if small else "4, 2, 1, 4"))
 
 
 def _split_launches(d, presplit, dgrad, name, call):
@@ -98,7 +99,8 @@ def _split_launches(d, presplit, dgrad, name, call):
     pp = lib().mcdseg_conv_split_parts(ctypes.byref(d), MATH_ID[CONV_MATH], int(presplit), int(dgrad)) if presplit else 0
     flops, byts = conv_work(d)
     if pp > 0:
-        with _timed(pingpong_kernel_name(dgrad), (flops * pp / pixels, byts * pp / pixels)):
+        wide = bool(lib().mcdseg_conv_split_wide_pingpong(ctypes.byref(d), MATH_ID[CONV_MATH], 1, int(dgrad)))
+        with _timed(pingpong_kernel_name(dgrad, wide=wide), (flops * pp / pixels, byts * pp / pixels)):
             call(1)
     if pp < pixels:
         if presplit and lib().mcdseg_conv_split_rest_pingpong(ctypes.byref(d), MATH_ID[CONV_MATH], 1, int(dgrad)):

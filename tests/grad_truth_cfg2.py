@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Test infrastructure (not collected by pytest; imports the oracle like the tests do): how far are the cross-entropy gradients of
+BASELINE config 2's full batch (16 x 6 x 480 x 640, drn_d_38, train-mode BatchNorm) from the TRUTH, for the HIP path and for the
+fp32 CPU oracle?  The oracle is run twice -- in fp32 (what tests/test_model_gpu.py::test_cfg2_full_batch_vs_oracle compares with)
+and in fp64 on the same parameters and batch -- and the relative L2 distances oracle32-fp64, HIP-fp64 and HIP-oracle32 are printed
+per family of tensors and over all of them.  The numbers set the bounds of that test.
+    python tests/grad_truth_cfg2.py [--n 16] [--math f16x3]"""
+import argparse
+import os
+import sys
+import time
+
+TESTS = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(TESTS)
+for p in (os.path.join(TESTS, "golden"), ROOT, os.path.join(ROOT, "multichannel-semseg-with-uda_amd")):
+    sys.path.insert(0, p)
+os.environ.setdefault("MCDSEG_PRETRAINED", "0")
+import torch  # noqa: E402
+
+from recipe import fill_state_, make_batch  # noqa: E402
+
+NC = 41
+
+
+def physical_cores():
+    cores, pid = set(), None
+    for line in open("/proc/cpuinfo"):
+        k, _, v = line.partition(":")
+        if k.strip() == "physical id":
+            pid = v.strip()
+        elif k.strip() == "core id":
+            cores.add((pid, v.strip()))
+    return len(cores) or os.cpu_count()
+
+
+def oracle_grads(src, lbl, double):
+    from oracle import ref_loss, ref_models
+    og, of1, of2 = ref_models.get_models("drn_d_38", 6, NC)
+    fill_state_(og, 11), fill_state_(of1, 12), fill_state_(of2, 13)
+    cw = ref_loss.class_weights(NC)
+    if double:
+        og, of1, of2, src, cw = og.double(), of1.double(), of2.double(), src.double(), cw.double()
+    og.train(), of1.train(), of2.train()
+    feat = og(src)
+    crit = ref_loss.CrossEntropyLoss2d(cw)
+    (crit(of1(feat), lbl) + crit(of2(feat), lbl)).backward()
+    gs = {k: v.grad.double().clone() for k, v in og.named_parameters()}
+    gs.update({"f%d.%s" % (i + 1, k): v.grad.double().clone() for i, m in enumerate((of1, of2)) for k, v in m.named_parameters()})
+    return gs
+
+
+def hip_grads(src, lbl, dev):
+    from loss import CrossEntropyLoss2d
+    from models.model_util import get_models
+    from oracle import ref_loss
+    g, f1, f2 = get_models("drn_d_38", 6, NC)
+    for m, seed in ((g, 11), (f1, 12), (f2, 13)):
+        fill_state_(m, seed)
+        m.to(dev)
+        m.train(True)
+    cw = ref_loss.class_weights(NC).to(dev)
+    feat = g(src.to(dev))
+    crit = CrossEntropyLoss2d(cw)
+    (crit(f1(feat), lbl.to(dev)) + crit(f2(feat), lbl.to(dev))).backward()
+    torch.cuda.synchronize()
+    gs = {k: v.grad.double().cpu() for k, v in g.named_parameters()}
+    gs.update({"f%d.%s" % (i + 1, k): v.grad.double().cpu() for i, m in enumerate((f1, f2)) for k, v in m.named_parameters()})
+    return gs
+
+
+def distance(a, b, keys):
+    num = den = 0.0
+    worst = (0.0, None)
+    for k in keys:
+        dn, rn = float((a[k] - b[k]).norm()), float(b[k].norm())
+        num, den = num + dn * dn, den + rn * rn
+        worst = max(worst, (dn / max(rn, 1e-300), k))
+    return (num / max(den, 1e-300)) ** 0.5, worst
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=16)
+    ap.add_argument("--math", default=None)
+    args = ap.parse_args()
+    from mcdseg import ops
+    if args.math:
+        ops.CONV_MATH = args.math
+    torch.set_num_threads(physical_cores())
+    src, lbl, _ = make_batch(78, args.n, 6, 480, 640, NC)
+    t0 = time.time()
+    g_hip = hip_grads(src, lbl, torch.device("cuda:0"))
+    t1 = time.time()
+    g32 = oracle_grads(src, lbl, False)
+    t2 = time.time()
+    g64 = oracle_grads(src, lbl, True)
+    t3 = time.time()
+    print("N = %d, %s: HIP %.1f s, oracle fp32 %.1f s, oracle fp64 %.1f s" % (args.n, ops.CONV_MATH, t1 - t0, t2 - t1, t3 - t2))
+    assert set(g_hip) == set(g32) == set(g64)
+    fams = {"all": list(g64), "conv weights": [k for k in g64 if g64[k].dim() == 4 and not k.startswith("f")],
+            "BatchNorm weight / bias": [k for k in g64 if g64[k].dim() == 1], "classifier up-sampling": [k for k in g64 if k.startswith("f")]}
+    for fam, keys in fams.items():
+        if not keys:
+            continue
+        a, wa = distance(g32, g64, keys)
+        b, wb = distance(g_hip, g64, keys)
+        c, wc = distance(g_hip, g32, keys)
+        print("%-26s %3d tensors  oracle32-fp64 %.3e (worst %.3e %s)  HIP-fp64 %.3e (worst %.3e %s)  HIP-oracle32 %.3e (worst %.3e %s)"
+              % (fam, len(keys), a, wa[0], wa[1], b, wb[0], wb[1], c, wc[0], wc[1]))
+
+
+if __name__ == "__main__":
+    main()

@@ -1073,6 +1073,7 @@ def test_conv_pingpong_tile(case, monkeypatch):
     cin, cout, k, stride, d, n, h, w, math = case
     monkeypatch.setattr(ops, "CONV_MATH", math)
     monkeypatch.setenv("MCDSEG_PP_MIN_ROUNDS", "1")  # (by default the kernels take a convolution from two whole rounds of tiles on)
+    monkeypatch.setenv("MCDSEG_PP_WIDE_FILL", "101")  # (... and the 256 x 320 tile takes it whole where that is cheaper: below, forced)
     x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, stride, d, h, w, n, False), 41)
     desc = ops.conv_desc(x.shape, wt.shape, stride, pad, d)
     pk = ops.PackedWeights()
@@ -1127,6 +1128,42 @@ def test_conv_pingpong_tile(case, monkeypatch):
         assert torch.equal(y_m, y) and rows_m == rows and torch.equal(part_m, part), "mode %s differs" % mode
         if dx is not None:
             assert torch.equal(ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound), dx), "data gradient, mode %s" % mode
+    # the 256 x 320 tile (mode 4 forces it; by default it takes a convolution with fewer than two rounds of 256 x 256 tiles whose 320-pixel
+    # tiles fill their rounds): the same output bits; its BatchNorm partial rows are one per 160 pixels -- the same moments, regrouped
+    monkeypatch.setenv("MCDSEG_PINGPONG", "4")
+    names = []
+
+    class _Names4:
+        def wants(self, name):
+            names.append(name)
+            return False
+    prev, ops.LAUNCH_TIMER = ops.LAUNCH_TIMER, _Names4()
+    try:
+        y_w, part_w, rows_w = ops._conv_fprop(desc, xg, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)
+        dx_w = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound) if dx is not None else None
+    finally:
+        ops.LAUNCH_TIMER = prev
+    if cout % 256 == 0:
+        assert ops.pingpong_kernel_name(False, wide=True) in names, names
+    if dx is not None and cin % 256 == 0:  # (the data gradient has M = Cin output rows)
+        assert L.mcdseg_conv_split_wide_pingpong(ctypes.byref(desc), mid, 1, 1) == 1 and ops.pingpong_kernel_name(True, wide=True) in names, names
+    pixels = n * desc.Ho * desc.Wo
+    if cout % 256 == 0:
+        assert L.mcdseg_conv_split_wide_pingpong(ctypes.byref(desc), mid, 1, 0) == 1
+        assert L.mcdseg_conv_split_parts(ctypes.byref(desc), mid, 1, 0) == pixels and rows_w == 2 * ((pixels + 319) // 320)
+    else:
+        assert L.mcdseg_conv_split_wide_pingpong(ctypes.byref(desc), mid, 1, 0) == 0 and rows_w == rows
+    assert torch.equal(y_w, y), "forward on the 256 x 320 tile differs (max %.3e)" % float((y_w - y).abs().max())
+    if dx is not None:
+        assert torch.equal(dx_w, dx), "data gradient on the 256 x 320 tile differs"
+    pw = part_w.double().view(rows_w, 3, -1)[:, :, :cout]
+    cnt, mean_r, m2_r = pw[:, 0], pw[:, 1], pw[:, 2]
+    assert float(cnt[:, 0].sum()) == pixels
+    mean = (cnt * mean_r).sum(0) / pixels
+    var = (m2_r + cnt * (mean_r - mean) ** 2).sum(0) / pixels
+    y64 = y.double().transpose(0, 1).reshape(cout, -1)
+    assert float((mean - y64.mean(1)).abs().max()) <= 1e-6 * float(y64.abs().max())
+    assert float((var - y64.var(1, unbiased=False)).abs().max()) <= 1e-6 * float(y64.var(1, unbiased=False).max())
     # parts 1 + 2 of the C ABI write exactly what part 0 writes (poisoned output, two calls)
     monkeypatch.setenv("MCDSEG_PINGPONG", "3")
     y2 = torch.full_like(y, float("nan"))

@@ -647,14 +647,13 @@ def test_cfg2_full_batch_vs_oracle():
     finally:
         ops.LAUNCH_TIMER = timer_prev
     if ops.CONV_MATH != "f32":
-        if ops.PIECES[ops.CONV_MATH] == 2:  # whole rounds of 256 x 256 ping-pong tiles, the rest on the 256 x 128 ping-pong tile
-            for nm in (ops.pingpong_kernel_name(False), ops.pingpong_kernel_name(True), ops.pingpong_kernel_name(False, small=True),
-                       ops.pingpong_kernel_name(True, small=True)):
+        if ops.PIECES[ops.CONV_MATH] == 2:  # 76800 pixels: the 256- and 512-channel layers on the 256 x 320 ping-pong tile (240 / 480 tiles)
+            for nm in (ops.pingpong_kernel_name(False, wide=True), ops.pingpong_kernel_name(True, wide=True)):
                 assert nm in names, "the pass did not run %s: %s" % (nm, sorted(set(names)))
         else:
             assert big in names, "the forward pass did not run %s: %s" % (big, sorted(set(names)))
             assert ops.gemm_kernel_name(512, 512, True, True, True, False, n * 60 * 80) in names, sorted(set(names))
-        assert ops.gemm_kernel_name(256, 256, False, True, True, False, n * 60 * 80) in names, sorted(set(names))  # the 128 x 128 family
+        assert ops.gemm_kernel_name(128, 128, False, True, True, False, n * 60 * 80) in names, sorted(set(names))  # the 128 x 128 family
         if ops.CONV_MATH == "f16x3":  # ... and the weight gradients ran on the ping-pong stream-K kernel / the 128 x 128 / 64-channel tiles
             for wg in ("conv_wgrad_split_pp_kernel<SplitF16x3>", "conv_wgrad_split_tr_kernel<SplitF16x3, 2, 2, 3, false>",
                        "conv_wgrad_split_tr64_kernel<SplitF16x3>", "conv_wgrad_thin_tr_kernel<SplitF16x3>"):
@@ -663,11 +662,13 @@ def test_cfg2_full_batch_vs_oracle():
     assert err <= 1e-3, "feat err %.3e" % err
     lerr = float((logits.detach()[:, :, ::8, ::8].cpu() - ref_logits).abs().max())
     assert lerr <= 1e-3, "logit err %.3e" % lerr
-    # EVERY parameter gradient of the benchmarked pass against the oracle's backward.  Both sides are fp32 through 41 train-mode
-    # BatchNorms: the oracle's own fp32 noise on a single tensor is 1-3 % of its scale, so a tensor may be
-    # 5e-2 off in relative L2; summed over all 26 M parameters the noise averages out, and the overall bound is tight enough to see a
-    # wrong factor of a few per cent in any one layer of the benchmarked tile families (an overall 2e-3 = one 512 x 512 x 3 x 3
-    # tensor off by ~1 %).
+    # EVERY parameter gradient of the benchmarked pass against the oracle's backward.  Both sides compute in fp32 through 41
+    # train-mode BatchNorms, and at this random initialisation that is worth 1 % on EVERY trunk tensor, whoever computes it:
+    # tests/grad_truth_cfg2.py runs the oracle in fp64 beside both (same parameters, same batch; profiles/r04_grad_truth_cfg2.txt):
+    # oracle fp32 - fp64 8.4e-3 overall (worst tensor 1.2e-2), HIP - fp64 9.3e-3 (1.2e-2), HIP - oracle fp32 1.04e-2 (1.4e-2),
+    # while the two up-sampling kernels, whose gradients do not pass through the trunk's backward, agree to 2e-6.  The bounds are
+    # twice those distances: a kernel that mis-weights one layer by a few per cent is caught by its own fp64 test
+    # (tests/test_kernels_gpu.py, <= 2e-5), a wrong schedule or a dropped term here.
     named = dict(g.named_parameters())
     assert set(named) == set(ref_gs)
     num = den = 0.0
@@ -677,12 +678,12 @@ def test_cfg2_full_batch_vs_oracle():
         dn, rn = float((got - rg).double().norm()), float(rg.double().norm())
         num, den = num + dn * dn, den + rn * rn
         worst = max(worst, (dn / rn, k))
-    assert worst[0] <= 5e-2, "%s: relative L2 difference %.3e" % (worst[1], worst[0])
+    assert worst[0] <= 3e-2, "%s: relative L2 difference %.3e" % (worst[1], worst[0])
     overall = (num / den) ** 0.5
-    assert overall <= 2e-3, "all generator gradients: relative L2 difference %.3e (worst tensor %s %.3e)" % (overall, worst[1], worst[0])
+    assert overall <= 2e-2, "all generator gradients: relative L2 difference %.3e (worst tensor %s %.3e)" % (overall, worst[1], worst[0])
     for m, rg in zip((f1, f2), ref_fgs):
         rel = float((m.up.weight.grad.cpu() - rg).norm() / rg.norm())
-        assert rel <= 2e-3, "up.weight: relative L2 difference %.3e" % rel
+        assert rel <= 1e-4, "up.weight: relative L2 difference %.3e" % rel
 
 
 def test_full_step_480x640_vs_oracle():
