@@ -1199,7 +1199,7 @@ extern "C" int32_t mcdseg_conv_split_wide_pingpong(const mcdseg_conv_desc* d, in
   if (!dgrad && mcdseg_internal_stem_ok(d)) return 0;
   ConvSplitParams p;
   if (dgrad ? fill_dgrad_params(d, math, d, p) : fill_fprop_params(d, math, d, p)) return 0;
-  return mcdseg_internal_conv_pp_wide(p, math, dgrad != 0);
+  return mcdseg_internal_conv_pp_wide(p, math, dgrad != 0);  // 1: 256 x 320; 2: 128 x 320 (output rows a multiple of 128 only)
 }
 
 extern "C" int mcdseg_conv_split_fprop_part(const mcdseg_conv_desc* d, int32_t math, const float* x, const void* x_cb, const float* x_bound,

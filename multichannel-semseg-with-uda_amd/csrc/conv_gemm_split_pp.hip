@@ -38,6 +38,7 @@ namespace {
 //   <4, 2, 1, 4>  256 x 256, waves of 128 x 64, ONE workgroup per CU (96 KB of LDS): the fewest operand bytes per FLOP;
 //   <2, 2, 2, 2>  256 x 128, waves of 64 x 64 (<= 128 VGPRs), TWO workgroups per CU (2 x 72 KB): half the tile, so a partial last
 //                 round of workgroups costs half as much, and one workgroup's epilogue hides behind the other's K loop.
+//   <1, 5, 2, 2>  128 x 320, waves of 32 x 160: the same for the 128-channel layers.
 //   <2, 5, 2, 2>  256 x 320, waves of 64 x 160, one workgroup per CU (120 KB): the tile WIDTH is the knob against round quantisation --
 //                 76800 pixels (BASELINE config 2, 1/8 resolution) are 300 tiles of 256 (1.17 rounds of 256 CUs: the last 44 tiles
 //                 cost a whole round) but 240 tiles of 320 (0.94 of ONE round).  A wave's 160 pixels are one BatchNorm partial row.
@@ -50,15 +51,16 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
   constexpr int NPU = P::NPU;        // ... of which the policy multiplies (and the loop stages) the first NPU
   constexpr int NQ = 2 * NP;         // (piece, k-half) planes per K-step
   typedef typename P::frag frag;
-  constexpr int A_DMAS = 2 * NPU * BM / NT;        // weight-slab DMAs per thread and K-step (piece-major slab: the staged pieces are its head)
+  constexpr int A_UNITS = 2 * NPU * BM;            // 16-byte units of the weight slab per K-step (piece-major slab: the staged pieces are its head)
+  constexpr int A_DMAS = (A_UNITS + NT - 1) / NT;  // per thread (units past A_UNITS: out of range, zeros past the staged planes)
   constexpr int B_UNITS = 2 * NPU * BN;            // 16-byte units of the pixel operand per K-step: [piece][k-half][pixel]
   constexpr int B_DMAS = (B_UNITS + NT - 1) / NT;  // per thread (units past B_UNITS: an out-of-range DMA that deposits zeros past the planes)
   constexpr int DMA_PER_STEP = A_DMAS + B_DMAS;
-  constexpr int A_BYTES = NQ * BM * 16, B_BYTES = (NQ * BN > B_DMAS * NT ? NQ * BN : B_DMAS * NT) * 16;
+  constexpr int A_BYTES = (NQ * BM > A_DMAS * NT ? NQ * BM : A_DMAS * NT) * 16, B_BYTES = (NQ * BN > B_DMAS * NT ? NQ * BN : B_DMAS * NT) * 16;
   // a pixel tile that divides the workgroup gives every thread ONE gather pixel for all its units; otherwise (320) one per unit
   constexpr bool SAMEPX = (NT % BN) == 0;
   constexpr int NPX = SAMEPX ? 1 : B_DMAS;
-  static_assert((2 * NPU * BM) % NT == 0 && BN % 64 == 0, "every wave issues the same number of DMAs (the waits are counted); a wave's units share a plane");
+  static_assert(BM % 64 == 0 && BN % 64 == 0, "every wave issues the same number of DMAs (the waits are counted); a wave's units share a plane");
   static_assert(NS * (A_BYTES + B_BYTES) <= 160 * 1024, "LDS");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (A_BYTES + B_BYTES)];
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
     const int id = t + i * NT;
     const int plane = id / BM;
     const int m = id - plane * BM;
-    a_voff[i] = ((unsigned)plane * (unsigned)p.Mp + (unsigned)m) * 16u;
+    a_voff[i] = id < A_UNITS ? ((unsigned)plane * (unsigned)p.Mp + (unsigned)m) * 16u : OOB;
   }
 
   // loader state: K order is channel-chunk outer, tap inner (the shifted re-reads of a 16-channel slab are back to back)
@@ -359,8 +361,8 @@ int pp_mode() {
   return e == nullptr ? 3 : atoi(e);
 }
 
-bool pp_applies(const ConvSplitParams& p, int math, bool dgrad) {
-  if (p.src_cb == nullptr || mcd_math_pieces(math) != 2 || (p.Mp % 256) != 0) return false;
+bool pp_applies(const ConvSplitParams& p, int math, bool dgrad, int bm = 256) {
+  if (p.src_cb == nullptr || mcd_math_pieces(math) != 2 || (p.Mp % bm) != 0) return false;
   return p.KH * p.KW <= 32 && !(dgrad && p.stride != 1) && (p.Cs & 7) == 0;
 }
 
@@ -394,29 +396,39 @@ void launch_math(const ConvSplitParams& q, int math, bool dgrad, hipStream_t st)
 // box, ms forward / data gradient): 256 -> 256 (240 wide tiles = 0.94 round; 4-wave tiles 0.246 / 0.246) 0.205 / 0.200;
 // 512 -> 512 (480 wide tiles, cost 2.5; hybrid cost 2.5, 0.793 / 0.773) 0.757 / 0.750 -- ties go to the single launch.
 // MCDSEG_PINGPONG = 4 forces the wide tile wherever the kernel applies.
-bool pp_wide(const ConvSplitParams& p, int math, bool dgrad) {
+// With output rows a multiple of 128 only (the 128-channel layers) the same kernel runs as a 128 x 320 tile (waves of 32 x 160) under the
+// fill rule alone: pp_wide returns 2.
+int pp_wide(const ConvSplitParams& p, int math, bool dgrad) {
   const int mode = pp_mode();
-  if ((mode != 3 && mode != 4) || !pp_applies(p, math, dgrad)) return false;
-  if (mode == 4) return true;
+  if ((mode != 3 && mode != 4) || !pp_applies(p, math, dgrad, 128)) return 0;
+  const int kind = (p.Mp % 256) == 0 ? 1 : 2;
+  if (mode == 4) return kind;
   const char* e = getenv("MCDSEG_PP_WIDE_FILL");
   const int64_t fill = e ? atoi(e) : 80;
-  if (fill > 100) return false;
-  const int64_t cus = compute_units(), m_tiles = p.Mp / 256;
+  if (fill > 100) return 0;
+  const int64_t cus = compute_units();
+  if (kind == 2) {
+    const char* e128 = getenv("MCDSEG_PP_WIDE128");  // development knob: 0 = the 128-row variant off
+    if (e128 && atoi(e128) == 0) return 0;
+    const int64_t tiles = ceil_div64(p.P, 320) * (p.Mp / 128), rounds_w = ceil_div64(tiles, cus);
+    return tiles * 100 >= fill * rounds_w * cus ? 2 : 0;
+  }
+  const int64_t m_tiles = p.Mp / 256;
   const int64_t tiles = ceil_div64(p.P, 320) * m_tiles, rounds_w = ceil_div64(tiles, cus);
   const int min_rounds = pp_min_rounds() > 1 ? pp_min_rounds() : 1;
   const int64_t rounds = (p.P / 256) * m_tiles / cus;
-  if (rounds < min_rounds) return tiles * 100 >= fill * rounds_w * cus;  // against the 4-wave tiles
+  if (rounds < min_rounds) return tiles * 100 >= fill * rounds_w * cus ? 1 : 0;  // against the 4-wave tiles
   int64_t n_pp = rounds * cus / m_tiles;  // (mcdseg_internal_conv_pp_pixels)
   if (n_pp > p.P / 256) n_pp = p.P / 256;
   const int64_t rest = ceil_div64(p.P - n_pp * 256, 128) * m_tiles;  // 256 x 128 workgroups
   // 4 x cost: hybrid = 4 rounds + 2 ceil(rest / CUs); wide = 5 rounds_w
-  return 5 * rounds_w <= 4 * rounds + 2 * ceil_div64(rest, cus);
+  return 5 * rounds_w <= 4 * rounds + 2 * ceil_div64(rest, cus) ? 1 : 0;
 }
 
 }  // namespace
 
 // 1 when the whole convolution runs on the 256 x 320 ping-pong tile (BatchNorm partial rows of 160 pixels)
-int mcdseg_internal_conv_pp_wide(const ConvSplitParams& p, int math, bool dgrad) { return pp_wide(p, math, dgrad) ? 1 : 0; }
+int mcdseg_internal_conv_pp_wide(const ConvSplitParams& p, int math, bool dgrad) { return pp_wide(p, math, dgrad); }
 
 // Pixels (a multiple of 256, counted from pixel 0) of this problem that the 256 x 256 ping-pong tile takes: whole rounds of one tile
 // per CU; 0 when it does not apply (no pre-split operand, three-piece arithmetic, output rows not a multiple of 256, strided data
@@ -446,10 +458,13 @@ int mcdseg_internal_conv_pp_launch(const ConvSplitParams& p, int math, bool dgra
   ConvSplitParams q = p;
   q.sub = 0;
   q.tile_n0 = 0;
-  if (pp_wide(p, math, dgrad)) {
+  if (const int kind = pp_wide(p, math, dgrad)) {
     q.tile_n1 = ceil_div(p.P, 320);
-    launch_math<2, 5, 2, 2>(q, math, dgrad, st);
-    MCD_LAUNCH_CHECK("conv_gemm_split_pp (256 x 320)");
+    if (kind == 1)
+      launch_math<2, 5, 2, 2>(q, math, dgrad, st);
+    else
+      launch_math<1, 5, 2, 2>(q, math, dgrad, st);
+    MCD_LAUNCH_CHECK("conv_gemm_split_pp (256 / 128 x 320)");
     return 0;
   }
   q.tile_n1 = (int)(pixels / 256);

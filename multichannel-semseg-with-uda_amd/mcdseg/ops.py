@@ -84,11 +84,11 @@ def gemm_kernel_name(m, k, dgrad, split=False, presplit=False, direct=False, pix
     return "conv_gemm_kernel<%s, %d, %s>" % (cfg, 8 if k <= 8 else 16, "true" if dgrad else "false")
 
 
-def pingpong_kernel_name(dgrad, math=None, small=False, wide=False):
+def pingpong_kernel_name(dgrad, math=None, small=False, wide=0):
     """rocprofv3's name of the 8-wave ping-pong kernel (csrc/conv_gemm_split_pp.hip): its 256 x 256 tile, the 256 x 128 one
-    (``small``) or the 256 x 320 one (``wide``)"""
-    return "conv_gemm_split_pp_kernel<%s, %s, %s>" % (POLICY[math or CONV_MATH], "true" if dgrad else "false",
-                                                      "2, 5, 2, 2" if wide else ("2, 2, 2, 2" if small else "4, 2, 1, 4"))
+    (``small``), the 256 x 320 one (``wide`` = 1) or the 128 x 320 one (``wide`` = 2, what ``mcdseg_conv_split_wide_pingpong`` returns)"""
+    tile = {0: "2, 2, 2, 2" if small else "4, 2, 1, 4", 1: "2, 5, 2, 2", 2: "1, 5, 2, 2"}[int(wide)]
+    return "conv_gemm_split_pp_kernel<%s, %s, %s>" % (POLICY[math or CONV_MATH], "true" if dgrad else "false", tile)
 
 
 def _split_launches(d, presplit, dgrad, name, call):
@@ -99,7 +99,7 @@ def _split_launches(d, presplit, dgrad, name, call):
     pp = lib().mcdseg_conv_split_parts(ctypes.byref(d), MATH_ID[CONV_MATH], int(presplit), int(dgrad)) if presplit else 0
     flops, byts = conv_work(d)
     if pp > 0:
-        wide = bool(lib().mcdseg_conv_split_wide_pingpong(ctypes.byref(d), MATH_ID[CONV_MATH], 1, int(dgrad)))
+        wide = lib().mcdseg_conv_split_wide_pingpong(ctypes.byref(d), MATH_ID[CONV_MATH], 1, int(dgrad))
         with _timed(pingpong_kernel_name(dgrad, wide=wide), (flops * pp / pixels, byts * pp / pixels)):
             call(1)
     if pp < pixels:

@@ -1552,6 +1552,66 @@ def test_conv_wgrad_large_tile_kernel(case, monkeypatch):
     assert torch.equal(dw_big, dw_small)
 
 
+@pytest.mark.parametrize("math", ["f16x3", "f16x1"])
+def test_conv_pingpong_wide_tile_by_default(math, monkeypatch):
+    """What the launcher chooses BY DEFAULT at BASELINE config 2's pixel count (76800 = 240 tiles of 320 pixels on 256 CUs): the
+    256 x 320 ping-pong tile for a 256-row problem, its 128 x 320 form for the 128-channel layers -- forward (+ partial rows of 160
+    pixels) and data gradient bit for bit those of the 4-wave tiles (MCDSEG_PINGPONG=0), the statistics the same moments, fp64 parity
+    of the default arithmetic."""
+    dev = _dev()
+    import ctypes
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "CONV_MATH", math)
+    monkeypatch.delenv("MCDSEG_PINGPONG", raising=False)
+    L, mid = ops.lib(), ops.MATH_ID[math]
+    for cin, cout, kind_f, kind_d in ((128, 256, 1, 2), (128, 128, 2, 2)):
+        n, h, w, dil = 4, 120, 160, 2
+        x, wt, _, s, pad, d = _conv_inputs((cin, cout, 3, 1, dil, h, w, n, False), 43)
+        desc = ops.conv_desc(x.shape, wt.shape, 1, pad, d)
+        pk = ops.PackedWeights()
+        wf, wd, mpf = pk.get(wt.to(dev), desc)
+        xg = x.to(dev)
+        gy = torch.randn(n, cout, desc.Ho, desc.Wo, generator=torch.Generator().manual_seed(44))
+        x_cb, x_bound = ops.split_companion(xg)
+        gy_cb, gy_bound = ops.split_companion(gy.to(dev))
+        pixels = n * h * w
+        assert L.mcdseg_conv_split_wide_pingpong(ctypes.byref(desc), mid, 1, 0) == kind_f
+        assert L.mcdseg_conv_split_wide_pingpong(ctypes.byref(desc), mid, 1, 1) == kind_d
+        names = []
+
+        class _Names:
+            def wants(self, name):
+                names.append(name)
+                return False
+        prev, ops.LAUNCH_TIMER = ops.LAUNCH_TIMER, _Names()
+        try:
+            y, part, rows = ops._conv_fprop(desc, xg, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)
+            dx = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound)
+        finally:
+            ops.LAUNCH_TIMER = prev
+        assert names == [ops.pingpong_kernel_name(False, wide=kind_f), ops.pingpong_kernel_name(True, wide=kind_d)], names
+        assert rows == 2 * (pixels // 320)
+        monkeypatch.setenv("MCDSEG_PINGPONG", "0")
+        y0, part0, rows0 = ops._conv_fprop(desc, xg, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)
+        dx0 = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound)
+        monkeypatch.delenv("MCDSEG_PINGPONG")
+        assert torch.equal(y, y0) and torch.equal(dx, dx0), "the wide tile's results differ from the 4-wave tiles'"
+        pw = part.double().view(rows, 3, -1)[:, :, :cout]
+        cnt, mean_r, m2_r = pw[:, 0], pw[:, 1], pw[:, 2]
+        assert float(cnt[:, 0].sum()) == pixels
+        mean = (cnt * mean_r).sum(0) / pixels
+        var = (m2_r + cnt * (mean_r - mean) ** 2).sum(0) / pixels
+        y64 = y.double().transpose(0, 1).reshape(cout, -1)
+        assert float((mean - y64.mean(1)).abs().max()) <= 1e-6 * float(y64.abs().max())
+        assert float((var - y64.var(1, unbiased=False)).abs().max()) <= 1e-6 * float(y64.var(1, unbiased=False).max())
+        if math == "f16x3":
+            x64 = x.double().requires_grad_()
+            ref = F.conv2d(x64, wt.double(), None, 1, pad, d)
+            _assert_close(y, ref, 2e-5, "forward (wide tile)")
+            (gx_ref,) = torch.autograd.grad(ref, [x64], gy.double())
+            _assert_close(dx, gx_ref, 2e-5, "data gradient (wide tile)")
+
+
 # (Cin, Cout, k, stride, dil, H, W, N, math): enough 16-pixel K-steps for the stream-K plan (>= 32 per CU)
 WGRAD_PP_CASES = [
     (512, 512, 3, 1, 2, 24, 32, 6, "f16x3"),   # 36 tiles x 288 K-steps: pieces of 41 K-steps, most of them inside one tile
