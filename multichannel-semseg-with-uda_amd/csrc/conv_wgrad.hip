@@ -465,7 +465,7 @@ size_t mcdseg_internal_wgrad_thin_tr_ws(const mcdseg_conv_desc* d);
 int mcdseg_internal_wgrad_thin_tr_launch(const mcdseg_conv_desc* d, const void* x_cb, const float* x_bound, const void* dy_cb,
                                          const float* dy_bound, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 // the 256-channel-and-wider layers from both companions: eight-wave ping-pong kernel over a stream-K decomposition (conv_wgrad_split_pp.hip)
-int mcdseg_internal_wgrad_pp_plan(const mcdseg_conv_desc* d, int math, int* L, size_t* slab_floats);
+int mcdseg_internal_wgrad_pp_plan(const mcdseg_conv_desc* d, int math, int* L, size_t* slab_floats, int* slabs = nullptr);
 int mcdseg_internal_wgrad_pp_launch(const mcdseg_conv_desc* d, int math, const void* x_cb, const float* x_bound, const void* dy_cb,
                                     const float* dy_bound, float* dw, float* slab, hipStream_t st);
 static bool thin_tr_applies(const mcdseg_conv_desc* d, int math, const void* x_cb, const void* dy_cb) {

@@ -39,7 +39,9 @@ struct WgradPpParams {
   int co_tiles, ci_tiles;  // 256-channel tiles
   int tiles_x, tiles_y;    // 16 x 1 pixel stages of one image: ceil(Wo / 16) per row, Ho rows
   int kt;                  // K-steps of one tile: N * tiles_x * tiles_y
-  int L, nwg;              // K-steps per workgroup, workgroups
+  int L, nwg;              // K-steps per workgroup (stream-K) or per slab (slab plan), workgroups
+  int slabs;               // 0: stream-K pieces; > 0: the slab plan -- item i = (K slab i / tiles, tile i % tiles), workgroup w takes items w, w + nwg, ...
+  int items;               // slabs * tiles
   int x_cb_bytes, dy_cb_bytes;                // ONE piece of each companion (this call's images)
   long long x_piece_stride, dy_piece_stride;  // bytes between the pieces (the companions' own batch: mcdseg_conv_desc.Ncb)
 };
@@ -70,13 +72,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams 
   const int l31 = lane & 31, lh = lane >> 5;
   const int T_ = p.KH * p.KW;
 
-  // fragments that share a tile on one XCD when the count allows (speed only)
-  const int w_id = (p.nwg & 7) == 0 ? (blockIdx.x & 7) * (p.nwg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  // consecutive workgroup numbers on one XCD (the dispatcher deals blockIdx round-robin over the 8 XCDs; the grid is a multiple of 8)
+  const int w_id = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   if (w_id >= p.nwg) return;
-  const long long total = (long long)p.co_tiles * p.ci_tiles * T_ * p.kt;
+  const int tiles_all = p.co_tiles * p.ci_tiles * T_;
+  const long long total = (long long)tiles_all * p.kt;
   long long g_next = (long long)w_id * p.L;
   long long g_end = g_next + p.L;
   if (g_end > total) g_end = total;
+  int item = w_id;  // (slab plan)
+  if (p.slabs > 0) {
+    g_next = 0;
+    g_end = item < p.items ? 1 : 0;
+  }
 
   // ---- DMA role of this wave (wave-uniform): operand side (0 = dZ, the "A" rows; 1 = X, the "B" rows), piece, 128-channel block
   const int opnd = wave >> 2;
@@ -137,11 +145,22 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams 
 #endif
 
   while (g_next < g_end) {  // the segments of this workgroup's piece: the rest of the current tile's K range, at most
-    const int tile = (int)(g_next / p.kt);
-    const int k0 = (int)(g_next - (long long)tile * p.kt);
-    const int k1 = (g_end - (long long)tile * p.kt < p.kt) ? (int)(g_end - (long long)tile * p.kt) : p.kt;
-    const int slab_id = (int)(g_next / p.L) + tile;
-    g_next += k1 - k0;
+    int tile, k0, k1, slab_id;
+    if (p.slabs > 0) {  // one item: the K slab item / tiles of tile item % tiles
+      const int sl = item / tiles_all;
+      tile = item - sl * tiles_all;
+      k0 = sl * p.L;
+      k1 = k0 + p.L < p.kt ? k0 + p.L : p.kt;
+      slab_id = item;
+      item += p.nwg;
+      if (item >= p.items) g_next = g_end;
+    } else {
+      tile = (int)(g_next / p.kt);
+      k0 = (int)(g_next - (long long)tile * p.kt);
+      k1 = (g_end - (long long)tile * p.kt < p.kt) ? (int)(g_end - (long long)tile * p.kt) : p.kt;
+      slab_id = (int)(g_next / p.L) + tile;
+      g_next += k1 - k0;
+    }
     const int tap = tile % T_;
     const int tile_ci = (tile / T_) % p.ci_tiles;
     const int tile_co = tile / (T_ * p.ci_tiles);
@@ -268,8 +287,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams 
 // dw[co][ci][tap] = scale * sum over the tile's slabs (in K order, fp64).  A block owns 64 consecutive ci of one co for all taps:
 // slab reads are coalesced along ci, the T values of a (co, ci) pair leave through LDS as one contiguous run of dw [Cout][Cin][T].
 __global__ __launch_bounds__(64) void wgrad_reduce_sk_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int T,
-                                                             int ci_tiles, int kt, int L, const float* __restrict__ x_bound,
-                                                             const float* __restrict__ dy_bound) {
+                                                             int ci_tiles, int kt, int L, int slabs, int tiles_all,
+                                                             const float* __restrict__ x_bound, const float* __restrict__ dy_bound) {
   __shared__ float stage[64 * 33];
   const int co = blockIdx.y;
   const int ci0 = blockIdx.x * 64;
@@ -279,11 +298,12 @@ __global__ __launch_bounds__(64) void wgrad_reduce_sk_kernel(const float* __rest
   for (int tap = 0; tap < T; ++tap) {
     const int tile = ((co >> 8) * ci_tiles + (ci0 >> 8)) * T + tap;
     const long long g0 = (long long)tile * kt;
-    const int s0 = (int)(g0 / L) + tile, s1 = (int)((g0 + kt - 1) / L) + tile;
+    // stream-K: the tile's consecutive slabs s0 .. s1; slab plan: slabs tile, tile + tiles_all, ... (K order either way)
+    const int s0 = slabs > 0 ? 0 : (int)(g0 / L) + tile, s1 = slabs > 0 ? slabs - 1 : (int)((g0 + kt - 1) / L) + tile;
     double s = 0.0;
     if (ci < Cin) {
-      const float* src = slab + ((size_t)s0 * 256 + (co & 255)) * 256 + (ci & 255);
-      constexpr size_t SL = 256 * 256;
+      const size_t SL = slabs > 0 ? (size_t)tiles_all * (256 * 256) : (size_t)(256 * 256);
+      const float* src = slab + ((size_t)(slabs > 0 ? tile : s0) * 256 + (co & 255)) * 256 + (ci & 255);
       int k = s0;
       for (; k + 3 <= s1; k += 4, src += 4 * SL) {  // four loads in flight, added in slab order
         const float v0 = src[0], v1 = src[SL], v2 = src[2 * SL], v3 = src[3 * SL];
@@ -318,9 +338,20 @@ int pp_compute_units() {
 // The stream-K plan of this geometry: workgroups and K-steps per workgroup; 0 workgroups when the kernel does not apply (two-piece
 // arithmetic on both companions, 256-channel blocks on both sides, at most 32 taps, and enough K-steps that a workgroup's piece
 // spans at most two tiles and is worth a launch).  MCDSEG_WGRAD_PP=0 turns it off (read per call: tests).
-int mcdseg_internal_wgrad_pp_plan(const mcdseg_conv_desc* d, int math, int* L, size_t* slab_floats) {
+//
+// Two decompositions (MCDSEG_WGRAD_PP: 1 = stream-K, 2 or unset = the slab plan; 0 = this kernel off):
+//   stream-K   the flattened (tile, K-step) range in nwg equal pieces -- perfect balance, but the workgroups of an XCD sit at 32 different
+//              K positions, so every tile streams its operands through the fabric by itself: measured 2 x FETCH_SIZE = 2.9 GB per launch
+//              for 0.22 GB of algorithmic bytes (profiles/r04z_pmc_traffic.json), and the rate falls with the batch (430 TFLOP/s at
+//              N = 8, 398 at 16, 382 at 32) as the operands outgrow the Infinity Cache;
+//   slab plan  the K range is cut into `slabs` = floor(rounds * CUs / tiles) slabs and item i = (slab i / tiles, tile i % tiles): the
+//              workgroups of one XCD hold consecutive items, i.e. the tiles (taps, channel blocks) of ONE slab, walk the same pixels
+//              at the same time and share them through the XCD's L2.  252 of 256 CUs busy at BASELINE config 2 (36, 18 or 9 tiles).
+int mcdseg_internal_wgrad_pp_plan(const mcdseg_conv_desc* d, int math, int* L, size_t* slab_floats, int* slabs_out) {
   const char* e = getenv("MCDSEG_WGRAD_PP");
   if (e != nullptr && atoi(e) == 0) return 0;
+  const bool stream_k = e != nullptr && atoi(e) == 1;
+  if (slabs_out) *slabs_out = 0;
   if (mcd_storage_math(math) != MCDSEG_MATH_F16X3 || (d->Cin & 7) || (d->Cout & 7) || d->Cin < 129 || d->Cout < 129) return 0;
   const int T = d->KH * d->KW;
   if (T > 32 || d->pad > 128) return 0;
@@ -330,6 +361,30 @@ int mcdseg_internal_wgrad_pp_plan(const mcdseg_conv_desc* d, int math, int* L, s
   const int64_t tiles = co_tiles * ci_tiles * T, total = tiles * kt;
   int64_t nwg = pp_compute_units();
   if (total < nwg * 32) return 0;  // (less than 32 K-steps per CU: the launch is all prologue and slab traffic)
+  if (!stream_k) {
+    // rounds of items per workgroup: the fewest whose slabs keep >= 95 % of the CUs busy (else the best of up to four)
+    int64_t best_r = 0, best_ls = 0, best_ns = 0;
+    double best_eff = 0.0;
+    for (int64_t r = 1; r <= 4; ++r) {
+      int64_t ns = r * nwg / tiles;
+      if (ns < 1) continue;
+      if (ns > kt / 32) ns = kt / 32;  // (an item of less than 32 K-steps is all prologue)
+      if (ns < 1) continue;
+      const int64_t ls = ceil_div64(kt, ns);
+      ns = ceil_div64(kt, ls);
+      const double eff = (double)total / ((double)nwg * (double)(ceil_div64(ns * tiles, nwg) * ls));
+      if (eff > best_eff + 0.02 || best_r == 0) best_r = r, best_ls = ls, best_ns = ns, best_eff = eff;
+      if (best_eff >= 0.95) break;
+    }
+    if (best_r > 0 && best_eff >= 0.80) {
+      const int64_t items = best_ns * tiles;
+      const int64_t rounds = ceil_div64(items, nwg);
+      if (L) *L = (int)best_ls;
+      if (slabs_out) *slabs_out = (int)best_ns;
+      if (slab_floats) *slab_floats = (size_t)items * 256 * 256;
+      return (int)ceil_div64(items, rounds);
+    }
+  }
   const int64_t l = ceil_div64(total, nwg);
   if (l > kt) return 0;  // (a piece would span more than two tiles)
   nwg = ceil_div64(total, l);
@@ -341,8 +396,8 @@ int mcdseg_internal_wgrad_pp_plan(const mcdseg_conv_desc* d, int math, int* L, s
 int mcdseg_internal_wgrad_pp_launch(const mcdseg_conv_desc* d, int math, const void* x_cb, const float* x_bound, const void* dy_cb,
                                     const float* dy_bound, float* dw, float* slab, hipStream_t st) {
   WgradPpParams p;
-  int L = 0;
-  const int nwg = mcdseg_internal_wgrad_pp_plan(d, math, &L, nullptr);
+  int L = 0, slabs = 0;
+  const int nwg = mcdseg_internal_wgrad_pp_plan(d, math, &L, nullptr, &slabs);
   MCD_REQUIRE(nwg > 0, "conv_wgrad_split_pp: the geometry has no stream-K plan");
   const int64_t xb = (int64_t)d->N * d->Cin * d->H * d->W * 2, yb = (int64_t)d->N * d->Cout * d->Ho * d->Wo * 2;
   MCD_REQUIRE(xb + 4096 < (1ll << 31) && yb + 4096 < (1ll << 31) && (d->Ncb == 0 || d->Ncb >= d->N),
@@ -354,6 +409,7 @@ int mcdseg_internal_wgrad_pp_launch(const mcdseg_conv_desc* d, int math, const v
   p.tiles_x = ceil_div(d->Wo, 16); p.tiles_y = d->Ho;
   p.kt = d->N * p.tiles_x * p.tiles_y;
   p.L = L; p.nwg = nwg;
+  p.slabs = slabs; p.items = slabs * p.co_tiles * p.ci_tiles * d->KH * d->KW;
   p.x_cb_bytes = (int)xb; p.dy_cb_bytes = (int)yb;
   p.x_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cin * d->H * d->W * 2;
   p.dy_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cout * d->Ho * d->Wo * 2;
@@ -366,7 +422,7 @@ int mcdseg_internal_wgrad_pp_launch(const mcdseg_conv_desc* d, int math, const v
   const int T = d->KH * d->KW;
   MCD_REQUIRE(T <= 33, "conv_wgrad_split_pp: more than 33 taps");
   hipLaunchKernelGGL(wgrad_reduce_sk_kernel, dim3((unsigned)ceil_div(d->Cin, 64), (unsigned)d->Cout), dim3(64), 0, st, (const float*)slab, dw, d->Cout,
-                     d->Cin, T, p.ci_tiles, p.kt, L, x_bound, dy_bound);
+                     d->Cin, T, p.ci_tiles, p.kt, L, slabs, p.co_tiles * p.ci_tiles * T, x_bound, dy_bound);
   MCD_LAUNCH_CHECK("wgrad_reduce_sk");
   return 0;
 }

@@ -1626,8 +1626,9 @@ WGRAD_PP_CASES = [
 @pytest.mark.parametrize("case", WGRAD_PP_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_wgrad_pingpong_stream_k(case, monkeypatch):
     """``conv_wgrad_split_pp_kernel`` (csrc/conv_wgrad_split_pp.hip): the weight gradient of the 256-channel-and-wider layers on
-    256 x 256 tiles, eight waves in two groups half a K-step apart, over a stream-K decomposition (one equal piece of the flattened
-    (tile, K-step) range per CU, a slab per (piece, tile) segment, summed in K order in fp64).  Named through
+    256 x 256 tiles, eight waves in two groups half a K-step apart, over a split of the pixel range -- by default K slabs whose tiles run
+    side by side on one XCD, or (MCDSEG_WGRAD_PP=1) stream-K: one equal piece of the flattened (tile, K-step) range per CU -- with one
+    fp32 slab per segment, summed in K order in fp64.  Named through
     ``mcdseg_conv_wgrad_variant == 17``; within 2e-5 of fp64; two runs agree bit for bit; and it equals the 4-wave transposed-read
     kernels (MCDSEG_WGRAD_PP=0) to the last bits -- the same products, only grouped into other partial sums."""
     dev = _dev()
@@ -1658,6 +1659,12 @@ def test_conv_wgrad_pingpong_stream_k(case, monkeypatch):
     assert names == ["conv_wgrad_split_pp_kernel<%s>" % ops.POLICY[math]], names
     dw_b = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
     assert torch.equal(dw, dw_b), "two runs differ"
+    # the default decomposition is the slab plan (K slabs whose tiles run side by side on one XCD); MCDSEG_WGRAD_PP=1 is stream-K
+    monkeypatch.setenv("MCDSEG_WGRAD_PP", "1")
+    assert L.mcdseg_conv_wgrad_variant(ctypes.byref(desc), mid, 1) == 17
+    dw_sk = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
+    assert torch.equal(dw_sk, ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)), "two stream-K runs differ"
+    assert float((dw - dw_sk).abs().max()) <= 2e-6 * float(dw.abs().max()), "the two decompositions differ by more than their rounding"
     monkeypatch.setenv("MCDSEG_WGRAD_PP", "0")
     assert L.mcdseg_conv_wgrad_variant(ctypes.byref(desc), mid, 1) in (12, 13)
     dw_tr = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)

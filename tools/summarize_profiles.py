@@ -81,9 +81,14 @@ def main(tag):
                             "(1024 SIMDs * kernel cycles), i.e. at the clock the kernel actually ran at; the wave-cycle fractions are of "
                             "SQ_WAVE_CYCLES (parked = s_waitcnt / barrier, issue_stalled = waiting on a pipe, mostly the MFMA pipe)",
                    "kernels": table}, open(os.path.join(out, tag + "_pmc_sq.json"), "w"), indent=1, sort_keys=True)
-    b = os.path.join(src, tag + "_bench.json")
-    if os.path.exists(b):
-        shutil.copy(b, os.path.join(out, tag + "_bench_line.json"))
+    for suffix in ("", "_profiled", "_bf16x6", "_f32mfma", "_f16x1"):  # the benchmark lines (the last line that parses as JSON)
+        b = os.path.join(src, tag + "_bench" + suffix + ".json")
+        if not os.path.exists(b):
+            continue
+        lines = [ln for ln in open(b).read().splitlines() if ln.startswith("{")]
+        if lines:
+            json.loads(lines[-1])
+            open(os.path.join(out, tag + "_bench_line" + suffix + ".json"), "w").write(lines[-1] + "\n")
     print("profiles/ updated for", tag)
 
 
