@@ -74,13 +74,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
   const int HWs = p.Hs * p.Ws;
   // parity class of this tile (uniform): ry, rx, class grid Hc x Wc, first tile of the class
   int cls = 0;
-  if (SUB) cls = (tile_n >= p.cls_tile0[1]) + (tile_n >= p.cls_tile0[2]) + (tile_n >= p.cls_tile0[3]);
+  // (sub == 2: the four classes have the same tile count and are interleaved -- tiles 4k .. 4k+3 are the four parities of ONE region,
+  // neighbours on one XCD: they gather the same dY window through that L2 and their stride-2 stores meet there as whole lines)
+  const bool ILV = SUB && p.sub == 2;
+  if (SUB) cls = ILV ? (tile_n & 3) : (tile_n >= p.cls_tile0[1]) + (tile_n >= p.cls_tile0[2]) + (tile_n >= p.cls_tile0[3]);
   const int ry = cls >> 1, rx = cls & 1;
   const int Hc = SUB ? (p.Hd - ry + 1) >> 1 : p.Hd;
   const int Wc = SUB ? (p.Wd - rx + 1) >> 1 : p.Wd;
   const int HWc = Hc * Wc;
   const int Pc = SUB ? p.N * HWc : p.P;
-  const int ltile = SUB ? tile_n - p.cls_tile0[cls] : tile_n;
+  const int ltile = SUB ? (ILV ? tile_n >> 2 : tile_n - p.cls_tile0[cls]) : tile_n;
   const int pix = ltile * BN + bj;
   const bool pv = pix < Pc;
   int pn = 0, py = 0, px = 0, yc = 0, xc = 0;
@@ -840,6 +843,9 @@ void launch_cfg(const ConvSplitParams& p, int64_t pix0, hipStream_t st) {
     }
     q.cls_tile0[4] = t0;
     n_tiles = t0;
+    const int c0 = q.cls_tile0[1];
+    static const bool interleave = [] { const char* e = getenv("MCDSEG_DGRAD_INTERLEAVE"); return e == nullptr || atoi(e) != 0; }();
+    if (interleave && q.cls_tile0[2] == 2 * c0 && q.cls_tile0[3] == 3 * c0 && t0 == 4 * c0) q.sub = 2;
   }
   dim3 grid(8 * ceil_div(n_tiles, 8) * (p.Mp / BM));
   if (p.src_cb != nullptr)
