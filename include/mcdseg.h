@@ -126,6 +126,12 @@ int mcdseg_conv_split_fprop_affine(const mcdseg_conv_desc* d, int32_t math, cons
                                    const float* residual, int32_t relu, float* y, void* stream);
 int mcdseg_conv_split_dgrad(const mcdseg_conv_desc* d, int32_t math, const float* dy, const void* dy_cb, const float* dy_bound,
                             const void* wp_dgrad, const float* w_bound, float* dx, void* stream);
+/* dx = data gradient + addend: the element-wise add autograd performs when the convolution's input has a second consumer (the
+ * shortcut of a residual block: models/drn.py:43-59 BasicBlock, :79-100 Bottleneck), folded into the epilogue -- same sum, same
+ * order, same bits; 80 such adds per MCD step at BASELINE config 2.  `addend`: fp32, dx's shape, not dx itself.  `part` as in
+ * mcdseg_conv_split_dgrad_part.  Not for geometries of the thin-layer window kernel (mcdseg_conv_split_window_ok(d, math, 1, 1)). */
+int mcdseg_conv_split_dgrad_add(const mcdseg_conv_desc* d, int32_t math, const float* dy, const void* dy_cb, const float* dy_bound,
+                                const void* wp_dgrad, const float* w_bound, const float* addend, float* dx, int32_t part, void* stream);
 /* One convolution may run as TWO launches: whole rounds of 256 x 256 tiles (one per CU) on the 8-wave ping-pong kernel
  * (csrc/conv_gemm_split_pp.hip), the remaining pixels on the 4-wave tiles.  mcdseg_conv_split_parts returns the number of output
  * pixels (a multiple of 256, counted from pixel 0 of the flattened (n, y, x) order) the first launch takes -- 0 when the geometry

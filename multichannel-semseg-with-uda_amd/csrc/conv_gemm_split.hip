@@ -605,6 +605,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
               if (p.ep_res != nullptr) v += p.ep_res[dbase[j] + (size_t)m * HWd];
               if (p.ep_relu) v = fmaxf(v, 0.f);
             }
+            // data gradient: the other gradient of the same tensor (a residual block's shortcut), added as autograd would add it
+            if (DGRAD && p.ep_res != nullptr) v += p.ep_res[dbase[j] + (size_t)m * HWd];
             p.dst[dbase[j] + (size_t)m * HWd] = v;
           }
       }
@@ -1150,11 +1152,13 @@ static int fill_dgrad_params(const mcdseg_conv_desc* d, int math, const void* dy
 }
 
 static int split_dgrad_impl(const mcdseg_conv_desc* d, int32_t math, const float* dy, const void* dy_cb, const float* dy_bound,
-                            const void* wp_dgrad, const float* w_bound, float* dx, void* stream, int part) {
+                            const void* wp_dgrad, const float* w_bound, float* dx, void* stream, int part, const float* addend = nullptr) {
   if (int rc = split_check(d, math, "conv_split_dgrad")) return rc;
   MCD_REQUIRE((dy || dy_cb) && wp_dgrad && dx, "conv_split_dgrad: null pointer");
   const int smath = mcd_storage_math(math);
   MCD_REQUIRE(smath != MCDSEG_MATH_F16X3 || (dy_bound && w_bound), "conv_split_dgrad: f16x3 needs the operand and weight bound scalars");
+  MCD_REQUIRE(addend == nullptr || !(smath == MCDSEG_MATH_F16X3 && dy_cb != nullptr && mcdseg_internal_thin_window_ok(d, 1)),
+              "conv_split_dgrad_add: the thin-layer window kernel takes no addend (mcdseg_conv_split_window_ok tells)");
   if (smath == MCDSEG_MATH_F16X3 && dy_cb != nullptr && mcdseg_internal_thin_window_ok(d, 1))
     return part == 1 ? 0
                      : mcdseg_internal_thin_window_launch(d, 1, dy_cb, dy_bound, wp_dgrad, split_image_bytes(math, d->Cin, d->Cout, d->KH * d->KW),
@@ -1163,7 +1167,7 @@ static int split_dgrad_impl(const mcdseg_conv_desc* d, int32_t math, const float
   if (int rc = fill_dgrad_params(d, math, dy_cb, p)) return rc;
   p.src_bound = dy_bound; p.w_bound = w_bound;
   p.src = dy; p.wp = wp_dgrad; p.bias = nullptr; p.dst = dx; p.stats = nullptr;
-  p.ep_scale = nullptr; p.ep_shift = nullptr; p.ep_res = nullptr; p.ep_relu = 0;
+  p.ep_scale = nullptr; p.ep_shift = nullptr; p.ep_res = addend; p.ep_relu = 0;
   if (int rc = launch_math<true>(math, p, part, (hipStream_t)stream)) return rc;
   MCD_LAUNCH_CHECK("conv_split_dgrad");
   return 0;
@@ -1172,6 +1176,17 @@ static int split_dgrad_impl(const mcdseg_conv_desc* d, int32_t math, const float
 extern "C" int mcdseg_conv_split_dgrad(const mcdseg_conv_desc* d, int32_t math, const float* dy, const void* dy_cb, const float* dy_bound,
                                        const void* wp_dgrad, const float* w_bound, float* dx, void* stream) {
   return split_dgrad_impl(d, math, dy, dy_cb, dy_bound, wp_dgrad, w_bound, dx, stream, 0);
+}
+
+// dx = data gradient + addend (an fp32 tensor of dx's shape; it may not alias dx): what autograd computes with a separate element-wise
+// add when the convolution's input has a second consumer -- the shortcut of a residual block (models/drn.py:43-59, 79-100).  The sum
+// is formed in the epilogue in the order of that add, so the result is bit for bit dgrad-then-add.  `part` as in _dgrad_part.
+extern "C" int mcdseg_conv_split_dgrad_add(const mcdseg_conv_desc* d, int32_t math, const float* dy, const void* dy_cb, const float* dy_bound,
+                                           const void* wp_dgrad, const float* w_bound, const float* addend, float* dx, int32_t part,
+                                           void* stream) {
+  MCD_REQUIRE(part >= 0 && part <= 2, "conv_split_dgrad_add: part must be 0 (whole), 1 (ping-pong tiles) or 2 (the rest)");
+  MCD_REQUIRE(addend != nullptr && addend != dx, "conv_split_dgrad_add: the addend is a tensor of its own");
+  return split_dgrad_impl(d, math, dy, dy_cb, dy_bound, wp_dgrad, w_bound, dx, stream, part, addend);
 }
 
 // ---- the two launches of one convolution, separately (profilers and bench.py's per-kernel HIP events; results are those of the whole call)

@@ -292,6 +292,8 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
               if (p.ep_res != nullptr) v += p.ep_res[dbase[j] + (size_t)m * HWd];
               if (p.ep_relu) v = fmaxf(v, 0.f);
             }
+            // data gradient: the other gradient of the same tensor (a residual block's shortcut), added as autograd would add it
+            if (DGRAD && p.ep_res != nullptr) v += p.ep_res[dbase[j] + (size_t)m * HWd];
             p.dst[dbase[j] + (size_t)m * HWd] = v;
           }
       }

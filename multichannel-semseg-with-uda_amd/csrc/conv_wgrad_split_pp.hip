@@ -286,16 +286,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams 
 
 // dw[co][ci][tap] = scale * sum over the tile's slabs (in K order, fp64).  A block owns 64 consecutive ci of one co for all taps:
 // slab reads are coalesced along ci, the T values of a (co, ci) pair leave through LDS as one contiguous run of dw [Cout][Cin][T].
-__global__ __launch_bounds__(64) void wgrad_reduce_sk_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int T,
+__global__ __launch_bounds__(256) void wgrad_reduce_sk_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int T,
                                                              int ci_tiles, int kt, int L, int slabs, int tiles_all,
                                                              const float* __restrict__ x_bound, const float* __restrict__ dy_bound) {
   __shared__ float stage[64 * 33];
   const int co = blockIdx.y;
   const int ci0 = blockIdx.x * 64;
-  const int ci = ci0 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // wave w sums taps w, w + 4, ...: four times the loads in flight per block
+  const int ci = ci0 + lane;
   const double sc = x_bound != nullptr ? (double)mcd_scale_of_bound(*x_bound) * (double)mcd_scale_of_bound(*dy_bound) : 1.0;
   const int nci = Cin - ci0 < 64 ? Cin - ci0 : 64;
-  for (int tap = 0; tap < T; ++tap) {
+  for (int tap = wave; tap < T; tap += 4) {
     const int tile = ((co >> 8) * ci_tiles + (ci0 >> 8)) * T + tap;
     const long long g0 = (long long)tile * kt;
     // stream-K: the tile's consecutive slabs s0 .. s1; slab plan: slabs tile, tile + tiles_all, ... (K order either way)
@@ -305,6 +306,18 @@ __global__ __launch_bounds__(64) void wgrad_reduce_sk_kernel(const float* __rest
       const size_t SL = slabs > 0 ? (size_t)tiles_all * (256 * 256) : (size_t)(256 * 256);
       const float* src = slab + ((size_t)(slabs > 0 ? tile : s0) * 256 + (co & 255)) * 256 + (ci & 255);
       int k = s0;
+      for (; k + 7 <= s1; k += 8, src += 8 * SL) {  // eight loads in flight, added in slab order
+        const float v0 = src[0], v1 = src[SL], v2 = src[2 * SL], v3 = src[3 * SL];
+        const float v4 = src[4 * SL], v5 = src[5 * SL], v6 = src[6 * SL], v7 = src[7 * SL];
+        s += (double)v0;
+        s += (double)v1;
+        s += (double)v2;
+        s += (double)v3;
+        s += (double)v4;
+        s += (double)v5;
+        s += (double)v6;
+        s += (double)v7;
+      }
       for (; k + 3 <= s1; k += 4, src += 4 * SL) {  // four loads in flight, added in slab order
         const float v0 = src[0], v1 = src[SL], v2 = src[2 * SL], v3 = src[3 * SL];
         s += (double)v0;
@@ -314,11 +327,11 @@ __global__ __launch_bounds__(64) void wgrad_reduce_sk_kernel(const float* __rest
       }
       for (; k <= s1; ++k, src += SL) s += (double)*src;
     }
-    stage[threadIdx.x * T + tap] = (float)(s * sc);
+    stage[lane * T + tap] = (float)(s * sc);
   }
   __syncthreads();
   float* out = dw + ((size_t)co * Cin + ci0) * T;
-  for (int i = threadIdx.x; i < nci * T; i += 64) out[i] = stage[i];
+  for (int i = threadIdx.x; i < nci * T; i += 256) out[i] = stage[i];
 }
 
 int pp_compute_units() {
@@ -421,7 +434,7 @@ int mcdseg_internal_wgrad_pp_launch(const mcdseg_conv_desc* d, int math, const v
   MCD_LAUNCH_CHECK("conv_wgrad_split_pp");
   const int T = d->KH * d->KW;
   MCD_REQUIRE(T <= 33, "conv_wgrad_split_pp: more than 33 taps");
-  hipLaunchKernelGGL(wgrad_reduce_sk_kernel, dim3((unsigned)ceil_div(d->Cin, 64), (unsigned)d->Cout), dim3(64), 0, st, (const float*)slab, dw, d->Cout,
+  hipLaunchKernelGGL(wgrad_reduce_sk_kernel, dim3((unsigned)ceil_div(d->Cin, 64), (unsigned)d->Cout), dim3(256), 0, st, (const float*)slab, dw, d->Cout,
                      d->Cin, T, p.ci_tiles, p.kt, L, slabs, p.co_tiles * p.ci_tiles * T, x_bound, dy_bound);
   MCD_LAUNCH_CHECK("wgrad_reduce_sk");
   return 0;

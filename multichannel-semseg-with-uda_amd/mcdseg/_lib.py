@@ -52,6 +52,7 @@ _SIGNATURES = {
     "mcdseg_conv_split_wide_pingpong": (c_i32, [_P(ConvDesc), c_i32, c_i32, c_i32]),
     "mcdseg_conv_split_fprop_part": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 8 + [c_i32, c_void_p]),
     "mcdseg_conv_split_dgrad_part": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 6 + [c_i32, c_void_p]),
+    "mcdseg_conv_split_dgrad_add": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 7 + [c_i32, c_void_p]),
     "mcdseg_split_cb": (c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "mcdseg_split_cb_padded": (c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "mcdseg_unsplit_cb": (c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p]),

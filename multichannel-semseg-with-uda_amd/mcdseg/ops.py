@@ -319,6 +319,44 @@ GROUP_PACK = os.environ.get("MCDSEG_GROUP_PACK", "1") != "0"
 FUSED_UP_LOSS = os.environ.get("MCDSEG_FUSED_UP_LOSS", "1") != "0"  # MCDSolver: up-sampler folded into the loss kernel
 # BatchNorm backward of a ReLU group without residual: the mask y > 0 recomputed from z (bit-identical), y never read
 BN_ZMASK = os.environ.get("MCDSEG_BN_ZMASK", "1") != "0"
+# the gradient of a residual block's input has two producers (the first convolution's data gradient and the shortcut); autograd would
+# add them with an element-wise kernel -- 80 adds of 40-160 MB tensors per MCD step, 7.3 ms at BASELINE config 2.  With this on the
+# one that runs second folds the other's tensor into its own epilogue (``GradBox``); "0": autograd's add (same bits, tests compare)
+FUSE_RES_ADD = os.environ.get("MCDSEG_FUSE_RES_ADD", "1") != "0"
+
+
+class GradBox:
+    """Mailbox between the producers of ONE tensor's gradient inside a residual block (models/drn.py BasicBlock / Bottleneck: the block
+    input feeds the first convolution and the shortcut -- the identity, or the 1x1 projection).  Each producer ``attach``es in the
+    forward pass; in the backward pass every producer but the last leaves its gradient here and reports None to autograd, the last
+    one returns the sum -- formed in its convolution's data-gradient epilogue when it is one (``_conv_dgrad``'s ``addend``).  The sum
+    is the one autograd's own accumulation would form, bit for bit (fp32 addition commutes), one kernel and three passes over the
+    tensor earlier.  A box lives as long as the graph of its forward pass; it may see several backward passes."""
+    __slots__ = ("n", "seen", "g")
+
+    def __init__(self):
+        self.n, self.seen, self.g = 0, 0, None
+
+    def attach(self):
+        self.n += 1
+        return self
+
+    def arrive(self):
+        """(gradient left by the earlier producers or None, whether the caller is the last producer of this backward pass)"""
+        self.seen += 1
+        g, self.g = self.g, None
+        last = self.seen >= self.n
+        if last:
+            self.seen = 0
+        return g, last
+
+    def leave(self, g):
+        self.g = g
+
+
+def grad_box(x):
+    """a ``GradBox`` for the gradient of ``x`` when there will be one (and the folding is on), else None"""
+    return GradBox() if (FUSE_RES_ADD and torch.is_grad_enabled() and x.requires_grad) else None
 
 
 class PackedWeights:
@@ -524,9 +562,13 @@ def _window_name(d, presplit, dgrad):
     return "conv_thin_window_kernel<%d, %d, %d, %s>" % (1 if stem else 2, m // 16, 13 if stem else 5, "true" if dgrad else "false")
 
 
-def _conv_dgrad(desc, dy, wd, dy_cb=None, dy_bound=None, w_bound=None):
-    """``dy`` may be None when its pre-split companion is given and the batch is not cut (the kernel reads only ``dy_cb``)"""
+def _conv_dgrad(desc, dy, wd, dy_cb=None, dy_bound=None, w_bound=None, addend=None):
+    """``dy`` may be None when its pre-split companion is given and the batch is not cut (the kernel reads only ``dy_cb``).
+    ``addend``: another gradient of the same input (``GradBox``); the result is data gradient + addend -- in the kernel's epilogue
+    where the kernel can (``mcdseg_conv_split_dgrad_add``), by an element-wise add otherwise: the same bits either way."""
     L = lib()
+    if addend is not None:
+        addend = _req(addend, "gradient addend")
     dx = torch.empty((desc.N, desc.Cin, desc.H, desc.W), dtype=torch.float32, device=(dy if dy is not None else dy_cb).device)
     pieces = _batch_pieces(desc)
     split = _is_split(wd)
@@ -536,6 +578,11 @@ def _conv_dgrad(desc, dy, wd, dy_cb=None, dy_bound=None, w_bound=None):
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a, desc.N if dy_cb is not None else 0)
         name = (_window_name(d, dy_cb is not None, True) if split else None) \
             or gemm_kernel_name(desc.Cin, desc.Cout, True, split, dy_cb is not None, False, d.N * d.H * d.W)
+        if split and addend is not None and _window_name(d, dy_cb is not None, True) is None:
+            _split_launches(d, dy_cb is not None, True, name, lambda part: check(L.mcdseg_conv_split_dgrad_add(
+                ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(dy, a, b)), _cb_slice(dy_cb, a, desc.Cout, desc.Ho * desc.Wo), _p(dy_bound),
+                _p(wd), _p(w_bound), _p(addend[a:b]), _p(dx[a:b]), part, _stream()), "conv_split_dgrad_add"))
+            continue
         if split:
             _split_launches(d, dy_cb is not None, True, name, lambda part: check(L.mcdseg_conv_split_dgrad_part(
                 ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(dy, a, b)), _cb_slice(dy_cb, a, desc.Cout, desc.Ho * desc.Wo), _p(dy_bound),
@@ -543,6 +590,8 @@ def _conv_dgrad(desc, dy, wd, dy_cb=None, dy_bound=None, w_bound=None):
         else:
             with _timed(name, conv_work(d)):
                 check(L.mcdseg_conv_dgrad(ctypes.byref(d), _p(dy[a:b]), _p(wd), _p(dx[a:b]), _stream()), "conv_dgrad")
+        if addend is not None:
+            dx[a:b].add_(addend[a:b])
     return dx
 
 
@@ -759,7 +808,8 @@ def _room_to_defer(device):
     return torch.cuda.memory_allocated(key) < DEFER_MEM_FRACTION * _TOTAL_MEM[key]
 
 
-def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_bound=None, x_bound=None, w_bound=None, defer=False, param=None):
+def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_bound=None, x_bound=None, w_bound=None, defer=False, param=None,
+                   dx_addend=None):
     """(dx, dw).  ``defer``: dw goes to a ``_LateGrad`` node, so mode "2" may leave it on the side stream.  ``param``: the parameter
     behind that node; when its optimizer has left a ``_mcd_grad_sink`` on it (FlatSGD's bucketed all-reduce, MCDSEG_DP_OVERLAP=1) a
     deferred gradient is handed to the sink ON THE SIDE STREAM, right behind its kernels -- the exchange of a bucket then starts when
@@ -773,7 +823,7 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_
         mode = "0"
         WGRAD_STREAM_STATS["no_room"] += 1
     if not (need_dx and need_dw and mode != "0"):
-        return ((_conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound) if need_dx else None),
+        return ((_conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound, dx_addend) if need_dx else None),
                 (_conv_wgrad(desc, x, dy, x_cb, dy_cb, x_bound, dy_bound) if need_dw else None))
     main = torch.cuda.current_stream()
     side = _side_stream(x.device)
@@ -788,7 +838,7 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_
         dw = _conv_wgrad(desc, x, dy, x_cb, dy_cb, x_bound, dy_bound)
     finally:
         keep, _LAUNCH.stream, _LAUNCH.keep = _LAUNCH.keep, None, None
-    dx = _conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound)
+    dx = _conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound, dx_addend)
     if mode == "1":
         main.wait_stream(side)
         return dx, dw
@@ -916,6 +966,7 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.packed, ctx.pack_key = packed, packed.key  # the data-gradient image is shared and re-packed in place: see backward
         ctx.defer_ok = hasattr(weight, "_mcd_param")  # the weight came through a _LateGrad alias (late_weight_grads)
         ctx.w_param = getattr(weight, "_mcd_param", None)
+        ctx.in_box, ctx.res_box = aux.get("in_box"), aux.get("res_box")
         ctx.has_bias = conv_bias is not None
         ctx.x_cb, ctx.x_bound = x_cb, x_bound  # wgrad reads the input's split companion too (an input of this node: safe to hold)
         ctx.x_virtual, ctx.compact = x_virtual, compact
@@ -998,8 +1049,23 @@ class _ConvBNAct(torch.autograd.Function):
         if DEBUG_TAPE is not None:  # kernel development (tools/op_contention.py): what the BN backward handed to the conv backward
             DEBUG_TAPE.append(dict(dy=dy, dz=dz, dz_cb=dz_cb, dz_bound=dz_bound, dgamma=dgamma, dbeta=dbeta, dres=dres, shape=(n, c, hw), z=z,
                                    y=y_mask, mean=mean, rstd=rstd, gamma=gamma, beta=beta, zmask=zmask))
+        # the gradients this group shares with another producer (GradBox): the shortcut's goes into its box -- or comes back summed when
+        # this group happens to be the last -- and the data gradient takes the box's tensor into its epilogue
+        if ctx.res_box is not None and dres is not None:
+            other, last = ctx.res_box.arrive()
+            if last:
+                dres = dres if other is None else dres + other
+            else:
+                ctx.res_box.leave(dres if other is None else dres + other)
+                dres = None
+        addend, dx_last = (None, True)
+        if ctx.in_box is not None and ctx.needs_input_grad[0]:
+            addend, dx_last = ctx.in_box.arrive()
         dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz_cb, x_cb, dz_bound,
-                                x_bound, ctx.w_bound, defer=ctx.defer_ok, param=ctx.w_param)
+                                x_bound, ctx.w_bound, defer=ctx.defer_ok, param=ctx.w_param, dx_addend=addend)
+        if not dx_last:
+            ctx.in_box.leave(dx)
+            dx = None
         dbias = None
         if ctx.has_bias and ctx.needs_input_grad[5]:
             # a bias in front of train-mode BN has zero gradient up to rounding (BN removes the channel mean);
@@ -1037,9 +1103,10 @@ def _conv_bn_act_inference(x, conv, bn, relu, residual):
     return y
 
 
-def conv_bn_act(x, conv, bn, relu=True, residual=None, internal=False):
+def conv_bn_act(x, conv, bn, relu=True, residual=None, internal=False, in_box=None, res_box=None):
     """y = act(bn(conv(x)) + residual) with the HIP kernels; ``conv``/``bn`` are the parameter-holding modules.
-    ``internal``: the caller promises that only the next fused group reads the result (see INTERNAL_SKIP_Y)."""
+    ``internal``: the caller promises that only the next fused group reads the result (see INTERNAL_SKIP_Y).
+    ``in_box`` / ``res_box``: the ``GradBox`` through which the gradient of ``x`` / of ``residual`` is summed with its other producer."""
     geom = (conv.stride[0], conv.padding[0], conv.dilation[0])
     training = bn.training
     if not training and not torch.is_grad_enabled() and bn.track_running_stats and bn.running_mean is not None:
@@ -1051,8 +1118,11 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, internal=False):
     x_cb, x_bound = _cb_of(x)
     res_cb, res_bound = _cb_of(residual) if residual is not None else (None, None)
     skip_y = internal and INTERNAL_SKIP_Y and BN_ZMASK and relu and residual is None and _scaled()
+    grads = torch.is_grad_enabled()
     aux = dict(x_virtual=is_virtual(x), res_virtual=is_virtual(residual), res_cb=res_cb, compact=_compact_now() or skip_y,
-               single_piece_only=skip_y and not _compact_now())
+               single_piece_only=skip_y and not _compact_now(),
+               in_box=in_box.attach() if (in_box is not None and grads and x.requires_grad) else None,
+               res_box=res_box.attach() if (res_box is not None and grads and residual is not None and residual.requires_grad) else None)
     y, y_cb, y_bound = _ConvBNAct.apply(x, _take_late(conv), bn.weight, bn.bias, residual, conv.bias, bn.running_mean if track else None,
                                         bn.running_var if track else None, bn.num_batches_tracked if track else None, conv._packed,
                                         geom, training, momentum, bn.eps, relu, x_cb, x_bound, res_bound, aux)

@@ -79,6 +79,14 @@ def conv3x3(cin, cout, stride=1, padding=1, dilation=1):
     return Conv2d(cin, cout, kernel_size=3, stride=stride, padding=padding, bias=False, dilation=dilation)
 
 
+def _project(downsample, x, box):
+    """the 1x1 projection shortcut of a block (a ``ConvBN``): as a fused group whose input gradient goes through the block's GradBox"""
+    mods = list(downsample.children()) if isinstance(downsample, FusedSequential) else []
+    if box is not None and len(mods) == 2 and isinstance(mods[0], Conv2d) and isinstance(mods[1], BatchNorm2d):
+        return ops.conv_bn_act(x, mods[0], mods[1], relu=False, in_box=box)
+    return downsample(x)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -94,11 +102,14 @@ class BasicBlock(nn.Module):
         self.residual = residual
 
     def forward(self, x):
-        h = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, internal=True)  # only conv2 below reads h
+        # the block input's gradient has two producers, conv1's data gradient and the shortcut: summed through a GradBox (ops.GradBox)
+        box = ops.grad_box(x) if self.residual else None
+        h = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, internal=True, in_box=box)  # only conv2 below reads h
         shortcut = None
         if self.residual:
-            shortcut = x if self.downsample is None else self.downsample(x)
-        return ops.conv_bn_act(h, self.conv2, self.bn2, relu=True, residual=shortcut)
+            shortcut = x if self.downsample is None else _project(self.downsample, x, box)
+        return ops.conv_bn_act(h, self.conv2, self.bn2, relu=True, residual=shortcut,
+                               res_box=box if self.downsample is None else None)
 
 
 class Bottleneck(nn.Module):
@@ -118,10 +129,12 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        h = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, internal=True)  # only the next convolution reads these two
+        box = ops.grad_box(x)  # (as in BasicBlock)
+        h = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, internal=True, in_box=box)  # only the next convolution reads these two
         h = ops.conv_bn_act(h, self.conv2, self.bn2, relu=True, internal=True)
-        shortcut = x if self.downsample is None else self.downsample(x)
-        return ops.conv_bn_act(h, self.conv3, self.bn3, relu=True, residual=shortcut)
+        shortcut = x if self.downsample is None else _project(self.downsample, x, box)
+        return ops.conv_bn_act(h, self.conv3, self.bn3, relu=True, residual=shortcut,
+                               res_box=box if self.downsample is None else None)
 
 
 class DRN(nn.Module):

@@ -296,6 +296,56 @@ def test_solver_fused_up_loss_is_bitwise_the_two_pass_step(golden, monkeypatch):
         assert abs(c0 - c1) <= 1e-6 * abs(c1) and abs(d0 - d1) <= 1e-6 * abs(d1)
 
 
+@pytest.mark.parametrize("net,cut", [("drn_d_38", False), ("drn_d_38", True), ("drn_d_105", False), ("drn_c_26", False)])
+def test_residual_gradient_fold_is_bitwise_autograd(net, cut, monkeypatch):
+    """The gradient of a residual block's input -- first convolution's data gradient + shortcut -- summed in the data-gradient kernel's
+    epilogue through ``ops.GradBox`` (identity shortcuts: BasicBlock / Bottleneck; 1x1 projections: two data gradients) against
+    autograd's own element-wise accumulation (MCDSEG_FUSE_RES_ADD=0): every parameter gradient and the input gradient of one
+    backward pass through the encoder are bit-identical, also with the batch cut into pieces, and a second backward pass through the
+    same graph gives the same again (the boxes are re-armed)."""
+    dev = _dev()
+    from mcdseg import ops
+    from models.model_util import get_models
+    if cut:
+        monkeypatch.setattr(ops, "MAX_CONV_BYTES", 400 << 10)  # (every layer then runs in two to four batch pieces)
+    src, lbl, _ = make_batch(91, 4, 6, 96, 128, NC)
+    grads = []
+    for fold in (True, False):
+        monkeypatch.setattr(ops, "FUSE_RES_ADD", fold)
+        g, _, _ = get_models(net, 6, NC)
+        fill_state_(g, 21)
+        g.to(dev).train()
+        x = src.to(dev).requires_grad_()
+        boxes = []
+        real_box = ops.GradBox
+
+        class _Counting(real_box):
+            __slots__ = ()
+
+            def __init__(self):
+                super().__init__()
+                boxes.append(self)
+        monkeypatch.setattr(ops, "GradBox", _Counting)
+        feat = g(x)
+        gfeat = torch.randn(feat.shape, generator=torch.Generator().manual_seed(92)).to(dev)
+        monkeypatch.setattr(ops, "GradBox", real_box)
+        assert (len(boxes) > 0) == fold
+        assert all(b.n == 2 for b in boxes), [b.n for b in boxes]
+        feat.backward(gfeat, retain_graph=True)
+        first = [x.grad.clone()] + [p.grad.clone() for p in g.parameters()]
+        assert all(b.g is None and b.seen == 0 for b in boxes), "a box kept a gradient"
+        x.grad = None
+        for p in g.parameters():
+            p.grad = None
+        feat.backward(gfeat)
+        second = [x.grad] + [p.grad for p in g.parameters()]
+        for a, b in zip(first, second):
+            assert torch.equal(a, b), "the second backward pass through the same graph differs"
+        grads.append(first)
+    for (k, _), a, b in zip([("input", None)] + list(g.named_parameters()), grads[0], grads[1]):
+        assert torch.equal(a, b), "%s: folded and accumulated gradients differ (max %.3e)" % (k, float((a - b).abs().max()))
+
+
 def test_solver_target_forward_reuse_is_bitwise_the_literal_schedule(golden):
     """Step B's generator forward on the target batch doubling as step C's first one (solvers/solver.py; each BatchNorm applies
     its running update twice) against the literal schedule of adapt_trainer.py:196/:209 (7 generator forwards): every
