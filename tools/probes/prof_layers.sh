@@ -25,4 +25,4 @@ for k, v in agg.items():
     print('%-70s n=%2d cyc/launch=%8d mfma_busy=%.3f parked=%.3f stalled=%.3f issuing=%.3f' % (k[:70], n, cyc / n, tot['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * cyc),
           tot['SQ_WAIT_ANY'] / tot['SQ_WAVE_CYCLES'], tot['SQ_WAIT_INST_ANY'] / tot['SQ_WAVE_CYCLES'], tot['SQ_ACTIVE_INST_ANY'] / tot['SQ_WAVE_CYCLES']))
 PY
-find "$OUT" -name "*.csv" -size +2M -delete
+find "$OUT/${TAG}_trace" "$OUT/${TAG}_sq" -name "*.csv" -size +2M -delete
