@@ -1074,6 +1074,61 @@ def test_d105_bottleneck_vs_reference(golden, storage, k, monkeypatch):
         assert e <= max(k * nz, 1e-3 * float(g64[name].abs().max())), "%s: err %.3e noise %.3e" % (name, e, nz)
 
 
+def test_cfg5_stated_batch_equals_its_replicated_quarter(monkeypatch):
+    """BASELINE config 5 at its STATED per-GPU batch -- drn_d_105, 32 x 6 x 720 x 1280, compact activation storage (232 GB of the 288) --
+    in a test that asserts something: the batch is four copies of an 8-pair batch.  Train-mode BatchNorm then sees the moments of the
+    8-pair batch, the mean-reduced losses and the gradients are those of the 8-pair step, and so is the update -- computed here through
+    the code paths only the full batch reaches (2048- and 1024-channel maps above one launch's 2 GiB, cut along N with their
+    companions; the two-launch ping-pong plan over 14 rounds of tiles; weight gradients refused by the side stream's memory guard).
+    One A+B+C step (num_k = 1) of both: both losses within 1e-3, the update of all parameters within the distance the SAME 8-pair step
+    shows between the default and the f32-MFMA arithmetic (the network's own fp32-grade noise, a few per cent at 105 BatchNorms)."""
+    dev = _dev()
+    import ctypes
+    from loss import CrossEntropyLoss2d, get_prob_distance_criterion
+    from mcdseg import ops
+    from models.model_util import get_models, get_optimizer
+    from solvers.solver import MCDSolver
+    if torch.cuda.get_device_properties(dev).total_memory < 250e9:
+        pytest.skip("needs the 288 GB of an MI355X")
+    s8, l8, t8 = (v.to(dev) for v in make_batch(7, 8, 6, 720, 1280, NC))
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    monkeypatch.setattr(ops, "ACT_STORAGE", "compact")
+    assert len(ops._batch_pieces(ops.conv_desc((32, 2048, 90, 160), (512, 2048, 1, 1), 1, 0, 1))) > 1  # (the cut path is reached)
+    out = {}
+    for name, math, rep in (("n8", "f16x3", 1), ("n8_f32", "f32", 1), ("n32", "f16x3", 4)):
+        monkeypatch.setattr(ops, "CONV_MATH", math)
+        ops.bump_weight_epoch()
+        g, f1, f2 = get_models("drn_d_105", 6, NC)
+        for m, seed in ((g, 71), (f1, 72), (f2, 73)):
+            fill_state_(m, seed)
+            m.to(dev).train()
+        before = {k: v.detach().clone() for k, v in g.named_parameters()}
+        og = get_optimizer(g.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+        of = get_optimizer(list(f1.parameters()) + list(f2.parameters()), "sgd", 1e-3, 0.9, 2e-5)
+        solver = MCDSolver(g, f1, f2, og, of, CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff"), num_k=1)
+        s, l, t = (v.repeat(rep, 1, 1, 1) if v.dim() == 4 else v.repeat(rep, 1, 1) for v in (s8, l8, t8))
+        c_loss, d_loss = solver.step(s, l, t)
+        out[name] = (float(c_loss), float(d_loss), {k: (v.detach() - before[k]).double().cpu() for k, v in g.named_parameters()},
+                     torch.cuda.max_memory_allocated(dev))
+        del g, f1, f2, og, of, solver, before, s, l, t
+        torch.cuda.empty_cache()
+
+    def dist(a, b):
+        num = sum(float(((a[k] - b[k]) ** 2).sum()) for k in a)
+        den = sum(float((b[k] ** 2).sum()) for k in b)
+        return (num / den) ** 0.5
+
+    (c8, d8, u8, _), (c8f, d8f, u8f, _), (c32, d32, u32, peak) = out["n8"], out["n8_f32"], out["n32"]
+    noise, err = dist(u8f, u8), dist(u32, u8)
+    print("cfg5 N=32 vs its quarter: c_loss %.6f / %.6f, d_loss %.6e / %.6e, updates differ by %.3e (arithmetic noise %.3e), peak %.1f GB"
+          % (c32, c8, d32, d8, err, noise, peak / 1e9))
+    assert np.isfinite(c32) and abs(c32 - c8) <= 1e-3 * abs(c8), (c8, c32)
+    assert abs(d32 - d8) <= max(1e-3 * abs(d8), 2 * abs(d8f - d8)), (d8, d32, d8f)
+    assert 0 < noise < 0.3, noise
+    assert err <= 2 * noise, "the 32-pair step's update is %.3e from its quarter's, the arithmetic's own noise is %.3e" % (err, noise)
+
+
 def test_cfg5_size_compact_storage_step(monkeypatch):
     """BASELINE config 5 at its stated image size (drn_d_105, 6x720x1280; N=2 here, N=32 is measured in DESIGN 6a): one full
     A+B+C step in compact activation storage against the same step in fp32 storage -- losses and every parameter update.
