@@ -1117,6 +1117,7 @@ static int fill_fprop_params(const mcdseg_conv_desc* d, int math, const void* x_
   MCD_REQUIRE(wb < (1ll << 31), "conv_split_fprop: packed weights exceed 2 GiB");
   p.wp_bytes = (int)wb;
   p.sub = 0; p.tile_n0 = 0; p.tile_n1 = 0;
+  p.ep_res_lds = 0; p.ep_res_bytes = 0;
   return 0;
 }
 
@@ -1148,6 +1149,7 @@ static int fill_dgrad_params(const mcdseg_conv_desc* d, int math, const void* dy
   MCD_REQUIRE(wb < (1ll << 31), "conv_split_dgrad: packed weights exceed 2 GiB");
   p.wp_bytes = (int)wb;
   p.sub = 0; p.tile_n0 = 0; p.tile_n1 = 0;
+  p.ep_res_lds = 0; p.ep_res_bytes = 0;
   return 0;
 }
 
@@ -1168,6 +1170,12 @@ static int split_dgrad_impl(const mcdseg_conv_desc* d, int32_t math, const float
   p.src_bound = dy_bound; p.w_bound = w_bound;
   p.src = dy; p.wp = wp_dgrad; p.bias = nullptr; p.dst = dx; p.stats = nullptr;
   p.ep_scale = nullptr; p.ep_shift = nullptr; p.ep_res = addend; p.ep_relu = 0;
+  if (addend != nullptr) {
+    static const bool stage = [] { const char* e = getenv("MCDSEG_DGRAD_ADD_LDS"); return e == nullptr || atoi(e) != 0; }();  // development knob
+    const int64_t bytes = (int64_t)d->N * d->Cin * d->H * d->W * 4;
+    p.ep_res_lds = stage && ((d->H * d->W) & 3) == 0 && (reinterpret_cast<uintptr_t>(addend) & 15) == 0 && bytes < (1ll << 32) ? 1 : 0;
+    p.ep_res_bytes = (unsigned)(bytes < (1ll << 32) ? bytes : 0);
+  }
   if (int rc = launch_math<true>(math, p, part, (hipStream_t)stream)) return rc;
   MCD_LAUNCH_CHECK("conv_split_dgrad");
   return 0;

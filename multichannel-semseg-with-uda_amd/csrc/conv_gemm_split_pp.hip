@@ -278,6 +278,52 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
     }
     dbase[j] = (size_t)n * p.M * HWd + rem;
   }
+  if (DGRAD && p.ep_res != nullptr && p.ep_res_lds) {
+    // ---- data gradient + addend, the addend's tile staged through LDS.  With one workgroup per CU nothing hides the latency of
+    // epilogue loads, and the accumulators leave ~20 registers to keep them in flight (measured: matrix pipe busy 0.78 -> 0.69 with
+    // the addend loaded value by value).  A pass stages 16 rows of every wave row block -- rows i * 32 + 16 h .. + 15, what the
+    // accumulator registers r = 8 h .. 8 h + 7 hold -- as [row][BN] floats by 16-byte LDS-DMAs (a quad of pixels never straddles two
+    // images: host), then every lane adds its values from LDS and stores.  Same sum, same order: bit for bit the direct form.
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int ROWS_PASS = 2 * QM * 16, U_ROW = BN / 4, UNITS = ROWS_PASS * U_ROW, UPT = UNITS / NT;
+    static_assert(UNITS % NT == 0 && ROWS_PASS * BN * 4 <= NS * (A_BYTES + B_BYTES), "a pass fits the LDS the K loop has left");
+    const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.ep_res, 0, p.ep_res_bytes, 0x00020000);
+    const float* stage = reinterpret_cast<const float*>(smem);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the previous pass's (the K loop's) readers are done
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) {
+          const int u = k * NT + t;
+          const int row_l = u / U_ROW, c4 = u - row_l * U_ROW;
+          const int m = tile_m * BM + (row_l >> 4) * (32 * WM) + i * 32 + h * 16 + (row_l & 15);
+          const int pp = tile_n * BN + c4 * 4;
+          unsigned voff = OOB;
+          if (m < p.M && pp < p.P) {
+            const int n = pp / HWd;
+            voff = ((unsigned)(n * p.M + m) * (unsigned)HWd + (unsigned)(pp - n * HWd)) * 4u;
+          }
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(res_rs, (__attribute__((address_space(3))) void*)(smem + (k * NT + wave * 64) * 16), 16, voff, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int r = h * 8 + rr;
+          const int e = (r & 3) + 8 * ((r >> 2) - 2 * h) + 4 * lh;
+          const int m = m_wave + i * 32 + h * 16 + e;
+          const float* srow = stage + (wm * 16 + e) * BN + wn * (32 * WN) + l31;
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            const float v = acc[i][j][r] + srow[j * 32];
+            if (m < p.M && colv[j]) p.dst[dbase[j] + (size_t)m * HWd] = v;
+          }
+        }
+      }
+#endif
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll

@@ -32,4 +32,9 @@ struct ConvSplitParams {
   // the rest to the 4-wave tiles): this launch's tiles are tile_n0 .. tile_n1 - 1 of the launch's own pixel-tile size.  Outputs
   // and BatchNorm partial rows (one per 64 pixels, numbered over the whole tensor) are those of a single launch.
   int tile_n0, tile_n1;
+  // data gradient + addend (ep_res with DGRAD): the ping-pong kernel may stage the addend's tile through LDS (free after the K loop)
+  // by LDS-DMA instead of loading it value by value into the few registers its accumulators leave: set by the host when a pixel
+  // quad never straddles two images and the tensor is 16-byte aligned
+  int ep_res_lds;
+  unsigned ep_res_bytes;
 };

@@ -1121,6 +1121,10 @@ def test_conv_pingpong_tile(case, monkeypatch):
         if dx is not None:
             (gx_ref,) = torch.autograd.grad(ref, [x64], gy.double())
             _assert_close(dx, gx_ref, 2e-5, "data gradient (ping-pong + rest)")
+    if dx is not None:  # data gradient + addend on the two-launch plan (256 x 256 + 256 x 128 tiles, ragged last tile)
+        addend = torch.randn(dx.shape, generator=torch.Generator().manual_seed(46)).to(dev)
+        dx_add = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound, addend=addend)
+        assert torch.equal(dx_add, dx + addend), "dgrad + addend differs from the separate add (max %.3e)" % float((dx_add - dx - addend).abs().max())
     # the 256 x 128 ping-pong tile alone (mode 2) and the 256 x 256 tile with the 4-wave tiles for the rest (mode 1): the same bits
     for mode in ("2", "1"):
         monkeypatch.setenv("MCDSEG_PINGPONG", mode)
@@ -1596,6 +1600,10 @@ def test_conv_pingpong_wide_tile_by_default(math, monkeypatch):
         dx0 = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound)
         monkeypatch.delenv("MCDSEG_PINGPONG")
         assert torch.equal(y, y0) and torch.equal(dx, dx0), "the wide tile's results differ from the 4-wave tiles'"
+        # data gradient + addend (a residual block's other gradient; the tile of the addend goes through LDS): the bits of dgrad-then-add
+        addend = torch.randn(dx.shape, generator=torch.Generator().manual_seed(45)).to(dev)
+        dx_add = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound, addend=addend)
+        assert torch.equal(dx_add, dx + addend), "dgrad + addend differs from the separate add (max %.3e)" % float((dx_add - dx - addend).abs().max())
         pw = part.double().view(rows, 3, -1)[:, :, :cout]
         cnt, mean_r, m2_r = pw[:, 0], pw[:, 1], pw[:, 2]
         assert float(cnt[:, 0].sum()) == pixels
