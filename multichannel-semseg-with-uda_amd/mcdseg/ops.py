@@ -12,6 +12,7 @@ mirror the ATen call sites of the reference's hot path:
   mcd_losses       both of the above in one fused kernel            adapt_trainer.py:163-212
 """
 import collections
+import contextlib
 import ctypes
 import os
 import threading
@@ -737,6 +738,83 @@ def join_side_streams(device_index=None):
             _HELD.pop(key, None)  # (after the wait: the operands of the deferred launches go back to the allocator)
 
 
+# ---- two independent forward passes side by side (MCD step B: the generator on the source and on the target batch, same weights).
+# A forward pass on ONE stream alternates matrix-bound convolutions with HBM-bound BatchNorm passes and nothing runs beside either;
+# two passes on two streams fill each other's gaps.  The only state they share is each BatchNorm's running statistics, which the
+# reference updates source-first (adapt_trainer.py:187-200): the pass that leads (source, side stream) records an event behind every
+# statistics launch, the pass that follows (target, main stream) waits for the layer's event before it touches the layer -- the same
+# updates in the same order (and the lazily re-packed weight images of the leading pass are complete before the follower reads
+# them).  MCDSEG_OVERLAP_STEPB=0: one after the other.
+OVERLAP_STEPB = os.environ.get("MCDSEG_OVERLAP_STEPB", "1") != "0"
+_FWD_SYNC = None  # "lead" / "follow" inside ForwardFork's contexts
+_FWD_LEAD_DONE = None  # event behind the last launch of the leading pass
+
+
+class ForwardFork:
+    def __init__(self, device):
+        self.device = device
+        self.main = torch.cuda.current_stream(device)
+        self.side = _side_stream(device)
+
+    @contextlib.contextmanager
+    def lead(self):
+        """the pass that goes first in the reference's order: on the side stream, without a tape"""
+        global _FWD_SYNC, _FWD_LEAD_DONE
+        self.side.wait_stream(self.main)
+        prev, _FWD_SYNC = _FWD_SYNC, "lead"
+        try:
+            with torch.cuda.stream(self.side), torch.no_grad():
+                yield
+            _FWD_LEAD_DONE = torch.cuda.Event()
+            _FWD_LEAD_DONE.record(self.side)
+        finally:
+            _FWD_SYNC = prev
+
+    @contextlib.contextmanager
+    def follow(self):
+        global _FWD_SYNC
+        prev, _FWD_SYNC = _FWD_SYNC, "follow"
+        try:
+            yield
+        finally:
+            _FWD_SYNC = prev
+
+    def join(self, tensors):
+        """the main stream waits for the leading pass; its results (allocated from the side stream's pool) now belong to both"""
+        global _FWD_LEAD_DONE
+        _FWD_LEAD_DONE = None
+        self.main.wait_stream(self.side)
+        for t in tensors:
+            t.record_stream(self.main)
+            for c in (getattr(t, "_mcd_cb", None) or ())[:2]:
+                if torch.is_tensor(c):
+                    c.record_stream(self.main)
+
+
+def forward_fork(device):
+    """a ``ForwardFork`` when two forward passes may run side by side on ``device`` now, else None"""
+    if not OVERLAP_STEPB or device.type != "cuda" or _LAUNCH.stream is not None:
+        return None
+    if LAUNCH_TIMER is not None and LAUNCH_TIMER.wants("conv_wgrad"):
+        return None  # a step whose launches are bracketed by HIP events runs every kernel alone
+    if not _room_to_defer(device):
+        return None
+    return ForwardFork(device)
+
+
+def _fwd_sync_wait(anchor):
+    ev = getattr(anchor, "_mcd_fwd_ev", None)
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+        anchor._mcd_fwd_ev = None
+
+
+def _fwd_sync_record(anchor):
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    anchor._mcd_fwd_ev = ev
+
+
 class _LateGrad(torch.autograd.Function):
     """identity on a convolution weight; its backward makes the main stream wait for the side stream, then passes the gradient on"""
 
@@ -892,6 +970,8 @@ class _ConvBNAct(torch.autograd.Function):
                 momentum, eps, relu, x_cb, x_bound, res_bound, aux):
         """aux: dict(x_virtual, res_virtual, res_cb, compact) -- compact activation storage (see ACT_STORAGE)"""
         L = lib()
+        if _FWD_SYNC == "follow":
+            _fwd_sync_wait(gamma)  # (ForwardFork: the leading pass is through with this layer)
         stride, pad, dil = geom
         desc = conv_desc(x.shape, weight.shape, stride, pad, dil)
         wf, wd, mpf = packed.get(getattr(weight, "_mcd_param", weight), desc)
@@ -945,6 +1025,8 @@ class _ConvBNAct(torch.autograd.Function):
                                                  _p(res_bound) if (y_bound is not None and has_res) else None, _p(y_bound),
                                                  int(BN_RUNNING_REPEAT if track else 1), _p(ws), ctypes.c_size_t(ws.numel() * 8), _stream()),
                       "bn_stats_finalize")
+            if _FWD_SYNC == "lead":
+                _fwd_sync_record(gamma)
         else:
             check(L.mcdseg_bn_eval_stats(_p(running_mean), _p(running_var), c, float(eps), _p(mean), _p(rstd), _stream()),
                   "bn_eval_stats")
@@ -1188,6 +1270,9 @@ def conv2d_bias(x, conv):
     if is_virtual(x):
         raise RuntimeError("mcdseg: a compact activation left its trunk (the trunk's last layer writes fp32)")
     x_cb, x_bound = _cb_of(x)
+    if _FWD_SYNC == "follow" and _FWD_LEAD_DONE is not None:
+        # a convolution without BatchNorm has no per-layer event: the follower of a ForwardFork runs it behind the whole leading pass
+        torch.cuda.current_stream().wait_event(_FWD_LEAD_DONE)
     return _Conv2dBias.apply(x, conv.weight, conv.bias, conv._packed, geom, x_cb, x_bound)
 
 

@@ -27,6 +27,7 @@ result:
     full-resolution logit tensors are never written or read.  Logits, losses and gradients are those of the two-pass form
     (bit for bit, up to the order of the loss's block partial sums).
 """
+import contextlib
 import os
 
 import torch
@@ -177,17 +178,26 @@ class MCDSolver:
         # ---- B: classifiers only (generator forward without a tape)
         self.opt_g.zero_grad()
         self.opt_f.zero_grad()
-        with torch.no_grad():
-            feats = self._features(src_imgs)
-        self._loss_backward(feats, src_lbls, ce_coef=1.0)
+        # the two generator passes of this step are independent (same weights): they run side by side on two streams, every BatchNorm's
+        # running statistics still updated source-first (ops.ForwardFork); the losses follow in the reference's order
+        fork = ops.forward_fork(src_imgs.device)
+        with (fork.lead() if fork is not None else torch.no_grad()):
+            feats_src = self._features(src_imgs)
+        if fork is None:
+            self._loss_backward(feats_src, src_lbls, ce_coef=1.0)
         taped = None
-        if self.reuse_tgt and self.num_k > 0:
-            with ops.bn_running_updates(2):  # this forward is also the first one of step C
-                taped = self._features(tgt_imgs)
-            feats = tuple(_detached(f) for f in taped)
-        else:
-            with torch.no_grad():
-                feats = self._features(tgt_imgs)
+        with (fork.follow() if fork is not None else contextlib.nullcontext()):
+            if self.reuse_tgt and self.num_k > 0:
+                with ops.bn_running_updates(2):  # this forward is also the first one of step C
+                    taped = self._features(tgt_imgs)
+                feats = tuple(_detached(f) for f in taped)
+            else:
+                with torch.no_grad():
+                    feats = self._features(tgt_imgs)
+        if fork is not None:
+            fork.join(feats_src)
+            self._loss_backward(feats_src, src_lbls, ce_coef=1.0)
+        del feats_src
         self._loss_backward(feats, None, diff_coef=-1.0)
         del feats
         self.opt_f.step()

@@ -346,6 +346,49 @@ def test_residual_gradient_fold_is_bitwise_autograd(net, cut, monkeypatch):
         assert torch.equal(a, b), "%s: folded and accumulated gradients differ (max %.3e)" % (k, float((a - b).abs().max()))
 
 
+@pytest.mark.parametrize("reuse", [True, False])
+def test_solver_step_b_forward_fork_is_bitwise_the_serial_step(golden, monkeypatch, reuse):
+    """Step B's two generator passes (source, target: same weights) side by side on two streams (``ops.ForwardFork``; every BatchNorm's
+    running statistics still updated source-first through per-layer events) against the same solver running them one after the other
+    (MCDSEG_OVERLAP_STEPB=0): every parameter, running statistic, ``num_batches_tracked`` and logged loss after three A/B/C iterations
+    is bit-identical, with and without the reuse of the target pass in step C."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, get_prob_distance_criterion
+    from mcdseg import ops
+    from models.model_util import get_optimizer
+    from solvers.solver import MCDSolver
+    tr = golden.json("traces.json")["mcd_small"]
+    n, ch, h, w = tr["shape"]
+    s, l, t = (v.to(dev) for v in make_batch(tr["seed_batch"], n, ch, h, w, NC))
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    states, losses, forks = [], [], []
+    real_fork = ops.forward_fork
+    for fork in (True, False):
+        monkeypatch.setattr(ops, "OVERLAP_STEPB", fork)
+        made = []
+
+        def counting(device, _made=made):
+            f = real_fork(device)
+            _made.append(f is not None)
+            return f
+        monkeypatch.setattr(ops, "forward_fork", counting)
+        g, f1, f2 = _mcd_models(dev)
+        og = get_optimizer(g.parameters(), "sgd", 1e-3, 0.9, 2e-5)
+        of = get_optimizer(list(f1.parameters()) + list(f2.parameters()), "sgd", 1e-3, 0.9, 2e-5)
+        solver = MCDSolver(g, f1, f2, og, of, CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff"), num_k=4)
+        solver.reuse_tgt = reuse
+        out = [solver.step(s, l, t) for _ in range(3)]
+        torch.cuda.synchronize()
+        losses.append([(float(a), float(b)) for a, b in out])
+        states.append({k: v.clone() for m in (g, f1, f2) for k, v in m.state_dict().items()})
+        forks.append(made)
+    assert forks[0] == [True] * 3 and forks[1] == [False] * 3, forks
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
+    assert losses[0] == losses[1], losses
+
+
 def test_solver_target_forward_reuse_is_bitwise_the_literal_schedule(golden):
     """Step B's generator forward on the target batch doubling as step C's first one (solvers/solver.py; each BatchNorm applies
     its running update twice) against the literal schedule of adapt_trainer.py:196/:209 (7 generator forwards): every
