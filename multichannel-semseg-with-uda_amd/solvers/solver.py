@@ -274,18 +274,29 @@ class MultiTaskMCDSolver:
 
         self.opt_enc.zero_grad()
         self.opt_dec.zero_grad()
-        with torch.no_grad():
+        # the encoder's two passes of this step side by side (ops.ForwardFork, as in MCDSolver.step); the decoders follow in the
+        # reference's order
+        fork = ops.forward_fork(src_rgbs.device)
+        with (fork.lead() if fork is not None else torch.no_grad()):
             src_fet = enc(src_rgbs)
-            dec.semseg_forward(src_fet)
-        src_semseg_loss, src_depth_loss = dec.get_loss(src_fet, src_gt_semseg, src_depths, separately_returning=True)
         taped = None
-        if self.reuse_tgt and self.num_k > 0:
-            with ops.bn_running_updates(2):  # this forward is also the first one of step C
-                taped = enc(tgt_rgbs)
-            tgt_fet = _detached(taped)
-        else:
+        with (fork.follow() if fork is not None else contextlib.nullcontext()):
+            if fork is None:
+                with torch.no_grad():
+                    dec.semseg_forward(src_fet)
+                src_semseg_loss, src_depth_loss = dec.get_loss(src_fet, src_gt_semseg, src_depths, separately_returning=True)
+            if self.reuse_tgt and self.num_k > 0:
+                with ops.bn_running_updates(2):  # this forward is also the first one of step C
+                    taped = enc(tgt_rgbs)
+                tgt_fet = _detached(taped)
+            else:
+                with torch.no_grad():
+                    tgt_fet = enc(tgt_rgbs)
+        if fork is not None:
+            fork.join([src_fet])
             with torch.no_grad():
-                tgt_fet = enc(tgt_rgbs)
+                dec.semseg_forward(src_fet)
+            src_semseg_loss, src_depth_loss = dec.get_loss(src_fet, src_gt_semseg, src_depths, separately_returning=True)
         tgt_depth_loss = dec.get_depth_loss(tgt_fet, tgt_depths)
         tgt_discrepancy = dec.get_cls_descrepancy(tgt_fet)
         loss = src_semseg_loss + src_depth_loss + tgt_depth_loss - tgt_discrepancy
