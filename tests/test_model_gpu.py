@@ -862,9 +862,9 @@ def test_cfg3_full_batch_vs_oracle():
     """BASELINE config 3 at its stated per-GPU size -- MFNet-ScoreAddFusion, two drn_d_38 encoders (RGB / HHA), 16 x 6 x 480 x 640 --
     against the CPU oracle: both encoders' score maps and the fused full-resolution logits (<= 1e-3, north_star), the two cross-entropy
     values, the gradients of the four up-sampling kernels and the gradients handed back to the two encoders.  (The oracle's encoders
-    run forward only -- their backward at this size is the cfg2 test's subject and two minutes of CPU; everything behind the score
-    maps is differentiated on both sides.)  What only this size reaches: the two-input up-sampling kernel and the stored-logit loss
-    kernel on 16 x 41 x 480 x 640 tensors (806 MB each)."""
+    run forward only for the RGB side -- its backward at this size is the cfg2 test's subject -- and with the tape for the HHA side,
+    whose every parameter gradient is compared too; everything behind the score maps is differentiated on both sides.)  What only
+    this size reaches: the two-input up-sampling kernel and the stored-logit loss kernel on 16 x 41 x 480 x 640 tensors (806 MB each)."""
     dev = _dev()
     from loss import CrossEntropyLoss2d
     from models.model_util import get_models
@@ -880,8 +880,10 @@ def test_cfg3_full_batch_vs_oracle():
     prev = _all_threads()
     try:
         with torch.no_grad():
-            ra, rb = ora[0](src[:, :3].contiguous()), ora[1](src[:, 3:].contiguous())
-        ra, rb = ra.requires_grad_(), rb.requires_grad_()
+            ra = ora[0](src[:, :3].contiguous())
+        rb = ora[1](src[:, 3:].contiguous())  # the HHA encoder WITH its tape: its parameter gradients are compared below
+        ra = ra.requires_grad_()
+        rb.retain_grad()
         ro1, ro2 = ora[2](ra, rb), ora[3](ra, rb)
         rcrit = ref_loss.CrossEntropyLoss2d(cw)
         rl1, rl2 = rcrit(ro1, lbl), rcrit(ro2, lbl)
@@ -890,6 +892,7 @@ def test_cfg3_full_batch_vs_oracle():
         torch.set_num_threads(prev)
     keys = [(2, "up1.weight"), (2, "up2.weight"), (3, "up1.weight"), (3, "up2.weight")]
     ref_gs = {k: dict(ora[k[0]].named_parameters())[k[1]].grad.clone() for k in keys}
+    ref_enc_gs = {k: v.grad.clone() for k, v in ora[1].named_parameters()}
     rga, rgb_ = ra.grad.clone(), rb.grad.clone()
     ra, rb, ro1s = ra.detach(), rb.detach(), ro1.detach()[:, :, ::8, ::8].clone()
     rl1, rl2 = float(rl1.detach()), float(rl2.detach())
@@ -912,6 +915,17 @@ def test_cfg3_full_batch_vs_oracle():
         rel = float((got.cpu() - rg).norm() / rg.norm())
         assert rel <= 2e-3, "%s: relative L2 difference %.3e" % (what, rel)
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in hip[0].parameters())  # ... and the encoders did back-propagate
+    # every parameter gradient of the HHA encoder (bounds as in the cfg2 test: fp32 through 41 train-mode BatchNorms)
+    named = dict(hip[1].named_parameters())
+    assert set(named) == set(ref_enc_gs)
+    num = den = 0.0
+    worst = (0.0, None)
+    for k, rg in ref_enc_gs.items():
+        dn, rn = float((named[k].grad.cpu() - rg).double().norm()), float(rg.double().norm())
+        num, den = num + dn * dn, den + rn * rn
+        worst = max(worst, (dn / rn, k))
+    assert worst[0] <= 4e-2, "%s: relative L2 difference %.3e" % (worst[1], worst[0])
+    assert (num / den) ** 0.5 <= 2.5e-2, "HHA encoder gradients: relative L2 difference %.3e (worst %s %.3e)" % ((num / den) ** 0.5, worst[1], worst[0])
 
 
 def test_cfg4_full_batch_vs_oracle():
