@@ -15,10 +15,13 @@
 // two 256 x 128 tiles.  tools/probes/pingpong.hip (512 -> 512, 3x3, dilation 4, N = 16, random data, two full rounds of
 // workgroups): 0.594 of 2.5 PFLOP/s against 0.527 for the 4-wave structure; without the stagger the same 8-wave tile gets 0.44.
 //
-// One workgroup per CU (96 KB of LDS: three stages of 16 + 16 KB), so a grid is worth whole rounds of 256 tiles only: the host
-// (conv_gemm_split.hip::launch) gives this kernel floor(tiles / CUs) * CUs tiles and the remaining pixels to the 4-wave tiles.
-// K order, term order and the epilogue are those of conv_gemm_split_kernel, so outputs and BatchNorm partial rows (one per 64
-// pixels) are bit for bit the same whichever kernel computes a pixel (tests/test_kernels_gpu.py::test_conv_pingpong_tile).
+// One workgroup per CU (256 x 256: 96 KB of LDS, three stages of 16 + 16 KB), so a grid is worth whole rounds of CUs only.  The host
+// (pp_wide / mcdseg_internal_conv_pp_pixels below, called from conv_gemm_split.hip::launch_math) plans a convolution either as ONE
+// launch of the 256 x 320 (128 x 320) tile -- whose width makes BASELINE config 2's 76800 pixels 0.94 of a round -- or as whole rounds of
+// 256 x 256 tiles plus the rest on 256 x 128 tiles, or leaves it to the 4-wave tiles.  K order, term order and the epilogue are those
+// of conv_gemm_split_kernel, so outputs are bit for bit the same whichever kernel computes a pixel, and so are the BatchNorm partial
+// rows of the 256- and 128-pixel tiles (one per 64 pixels; the 320-pixel tiles emit one per 160: the same moments, regrouped)
+// (tests/test_kernels_gpu.py::test_conv_pingpong_tile, ::test_conv_pingpong_wide_tile_by_default).
 //
 // LDS timeline (stage of step s = s mod 3; "interval" = the time between two consecutive workgroup barriers; group g reads
 // step s in interval 2s + g and multiplies it in interval 2s + g + 1):
@@ -34,7 +37,7 @@
 
 namespace {
 
-// WM x WN: 32 x 32 accumulator tiles per wave; QM x QN: the four waves of a group; the two groups split the rows.  Two shapes are built:
+// WM x WN: 32 x 32 accumulator tiles per wave; QM x QN: the four waves of a group; the two groups split the rows.  Four shapes are built:
 //   <4, 2, 1, 4>  256 x 256, waves of 128 x 64, ONE workgroup per CU (96 KB of LDS): the fewest operand bytes per FLOP;
 //   <2, 2, 2, 2>  256 x 128, waves of 64 x 64 (<= 128 VGPRs), TWO workgroups per CU (2 x 72 KB): half the tile, so a partial last
 //                 round of workgroups costs half as much, and one workgroup's epilogue hides behind the other's K loop.
