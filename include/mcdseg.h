@@ -142,7 +142,8 @@ int64_t mcdseg_conv_split_parts(const mcdseg_conv_desc* d, int32_t math, int32_t
 /* 1 when "the rest" (part 2; the whole convolution when mcdseg_conv_split_parts returns 0) runs on the ping-pong kernel's 256 x 128
  * tile, 0 when it runs on the 4-wave tiles -- the kernel name a profiler will see. */
 int32_t mcdseg_conv_split_rest_pingpong(const mcdseg_conv_desc* d, int32_t math, int32_t presplit, int32_t dgrad);
-/* 1 (2: its 128 x 320 form, for output rows that are a multiple of 128 only) when the WHOLE convolution runs as one launch of the
+/* 1 (2: its 128 x 320 form, for output rows that are a multiple of 128 only; 3: its 256 x 160 form, where only 160-pixel tiles fill
+ * their rounds -- partial rows of 160 pixels as well, one per tile) when the WHOLE convolution runs as one launch of the
  * ping-pong kernel's 256 x 320 tile (chosen when fewer than two rounds of
  * 256 x 256 tiles exist but tiles 320 pixels wide fill their rounds to 80 %: 76800 pixels x 256 channels = 240 tiles on 256 CUs);
  * mcdseg_conv_split_parts then returns every pixel, and the BatchNorm partial rows are one per 160 pixels

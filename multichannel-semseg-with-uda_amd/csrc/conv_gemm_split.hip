@@ -962,8 +962,11 @@ extern "C" int64_t mcdseg_conv_split_stat_rows_for(const mcdseg_conv_desc* d, in
   if (mcdseg_internal_stem_ok(d)) return mcdseg_internal_stem_stat_rows(d);
   if (presplit) {  // the 256 x 320 ping-pong tile: one row per wave column of 160 pixels
     ConvSplitParams p;
-    if (fill_fprop_params(d, math, d, p) == 0 && mcdseg_internal_conv_pp_wide(p, math, false))
-      return 2 * ceil_div64((int64_t)d->N * d->Ho * d->Wo, 320);
+    if (fill_fprop_params(d, math, d, p) == 0) {
+      const int kind = mcdseg_internal_conv_pp_wide(p, math, false);
+      if (kind == 3) return ceil_div64((int64_t)d->N * d->Ho * d->Wo, 160);  // (256 x 160: one wave column)
+      if (kind) return 2 * ceil_div64((int64_t)d->N * d->Ho * d->Wo, 320);
+    }
   }
   return stat_rows_of(d, presplit != 0);
 }
@@ -1228,7 +1231,7 @@ extern "C" int32_t mcdseg_conv_split_wide_pingpong(const mcdseg_conv_desc* d, in
   if (!dgrad && mcdseg_internal_stem_ok(d)) return 0;
   ConvSplitParams p;
   if (dgrad ? fill_dgrad_params(d, math, d, p) : fill_fprop_params(d, math, d, p)) return 0;
-  return mcdseg_internal_conv_pp_wide(p, math, dgrad != 0);  // 1: 256 x 320; 2: 128 x 320 (output rows a multiple of 128 only)
+  return mcdseg_internal_conv_pp_wide(p, math, dgrad != 0);  // 1: 256 x 320; 2: 128 x 320 (output rows a multiple of 128 only); 3: 256 x 160
 }
 
 extern "C" int mcdseg_conv_split_fprop_part(const mcdseg_conv_desc* d, int32_t math, const float* x, const void* x_cb, const float* x_bound,

@@ -37,11 +37,12 @@
 
 namespace {
 
-// WM x WN: 32 x 32 accumulator tiles per wave; QM x QN: the four waves of a group; the two groups split the rows.  Four shapes are built:
+// WM x WN: 32 x 32 accumulator tiles per wave; QM x QN: the four waves of a group; the two groups split the rows.  Five shapes are built:
 //   <4, 2, 1, 4>  256 x 256, waves of 128 x 64, ONE workgroup per CU (96 KB of LDS): the fewest operand bytes per FLOP;
 //   <2, 2, 2, 2>  256 x 128, waves of 64 x 64 (<= 128 VGPRs), TWO workgroups per CU (2 x 72 KB): half the tile, so a partial last
 //                 round of workgroups costs half as much, and one workgroup's epilogue hides behind the other's K loop.
 //   <1, 5, 2, 2>  128 x 320, waves of 32 x 160: the same for the 128-channel layers.
+//   <1, 5, 4, 1>  256 x 160, waves of 32 x 160: for HALF the pixels (N = 8: 38400 = 240 tiles of 160).
 //   <2, 5, 2, 2>  256 x 320, waves of 64 x 160, one workgroup per CU (120 KB): the tile WIDTH is the knob against round quantisation --
 //                 76800 pixels (BASELINE config 2, 1/8 resolution) are 300 tiles of 256 (1.17 rounds of 256 CUs: the last 44 tiles
 //                 cost a whole round) but 240 tiles of 320 (0.94 of ONE round).  A wave's 160 pixels are one BatchNorm partial row.
@@ -63,7 +64,11 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
   // a pixel tile that divides the workgroup gives every thread ONE gather pixel for all its units; otherwise (320) one per unit
   constexpr bool SAMEPX = (NT % BN) == 0;
   constexpr int NPX = SAMEPX ? 1 : B_DMAS;
-  static_assert(BM % 64 == 0 && BN % 64 == 0, "every wave issues the same number of DMAs (the waits are counted); a wave's units share a plane");
+  // a pixel tile of 160: a wave's 64 units may straddle the two k-halves of a piece (never two pieces: 2 BN % 64 == 0), so the k-half
+  // is the LANE's -- folded into its base offset -- and the scalar offset addresses the chunk's first channel group only
+  constexpr bool LANEHALF = (BN % 64) != 0;
+  static_assert(BM % 64 == 0 && (2 * BN) % 64 == 0 && (!LANEHALF || !SAMEPX),
+                "every wave issues the same number of DMAs (the waits are counted); a wave's units share a piece");
   static_assert(NS * (A_BYTES + B_BYTES) <= 160 * 1024, "LDS");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (A_BYTES + B_BYTES)];
@@ -102,8 +107,11 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
   // whether tap q of a pixel falls into the zero padding is one bit of a per-thread mask; the tap's address offset is the same for
   // every thread (scalar ALU): a K-step spends three vector instructions per gather pixel on addressing
   unsigned valid_mask[NPX], vbase[NPX];
+  int khalf[NPX];
 #pragma unroll
   for (int x = 0; x < NPX; ++x) {
+    const int plane_l = (t + x * NT) / BN;  // (LANEHALF: this lane's plane; else the wave's)
+    khalf[x] = LANEHALF ? (plane_l & 1) : 0;
     const int bj = (t + x * NT) % BN;
     const int pix = tile_n * BN + bj;
     const bool pv = pix < p.P;
@@ -122,8 +130,9 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
       const int sx = DGRAD ? px + p.pad - kx * p.dil : px * p.stride + kx * p.dil - p.pad;
       vm |= (pv && sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws ? 1u : 0u) << q;
     }
-    valid_mask[x] = vm;
+    valid_mask[x] = (LANEHALF && plane_l >= 2 * NPU) ? 0u : vm;  // (a unit past the staged planes)
     vbase[x] = DGRAD ? pix_base + (unsigned)(py * p.Ws + px) : pix_base + (unsigned)(py * p.stride * p.Ws + px * p.stride);
+    if (LANEHALF) vbase[x] += (unsigned)(khalf[x] * HWs);
   }
 
   unsigned a_voff[A_DMAS];
@@ -147,11 +156,15 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
     const int rel = DGRAD ? (p.pad - l_ky * p.dil) * p.Ws + (p.pad - l_kx * p.dil) : (l_ky * p.dil - p.pad) * p.Ws + (l_kx * p.dil - p.pad);
     unsigned voff[NPX];
 #pragma unroll
-    for (int x = 0; x < NPX; ++x) voff[x] = ((valid_mask[x] >> l_tap) & 1u) ? (vbase[x] + (unsigned)rel) * 16u : OOB;
+    for (int x = 0; x < NPX; ++x) {
+      bool ok = ((valid_mask[x] >> l_tap) & 1u) != 0;
+      if (LANEHALF) ok = ok && (l_c0 >> 3) + khalf[x] < C8;  // (the ragged last chunk's second k-half)
+      voff[x] = ok ? (vbase[x] + (unsigned)rel) * 16u : OOB;
+    }
 #pragma unroll
     for (int i = 0; i < B_DMAS; ++i) {
-      const int unit0 = wave * 64 + i * NT;  // this wave's first unit of the stage: wave-uniform, and so is its plane
-      const int plane = unit0 / BN;          // piece = plane / 2, k-half = plane % 2
+      const int unit0 = wave * 64 + i * NT;  // this wave's first unit of the stage: wave-uniform, and so is its plane (LANEHALF: its piece)
+      const int plane = LANEHALF ? 2 * (unit0 / (2 * BN)) : unit0 / BN;  // piece = plane / 2, k-half = plane % 2
       const int grp = (l_c0 >> 3) + (plane & 1);
       // (a ragged last chunk, or a unit past the staged pieces: the range check deposits zeros)
       const int soff = (grp < C8 && plane < 2 * NPU) ? grp * HWs * 16 : 0x7FFFFFFF;
@@ -288,20 +301,22 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
     // accumulator registers r = 8 h .. 8 h + 7 hold -- as [row][BN] floats by 16-byte LDS-DMAs (a quad of pixels never straddles two
     // images: host), then every lane adds its values from LDS and stores.  Same sum, same order: bit for bit the direct form.
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int ROWS_PASS = 2 * QM * 16, U_ROW = BN / 4, UNITS = ROWS_PASS * U_ROW, UPT = UNITS / NT;
+    // rows of a 32-row block per pass: 16 (the registers r = 8 h .. 8 h + 7), or 8 (r = 4 h .. 4 h + 3) where 16 do not fit the LDS
+    constexpr int RPB = (2 * QM * 16 * BN * 4 <= NS * (A_BYTES + B_BYTES)) ? 16 : 8;
+    constexpr int ROWS_PASS = 2 * QM * RPB, U_ROW = BN / 4, UNITS = ROWS_PASS * U_ROW, UPT = UNITS / NT;
     static_assert(UNITS % NT == 0 && ROWS_PASS * BN * 4 <= NS * (A_BYTES + B_BYTES), "a pass fits the LDS the K loop has left");
     const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.ep_res, 0, p.ep_res_bytes, 0x00020000);
     const float* stage = reinterpret_cast<const float*>(smem);
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < 32 / RPB; ++h) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the previous pass's (the K loop's) readers are done
 #pragma unroll
         for (int k = 0; k < UPT; ++k) {
           const int u = k * NT + t;
           const int row_l = u / U_ROW, c4 = u - row_l * U_ROW;
-          const int m = tile_m * BM + (row_l >> 4) * (32 * WM) + i * 32 + h * 16 + (row_l & 15);
+          const int m = tile_m * BM + (row_l / RPB) * (32 * WM) + i * 32 + h * RPB + (row_l % RPB);
           const int pp = tile_n * BN + c4 * 4;
           unsigned voff = OOB;
           if (m < p.M && pp < p.P) {
@@ -312,11 +327,11 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-          const int r = h * 8 + rr;
-          const int e = (r & 3) + 8 * ((r >> 2) - 2 * h) + 4 * lh;
-          const int m = m_wave + i * 32 + h * 16 + e;
-          const float* srow = stage + (wm * 16 + e) * BN + wn * (32 * WN) + l31;
+        for (int rr = 0; rr < RPB / 2; ++rr) {
+          const int r = h * (RPB / 2) + rr;
+          const int e = (r & 3) + 8 * (r >> 2) + 4 * lh - h * RPB;  // row of the block inside this pass
+          const int m = m_wave + i * 32 + h * RPB + e;
+          const float* srow = stage + (wm * RPB + e) * BN + wn * (32 * WN) + l31;
 #pragma unroll
           for (int j = 0; j < WN; ++j) {
             const float v = acc[i][j][r] + srow[j * 32];
@@ -448,7 +463,8 @@ void launch_math(const ConvSplitParams& q, int math, bool dgrad, hipStream_t st)
 // 512 -> 512 (480 wide tiles, cost 2.5; hybrid cost 2.5, 0.793 / 0.773) 0.757 / 0.750 -- ties go to the single launch.
 // MCDSEG_PINGPONG = 4 forces the wide tile wherever the kernel applies.
 // With output rows a multiple of 128 only (the 128-channel layers) the same kernel runs as a 128 x 320 tile (waves of 32 x 160) under the
-// fill rule alone: pp_wide returns 2.
+// fill rule alone: pp_wide returns 2.  Where the 320-pixel tile does not fill its rounds but a 160-pixel one does (256 rows at half of
+// config 2's pixels: config 4's N = 8) the 256 x 160 tile takes the convolution: 3.
 int pp_wide(const ConvSplitParams& p, int math, bool dgrad) {
   const int mode = pp_mode();
   if ((mode != 3 && mode != 4) || !pp_applies(p, math, dgrad, 128)) return 0;
@@ -468,7 +484,11 @@ int pp_wide(const ConvSplitParams& p, int math, bool dgrad) {
   const int64_t tiles = ceil_div64(p.P, 320) * m_tiles, rounds_w = ceil_div64(tiles, cus);
   const int min_rounds = pp_min_rounds() > 1 ? pp_min_rounds() : 1;
   const int64_t rounds = (p.P / 256) * m_tiles / cus;
-  if (rounds < min_rounds) return tiles * 100 >= fill * rounds_w * cus ? 1 : 0;  // against the 4-wave tiles
+  if (rounds < min_rounds) {  // against the 4-wave tiles: the 320-pixel tile, else the 160-pixel one, where either fills its rounds
+    if (tiles * 100 >= fill * rounds_w * cus) return 1;
+    const int64_t tiles_h = ceil_div64(p.P, 160) * m_tiles, rounds_h = ceil_div64(tiles_h, cus);
+    return tiles_h * 100 >= fill * rounds_h * cus ? 3 : 0;
+  }
   int64_t n_pp = rounds * cus / m_tiles;  // (mcdseg_internal_conv_pp_pixels)
   if (n_pp > p.P / 256) n_pp = p.P / 256;
   const int64_t rest = ceil_div64(p.P - n_pp * 256, 128) * m_tiles;  // 256 x 128 workgroups
@@ -510,12 +530,14 @@ int mcdseg_internal_conv_pp_launch(const ConvSplitParams& p, int math, bool dgra
   q.sub = 0;
   q.tile_n0 = 0;
   if (const int kind = pp_wide(p, math, dgrad)) {
-    q.tile_n1 = ceil_div(p.P, 320);
+    q.tile_n1 = ceil_div(p.P, kind == 3 ? 160 : 320);
     if (kind == 1)
       launch_math<2, 5, 2, 2>(q, math, dgrad, st);
-    else
+    else if (kind == 2)
       launch_math<1, 5, 2, 2>(q, math, dgrad, st);
-    MCD_LAUNCH_CHECK("conv_gemm_split_pp (256 / 128 x 320)");
+    else
+      launch_math<1, 5, 4, 1>(q, math, dgrad, st);
+    MCD_LAUNCH_CHECK("conv_gemm_split_pp (256 / 128 x 320, 256 x 160)");
     return 0;
   }
   q.tile_n1 = (int)(pixels / 256);

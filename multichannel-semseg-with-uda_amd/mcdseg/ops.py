@@ -87,8 +87,8 @@ def gemm_kernel_name(m, k, dgrad, split=False, presplit=False, direct=False, pix
 
 def pingpong_kernel_name(dgrad, math=None, small=False, wide=0):
     """rocprofv3's name of the 8-wave ping-pong kernel (csrc/conv_gemm_split_pp.hip): its 256 x 256 tile, the 256 x 128 one
-    (``small``), the 256 x 320 one (``wide`` = 1) or the 128 x 320 one (``wide`` = 2, what ``mcdseg_conv_split_wide_pingpong`` returns)"""
-    tile = {0: "2, 2, 2, 2" if small else "4, 2, 1, 4", 1: "2, 5, 2, 2", 2: "1, 5, 2, 2"}[int(wide)]
+    (``small``), the 256 x 320 one (``wide`` = 1), the 128 x 320 one (2) or the 256 x 160 one (3: what ``mcdseg_conv_split_wide_pingpong`` returns)"""
+    tile = {0: "2, 2, 2, 2" if small else "4, 2, 1, 4", 1: "2, 5, 2, 2", 2: "1, 5, 2, 2", 3: "1, 5, 4, 1"}[int(wide)]
     return "conv_gemm_split_pp_kernel<%s, %s, %s>" % (POLICY[math or CONV_MATH], "true" if dgrad else "false", tile)
 
 

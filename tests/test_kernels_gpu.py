@@ -1568,8 +1568,10 @@ def test_conv_pingpong_wide_tile_by_default(math, monkeypatch):
     monkeypatch.setattr(ops, "CONV_MATH", math)
     monkeypatch.delenv("MCDSEG_PINGPONG", raising=False)
     L, mid = ops.lib(), ops.MATH_ID[math]
-    for cin, cout, kind_f, kind_d in ((128, 256, 1, 2), (128, 128, 2, 2)):
-        n, h, w, dil = 4, 120, 160, 2
+    # (Cin, Cout, N, forward tile, data-gradient tile): 76800 pixels = 240 tiles of 320; 38400 pixels (half: BASELINE config 4's N = 8)
+    # = 240 tiles of 160 for a 256-row problem, and nothing for a 128-row one (0: the 4-wave tiles keep it)
+    for cin, cout, n, kind_f, kind_d in ((128, 256, 4, 1, 2), (128, 128, 4, 2, 2), (256, 256, 2, 3, 3), (128, 256, 2, 3, 0)):
+        h, w, dil = 120, 160, 2
         x, wt, _, s, pad, d = _conv_inputs((cin, cout, 3, 1, dil, h, w, n, False), 43)
         desc = ops.conv_desc(x.shape, wt.shape, 1, pad, d)
         pk = ops.PackedWeights()
@@ -1593,8 +1595,9 @@ def test_conv_pingpong_wide_tile_by_default(math, monkeypatch):
             dx = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound)
         finally:
             ops.LAUNCH_TIMER = prev
-        assert names == [ops.pingpong_kernel_name(False, wide=kind_f), ops.pingpong_kernel_name(True, wide=kind_d)], names
-        assert rows == 2 * (pixels // 320)
+        assert names[0] == ops.pingpong_kernel_name(False, wide=kind_f) and len(names) == 2, names
+        assert names[1] == ops.pingpong_kernel_name(True, wide=kind_d) if kind_d else "conv_gemm_split_pp_kernel" not in names[1], names
+        assert rows == (pixels // 160 if kind_f == 3 else 2 * (pixels // 320))
         monkeypatch.setenv("MCDSEG_PINGPONG", "0")
         y0, part0, rows0 = ops._conv_fprop(desc, xg, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)
         dx0 = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound)
