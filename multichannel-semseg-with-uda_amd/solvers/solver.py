@@ -35,6 +35,19 @@ import torch
 from mcdseg import ops
 
 REUSE_TARGET_FORWARD = os.environ.get("MCDSEG_REUSE_TARGET_FORWARD", "1") != "0"
+# MFNet: the two modality encoders share nothing and run on two streams -- each one's HBM-bound BatchNorm passes beside the other's
+# convolutions, forward and (autograd runs a node's backward on its forward's stream) backward: BASELINE config 3 409.4 -> 398.2 ms per
+# step, bit-identical results (tests/test_model_gpu.py::test_mfnet_encoders_on_two_streams_are_bitwise).  "0": one after the other.
+MFNET_TWO_STREAMS = os.environ.get("MCDSEG_MFNET_TWO_STREAMS", "1") != "0"
+_SECOND = {}
+
+
+def _second_stream(device, cur):
+    """a stream for the second encoder, distinct from ``cur`` (the fork of step B may have made the side stream current)"""
+    key = (device.index, cur.cuda_stream)
+    if key not in _SECOND:
+        _SECOND[key] = torch.cuda.Stream(device=device)
+    return _SECOND[key]
 
 
 def _detached(t):
@@ -231,7 +244,22 @@ class MFNetMCDSolver(MCDSolver):
                          num_multiply_d_loss=1)  # adapt_mfnet_trainer.py:226-235 applies no multiplier
 
     def _features(self, x):
-        return self.g_3ch(x[:, :3, :, :]), self.g_1ch(x[:, 3:, :, :])
+        if not (MFNET_TWO_STREAMS and x.is_cuda):
+            return self.g_3ch(x[:, :3, :, :]), self.g_1ch(x[:, 3:, :, :])
+        # the two encoders share nothing: the HHA one runs on a stream of its own (forward here; autograd runs a node's backward on its
+        # forward's stream), so that each encoder's HBM-bound BatchNorm passes overlap the other's convolutions
+        cur = torch.cuda.current_stream(x.device)
+        other = _second_stream(x.device, cur)
+        other.wait_stream(cur)
+        a = self.g_3ch(x[:, :3, :, :])
+        with torch.cuda.stream(other):
+            b = self.g_1ch(x[:, 3:, :, :])
+        cur.wait_stream(other)
+        b.record_stream(cur)
+        for c in (getattr(b, "_mcd_cb", None) or ())[:2]:
+            if torch.is_tensor(c):
+                c.record_stream(cur)
+        return a, b
 
     def _generators(self):
         return [self.g_3ch, self.g_1ch]

@@ -478,6 +478,34 @@ def test_target_forward_reuse_is_bitwise_for_other_generators(kind):
         assert torch.equal(states[0][k], states[1][k]), k
 
 
+def test_mfnet_encoders_on_two_streams_are_bitwise(monkeypatch):
+    """The MFNet solver runs its two modality encoders on two streams (forward; their backward passes follow on the same streams):
+    state and logged losses after two A/B/C iterations equal those of the one-stream solver (MCDSEG_MFNET_TWO_STREAMS=0) bit for bit."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d, get_prob_distance_criterion
+    from models.model_util import get_models, get_optimizer
+    from solvers import solver as S
+    s, l, t = (v.to(dev) for v in make_batch(33, 2, 6, 64, 96, NC))
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    states, losses = [], []
+    for two in (True, False):
+        monkeypatch.setattr(S, "MFNET_TWO_STREAMS", two)
+        ms = get_models("drn_d_22", 6, NC, method="MFNet-ScoreAddFusion")
+        for i, m in enumerate(ms):
+            fill_state_(m, 60 + i)
+            m.to(dev).train()
+        og = get_optimizer([p for m in ms[:2] for p in m.parameters()], "sgd", 1e-3, 0.9, 2e-5)
+        of = get_optimizer([p for m in ms[2:] for p in m.parameters()], "sgd", 1e-3, 0.9, 2e-5)
+        solver = S.MFNetMCDSolver(ms[0], ms[1], ms[2], ms[3], og, of, CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff"), num_k=2)
+        losses.append([tuple(float(v) for v in solver.step(s, l, t)) for _ in range(2)])
+        torch.cuda.synchronize()
+        states.append({"%d.%s" % (i, k): v.clone() for i, m in enumerate(ms) for k, v in m.state_dict().items()})
+    assert losses[0] == losses[1], losses
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
+
+
 @pytest.mark.parametrize("math", ["f16x3", "f16x1"])
 def test_training_on_a_fixed_batch_reduces_the_source_loss(math, monkeypatch):
     """End-to-end sanity of the whole update path over many steps (weights, BN statistics and the per-tensor fp16 scales all
