@@ -336,6 +336,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_sk_kernel(const float* __res
 
 int pp_compute_units() {
   static const int n = [] {
+    const char* w = getenv("MCDSEG_WGRAD_PP_CUS");  // development knob: plan the weight gradient for fewer CUs than the chip has
+    if (w && atoi(w) > 0) return atoi(w);
     const char* e = getenv("MCDSEG_PP_CUS");  // development knob (shared with conv_gemm_split_pp.hip)
     if (e && atoi(e) > 0) return atoi(e);
     int dev = 0, cus = 0;
