@@ -735,6 +735,11 @@ def join_side_streams(device_index=None):
         rec = _PENDING.pop(key, None)
         if rec is not None:
             rec[1].wait_event(rec[0])
+            # backward passes of two sub-graphs may run on two streams (MFNet's encoders, solvers/solver.py) and share the side stream:
+            # whoever joins waits too, whichever stream recorded the event last
+            cur = torch.cuda.current_stream(rec[1].device)
+            if cur != rec[1]:
+                cur.wait_event(rec[0])
             _HELD.pop(key, None)  # (after the wait: the operands of the deferred launches go back to the allocator)
 
 
