@@ -102,6 +102,43 @@ def test_weight_gradient_batch_pieces_respect_the_library_limit(monkeypatch, mat
     assert ops._batch_pieces(d, wgrad_cb=True) == ops._batch_pieces(d) == [(0, 2), (2, 4), (4, 5)]
 
 
+def test_grad_box_protocol_and_kernel_names():
+    """Host logic of round 4 that needs no GPU: ``ops.GradBox`` (every producer of a shared gradient but the last leaves its tensor and
+    reports None, the last returns what was left -- over several backward passes through one graph), the ping-pong kernel names the
+    profilers key on, ``forward_fork`` off the GPU, and ``bench.is_forward_conv``'s reading of the template arguments."""
+    import importlib.util
+    from mcdseg import ops
+    box = ops.GradBox()
+    assert box.attach() is box and box.attach() is box and box.n == 2
+    for _ in range(2):  # two backward passes through the same graph
+        g, last = box.arrive()
+        assert g is None and not last
+        box.leave("first")
+        g, last = box.arrive()
+        assert g == "first" and last and box.g is None and box.seen == 0
+    one = ops.GradBox().attach()
+    assert one.arrive() == (None, True)  # a single producer returns its own gradient at once
+    x = torch.zeros(1, requires_grad=True)
+    assert isinstance(ops.grad_box(x), ops.GradBox) == ops.FUSE_RES_ADD
+    with torch.no_grad():
+        assert ops.grad_box(x) is None
+    assert ops.grad_box(torch.zeros(1)) is None
+    assert ops.forward_fork(torch.device("cpu")) is None
+    names = {ops.pingpong_kernel_name(False, "f16x3"): "4, 2, 1, 4", ops.pingpong_kernel_name(True, "f16x3", small=True): "2, 2, 2, 2",
+             ops.pingpong_kernel_name(False, "f16x3", wide=1): "2, 5, 2, 2", ops.pingpong_kernel_name(True, "f16x3", wide=2): "1, 5, 2, 2",
+             ops.pingpong_kernel_name(False, "f16x1", wide=3): "1, 5, 4, 1"}
+    for name, tile in names.items():
+        assert name.startswith("conv_gemm_split_pp_kernel<Split") and name.endswith(tile + ">"), name
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fwd = ["conv_gemm_split_pp_kernel<SplitF16x3, false, 2, 5, 2, 2>", "conv_gemm_split_kernel<SplitF16x3, 2, 2, 2, 2, false, true>",
+           "conv_gemm_kernel<2, 2, 2, 2, 16, false>"]
+    bwd = ["conv_gemm_split_pp_kernel<SplitF16x3, true, 4, 2, 1, 4>", "conv_gemm_split_kernel<SplitF16x3, 2, 2, 2, 2, true, false>",
+           "conv_gemm_kernel<2, 2, 2, 2, 16, true>", "conv_stem_x6_kernel", "bn_apply_cb"]
+    assert all(bench.is_forward_conv(n) for n in fwd) and not any(bench.is_forward_conv(n) for n in bwd)
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "multichannel-semseg-with-uda_amd")
     for dirpath, _, files in os.walk(pkg):
