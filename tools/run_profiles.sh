@@ -1,10 +1,10 @@
 #!/bin/bash
 # On the GPU box (gpurun): the round's measurements -- rocprofv3 kernel stats, HBM-traffic and SQ counter passes (separate runs, counters
 # never combined with trace domains), and the benchmark lines of the default arithmetic, of the 24-bit alternatives and of the
-# reduced-precision mode.  Usage: bash tools/run_profiles.sh r03z [quick]    (raw output under gpurun_out/, summaries via
+# reduced-precision mode.  Usage: bash tools/run_profiles.sh r04z [quick]    (raw output under gpurun_out/, summaries via
 # tools/summarize_profiles.py <tag> afterwards)
 set -u
-TAG=${1:-r03z}
+TAG=${1:-r04z}
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
