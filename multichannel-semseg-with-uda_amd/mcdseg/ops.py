@@ -332,11 +332,17 @@ class GradBox:
     forward pass; in the backward pass every producer but the last leaves its gradient here and reports None to autograd, the last
     one returns the sum -- formed in its convolution's data-gradient epilogue when it is one (``_conv_dgrad``'s ``addend``).  The sum
     is the one autograd's own accumulation would form, bit for bit (fp32 addition commutes), one kernel and three passes over the
-    tensor earlier.  A box lives as long as the graph of its forward pass; it may see several backward passes."""
-    __slots__ = ("n", "seen", "g")
+    tensor earlier.  A box lives as long as the graph of its forward pass; it may see several backward passes -- also PARTIAL ones
+    (``torch.autograd.grad(..., inputs=[...])``, ``backward(inputs=...)``, a pass that died in an exception) in which only some of
+    the producers run: what such a pass left behind is dropped when a producer of ANOTHER pass arrives (the passes are told apart by
+    the autograd engine's graph-task id), so a stale count or tensor never enters a later sum.  (In a partial pass the gradient of the
+    block input is complete only if all its producers run -- which they do whenever the engine needs that gradient at all, since every
+    producer lies on a path to it; a producer that runs only for its own weight's sake parks a tensor nobody asked for.)  Tensor hooks
+    on the block input see ONE call, with the sum."""
+    __slots__ = ("n", "seen", "g", "task")
 
     def __init__(self):
-        self.n, self.seen, self.g = 0, 0, None
+        self.n, self.seen, self.g, self.task = 0, 0, None, None
 
     def attach(self):
         self.n += 1
@@ -344,6 +350,9 @@ class GradBox:
 
     def arrive(self):
         """(gradient left by the earlier producers or None, whether the caller is the last producer of this backward pass)"""
+        task = _graph_task_id()
+        if task != self.task:
+            self.task, self.seen, self.g = task, 0, None
         self.seen += 1
         g, self.g = self.g, None
         last = self.seen >= self.n
@@ -353,6 +362,11 @@ class GradBox:
 
     def leave(self, g):
         self.g = g
+
+
+def _graph_task_id():
+    """id of the backward pass the calling autograd node runs in (-1 outside one)"""
+    return torch._C._current_graph_task_id()
 
 
 def grad_box(x):
@@ -878,6 +892,7 @@ def _take_late(conv):
 # deferred while the allocator holds more than DEFER_MEM_FRACTION of the device's memory (cfg5 at N = 32: 232 of 288 GB).
 MAX_LAG = int(os.environ.get("MCDSEG_OVERLAP_WGRAD_LAG", "4"))
 DEFER_MEM_FRACTION = float(os.environ.get("MCDSEG_OVERLAP_WGRAD_MEM", "0.6"))
+DEFER_RESERVED_FRACTION = float(os.environ.get("MCDSEG_OVERLAP_WGRAD_RESERVED", "0.85"))
 WGRAD_STREAM_STATS = {"deferred": 0, "no_room": 0}  # launches left on the side stream / kept on the main stream for lack of memory
 _TOTAL_MEM = {}
 _HELD = {}  # device index -> deque of (event behind a deferred weight gradient, [tensors it uses])
@@ -887,8 +902,12 @@ def _room_to_defer(device):
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _TOTAL_MEM:
         _TOTAL_MEM[key] = torch.cuda.get_device_properties(key).total_memory
-    # (memory IN USE, not memory_reserved: cached-but-free blocks left by one large pass would latch deferral off for the rest of the run)
-    return torch.cuda.memory_allocated(key) < DEFER_MEM_FRACTION * _TOTAL_MEM[key]
+    # memory IN USE decides (with memory_reserved alone, cached-but-free blocks left by one large pass would latch deferral off for the
+    # rest of the run) -- under a higher ceiling on what the allocator HOLDS: the side stream's pool (ForwardFork's leading pass) caches
+    # blocks that cannot serve the main stream and that memory_allocated does not see; past the ceiling the allocator is one large
+    # request away from its free-everything-and-retry path (14-18 s per step at BASELINE config 5)
+    return (torch.cuda.memory_allocated(key) < DEFER_MEM_FRACTION * _TOTAL_MEM[key]
+            and torch.cuda.memory_reserved(key) < DEFER_RESERVED_FRACTION * _TOTAL_MEM[key])
 
 
 def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_bound=None, x_bound=None, w_bound=None, defer=False, param=None,
@@ -898,14 +917,19 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_
     deferred gradient is handed to the sink ON THE SIDE STREAM, right behind its kernels -- the exchange of a bucket then starts when
     its last weight gradient has been enqueued, long before the ``_LateGrad`` nodes pass the gradients on at the end of the pass."""
     mode = OVERLAP_WGRAD
+    sink = getattr(param, "_mcd_grad_sink", None) if param is not None else None
     if mode == "2" and not (defer and x_cb is not None and dy_cb is not None):
         mode = "0"  # (without companions the weight gradient measures bounds and caches them on tensors the main stream reads)
     if mode != "0" and LAUNCH_TIMER is not None and LAUNCH_TIMER.wants("conv_wgrad"):
         mode = "0"  # a step whose launches are bracketed by HIP events runs every kernel alone, so that the pairs time kernels
-    if mode == "2" and not _room_to_defer(x.device):
+    # (a weight whose optimizer exchanges gradients in buckets is deferred whatever the allocator holds: WHICH gradients arrive early
+    # must not depend on one rank's memory -- the held operands are bounded by MAX_LAG launches)
+    if mode == "2" and sink is None and not _room_to_defer(x.device):
         mode = "0"
         WGRAD_STREAM_STATS["no_room"] += 1
     if not (need_dx and need_dw and mode != "0"):
+        if sink is not None and need_dw:
+            sink(param, None)  # this contribution to the weight's gradient reaches p.grad WITHOUT passing through the sink
         return ((_conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound, dx_addend) if need_dx else None),
                 (_conv_wgrad(desc, x, dy, x_cb, dy_cb, x_bound, dy_bound) if need_dw else None))
     main = torch.cuda.current_stream()
@@ -924,8 +948,9 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_
     dx = _conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound, dx_addend)
     if mode == "1":
         main.wait_stream(side)
+        if sink is not None:
+            sink(param, None)
         return dx, dw
-    sink = getattr(param, "_mcd_grad_sink", None) if param is not None else None
     if sink is not None:
         with torch.cuda.stream(side):
             sink(param, dw)
@@ -1053,6 +1078,8 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.packed, ctx.pack_key = packed, packed.key  # the data-gradient image is shared and re-packed in place: see backward
         ctx.defer_ok = hasattr(weight, "_mcd_param")  # the weight came through a _LateGrad alias (late_weight_grads)
         ctx.w_param = getattr(weight, "_mcd_param", None)
+        if ctx.w_param is None and getattr(weight, "_mcd_grad_sink", None) is not None:
+            ctx.w_param = weight  # (no alias -- a second use of the module in one graph: its gradient is reported to the sink as "not early")
         ctx.in_box, ctx.res_box = aux.get("in_box"), aux.get("res_box")
         ctx.has_bias = conv_bias is not None
         ctx.x_cb, ctx.x_bound = x_cb, x_bound  # wgrad reads the input's split companion too (an input of this node: safe to hold)

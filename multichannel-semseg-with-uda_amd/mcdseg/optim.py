@@ -23,6 +23,10 @@ _ALIGN = 64  # floats; keeps every view 256-byte aligned for the float4 kernels
 # parameter of a bucket has arrived the bucket's slice is reduced asynchronously (RCCL's own stream).  OFF by default: the five
 # 104 MB all-reduces of an MCD step are ~2 % of its time on xGMI; the switch exists so that a measured
 # scaling curve can be acted on without new code.  Results are those of the single all-reduce (sums of the same values).
+# The ORDER in which the buckets' collectives are started is the same on every rank whatever the ranks' timing: a bucket whose last
+# gradient has arrived is only "ready", and collectives are started strictly in bucket order (``_drain``) -- WHEN a gradient arrives
+# depends on rank-local state (a weight gradient left on the side stream arrives early through ``_early_grad``, one kept on the main
+# stream for lack of memory only at the end of the pass), WHETHER a bucket becomes ready in a pass depends on the graph alone.
 DP_OVERLAP = os.environ.get("MCDSEG_DP_OVERLAP", "0") == "1"
 DP_BUCKET_MB = float(os.environ.get("MCDSEG_DP_BUCKET_MB", "25"))
 
@@ -97,37 +101,80 @@ class FlatSGD(torch.optim.Optimizer):
         for p, o in reversed(list(zip(fl["params"], fl["offs"]))):
             n = p.numel()
             if cur is None or cur["hi"] - o > limit:
-                cur = dict(lo=o, hi=o + n, ids=set(), arrived=0, work=None, dirty=False, early=set(), early_seen={})
+                cur = dict(lo=o, hi=o + n, ids=set(), arrived=0, work=None, dirty=False, early=set(), early_seen={}, ready=False,
+                           launched=False, unsunk=set(), events=[], index=len(fl["buckets"]))
                 fl["buckets"].append(cur)
             cur["lo"] = o
             cur["ids"].add(id(p))
             fl["bucket_of"][id(p)] = cur
+        fl["next"] = 0  # the first bucket whose collective has not been started in this pass (``_drain``)
         for p in fl["params"]:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._grad_arrived))
             p._mcd_grad_sink = self._early_grad  # (ops._conv_backward: a weight gradient left on the side stream arrives here first)
 
     def _early_grad(self, p, dw):
         """A weight gradient whose kernels have just been enqueued on the side stream (ops._conv_backward, MCDSEG_OVERLAP_WGRAD=2);
-        the CURRENT stream is that side stream.  Copy it into the flat view there and, when it completes its bucket, start the
-        bucket's all-reduce from there -- RCCL's stream then waits for the side stream only, and the main stream's backward pass goes
-        on.  The gradient reaches ``p.grad`` through its ``_LateGrad`` node at the end of the pass; ``_grad_arrived`` then finds the
-        parameter in ``early`` and has nothing left to do.  Anything but "first gradient of this parameter since the last step / zero_grad,
-        nothing accumulated yet" leaves the bucket to step()'s copy-and-reduce path."""
+        the CURRENT stream is that side stream.  Copy it into the flat view there and, when it completes its bucket, mark the bucket
+        ready -- its all-reduce then starts from there as soon as every earlier bucket's has (``_drain``): RCCL's stream waits for the
+        side stream only, and the main stream's backward pass goes on.  The gradient reaches ``p.grad`` through its ``_LateGrad`` node
+        at the end of the pass; ``_grad_arrived`` then finds the parameter in ``early`` and has nothing left to do.  Anything but
+        "first gradient of this parameter since the last step / zero_grad, nothing accumulated yet" leaves the bucket to step()'s
+        copy-and-reduce path.  ``dw`` None: ops reports a contribution to this parameter's gradient that does NOT come through here
+        (a second use of the weight in one graph, a weight gradient kept on the main stream) -- what ``p.grad`` will hold is then
+        more than an early copy, so an early copy of the same pass must not stand for it."""
         fl = self._flat
         b = fl["bucket_of"].get(id(p)) if fl is not None else None
         if b is None:
             return
-        if b["work"] is not None or b["dirty"] or id(p) in b["early"] or p.grad is not None or b["arrived"] >= len(b["ids"]):
-            if b["work"] is not None:
-                b["work"].wait()
-                b["work"] = None
-            b["dirty"] = True
+        if dw is None:
+            b["unsunk"].add(id(p))
+            if id(p) in b["early"]:
+                self._spoil(b)
+            return
+        if (b["ready"] or b["dirty"] or id(p) in b["early"] or id(p) in b["unsunk"] or p.grad is not None
+                or b["arrived"] >= len(b["ids"])):
+            self._spoil(b)
             return
         fl["views"][id(p)][3].copy_(dw)
+        self._copied(b, dw)
         b["early"].add(id(p))
         b["arrived"] += 1
         if b["arrived"] == len(b["ids"]):
-            self._launch_reduce(b)
+            b["ready"] = True
+            self._drain()
+
+    @staticmethod
+    def _copied(b, t):
+        if t.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()  # (on the current stream: the one the copy was enqueued on)
+            b["events"].append(ev)
+
+    def _spoil(self, b):
+        """the bucket's slice no longer equals the gradients step() will find in ``p.grad``: wait for its collective if one is in
+        flight (step()'s copies must not race it) and leave the bucket to step()'s copy-and-reduce path.  A bucket that was ready
+        keeps its place in the launch order (``_drain`` starts its -- now useless -- collective all the same: another rank may have
+        started it before the bucket was spoilt there)."""
+        if b["work"] is not None:
+            b["work"].wait()
+            b["work"] = None
+        b["dirty"] = True
+
+    def _drain(self, flush=False):
+        """start the all-reduce of every ready bucket whose predecessors have all been started -- strictly in bucket order, so that
+        all ranks issue the same sequence of collectives (module comment).  ``flush`` (step()): also past buckets that did not
+        become ready in this pass; which those are depends on the graph only."""
+        fl = self._flat
+        bs, i = fl["buckets"], fl["next"]
+        while i < len(bs):
+            b = bs[i]
+            if not b["ready"]:
+                if not flush:
+                    break
+            elif not b["launched"]:
+                self._launch_reduce(b)
+            i += 1
+        fl["next"] = i
 
     def _launch_reduce(self, b):
         """every gradient of the bucket sits in its flat view: start the all-reduce of the slice.  When some of them were copied on the
@@ -135,41 +182,50 @@ class FlatSGD(torch.optim.Optimizer):
         own: RCCL's stream then waits for the side stream, and the stream running the backward pass waits for nobody."""
         fl = self._flat
         flat = fl["g"][b["lo"]:b["hi"]]
-        if b["early"] and flat.is_cuda:
-            side = ops._side_stream(flat.device)
-            side.wait_stream(torch.cuda.current_stream())  # (a no-op when the side stream is the current one)
-            with torch.cuda.stream(side):
+        b["launched"] = True
+        if flat.is_cuda:
+            # the copies into this slice ran on the main stream (``_grad_arrived``) and / or on the side stream (``_early_grad``), and a
+            # bucket may be started from either (``_drain`` runs where the LAST bucket in line became ready): the launching stream
+            # waits for the event behind every copy
+            stream = ops._side_stream(flat.device) if b["early"] else torch.cuda.current_stream(flat.device)
+            for ev in b["events"]:
+                stream.wait_event(ev)
+            with torch.cuda.stream(stream):
                 b["work"] = mdist.all_reduce_sum_async(flat)
         else:
             b["work"] = mdist.all_reduce_sum_async(flat)
+        if b["dirty"] and b["work"] is not None:  # (spoilt before its turn came: nobody will wait for it in step())
+            b["work"].wait()
+            b["work"] = None
 
     def _grad_arrived(self, p):
         fl = self._flat
         if fl is None or id(p) not in fl["bucket_of"] or p.grad is None:
             return
         b = fl["bucket_of"][id(p)]
-        if id(p) in b["early"] and not b["dirty"] and p.grad is not None and b["early_seen"].get(id(p), 0) == 0:
+        if (id(p) in b["early"] and not b["dirty"] and id(p) not in b["unsunk"] and b["early_seen"].get(id(p), 0) == 0):
             b["early_seen"][id(p)] = 1  # the gradient the side stream delivered (``_early_grad``) has now reached p.grad: nothing to do
             return
-        if b["work"] is not None or b["dirty"] or b["arrived"] >= len(b["ids"]):
+        if b["ready"] or b["dirty"] or b["arrived"] >= len(b["ids"]) or id(p) in b["early"]:
             # A SECOND backward pass before step() (MCDSolver's step B: two loss.backward() calls, then optimizer_f.step()): p.grad
             # now holds the accumulated local gradient, while the bucket's slice is being -- or has been -- summed over the ranks
-            # from the first pass alone.  Wait for the collective in flight (the copy below must not race it), and leave the
-            # bucket to step()'s copy-and-reduce path, which reads the accumulated p.grad of every parameter.
-            if b["work"] is not None:
-                b["work"].wait()
-                b["work"] = None
-            b["dirty"] = True
+            # from the first pass alone.  (Or: p.grad holds more than the early copy, ``unsunk``.)  Wait for the collective in flight
+            # (the copy below must not race it), and leave the bucket to step()'s copy-and-reduce path, which reads the accumulated
+            # p.grad of every parameter.
+            self._spoil(b)
             return
         fl["views"][id(p)][3].copy_(p.grad)
+        self._copied(b, p.grad)
         b["arrived"] += 1
         if b["arrived"] == len(b["ids"]):
-            self._launch_reduce(b)
+            b["ready"] = True
+            self._drain()
 
     def _finish_overlap(self, ps):
         """waits for the collectives the hooks started; True when every gradient of ``ps`` has been reduced that way (else the
         caller copies and reduces the whole run again -- correct, merely redundant for the buckets that were complete)"""
         fl = self._flat
+        self._drain(flush=True)
         buckets = {id(b): b for b in (fl["bucket_of"].get(id(p)) for p in ps) if b is not None}
         for b in buckets.values():
             if b["work"] is not None:
@@ -181,8 +237,10 @@ class FlatSGD(torch.optim.Optimizer):
         for b in (self._flat or {}).get("buckets", []):
             if b["work"] is not None:  # (zero_grad() without step(): the reference's literal loop computes G's gradients in step B and
                 b["work"].wait()       # never applies them -- the next pass's copies must not race a collective still in flight)
-            b["arrived"], b["work"], b["dirty"] = 0, None, False
-            b["early"].clear(), b["early_seen"].clear()
+            b["arrived"], b["work"], b["dirty"], b["ready"], b["launched"] = 0, None, False, False, False
+            b["early"].clear(), b["early_seen"].clear(), b["unsunk"].clear(), b["events"].clear()
+        if self._flat is not None and "next" in self._flat:
+            self._flat["next"] = 0
 
     def _ensure_flat(self):
         if self._flat is None:

@@ -125,7 +125,12 @@ class MCDSolver:
         self.num_k = num_k
         self.mult = float(num_multiply_d_loss)
         # step B's target forward doubles as step C's first (see the module docstring) -- for generator classes known to be repeatable
-        self.reuse_tgt = REUSE_TARGET_FORWARD and _forward_is_repeatable(self._generators())
+        repeatable = _forward_is_repeatable(self._generators())
+        self.reuse_tgt = REUSE_TARGET_FORWARD and repeatable
+        # step B's two generator passes side by side on two streams (ops.ForwardFork) -- for the same generator classes only: what orders
+        # the two passes' BatchNorm running-statistics updates is the per-layer event inside the fused groups; a generator with a plain
+        # nn.BatchNorm2d (or any other state outside those groups) would update it from both streams at once
+        self.fork_ok = repeatable
         self.fused_up = (self.prob_criterion is None and ops.FUSED_UP_LOSS
                          and all(type(f).__name__ == "DRNSegPixelClassifier" and getattr(f, "ver", None) == "ver1"
                                  and type(getattr(f, "up", None)).__name__ == "Up8" for f in (model_f1, model_f2)))
@@ -193,7 +198,7 @@ class MCDSolver:
         self.opt_f.zero_grad()
         # the two generator passes of this step are independent (same weights): they run side by side on two streams, every BatchNorm's
         # running statistics still updated source-first (ops.ForwardFork); the losses follow in the reference's order
-        fork = ops.forward_fork(src_imgs.device)
+        fork = ops.forward_fork(src_imgs.device) if self.fork_ok else None
         with (fork.lead() if fork is not None else torch.no_grad()):
             feats_src = self._features(src_imgs)
         if fork is None:
@@ -281,7 +286,9 @@ class MultiTaskMCDSolver:
         self.enc, self.dec = model_enc, model_dec
         self.opt_enc, self.opt_dec = optimizer_enc, optimizer_dec
         self.num_k, self.mult = num_k, num_multiply_d_loss
-        self.reuse_tgt = REUSE_TARGET_FORWARD and _forward_is_repeatable([model_enc])
+        repeatable = _forward_is_repeatable([model_enc])
+        self.reuse_tgt = REUSE_TARGET_FORWARD and repeatable
+        self.fork_ok = repeatable  # (as in MCDSolver: the fork's ordering exists inside the fused groups only)
 
     def step(self, src_imgs, src_gt_semseg, tgt_imgs):
         enc, dec = self.enc, self.dec
@@ -304,7 +311,7 @@ class MultiTaskMCDSolver:
         self.opt_dec.zero_grad()
         # the encoder's two passes of this step side by side (ops.ForwardFork, as in MCDSolver.step); the decoders follow in the
         # reference's order
-        fork = ops.forward_fork(src_rgbs.device)
+        fork = ops.forward_fork(src_rgbs.device) if self.fork_ok else None
         with (fork.lead() if fork is not None else torch.no_grad()):
             src_fet = enc(src_rgbs)
         taped = None

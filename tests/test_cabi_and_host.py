@@ -118,6 +118,23 @@ def test_grad_box_protocol_and_kernel_names():
         assert g == "first" and last and box.g is None and box.seen == 0
     one = ops.GradBox().attach()
     assert one.arrive() == (None, True)  # a single producer returns its own gradient at once
+    # a PARTIAL backward pass (autograd.grad(inputs=...), an exception mid-pass) runs only some producers: what it leaves behind must
+    # not enter the next pass's sum -- passes are told apart by the engine's graph-task id
+    task = [7]
+    real = ops._graph_task_id
+    ops._graph_task_id = lambda: task[0]
+    try:
+        box = ops.GradBox()
+        box.attach(), box.attach()
+        assert box.arrive() == (None, False)
+        box.leave("stale")          # ... and the second producer of pass 7 never runs
+        task[0] = 8
+        assert box.arrive() == (None, False)   # first arrival of pass 8: not taken for the last one, the stale tensor is gone
+        box.leave("fresh")
+        assert box.arrive() == ("fresh", True)
+    finally:
+        ops._graph_task_id = real
+    assert ops._graph_task_id() == -1  # (outside a backward pass)
     x = torch.zeros(1, requires_grad=True)
     assert isinstance(ops.grad_box(x), ops.GradBox) == ops.FUSE_RES_ADD
     with torch.no_grad():

@@ -61,6 +61,28 @@ def _worker(rank, world, port, tmp, overlap=False):
             sum((p * g).sum() for p, g in zip(params, extra[rank])).backward()
             assert all(b["dirty"] and b["work"] is None for b in opt._flat["buckets"])
             grads_all = [[a + b for a, b in zip(grads_all[k], extra[k])] for k in range(world)]
+        elif overlap == "skew" and step > 0:
+            # WHEN a gradient arrives depends on rank-local state (a weight gradient deferred to the side stream arrives
+            # early, one kept back by the memory guard at the end of the pass): here rank 0 sees the gradients in backward order and
+            # rank 1 in forward order, one of them as an "early" side-stream delivery.  The collectives must still be issued in the
+            # same (bucket) order on both ranks -- out of order, gloo pairs slices of different sizes and fails or hangs.
+            fl = opt._flat
+            order = list(reversed(range(len(params)))) if rank == 0 else list(range(len(params)))
+            launched = []
+            real_launch = opt._launch_reduce
+            opt._launch_reduce = lambda b: (launched.append(b["index"]), real_launch(b))[1]
+            for n_seen, i in enumerate(order):
+                p = params[i]
+                if rank == 1 and i == 0:
+                    opt._early_grad(p, grads_all[rank][i])      # the side stream's delivery ...
+                    p.grad = grads_all[rank][i].clone()
+                    opt._grad_arrived(p)                         # ... reaches p.grad through its _LateGrad node later
+                else:
+                    p.grad = grads_all[rank][i].clone()
+                    opt._grad_arrived(p)
+            opt._launch_reduce = real_launch
+            assert launched == sorted(launched) == list(range(len(fl["buckets"]))), launched
+            assert all(b["work"] is not None and not b["dirty"] for b in fl["buckets"])
         elif overlap and step > 0:  # through autograd, so that the hooks see the gradients arrive (step 0: plain assignment -> fallback path)
             loss = sum((p * g).sum() for p, g in zip(params, grads_all[rank]))
             loss.backward()
@@ -110,6 +132,54 @@ def test_flat_sgd_bucketed_overlap_two_backward_passes_gloo(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "twice"), nprocs=world, join=True)
     assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
+
+
+def test_flat_sgd_bucketed_overlap_is_rank_invariant_in_launch_order_gloo(tmp_path):
+    """MCDSEG_DP_OVERLAP=1 with the two ranks receiving their gradients in opposite orders: buckets are exchanged in bucket order on
+    both, and the update is the reference update of the averaged gradients"""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "skew"), nprocs=world, join=True)
+    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
+
+
+def test_flat_sgd_early_copy_does_not_stand_for_a_summed_gradient():
+    """a weight with TWO contributions in one backward pass, one delivered early through the sink and one not --
+    ``p.grad`` then holds the sum while the flat slice holds the early part only; the bucket must be left to step()'s copy path.
+    Single process: the bucket bookkeeping only (no process group needed for it)."""
+    from mcdseg import optim
+    from mcdseg.optim import FlatSGD
+    old = (optim.DP_OVERLAP, optim.mdist.is_distributed, FlatSGD._require_gpu, optim.mdist.all_reduce_sum_async)
+    optim.DP_OVERLAP, FlatSGD._require_gpu = True, False
+    optim.mdist.is_distributed = lambda: True
+
+    class _Work:
+        def wait(self):
+            pass
+
+    optim.mdist.all_reduce_sum_async = lambda flat: _Work()
+    try:
+        for order in ("early_first", "early_second"):
+            p = torch.nn.Parameter(torch.zeros(4))
+            opt = FlatSGD([p], lr=0.1)
+            opt._ensure_flat()
+            b = opt._flat["buckets"][0]
+            part = torch.ones(4)
+            if order == "early_first":
+                opt._early_grad(p, part)          # deferred contribution: copied, bucket ready and started
+                assert b["ready"] and b["launched"] and not b["dirty"]
+                opt._early_grad(p, None)          # a second contribution that does not pass through the sink
+            else:
+                opt._early_grad(p, None)
+                opt._early_grad(p, part)          # an early copy behind a plain contribution: cannot stand for p.grad either
+            assert b["dirty"] and b["work"] is None
+            p.grad = 2 * part
+            opt._grad_arrived(p)
+            assert b["dirty"]
+            assert not opt._finish_overlap([p])   # step() copies p.grad and reduces the run itself
+            opt._reset_overlap()
+            assert not (b["dirty"] or b["ready"] or b["launched"] or b["unsunk"] or b["early"]) and opt._flat["next"] == 0
+    finally:
+        optim.DP_OVERLAP, optim.mdist.is_distributed, FlatSGD._require_gpu, optim.mdist.all_reduce_sum_async = old
 
 
 def test_single_process_helpers():

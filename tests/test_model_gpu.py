@@ -440,7 +440,15 @@ def test_solver_target_forward_reuse_is_bitwise_the_literal_schedule(golden):
     g2 = Wrapped(_mcd_models(dev)[0])
     assert not S._forward_is_repeatable([g2])
     og = get_optimizer(g2.parameters(), "sgd", 1e-3, 0.9, 2e-5)
-    assert not S.MCDSolver(g2, f1, f2, og, of, CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff")).reuse_tgt
+    unknown = S.MCDSolver(g2, f1, f2, og, of, CrossEntropyLoss2d(cw.to(dev)), get_prob_distance_criterion("diff"))
+    assert not unknown.reuse_tgt
+    # ... and no two-stream fork of step B either: state outside the fused groups would be updated from both streams
+    assert not unknown.fork_ok
+    made = []
+    monkeypatch.setattr(ops, "forward_fork", lambda device: made.append(device))
+    src, lbl, tgt = (t.to(dev) for t in make_batch(41, 2, 6, 64, 96, 41))
+    unknown.step(src, lbl, tgt)
+    assert made == []
 
 
 @pytest.mark.parametrize("kind", ["mfnet", "drn_c"])
