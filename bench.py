@@ -123,9 +123,21 @@ def build_hip(args, dev):
     return solver, (g, f1, f2)
 
 
-def other_config(tag, dev, steps, n_class=41):
+ARITHMETIC_NOTE = {
+    "cfg5": "f16x3, the fp32-grade arithmetic of the judged line (22-bit operands, fp32 accumulation).  BASELINE config 5 says 'bf16': the "
+            "reduced-precision counterpart is the cfg5_f16 entry",
+    "cfg5_f16": "f16x1 = the stand-in for BASELINE config 5's 'bf16': operands rounded to ONE scaled fp16 piece (11 significant bits where bf16 "
+                "keeps 8), fp32 accumulation / BatchNorm / loss / optimizer; gfx950 runs fp16 and bf16 MFMA at the same rate",
+    "cfg2_bf16x6": "strict fp32: three bf16 pieces per operand (24 bits), six cross terms, no per-tensor scale",
+    "cfg2_f32": "strict fp32: v_mfma_f32_32x32x2_f32, the exact k-ordered fp32 FMA chain",
+}
+
+
+def other_config(tag, dev, steps, n_class=41, want_roofline=False):
     """One of BASELINE's other configurations on synthetic device-resident batches: 1 warm-up + ``steps`` timed full A+B+C steps
-    (adapt_mfnet_trainer.py:174-244, adapt_multitask_trainer.py:166-239, adapt_trainer.py:155-220 on drn_d_105)."""
+    (adapt_mfnet_trainer.py:174-244, adapt_multitask_trainer.py:166-239, adapt_trainer.py:155-220 on drn_d_105); ``cfg2_bf16x6`` /
+    ``cfg2_f32``: the judged configuration in the two strict-fp32 arithmetics.  ``want_roofline``: one more step whose launches carry
+    HIP-event pairs (every kernel alone on the main stream), reduced to the roofline entry of the kernel with the largest summed time."""
     import torch
     from loss import CrossEntropyLoss2d, Diff2d, get_prob_distance_criterion
     from mcdseg import ops
@@ -133,7 +145,9 @@ def other_config(tag, dev, steps, n_class=41):
     from solvers.solver import MCDSolver, MFNetMCDSolver, MultiTaskMCDSolver
     n, h, w, net, math, storage = {"cfg3": (16, 480, 640, "drn_d_38", None, "fp32"), "cfg4": (8, 480, 640, "drn_d_38", None, "fp32"),
                                    "cfg5": (32, 720, 1280, "drn_d_105", None, "compact"),
-                                   "cfg5_f16": (32, 720, 1280, "drn_d_105", "f16x1", "compact")}[tag]
+                                   "cfg5_f16": (32, 720, 1280, "drn_d_105", "f16x1", "compact"),
+                                   "cfg2_bf16x6": (16, 480, 640, "drn_d_38", "bf16x6", "fp32"),
+                                   "cfg2_f32": (16, 480, 640, "drn_d_38", "f32", "fp32")}[tag]
     prev = (ops.CONV_MATH, ops.ACT_STORAGE)
     ops.CONV_MATH, ops.ACT_STORAGE = math or prev[0], storage
     try:
@@ -160,7 +174,8 @@ def other_config(tag, dev, steps, n_class=41):
             for m in (g, f1, f2):
                 m.to(dev).train()
             solver = MCDSolver(g, f1, f2, opt(g.parameters()), opt(list(f1.parameters()) + list(f2.parameters())), crit, crit_d, num_k=4)
-            what = "adapt_trainer MCD drn_d_105, activations kept as 2 x fp16 companions (MCDSEG_ACT_STORAGE=compact)"
+            what = ("adapt_trainer MCD drn_d_105, activations kept as 2 x fp16 companions (MCDSEG_ACT_STORAGE=compact)" if tag.startswith("cfg5")
+                    else "adapt_trainer MCD early-fusion drn_d_38 6-ch (the judged configuration in another arithmetic)")
         gen = torch.Generator(device=dev).manual_seed(1234)
         src = torch.randn(n, 6, h, w, generator=gen, device=dev)
         lbl = torch.randint(0, n_class, (n, h, w), generator=gen, device=dev, dtype=torch.int64)
@@ -176,8 +191,28 @@ def other_config(tag, dev, steps, n_class=41):
         dt = (time.perf_counter() - t0) / steps
         res = {"workload": "%s, bs=%d/GPU synthetic 6x%dx%d, full A+B+C step (num_k=4)" % (what, n, h, w), "conv_math": ops.CONV_MATH,
                "steps": steps, "ms_per_step": round(1e3 * dt, 1), "pairs_per_s": round(n / dt, 3),
-               "peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1), "c_loss": float(out[0]), "d_loss": float(out[1]),
+               "peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+               "peak_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1), "c_loss": float(out[0]), "d_loss": float(out[1]),
                "wgrad_stream": dict(ops.WGRAD_STREAM_STATS)}
+        if tag in ARITHMETIC_NOTE:
+            res["arithmetic"] = ARITHMETIC_NOTE[tag]
+        if want_roofline:
+            timer = LaunchTimer(TIMED_FAMILIES["all"])
+            timer.enabled, ops.LAUNCH_TIMER = True, timer
+            try:
+                solver.step(src, lbl, tgt)
+                torch.cuda.synchronize()
+            finally:
+                ops.LAUNCH_TIMER = None
+            kern = timer.summary()
+            if kern:
+                total = sum(k["ms"] for k in kern.values()) or 1.0
+                for k in kern.values():
+                    k["share"] = round(k["ms"] / total, 4)
+                dom = max(kern, key=lambda n: kern[n]["ms"])
+                res["roofline"] = kernel_roofline(dom, kern[dom], ops.CONV_MATH, None)
+                res["timed_kernel_ms_per_step"] = round(total, 1)
+                res["kernel_ms"] = {n: round(v["ms"], 1) for n, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]}
         del solver, src, lbl, tgt
         return res
     finally:
@@ -316,7 +351,11 @@ def kernel_roofline(name, k, math, traffic):
             mult, peak, what = MATH["f32"]
         tfl = k["flops"] / (k["ms"] * 1e-3) / 1e12
         return {"bound": "mfma", "kernel": "%s (%s)" % (name, what), "achieved": round(mult * tfl, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(mult * tfl / peak, 4), "traffic": traffic, "alg_tflops_fp32_equivalent": round(tfl, 2),
+                "frac": round(mult * tfl / peak, 4), "frac_algorithmic": round(tfl / peak, 4),
+                "frac_of_fp32_peak": round(tfl / PEAK_FP32_TFLOPS, 4), "traffic": traffic, "alg_tflops_fp32_equivalent": round(tfl, 2),
+                "frac_note": "frac prices the EXECUTED 16-bit flops (executed_flops_per_alg_flop per algorithmic flop) against the dense MFMA "
+                             "peak; frac_algorithmic prices the algorithmic (fp32-equivalent) flops against the same peak; frac_of_fp32_peak "
+                             "against the %.1f TFLOP/s fp32 pipe" % PEAK_FP32_TFLOPS,
                 "executed_flops_per_alg_flop": mult, "alg_bytes_per_launch": k["bytes"] / k["launches"], "launches": k["launches"],
                 "avg_launch_ms": round(k["ms"] / k["launches"], 4), "alg_flops_per_launch": k["flops"] / k["launches"],
                 "share_of_timed_kernel_ms": k.get("share")}
@@ -326,16 +365,32 @@ def kernel_roofline(name, k, math, traffic):
             "avg_launch_ms": round(k["ms"] / k["launches"], 4), "share_of_timed_kernel_ms": k.get("share")}
 
 
-def pmc_traffic(name):
-    """HBM-side bytes per launch from the committed PMC passes (profiles/<round>_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE
-    collected in separate rocprofv3 --pmc runs of this same bench, FETCH_SIZE doubled per the gfx950 note); newest round first"""
+def pmc_traffic(name, kern=None, timer_steps=1):
+    """(HBM-side bytes per launch of kernel ``name``, where the figure comes from) out of the newest committed PMC table
+    (profiles/<round>_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes of this same bench,
+    FETCH_SIZE doubled per the gfx950 note).  The table is a LOOKUP, so it is refused -- (None, why) -- unless it was made from a run
+    of THIS set of kernels: every templated convolution kernel this run timed (``kern``: the launch timer's summary) must be in it,
+    and ``name`` must have been launched as often per step there as here."""
     import glob
-    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
-        try:
-            return json.load(open(fn))["kernels"][name]["hbm_bytes_per_launch"]
-        except (KeyError, ValueError, OSError):
-            continue
-    return None
+    tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True)
+    if not tables:
+        return None, "no profiles/*_pmc_traffic.json"
+    fn = tables[0]
+    rel = os.path.relpath(fn, ROOT)
+    try:
+        table = json.load(open(fn))["kernels"]
+    except (KeyError, ValueError, OSError) as e:
+        return None, "%s unreadable (%s)" % (rel, type(e).__name__)
+    if kern is not None:
+        missing = sorted(n for n in kern if n.startswith("conv_") and "<" in n and n not in table)
+        if missing:
+            return None, "%s is stale: it has no entry for %s" % (rel, ", ".join(missing))
+        per_step = kern[name]["launches"] / float(max(1, timer_steps)) if name in kern else None
+        if name in table and per_step is not None and table[name].get("launches_per_step") not in (None, per_step):
+            return None, "%s is stale: %s ran %s times per step there, %s here" % (rel, name, table[name].get("launches_per_step"), per_step)
+    if name not in table:
+        return None, "%s has no entry for %s" % (rel, name)
+    return table[name]["hbm_bytes_per_launch"], rel
 
 
 def main():
@@ -376,6 +431,9 @@ def _main():
                     help="BASELINE configs 3-5 timed after the judged region (N = 1 only; '' = skip): cfg3 MFNet N=16, cfg4 multitask N=8, "
                          "cfg5 drn_d_105 N=32 at 720x1280 with compact activation storage, cfg5_f16 the same in the reduced-precision arithmetic")
     ap.add_argument("--other_steps", type=int, default=3)
+    ap.add_argument("--strict_steps", type=int, default=3,
+                    help="timed steps of the judged configuration in each strict-fp32 arithmetic (bf16x6, f32 MFMA) after the timed region, "
+                         "reported as 'strict_fp32' (0 = skip)")
     ap.add_argument("--timer", choices=sorted(TIMED_FAMILIES), default="all", help="kernel families bracketed by HIP events")
     ap.add_argument("--timer_steps", type=int, default=1,
                     help="how many of the timed steps (the last ones) carry the per-launch HIP events: bracketing all ~1 500 launches "
@@ -514,12 +572,28 @@ def _main():
         others = {}
         for tag in [t.strip() for t in args.other_configs.split(",") if t.strip()]:
             try:
-                others[tag] = other_config(tag, dev, max(1, args.other_steps), args.n_class)
+                others[tag] = other_config(tag, dev, max(1, args.other_steps), args.n_class, want_roofline=tag.startswith("cfg5"))
             except Exception as e:  # (a configuration that does not fit or fails must not take the judged line down)
                 others[tag] = {"error": "%s: %s" % (type(e).__name__, e)}
                 torch.cuda.empty_cache()
     else:
         kern_summary, reuse_tgt = timer.summary(), solver.reuse_tgt
+        ops.LAUNCH_TIMER = None
+        del solver, models, pool
+        torch.cuda.empty_cache()
+    # the judged configuration in the two STRICT fp32 arithmetics (24-bit operands), after the timed region: what an IEEE-grade
+    # product costs next to the default's 22-bit operands
+    strict = None
+    if world == 1 and not mdist.is_distributed() and judged_cfg and args.strict_steps > 0 and ops.CONV_MATH == "f16x3":
+        strict = {}
+        for tag, key in (("cfg2_bf16x6", "bf16x6"), ("cfg2_f32", "f32")):
+            try:
+                r = other_config(tag, dev, args.strict_steps, args.n_class)
+                strict[key] = {"ms_per_step": r["ms_per_step"], "value": r["pairs_per_s"], "steps": r["steps"], "arithmetic": r["arithmetic"],
+                               "c_loss": r["c_loss"], "d_loss": r["d_loss"]}
+            except Exception as e:
+                strict[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+                torch.cuda.empty_cache()
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -536,17 +610,23 @@ def _main():
         # dominant kernel = the one with the largest summed duration inside the timed region; in the steps that carry the event
         # pairs every launch runs alone (ops._conv_backward keeps the weight gradients on the main stream there)
         roofline = roofline_fwd = roofline_wg = None
+        tsteps = max(1, min(args.steps, args.timer_steps))
+
+        def priced(name, table):
+            traffic, source = pmc_traffic(name, kern, tsteps) if default_cfg else (None, "not the judged configuration")
+            r = kernel_roofline(name, table[name], ops.CONV_MATH, traffic)
+            r["traffic_source"] = source
+            return r
+
         if kern:
             dom = max(kern, key=lambda n: kern[n]["ms"])
-            roofline = kernel_roofline(dom, kern[dom], ops.CONV_MATH, pmc_traffic(dom) if default_cfg else None)
+            roofline = priced(dom, kern)
             fwd = {n: v for n, v in kern.items() if is_forward_conv(n)}
             if fwd:
-                fn = max(fwd, key=lambda n: fwd[n]["flops"])
-                roofline_fwd = kernel_roofline(fn, fwd[fn], ops.CONV_MATH, pmc_traffic(fn) if default_cfg else None)
+                roofline_fwd = priced(max(fwd, key=lambda n: fwd[n]["flops"]), fwd)
             wgk = {n: v for n, v in kern.items() if n.startswith("conv_wgrad")}
             if wgk:
-                wn = max(wgk, key=lambda n: wgk[n]["flops"])
-                roofline_wg = kernel_roofline(wn, wgk[wn], ops.CONV_MATH, pmc_traffic(wn) if default_cfg else None)
+                roofline_wg = priced(max(wgk, key=lambda n: wgk[n]["flops"]), wgk)
         # whole-step accounting on the algorithmic work of SURVEY.md 8d (drn_d_38 @ 6x480x640 only)
         step_acc = None
         if args.net == "drn_d_38" and (args.height, args.width, args.input_ch) == (480, 640, 6):
@@ -596,6 +676,7 @@ def _main():
             "wgrad_stream": wgrad_stream,
             "collectives": coll,
             "other_configs": others,
+            "strict_fp32": strict,
             "roofline": roofline,
             "roofline_forward": roofline_fwd,
             "roofline_wgrad": roofline_wg,

@@ -107,6 +107,110 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
   }
 }
 
+// Both stages in ONE launch, for the layers whose partial rows are few (the 1/8-resolution maps: 480 rows at BASELINE config 2, three
+// quarters of a network's BatchNorm layers): one wave per channel does what stage 1's blocks and stage 2's wave do for that channel, in
+// the SAME order -- lane L owns the slices L, L + 64, ...; per slice the eight row-group sums are formed row by row and added in group
+// order, exactly as stage 1's threads and its shared-memory fold do; then stage 2's wave reduction -- so mean, rstd and the running
+// statistics are bit for bit those of the two launches.  The output bound depends on gamma, beta and the pixel count only: the first
+// wave of the grid forms its maximum over all channels directly (a max is order-independent), no zeroing launch and no atomics.
+__global__ __launch_bounds__(256) void bn_stats_one_kernel(const float* __restrict__ part, int64_t rows, int S, int C, int Mp,
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           int64_t* nbt, float momentum, float eps, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ res_bound,
+                                                           float* __restrict__ y_bound, int updates) {
+  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += updates;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= C) return;  // wave-uniform
+  const int64_t per = (rows + S - 1) / S;
+  double n = 0.0, s1 = 0.0, q = 0.0;
+  for (int k = lane; k < S; k += 64) {
+    const int64_t r0 = k * per;
+    int64_t r1 = r0 + per;
+    if (r1 > rows) r1 = rows;
+    // eight rows at a time -- one per row group, 24 independent loads in flight -- each added to its own group's sums, so that a
+    // group still sees its rows r0 + g, r0 + g + 8, ... in order
+    double gn[8], gs[8], gq[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) gn[g] = gs[g] = gq[g] = 0.0;
+    for (int64_t rb = r0; rb < r1; rb += 8) {
+      float cnt[8], mu[8], m2[8];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const float* row = part + (size_t)(rb + g < r1 ? rb + g : r0) * 3 * Mp;
+        cnt[g] = row[c];
+        mu[g] = row[Mp + c];
+        m2[g] = row[2 * (size_t)Mp + c];
+      }
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        if (rb + g < r1) {
+          const double dc = (double)cnt[g], dm = (double)mu[g];
+          gn[g] += dc;
+          gs[g] += dc * dm;
+          gq[g] += (double)m2[g] + dc * dm * dm;
+        }
+      }
+    }
+    double tn = 0.0, ts = 0.0, tq = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      tn += gn[g];
+      ts += gs[g];
+      tq += gq[g];
+    }
+    n += tn;
+    s1 += ts;
+    q += tq;
+  }
+  n = wave_sum_d(n);
+  s1 = wave_sum_d(s1);
+  q = wave_sum_d(q);
+  n = __shfl(n, 0);  // (every lane of the first wave needs the count for the bound below)
+  if (lane == 0) {
+    const double mean = n > 0.0 ? s1 / n : 0.0;
+    double m2 = q - s1 * mean;
+    if (m2 < 0.0) m2 = 0.0;
+    const double var = n > 0.0 ? m2 / n : 0.0;
+    mean_out[c] = (float)mean;
+    rstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean != nullptr) {
+      const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
+      float rm = running_mean[c], rv = running_var[c];
+      for (int u = 0; u < updates; ++u) {
+        rm = (float)((1.0 - (double)momentum) * (double)rm + (double)momentum * mean);
+        rv = (float)((1.0 - (double)momentum) * (double)rv + (double)momentum * unbiased);
+      }
+      running_mean[c] = rm;
+      running_var[c] = rv;
+    }
+  }
+  if (y_bound != nullptr && c == 0) {  // the first wave of the grid: max over all channels of what stage 2 feeds its atomic max
+    const float sq = (float)sqrt(n > 1.0 ? n - 1.0 : 1.0);
+    const float rb = res_bound ? *res_bound : 0.f;
+    unsigned m = 0u;
+    for (int cc = lane; cc < C; cc += 64) {
+      float bound = fabsf(gamma[cc]) * sq * 1.0001f + fabsf(beta[cc]);
+      bound += rb;
+      if (!(bound == bound)) bound = __uint_as_float(0x7FC00000u);
+      const unsigned bits = __float_as_uint(bound) & 0x7FFFFFFFu;
+      m = bits > m ? bits : m;
+    }
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned other = (unsigned)__shfl_xor((int)m, o);
+      m = other > m ? other : m;
+    }
+    if (lane == 0) *y_bound = __uint_as_float(m);
+  }
+}
+
+// rows up to which the one-launch form is used (MCDSEG_BN_STATS_ONE, read per call: tests compare the two forms; 0 = never)
+int64_t stats_one_rows() {
+  const char* e = getenv("MCDSEG_BN_STATS_ONE");
+  return e ? atoll(e) : 1024;
+}
+
 __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int C, float eps,
                                      float* __restrict__ mean, float* __restrict__ rstd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -817,6 +921,12 @@ extern "C" int mcdseg_bn_stats_finalize(const float* stat_partials, int64_t rows
   MCD_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "bn_stats_finalize: workspace must be 8-byte aligned");
   const int S = stats_slices(rows, C);
   hipStream_t st = (hipStream_t)stream;
+  if (rows <= stats_one_rows()) {
+    hipLaunchKernelGGL(bn_stats_one_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, stat_partials, rows, S, C, Mp, mean, rstd, running_mean,
+                       running_var, num_batches_tracked, momentum, eps, gamma, beta, res_bound, y_bound, running_updates);
+    MCD_LAUNCH_CHECK("bn_stats_one");
+    return 0;
+  }
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(ceil_div(C, 32), S), dim3(256), 0, st, stat_partials, rows, C, Mp,
                      (double*)workspace, y_bound);
   MCD_LAUNCH_CHECK("bn_stats_partial");

@@ -43,6 +43,11 @@ namespace {
 //                 round of workgroups costs half as much, and one workgroup's epilogue hides behind the other's K loop.
 //   <1, 5, 2, 2>  128 x 320, waves of 32 x 160: the same for the 128-channel layers.
 //   <1, 5, 4, 1>  256 x 160, waves of 32 x 160: for HALF the pixels (N = 8: 38400 = 240 tiles of 160).
+// (Round 5 built <1, 5, 1, 4> too -- 64 x 640 for the 64-channel layers, 307200 pixels = 480 tiles -- and measured it SLOWER than the
+// 4-wave 64 x 256 tiles: forward 0.115 against 0.091 ms, data gradient 0.105 against 0.088, the step + 1.4 ms.  With 64 output rows a
+// K-step moves 12 KB of operands per executed MFLOP through L2 whatever the tile's width -- three times the big tiles' -- and the
+// 4-wave kernel, three workgroups to a CU, keeps more of those loads in flight than one 8-wave workgroup does; what would help these
+// layers is re-using a staged pixel window across the nine taps, not a wider tile.  DESIGN.md section 4.1f.)
 //   <2, 5, 2, 2>  256 x 320, waves of 64 x 160, one workgroup per CU (120 KB): the tile WIDTH is the knob against round quantisation --
 //                 76800 pixels (BASELINE config 2, 1/8 resolution) are 300 tiles of 256 (1.17 rounds of 256 CUs: the last 44 tiles
 //                 cost a whole round) but 240 tiles of 320 (0.94 of ONE round).  A wave's 160 pixels are one BatchNorm partial row.
@@ -408,9 +413,11 @@ int pp_min_rounds() {
 }
 
 int compute_units() {  // one workgroup per CU: a launch is worth whole rounds of this many tiles
+  // MCDSEG_PP_CUS (read per call): a test plans a small batch as if the chip had fewer CUs, which gives it the rounds -- and hence the
+  // launch plan -- of a batch that many times larger (BASELINE config 5's N = 32 plan at N = 2 with 16 "CUs")
+  const char* e = getenv("MCDSEG_PP_CUS");
+  if (e && atoi(e) > 0) return atoi(e);
   static const int n = [] {
-    const char* e = getenv("MCDSEG_PP_CUS");  // development knob
-    if (e && atoi(e) > 0) return atoi(e);
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       cus = 256;  // MI355X

@@ -49,7 +49,10 @@ WgradPlan make_plan(const mcdseg_conv_desc* d) {
     pl.groups = ceil_div(T, 32 / pl.cinp);
   } else if (lo > 64) {
     pl.cfg = 0; pl.bm = 128; pl.bn = 128;
-  } else if (lo > 32) {
+  } else if (lo > 32 || (lo > 16 && (d->Cin & 7) == 0 && (d->Cout & 7) == 0)) {
+    // (24- and 32-channel sides too when the channel-blocked layout applies: half of a 64 x 64 tile is padding, but the plan that reads
+    // both companions -- conv_wgrad_split_tr64_kernel -- moves the 32 -> 64 stride-2 layers at their bytes where the one-wave f32
+    // tiles below ran at 35 TFLOP/s: round 5)
     pl.cfg = 1; pl.bm = 64; pl.bn = 64;
   } else {
     pl.cfg = 2; pl.bm = 32; pl.bn = 32;

@@ -114,7 +114,8 @@ def wgrad_kernel_name(cout, cin, taps=9):
     if cin <= 16 and taps > 1:
         return "conv_wgrad_thin_kernel<%d, %s>" % (8 if cin <= 8 else 16, "true" if cout <= 16 else "false")
     lo = min(cout, cin)
-    return "conv_wgrad_kernel<%s>" % ("2, 2, 2, 2, 16" if lo > 64 else ("1, 1, 2, 2, 32" if lo > 32 else "1, 1, 1, 1, 32"))
+    mid = lo > 32 or (lo > 16 and cin % 8 == 0 and cout % 8 == 0)  # (make_plan of csrc/conv_wgrad.hip: the 64 x 64 plan)
+    return "conv_wgrad_kernel<%s>" % ("2, 2, 2, 2, 16" if lo > 64 else ("1, 1, 2, 2, 32" if mid else "1, 1, 1, 1, 32"))
 
 
 def _p(t):
@@ -652,9 +653,17 @@ def split_companion_padded(x, bound=None):
 # mcdseg_conv_wgrad_variant code -> the kernel name rocprofv3 prints
 _WGRAD_NAMES = {10: "conv_wgrad_split_kernel<%s>", 11: "conv_wgrad_split_cb_kernel<%s>", 12: "conv_wgrad_split_tr_kernel<%s, 2, 2, 3, false>",
                 13: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3, false>", 14: "conv_wgrad_split_tr64_kernel<%s>",
-                15: "conv_wgrad_thin_tr_kernel<%s>", 16: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3, true>",
+                16: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3, true>",
                 17: "conv_wgrad_split_pp_kernel<%s>"}
 WGRAD_TR64 = os.environ.get("MCDSEG_WGRAD_TR64", "1") != "0"
+
+
+def wgrad_split_kernel_name(d, have_cb):
+    """rocprofv3's name of the split-arithmetic weight-gradient kernel the library launches for this geometry"""
+    v = lib().mcdseg_conv_wgrad_variant(ctypes.byref(d), MATH_ID[CONV_MATH], int(have_cb))
+    if v == 15:  # csrc/conv_wgrad_thin_tr.hip: <channel groups of the input, row tiles, column tiles, tile rows> (no policy argument)
+        return "conv_wgrad_thin_tr_kernel<%s>" % ("1, 1, 25, 8" if d.Cin <= 8 else ("2, 1, 9, 8" if d.Cout <= 16 else "2, 2, 9, 4"))
+    return _WGRAD_NAMES.get(v, "conv_wgrad<%s>") % POLICY[CONV_MATH]
 
 
 def _wgrad_thin_tr(desc):
@@ -673,7 +682,7 @@ def _wgrad_split_plan(desc, have_cb=False):
     lo = min(desc.Cout, desc.Cin)
     if lo > 64:
         return True
-    return WGRAD_TR64 and have_cb and _scaled() and lo > 32 and desc.Cin % 8 == 0 and desc.Cout % 8 == 0
+    return WGRAD_TR64 and have_cb and _scaled() and lo > 16 and desc.Cin % 8 == 0 and desc.Cout % 8 == 0
 
 
 def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None, x_bound=None, dy_bound=None):
@@ -692,8 +701,7 @@ def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None, x_bound=None, dy_bound=None)
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a, desc.N if x_cb is not None else 0)
         ws = _ws(L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(d)), (x if x is not None else x_cb).device)
         dw = torch.empty((desc.Cout, desc.Cin, desc.KH, desc.KW), dtype=torch.float32, device=ws.device)
-        name = _WGRAD_NAMES.get(L.mcdseg_conv_wgrad_variant(ctypes.byref(d), MATH_ID[CONV_MATH], int(x_cb is not None)), "conv_wgrad<%s>") \
-            % POLICY[CONV_MATH] if split else wgrad_kernel_name(desc.Cout, desc.Cin, desc.KH * desc.KW)
+        name = wgrad_split_kernel_name(d, x_cb is not None) if split else wgrad_kernel_name(desc.Cout, desc.Cin, desc.KH * desc.KW)
         with _timed(name, conv_work(d)):
             if split:
                 check(L.mcdseg_conv_split_wgrad(ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(x, a, b)), _cb_slice(x_cb, a, desc.Cin, desc.H * desc.W),

@@ -4,7 +4,11 @@ BASELINE config 2's full batch (16 x 6 x 480 x 640, drn_d_38, train-mode BatchNo
 fp32 CPU oracle?  The oracle is run twice -- in fp32 (what tests/test_model_gpu.py::test_cfg2_full_batch_vs_oracle compares with)
 and in fp64 on the same parameters and batch -- and the relative L2 distances oracle32-fp64, HIP-fp64 and HIP-oracle32 are printed
 per family of tensors and over all of them.  The numbers set the bounds of that test.
-    python tests/grad_truth_cfg2.py [--n 16] [--math f16x3]"""
+    python tests/grad_truth_cfg2.py [--n 16] [--math f16x3]
+``--cfg5``: the same question for BASELINE config 5's network at its geometry -- drn_d_105 (Bottleneck), 6 x 720 x 1280, compact
+activation storage, the launch plan of its N = 32 batch (MCDSEG_PP_CUS, a batch cut along N) -- plus the distances of the encoder
+features and of the logits; sets the bounds of tests/test_model_gpu.py::test_cfg5_geometry_vs_oracle.
+    python tests/grad_truth_cfg2.py --cfg5 [--n 2]"""
 import argparse
 import os
 import sys
@@ -33,17 +37,23 @@ def physical_cores():
     return len(cores) or os.cpu_count()
 
 
+NET, SEEDS, SIZE = "drn_d_38", (11, 12, 13), (480, 640)
+OUT = {}  # name -> (encoder features, logits of F1 sub-sampled 8 x 8) as fp64 CPU tensors
+
+
 def oracle_grads(src, lbl, double):
     from oracle import ref_loss, ref_models
-    og, of1, of2 = ref_models.get_models("drn_d_38", 6, NC)
-    fill_state_(og, 11), fill_state_(of1, 12), fill_state_(of2, 13)
+    og, of1, of2 = ref_models.get_models(NET, 6, NC)
+    fill_state_(og, SEEDS[0]), fill_state_(of1, SEEDS[1]), fill_state_(of2, SEEDS[2])
     cw = ref_loss.class_weights(NC)
     if double:
         og, of1, of2, src, cw = og.double(), of1.double(), of2.double(), src.double(), cw.double()
     og.train(), of1.train(), of2.train()
     feat = og(src)
     crit = ref_loss.CrossEntropyLoss2d(cw)
-    (crit(of1(feat), lbl) + crit(of2(feat), lbl)).backward()
+    logits = of1(feat)
+    (crit(logits, lbl) + crit(of2(feat), lbl)).backward()
+    OUT["o64" if double else "o32"] = (feat.detach().double(), logits.detach()[:, :, ::8, ::8].double())
     gs = {k: v.grad.double().clone() for k, v in og.named_parameters()}
     gs.update({"f%d.%s" % (i + 1, k): v.grad.double().clone() for i, m in enumerate((of1, of2)) for k, v in m.named_parameters()})
     return gs
@@ -53,16 +63,18 @@ def hip_grads(src, lbl, dev):
     from loss import CrossEntropyLoss2d
     from models.model_util import get_models
     from oracle import ref_loss
-    g, f1, f2 = get_models("drn_d_38", 6, NC)
-    for m, seed in ((g, 11), (f1, 12), (f2, 13)):
+    g, f1, f2 = get_models(NET, 6, NC)
+    for m, seed in zip((g, f1, f2), SEEDS):
         fill_state_(m, seed)
         m.to(dev)
         m.train(True)
     cw = ref_loss.class_weights(NC).to(dev)
     feat = g(src.to(dev))
     crit = CrossEntropyLoss2d(cw)
-    (crit(f1(feat), lbl.to(dev)) + crit(f2(feat), lbl.to(dev))).backward()
+    logits = f1(feat)
+    (crit(logits, lbl.to(dev)) + crit(f2(feat), lbl.to(dev))).backward()
     torch.cuda.synchronize()
+    OUT["hip"] = (feat.detach().double().cpu(), logits.detach()[:, :, ::8, ::8].double().cpu())
     gs = {k: v.grad.double().cpu() for k, v in g.named_parameters()}
     gs.update({"f%d.%s" % (i + 1, k): v.grad.double().cpu() for i, m in enumerate((f1, f2)) for k, v in m.named_parameters()})
     return gs
@@ -82,12 +94,22 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=16)
     ap.add_argument("--math", default=None)
+    ap.add_argument("--cfg5", action="store_true")
     args = ap.parse_args()
+    global NET, SEEDS, SIZE
+    if args.cfg5:
+        NET, SEEDS, SIZE = "drn_d_105", (71, 72, 73), (720, 1280)
+        if args.n == 16:
+            args.n = 2
+        os.environ["MCDSEG_PP_CUS"] = str(8 * args.n)  # 256 CUs at N = 32: the same rounds of tiles, hence the same launch plan
     from mcdseg import ops
     if args.math:
         ops.CONV_MATH = args.math
+    if args.cfg5:
+        ops.ACT_STORAGE = "compact"
+        ops.MAX_CONV_BYTES = 150 << 20  # the 2048-channel maps (118 MB per image) are cut along N, as 3.8 GB tensors are at N = 32
     torch.set_num_threads(physical_cores())
-    src, lbl, _ = make_batch(78, args.n, 6, 480, 640, NC)
+    src, lbl, _ = make_batch(78, args.n, 6, SIZE[0], SIZE[1], NC)
     t0 = time.time()
     g_hip = hip_grads(src, lbl, torch.device("cuda:0"))
     t1 = time.time()
@@ -95,7 +117,12 @@ def main():
     t2 = time.time()
     g64 = oracle_grads(src, lbl, True)
     t3 = time.time()
-    print("N = %d, %s: HIP %.1f s, oracle fp32 %.1f s, oracle fp64 %.1f s" % (args.n, ops.CONV_MATH, t1 - t0, t2 - t1, t3 - t2))
+    print("%s N = %d at %d x %d, %s%s: HIP %.1f s, oracle fp32 %.1f s, oracle fp64 %.1f s"
+          % (NET, args.n, SIZE[0], SIZE[1], ops.CONV_MATH, " compact storage" if ops.ACT_STORAGE == "compact" else "", t1 - t0, t2 - t1, t3 - t2))
+    for i, what in enumerate(("encoder features", "logits (every 8th pixel)")):
+        h, a, b = OUT["hip"][i], OUT["o32"][i], OUT["o64"][i]
+        print("%-26s scale %.3e  max |oracle32-fp64| %.3e  max |HIP-fp64| %.3e  max |HIP-oracle32| %.3e"
+              % (what, float(b.abs().max()), float((a - b).abs().max()), float((h - b).abs().max()), float((h - a).abs().max())))
     assert set(g_hip) == set(g32) == set(g64)
     fams = {"all": list(g64), "conv weights": [k for k in g64 if g64[k].dim() == 4 and not k.startswith("f")],
             "BatchNorm weight / bias": [k for k in g64 if g64[k].dim() == 1], "classifier up-sampling": [k for k in g64 if k.startswith("f")]}

@@ -154,6 +154,21 @@ def test_grad_box_protocol_and_kernel_names():
     bwd = ["conv_gemm_split_pp_kernel<SplitF16x3, true, 4, 2, 1, 4>", "conv_gemm_split_kernel<SplitF16x3, 2, 2, 2, 2, true, false>",
            "conv_gemm_kernel<2, 2, 2, 2, 16, true>", "conv_stem_x6_kernel", "bn_apply_cb"]
     assert all(bench.is_forward_conv(n) for n in fwd) and not any(bench.is_forward_conv(n) for n in bwd)
+    # roofline.traffic is a lookup in the newest committed PMC table: refused unless the table was made from THIS set of kernels
+    import glob
+    import json
+    tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    table = json.load(open(tables[-1]))["kernels"]
+    name = next(n for n in table if n.startswith("conv_gemm_split_pp_kernel<SplitF16x3, false"))
+    run = {n: dict(launches=v["launches_per_step"]) for n, v in table.items() if n.startswith("conv_") and "<" in n}
+    got, source = bench.pmc_traffic(name, run, 1)
+    assert got == table[name]["hbm_bytes_per_launch"] and source.endswith(os.path.basename(tables[-1]))
+    got, why = bench.pmc_traffic(name, dict(run, **{"conv_renamed_kernel<1, 2>": dict(launches=3)}), 1)
+    assert got is None and "stale" in why and "conv_renamed_kernel<1, 2>" in why
+    got, why = bench.pmc_traffic(name, dict(run, **{name: dict(launches=run[name]["launches"] + 6)}), 1)
+    assert got is None and "times per step" in why
+    r = bench.kernel_roofline(name, dict(flops=3e12, bytes=1e9, ms=3.0, launches=10), "f16x3", None)
+    assert abs(r["frac"] - 3 * r["frac_algorithmic"]) < 1e-3 and abs(r["frac_algorithmic"] - 1000.0 / 2500.0) < 1e-3
 
 
 def test_product_never_imports_the_oracle():

@@ -1049,6 +1049,51 @@ def test_conv_large_tile_kernels(case):
     _assert_close(rstd, (r.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt(), 1e-5, "fused BN rstd")
 
 
+@pytest.mark.parametrize("rows,c,mp", [(480, 512, 512), (480, 128, 128), (7, 16, 32), (1000, 41, 64), (1024, 2048, 2048), (333, 24, 32)])
+def test_bn_statistics_in_one_launch_are_bitwise_the_two_stage_result(rows, c, mp, monkeypatch):
+    """``bn_stats_one_kernel`` (csrc/bn.hip): the merge of the convolution epilogue's partial rows into mean / rstd /
+    running statistics / output bound as ONE launch for layers with few partial rows (<= 1024: the 1/8-resolution maps) -- the same fp64
+    sums in the same order as ``bn_stats_partial_kernel`` + ``bn_stats_finalize_kernel`` (MCDSEG_BN_STATS_ONE=0), so every output is
+    bit for bit theirs; also with two running-statistics updates, a residual bound, and ragged channel counts."""
+    dev = _dev()
+    import ctypes
+    from mcdseg import ops
+    L = ops.lib()
+    g = torch.Generator().manual_seed(rows * 131 + c)
+    part = torch.zeros(rows, 3, mp)
+    part[:, 0, :c] = torch.randint(1, 161, (rows, 1), generator=g).float()          # counts: the same for every channel of a row
+    part[:, 1, :c] = torch.randn(rows, c, generator=g) * 3.0 + 1.5                  # means
+    part[:, 2, :c] = torch.rand(rows, c, generator=g) * 100.0                       # M2
+    part = part.to(dev)
+    gam, bet = torch.randn(c, generator=g).to(dev), torch.randn(c, generator=g).to(dev)
+    resb = torch.tensor([2.75], device=dev)
+    out = {}
+    for mode in ("0", None):
+        if mode is None:
+            monkeypatch.delenv("MCDSEG_BN_STATS_ONE", raising=False)
+        else:
+            monkeypatch.setenv("MCDSEG_BN_STATS_ONE", mode)
+        mean, rstd = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        rm, rv = torch.full((c,), 0.25, device=dev), torch.full((c,), 1.5, device=dev)
+        nbt = torch.full((1,), 5, dtype=torch.int64, device=dev)
+        yb = torch.full((1,), 1e30 if mode is None else 0.0, device=dev)  # (the one-launch form must not depend on what the scalar held)
+        ws = torch.empty(L.mcdseg_bn_stats_workspace_bytes(rows, c) // 8 + 1, dtype=torch.float64, device=dev)
+        names = []
+        ops.check(L.mcdseg_bn_stats_finalize(ops._p(part), rows, c, mp, ops._p(mean), ops._p(rstd), ops._p(rm), ops._p(rv), ops._p(nbt), 0.1, 1e-5,
+                                             ops._p(gam), ops._p(bet), ops._p(resb), ops._p(yb), 2, ops._p(ws), ctypes.c_size_t(ws.numel() * 8),
+                                             ops._stream()), "bn_stats_finalize")
+        torch.cuda.synchronize()
+        out[mode] = (mean, rstd, rm, rv, nbt, yb)
+    for a, b, what in zip(out["0"], out[None], ("mean", "rstd", "running_mean", "running_var", "num_batches_tracked", "y_bound")):
+        assert torch.equal(a, b), "%s differs between the one-launch and the two-stage statistics" % what
+    assert int(out[None][4]) == 7
+    cnt = part[:, 0, 0].double().cpu()
+    mu = part[:, 1, :c].double().cpu()
+    n = cnt.sum()
+    ref_mean = (cnt[:, None] * mu).sum(0) / n
+    assert float((out[None][0].double().cpu() - ref_mean).abs().max()) <= 1e-6 * float(ref_mean.abs().max())
+
+
 # (Cin, Cout, k, stride, dil, N, H, W, math): one or two rounds of 256 x 256 tiles for the 8-wave ping-pong kernel plus a ragged rest
 PINGPONG_CASES = [
     (64, 512, 3, 1, 2, 2, 160, 131, "f16x3"),   # forward M = 512: 326 tiles -> one round (128 pixel tiles) + 9 152 ragged pixels on 256 x 128
@@ -1488,6 +1533,9 @@ WGRAD_CB_CASES = [
     (64, 128, 3, 2, 1, 15, 17, 2),    # ... stride 2, two co tiles
     (48, 64, 3, 1, 2, 13, 19, 2),     # ... ragged channel groups, dilation 2
     (64, 128, 1, 2, 1, 11, 13, 2),    # ... 1x1 stride 2: a single tap (the pair's second half is empty)
+    (32, 64, 3, 2, 1, 23, 31, 2),     # ... base.3.0 conv1: 32 input channels on the 64-wide tile (half of it padding; round 5)
+    (32, 64, 1, 2, 1, 23, 31, 2),     # ... base.3.0 downsample
+    (24, 40, 3, 1, 1, 9, 14, 1),      # ... ragged on both sides
     (16, 16, 3, 1, 1, 16, 64, 1),     # thin layers (layer1): the window kernel, whole 8 x 32 tiles
     (16, 16, 3, 1, 1, 21, 45, 2),     # ... ragged rows and columns
     (16, 32, 3, 2, 1, 23, 70, 2),     # ... layer2: stride 2, two row tiles of output channels
@@ -1515,6 +1563,9 @@ def test_conv_wgrad_presplit_operands(case, math, monkeypatch):
     if cin <= 16 and math == "f16x3":  # the thin-layer window kernel is what the companions select here
         import ctypes
         assert ops.lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), ops.MATH_ID[math], 1) == 15
+    if 16 < min(cin, cout) <= 64 and math == "f16x3":  # the tap-pair kernel of the 64-wide plan, from 24 channels up
+        import ctypes
+        assert ops.lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), ops.MATH_ID[math], 1) == 14
     dw_loop = ops._conv_wgrad(desc, xg, gyg, None, None, x_bound, gy_bound)
     dw_cb = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
     _assert_close(dw_loop, gw_ref, 2e-5, "wgrad (in-loop split)")
@@ -1631,6 +1682,10 @@ WGRAD_PP_CASES = [
     (256, 512, 1, 1, 1, 61, 83, 16, "f16x3"),  # 1x1: two tiles, pieces far shorter than a tile
     (256, 400, 3, 2, 1, 63, 81, 6, "f16x3"),   # stride 2: X is gathered through the convolution geometry
     (512, 512, 3, 1, 2, 24, 32, 6, "f16x1"),   # the reduced-precision arithmetic (the piece-1 waves move nothing)
+    # BASELINE config 2's own shapes (N = 16, 60 x 80 maps): the slab plan at exactly the 9 / 18 / 36 tiles the benchmark launches
+    (256, 256, 3, 1, 2, 60, 80, 16, "f16x3"),  # base.5.{1..5}: 9 tiles
+    (256, 512, 3, 1, 4, 60, 80, 16, "f16x3"),  # base.6.0 conv1: 18 tiles
+    (512, 512, 3, 1, 4, 60, 80, 16, "f16x3"),  # base.6.{0,1,2}: 36 tiles
 ]
 
 
@@ -1675,12 +1730,14 @@ def test_conv_wgrad_pingpong_stream_k(case, monkeypatch):
     assert L.mcdseg_conv_wgrad_variant(ctypes.byref(desc), mid, 1) == 17
     dw_sk = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
     assert torch.equal(dw_sk, ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)), "two stream-K runs differ"
-    assert float((dw - dw_sk).abs().max()) <= 2e-6 * float(dw.abs().max()), "the two decompositions differ by more than their rounding"
+    # (fp32 accumulation inside a slab / a stream-K piece: the two plans cut K = N Ho Wo pixels differently, and at the benchmark's 76800
+    # pixels a slab sums ~11 000 products per accumulator -- 2.1e-6 of the scale measured there, 1e-6 at the smaller cases)
+    assert float((dw - dw_sk).abs().max()) <= 4e-6 * float(dw.abs().max()), "the two decompositions differ by more than their rounding"
     monkeypatch.setenv("MCDSEG_WGRAD_PP", "0")
     assert L.mcdseg_conv_wgrad_variant(ctypes.byref(desc), mid, 1) in (12, 13)
     dw_tr = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
     scale = float(dw_tr.abs().max())
-    assert float((dw - dw_tr).abs().max()) <= 2e-6 * scale, float((dw - dw_tr).abs().max()) / scale
+    assert float((dw - dw_tr).abs().max()) <= 4e-6 * scale, float((dw - dw_tr).abs().max()) / scale
     if math == "f16x3":
         x64, w64 = x.double(), wt.double().requires_grad_()
         ref = F.conv2d(x64, w64, None, stride=s, padding=pad, dilation=d)

@@ -389,7 +389,7 @@ def test_solver_step_b_forward_fork_is_bitwise_the_serial_step(golden, monkeypat
     assert losses[0] == losses[1], losses
 
 
-def test_solver_target_forward_reuse_is_bitwise_the_literal_schedule(golden):
+def test_solver_target_forward_reuse_is_bitwise_the_literal_schedule(golden, monkeypatch):
     """Step B's generator forward on the target batch doubling as step C's first one (solvers/solver.py; each BatchNorm applies
     its running update twice) against the literal schedule of adapt_trainer.py:196/:209 (7 generator forwards): every
     parameter, running statistic, num_batches_tracked and logged loss after three A/B/C iterations is bit-identical.  A
@@ -788,7 +788,8 @@ def test_cfg2_full_batch_vs_oracle():
         assert ops.gemm_kernel_name(64, 64, False, True, True, False, n * 120 * 160) in names, sorted(set(names))  # the 4-wave tiles (64 rows)
         if ops.CONV_MATH == "f16x3":  # ... and the weight gradients ran on the ping-pong stream-K kernel / the 128 x 128 / 64-channel tiles
             for wg in ("conv_wgrad_split_pp_kernel<SplitF16x3>", "conv_wgrad_split_tr_kernel<SplitF16x3, 2, 2, 3, false>",
-                       "conv_wgrad_split_tr64_kernel<SplitF16x3>", "conv_wgrad_thin_tr_kernel<SplitF16x3>"):
+                       "conv_wgrad_split_tr64_kernel<SplitF16x3>", "conv_wgrad_thin_tr_kernel<1, 1, 25, 8>",
+                       "conv_wgrad_thin_tr_kernel<2, 1, 9, 8>", "conv_wgrad_thin_tr_kernel<2, 2, 9, 4>"):
                 assert wg in names, "the backward pass did not run %s: %s" % (wg, sorted(set(names)))
     err = float((feat.detach().cpu() - ref_feat).abs().max())
     assert err <= 1e-3, "feat err %.3e" % err
@@ -898,8 +899,7 @@ def test_cfg3_full_batch_vs_oracle():
     """BASELINE config 3 at its stated per-GPU size -- MFNet-ScoreAddFusion, two drn_d_38 encoders (RGB / HHA), 16 x 6 x 480 x 640 --
     against the CPU oracle: both encoders' score maps and the fused full-resolution logits (<= 1e-3, north_star), the two cross-entropy
     values, the gradients of the four up-sampling kernels and the gradients handed back to the two encoders.  (The oracle's encoders
-    run forward only for the RGB side -- its backward at this size is the cfg2 test's subject -- and with the tape for the HHA side,
-    whose every parameter gradient is compared too; everything behind the score maps is differentiated on both sides.)  What only
+    run with their tapes: every parameter gradient of BOTH is compared.)  What only
     this size reaches: the two-input up-sampling kernel and the stored-logit loss kernel on 16 x 41 x 480 x 640 tensors (806 MB each)."""
     dev = _dev()
     from loss import CrossEntropyLoss2d
@@ -915,10 +915,9 @@ def test_cfg3_full_batch_vs_oracle():
     cw = ref_loss.class_weights(NC)
     prev = _all_threads()
     try:
-        with torch.no_grad():
-            ra = ora[0](src[:, :3].contiguous())
-        rb = ora[1](src[:, 3:].contiguous())  # the HHA encoder WITH its tape: its parameter gradients are compared below
-        ra = ra.requires_grad_()
+        ra = ora[0](src[:, :3].contiguous())  # both encoders WITH their tapes: every parameter gradient of both is compared below
+        rb = ora[1](src[:, 3:].contiguous())
+        ra.retain_grad()
         rb.retain_grad()
         ro1, ro2 = ora[2](ra, rb), ora[3](ra, rb)
         rcrit = ref_loss.CrossEntropyLoss2d(cw)
@@ -928,7 +927,7 @@ def test_cfg3_full_batch_vs_oracle():
         torch.set_num_threads(prev)
     keys = [(2, "up1.weight"), (2, "up2.weight"), (3, "up1.weight"), (3, "up2.weight")]
     ref_gs = {k: dict(ora[k[0]].named_parameters())[k[1]].grad.clone() for k in keys}
-    ref_enc_gs = {k: v.grad.clone() for k, v in ora[1].named_parameters()}
+    ref_enc_gs = [{k: v.grad.clone() for k, v in ora[e].named_parameters()} for e in (0, 1)]
     rga, rgb_ = ra.grad.clone(), rb.grad.clone()
     ra, rb, ro1s = ra.detach(), rb.detach(), ro1.detach()[:, :, ::8, ::8].clone()
     rl1, rl2 = float(rl1.detach()), float(rl2.detach())
@@ -951,17 +950,18 @@ def test_cfg3_full_batch_vs_oracle():
         rel = float((got.cpu() - rg).norm() / rg.norm())
         assert rel <= 2e-3, "%s: relative L2 difference %.3e" % (what, rel)
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in hip[0].parameters())  # ... and the encoders did back-propagate
-    # every parameter gradient of the HHA encoder (bounds as in the cfg2 test: fp32 through 41 train-mode BatchNorms)
-    named = dict(hip[1].named_parameters())
-    assert set(named) == set(ref_enc_gs)
-    num = den = 0.0
-    worst = (0.0, None)
-    for k, rg in ref_enc_gs.items():
-        dn, rn = float((named[k].grad.cpu() - rg).double().norm()), float(rg.double().norm())
-        num, den = num + dn * dn, den + rn * rn
-        worst = max(worst, (dn / rn, k))
-    assert worst[0] <= 4e-2, "%s: relative L2 difference %.3e" % (worst[1], worst[0])
-    assert (num / den) ** 0.5 <= 2.5e-2, "HHA encoder gradients: relative L2 difference %.3e (worst %s %.3e)" % ((num / den) ** 0.5, worst[1], worst[0])
+    # every parameter gradient of BOTH encoders (bounds as in the cfg2 test: fp32 through 41 train-mode BatchNorms)
+    for e, what in ((0, "RGB"), (1, "HHA")):
+        named = dict(hip[e].named_parameters())
+        assert set(named) == set(ref_enc_gs[e])
+        num = den = 0.0
+        worst = (0.0, None)
+        for k, rg in ref_enc_gs[e].items():
+            dn, rn = float((named[k].grad.cpu() - rg).double().norm()), float(rg.double().norm())
+            num, den = num + dn * dn, den + rn * rn
+            worst = max(worst, (dn / rn, k))
+        assert worst[0] <= 4e-2, "%s encoder, %s: relative L2 difference %.3e" % (what, worst[1], worst[0])
+        assert (num / den) ** 0.5 <= 2.5e-2, "%s encoder gradients: relative L2 difference %.3e (worst %s %.3e)" % (what, (num / den) ** 0.5, worst[1], worst[0])
 
 
 def test_cfg4_full_batch_vs_oracle():
@@ -1165,6 +1165,110 @@ def test_d105_bottleneck_vs_reference(golden, storage, k, monkeypatch):
         nz = float((g32[name] - g64[name]).abs().max())
         e = float((named[name].grad.double().cpu() - g64[name]).abs().max())
         assert e <= max(k * nz, 1e-3 * float(g64[name].abs().max())), "%s: err %.3e noise %.3e" % (name, e, nz)
+
+
+def test_cfg5_geometry_vs_oracle(monkeypatch):
+    """BASELINE config 5's network at ITS geometry against the CPU oracle: drn_d_105 (Bottleneck blocks,
+    models/drn.py:62-100, 344-348), 2 x 6 x 720 x 1280, train-mode BatchNorm, compact activation storage -- with the launch plan of the
+    stated N = 32 batch: MCDSEG_PP_CUS = 16 gives the 28800 pixels of the 90 x 160 maps the rounds of tiles 460800 pixels have on 256
+    CUs (whole rounds of 256 x 256 ping-pong tiles + the rest on 256 x 128 ones), and a 150 MB launch limit cuts the 2048-channel maps
+    along N with their companions, as the 2 GiB limit cuts them at N = 32.  Encoder features and logits against the oracle's fp32
+    forward (<= 1e-3, north_star), the cross-entropy gradient of EVERY parameter against the oracle's backward, kernel names asserted.
+    The gradient bounds are twice the distances tests/grad_truth_cfg2.py --cfg5 measured with an fp64 run of the oracle beside both
+    (profiles/r05_grad_truth_cfg5.txt)."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d
+    from mcdseg import ops
+    from models.model_util import get_models
+    from oracle import ref_loss, ref_models
+    if ops.CONV_MATH != "f16x3":
+        pytest.skip("the configuration's arithmetic is f16x3")
+    n = 2
+    monkeypatch.setenv("MCDSEG_PP_CUS", str(8 * n))
+    monkeypatch.setattr(ops, "ACT_STORAGE", "compact")
+    monkeypatch.setattr(ops, "MAX_CONV_BYTES", 150 << 20)
+    assert len(ops._batch_pieces(ops.conv_desc((n, 2048, 90, 160), (512, 2048, 1, 1), 1, 0, 1))) == 2  # (the cut path is reached ...)
+    assert len(ops._batch_pieces(ops.conv_desc((n, 1024, 90, 160), (256, 1024, 1, 1), 1, 0, 1))) == 1  # (... by the 2048-channel maps only)
+    g, f1, f2 = get_models("drn_d_105", 6, NC)
+    og, of1, of2 = ref_models.get_models("drn_d_105", 6, NC)
+    for m, o, seed in ((g, og, 71), (f1, of1, 72), (f2, of2, 73)):
+        fill_state_(m, seed), fill_state_(o, seed)
+        m.to(dev).train(), o.train()
+    src, lbl, _ = make_batch(78, n, 6, 720, 1280, NC)
+    cw = ref_loss.class_weights(NC)
+    threads = _all_threads()
+    try:
+        ref_feat = og(src)
+        ref_logits = of1(ref_feat)
+        rcrit = ref_loss.CrossEntropyLoss2d(cw)
+        (rcrit(ref_logits, lbl) + rcrit(of2(ref_feat), lbl)).backward()
+    finally:
+        torch.set_num_threads(threads)
+    ref_gs = {k: v.grad.clone() for k, v in og.named_parameters()}
+    ref_fgs = [m.up.weight.grad.clone() for m in (of1, of2)]
+    ref_feat, ref_logits = ref_feat.detach(), ref_logits.detach()[:, :, ::8, ::8].clone()
+    del og, of1, of2
+    names = []
+    timer_prev = ops.LAUNCH_TIMER
+
+    class _Names:
+        def wants(self, name):
+            names.append(name)
+            return False
+    ops.LAUNCH_TIMER = _Names()
+    try:
+        feat = g(src.to(dev))
+        logits = f1(feat)
+        crit = CrossEntropyLoss2d(cw.to(dev))
+        (crit(logits, lbl.to(dev)) + crit(f2(feat), lbl.to(dev))).backward()
+    finally:
+        ops.LAUNCH_TIMER = timer_prev
+    ran = set(names)
+    # the N = 32 plan: whole rounds of 256 x 256 ping-pong tiles and the rest on 256 x 128 ones, forward and data gradient
+    for nm in (ops.pingpong_kernel_name(False), ops.pingpong_kernel_name(False, small=True), ops.pingpong_kernel_name(True),
+               ops.pingpong_kernel_name(True, small=True)):
+        assert nm in ran, "the pass did not run %s: %s" % (nm, sorted(ran))
+    # every trunk convolution read companions -- also the slices of the batches cut along N: no forward pass on the fp32-gather form of
+    # the GEMM kernel, no weight gradient on the plans that gather fp32 (the f32 kernels keep the 41-channel seg head only)
+    assert not [nm for nm in ran if nm.startswith("conv_gemm_split_kernel<") and nm.endswith("false, false>")], sorted(ran)
+    assert "conv_wgrad_split_kernel<SplitF16x3>" not in ran and "conv_wgrad_split_cb_kernel<SplitF16x3>" not in ran, sorted(ran)
+    for wg in ("conv_wgrad_split_pp_kernel<SplitF16x3>", "conv_wgrad_split_tr_kernel<SplitF16x3, 2, 2, 3, false>",
+               "conv_wgrad_split_tr64_kernel<SplitF16x3>", "conv_wgrad_thin_tr_kernel<2, 1, 9, 8>", "conv_wgrad_thin_tr_kernel<2, 2, 9, 4>",
+               # (the stem's weight gradient: its full-resolution operands are cut along N -- here by the 150 MB limit, at N = 32 by the
+               # 2 GiB one -- and a cut batch runs it on the f32 tap-packed kernel)
+               "conv_wgrad_thin_kernel<8, true>"):
+        assert wg in ran, "the backward pass did not run %s: %s" % (wg, sorted(ran))
+    err = float((feat.detach().cpu() - ref_feat).abs().max())
+    lerr = float((logits.detach()[:, :, ::8, ::8].cpu() - ref_logits).abs().max())
+    named = dict(g.named_parameters())
+    assert set(named) == set(ref_gs)
+    num = den = 0.0
+    worst = (0.0, None)
+    for k, rg in ref_gs.items():
+        got = named[k].grad.cpu()
+        dn, rn = float((got - rg).double().norm()), float(rg.double().norm())
+        num, den = num + dn * dn, den + rn * rn
+        worst = max(worst, (dn / rn, k))
+    overall = (num / den) ** 0.5
+    ups = [float((m.up.weight.grad.cpu() - rg).norm() / rg.norm()) for m, rg in zip((f1, f2), ref_fgs)]
+    print("cfg5 geometry N=%d: feat err %.3e, logit err %.3e, gradients overall %.3e, worst %s %.3e, up-sampling %.3e / %.3e"
+          % (n, err, lerr, overall, worst[1], worst[0], ups[0], ups[1]))
+    assert err <= CFG5_FEAT_ABS, "feat err %.3e" % err
+    assert lerr <= CFG5_LOGIT_ABS, "logit err %.3e" % lerr
+    assert worst[0] <= CFG5_GRAD_WORST, "%s: relative L2 difference %.3e" % (worst[1], worst[0])
+    assert overall <= CFG5_GRAD_OVERALL, "all generator gradients: relative L2 difference %.3e (worst tensor %s %.3e)" % (overall, worst[1], worst[0])
+    assert max(ups) <= CFG5_UP_REL, "up.weight: relative L2 difference %.3e / %.3e" % tuple(ups)
+
+
+# Bounds of test_cfg5_geometry_vs_oracle = twice the HIP - oracle-fp32 distances of profiles/r05_grad_truth_cfg5.txt, the run of
+# tests/grad_truth_cfg2.py --cfg5 that has the oracle in fp64 beside both.  north_star's 1e-3 on logits is NOT what fp32 delivers on this
+# network at this random initialisation, whoever computes it: through 105 train-mode BatchNorms the oracle's own fp32 logits are 2.6e-3
+# from its fp64 logits (features 1.3e-2 on a scale of 22), the HIP path's 2.9e-3 (1.4e-2), the two fp32 results 3.8e-3 (1.9e-2) from each
+# other; parameter gradients: oracle fp32 - fp64 5.8e-2 relative L2 over all 328 tensors (worst tensor 7.8e-2), HIP - fp64 5.8e-2
+# (8.1e-2), HIP - oracle fp32 6.9e-2 (8.8e-2); up-sampling kernels 6.7e-5 / 6.8e-5 / 9.4e-5.  The HIP path is as close to the truth as
+# the reference's arithmetic is; the test holds it to twice its measured distance from the oracle's fp32.
+CFG5_FEAT_ABS, CFG5_LOGIT_ABS = 4e-2, 8e-3
+CFG5_GRAD_WORST, CFG5_GRAD_OVERALL, CFG5_UP_REL = 0.18, 0.14, 2e-4
 
 
 def test_cfg5_stated_batch_equals_its_replicated_quarter(monkeypatch):
