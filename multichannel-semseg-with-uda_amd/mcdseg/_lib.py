@@ -175,10 +175,16 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+_DISASSEMBLY = {}
+
+
 def device_disassembly(path=None):
     """ISA text of every gfx950 code object bundled in the library (llvm-objdump from the ROCm toolchain; no GPU needed)"""
     import tempfile
     path = path or LIB_PATH
+    key = (path, os.path.getmtime(path))
+    if _DISASSEMBLY.get("key") == key:  # (the guards below each walk the same text)
+        return _DISASSEMBLY["text"]
     llvm = os.environ.get("ROCM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
     out = []
     with tempfile.TemporaryDirectory() as tmp:
@@ -188,7 +194,8 @@ def device_disassembly(path=None):
         subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", copy], check=True, capture_output=True, cwd=tmp)
         for co in sorted(glob.glob(os.path.join(tmp, "lib.so.*gfx950*"))):
             out.append(subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", co], check=True, capture_output=True, text=True).stdout)
-    return "\n".join(out)
+    _DISASSEMBLY.update(key=key, text="\n".join(out))
+    return _DISASSEMBLY["text"]
 
 
 def packed_f32_opsel_sites(path=None):
@@ -204,6 +211,33 @@ def packed_f32_opsel_sites(path=None):
         elif pat.search(line):
             sites.append((sym, line.strip()))
     return sites
+
+
+def spills_inside_matrix_loops(path=None, prefix=("conv_gemm_split_pp_kernel", "conv_wgrad_split_pp_kernel")):
+    """[(kernel symbol, line offset)] of every scratch (spill) access that lies BETWEEN the first and the last matrix instruction of a
+    ping-pong kernel, i.e. inside or between its K loops; must be empty.  (The 256 x 256 and 256 x 128 forward tiles hold 10 / 13
+    spilled registers -- values parked before the K loop and fetched back in the epilogue, which costs a few scratch accesses per
+    wave and tile; a spill inside the loop would cost them per K-step.)"""
+    import re
+    out, sym, body = [], None, []
+
+    def close():
+        if sym is None or not any(p in sym for p in prefix):
+            return
+        mf = [i for i, ln in enumerate(body) if "v_mfma" in ln]
+        if not mf:
+            return
+        out.extend((sym, i) for i, ln in enumerate(body) if "scratch_" in ln and mf[0] < i < mf[-1])
+
+    for line in device_disassembly(path).splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+        if m:
+            close()
+            sym, body = m.group(1), []
+        else:
+            body.append(line)
+    close()
+    return out
 
 
 def lib():

@@ -26,6 +26,9 @@ def test_no_packed_fp32_instruction_with_op_sel_in_the_library():
     text = _lib.device_disassembly()
     assert text.count("v_mfma_f32_32x32x16_f16") > 500, "the disassembly does not look like libmcdseg's"
     assert _lib.packed_f32_opsel_sites() == []
+    # the register spills of the 256 x 256 / 256 x 128 forward tiles (BASELINE config 5's plan) sit in the prologue and
+    # the epilogue -- no scratch access between the first and the last matrix instruction of any ping-pong kernel
+    assert _lib.spills_inside_matrix_loops() == []
 
 
 def test_library_exports_every_header_symbol():
