@@ -459,6 +459,8 @@ def _main():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only implementation (no CPU fallback)")
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
+    if os.environ.get("MCDSEG_BENCH_MAIN_STREAM") == "1":  # (experiments: the step on a stream of its own instead of the legacy default stream)
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
 
     solver, models = build_hip(args, dev)
     # a pool of pre-staged batches (device-resident, as the metric asks), visited round-robin; the caches ops.py hangs on a batch

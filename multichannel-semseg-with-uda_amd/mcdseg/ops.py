@@ -744,8 +744,29 @@ def _side_stream(device):
     # measured too: 235.1 vs 236.2 ms on one box, 236.1 / 234.6 vs 234.8 / 235.0 on another; within the noise, not kept)
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
+        _SIDE[key] = _masked_stream(device, SIDE_CUS) if SIDE_CUS > 0 else torch.cuda.Stream(device=device)
     return _SIDE[key]
+
+
+# MCDSEG_SIDE_CUS=n (experiment, round 5): the side stream as a HIP stream restricted to the first n compute units
+# (hipExtStreamCreateWithCUMask), so that the main stream's HBM-bound BatchNorm passes always find CUs no weight-gradient workgroup
+# holds.  0 (default): an ordinary stream.
+SIDE_CUS = int(os.environ.get("MCDSEG_SIDE_CUS", "0"))
+
+
+def _masked_stream(device, n_cus):
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    total = torch.cuda.get_device_properties(device).multi_processor_count
+    words = (total + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for b in range(min(n_cus, total)):
+        mask[b // 32] |= 1 << (b % 32)
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), mask)
+    if rc != 0 or not handle.value:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
+    return torch.cuda.ExternalStream(handle.value, device=device)
 
 
 def join_side_streams(device_index=None):

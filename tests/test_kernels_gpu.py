@@ -868,10 +868,11 @@ def test_presplit_operands_are_bitwise_equivalent(math, monkeypatch):
 
     a, b = run(True), run(False)
     for name, u, v in zip(["y1", "y2", "y3", "dx", "dw1", "dw2", "dw3"], a, b):
-        if name == "dw2" and math == "f16x3":
-            # 40 -> 64 channels: with both companions the weight gradient runs the 64-channel tap-pair kernel in the split
-            # arithmetic, without them the f32-MFMA kernel -- same result to fp32 accuracy, not the same bits
-            _assert_close(u, v, 2e-5, "dw2 (split tap-pair kernel vs f32 kernel)")
+        if name in ("dw2", "dw3") and math == "f16x3":
+            # 40 -> 64 and (round 5: the 64-wide plan from 24 channels up) 64 -> 32 channels: with both companions the weight gradient
+            # runs the tap-pair kernel in the split arithmetic, without them the f32-MFMA kernel -- same result to fp32 accuracy, not
+            # the same bits
+            _assert_close(u, v, 2e-5, "%s (split tap-pair kernel vs f32 kernel)" % name)
             continue
         assert torch.equal(u, v), "%s differs between pre-split and in-loop split (max %.3e)" % (name, float((u - v).abs().max()))
 
