@@ -165,11 +165,12 @@ int mcdseg_conv_split_wgrad(const mcdseg_conv_desc* d, int32_t math, const float
  * (128x128, 64x64, 32x32 tiles, tap-packed thin inputs), 10 split arithmetic from fp32 operands, 11 / 12 / 13 from both
  * pre-split companions (register-transposing, transposed-read 128x128, transposed-read 256x128), 14 the 64-channel tap pairs,
  * 15 the thin-layer window kernel, 16 two taps per workgroup, 17 the eight-wave ping-pong kernel over a stream-K decomposition
- * (256-channel blocks on both sides; csrc/conv_wgrad_split_pp.hip).  For profilers and bench.py's per-kernel accounting. */
+ * (256-channel blocks on both sides; csrc/conv_wgrad_split_pp.hip), 18 its row-of-taps form for 3 x KH kernels with at most 128
+ * channels on one side (tiles of 128 co x three taps x 128 ci).  For profilers and bench.py's per-kernel accounting. */
 int32_t mcdseg_conv_wgrad_variant(const mcdseg_conv_desc* d, int32_t math, int32_t presplit);
 /* 1 when ONE launch of mcdseg_conv_wgrad (math = 0) / mcdseg_conv_split_wgrad (presplit: both companions are passed) can address
  * this descriptor's operands with its 32-bit buffer offsets: (N*C + 128 channels of slack) planes below 2 GiB for the kernels that
- * read the fp32 tensors, N*C planes for the plans that read the companions (variants 11..16).  The host cuts larger batches along
+ * read the fp32 tensors, N*C planes for the plans that read the companions (variants 11..18).  The host cuts larger batches along
  * N -- the reference has no such limit (nn.Conv2d, models/drn.py:21-23).  Host-side arithmetic, no launch. */
 int32_t mcdseg_conv_wgrad_fits(const mcdseg_conv_desc* d, int32_t math, int32_t presplit);
 /* dw = x (*) dy ; split over pixels into slabs in `workspace`, then reduced in a fixed order. */

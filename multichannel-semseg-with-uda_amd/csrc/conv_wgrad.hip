@@ -480,6 +480,10 @@ int mcdseg_internal_wgrad_thin_tr_launch(const mcdseg_conv_desc* d, const void* 
 int mcdseg_internal_wgrad_pp_plan(const mcdseg_conv_desc* d, int math, int* L, size_t* slab_floats, int* slabs = nullptr);
 int mcdseg_internal_wgrad_pp_launch(const mcdseg_conv_desc* d, int math, const void* x_cb, const float* x_bound, const void* dy_cb,
                                     const float* dy_bound, float* dw, float* slab, hipStream_t st);
+// ... and the 128-channel layers: the same kernel structure on tiles of 128 (co) x one kernel row of three taps x 128 (ci)
+int mcdseg_internal_wgrad_pp3_plan(const mcdseg_conv_desc* d, int math, int* L, size_t* slab_floats, int* slabs = nullptr);
+int mcdseg_internal_wgrad_pp3_launch(const mcdseg_conv_desc* d, int math, const void* x_cb, const float* x_bound, const void* dy_cb,
+                                     const float* dy_bound, float* dw, float* slab, hipStream_t st);
 static bool thin_tr_applies(const mcdseg_conv_desc* d, int math, const void* x_cb, const void* dy_cb) {
   static const bool on = [] {
     const char* e = getenv("MCDSEG_WGRAD_THIN_TR");
@@ -503,12 +507,14 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
 // Which kernel mcdseg_conv_wgrad / mcdseg_conv_split_wgrad launch for this geometry (math = 0 for mcdseg_conv_wgrad):
 // 0..3 the f32 plans (128x128, 64x64, 32x32 tiles, tap-packed thin), 10 split arithmetic from fp32 operands, 11 / 12 / 13 / 14 from
 // both pre-split companions: register-transposing, transposed-read 128x128, transposed-read 256x128, transposed-read 64-channel
-// tap pairs, 15 the thin-layer window kernel, 16 transposed-read 128-channel tiles with two taps per workgroup.  For profilers and the benchmark's per-kernel accounting; never needed to call the operators.
+// tap pairs, 15 the thin-layer window kernel, 16 transposed-read 128-channel tiles with two taps per workgroup, 17 the eight-wave
+// ping-pong kernel (256 x 256 tiles), 18 its row-of-taps form for the 128-channel layers.  For profilers and the benchmark's per-kernel accounting; never needed to call the operators.
 extern "C" int32_t mcdseg_conv_wgrad_variant(const mcdseg_conv_desc* d, int32_t math, int32_t presplit) {
   if (d == nullptr) return -22;
   const WgradPlan pl = make_plan(d);
   if (presplit && thin_tr_applies(d, math, d, d)) return 15;
   if (presplit && math && pl.cfg == 0 && mcdseg_internal_wgrad_pp_plan(d, math, nullptr, nullptr) > 0) return 17;
+  if (presplit && math && pl.cfg == 0 && mcdseg_internal_wgrad_pp3_plan(d, math, nullptr, nullptr) > 0) return 18;
   if (pl.cfg == 1 && presplit && tr64_applies(d, math, d, d, 1)) return 14;
   if (pl.cfg != 0 || math == 0) return pl.cfg;
   if (!(presplit && (d->Cin & 7) == 0 && (d->Cout & 7) == 0)) return 10;
@@ -557,6 +563,8 @@ extern "C" size_t mcdseg_conv_wgrad_workspace_bytes(const mcdseg_conv_desc* d) {
   size_t a = (size_t)make_plan(d).slab_floats * sizeof(float), c = 0;
   const size_t b = mcdseg_internal_wgrad_thin_tr_ws(d);
   if (mcdseg_internal_wgrad_pp_plan(d, MCDSEG_MATH_F16X3, nullptr, &c) > 0 && c * sizeof(float) > a) a = c * sizeof(float);
+  c = 0;
+  if (make_plan(d).cfg == 0 && mcdseg_internal_wgrad_pp3_plan(d, MCDSEG_MATH_F16X3, nullptr, &c) > 0 && c * sizeof(float) > a) a = c * sizeof(float);
   return a > b ? a : b;
 }
 
@@ -570,6 +578,11 @@ static int wgrad_impl(const mcdseg_conv_desc* d, const float* x, const float* dy
     if (mcdseg_internal_wgrad_pp_plan(d, math, nullptr, &sf) > 0) {
       MCD_REQUIRE(workspace_bytes >= sf * sizeof(float), "conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, sf * sizeof(float));
       return mcdseg_internal_wgrad_pp_launch(d, math, x_cb, x_bound, dy_cb, dy_bound, dw, (float*)workspace, (hipStream_t)stream);
+    }
+    sf = 0;
+    if (mcdseg_internal_wgrad_pp3_plan(d, math, nullptr, &sf) > 0) {
+      MCD_REQUIRE(workspace_bytes >= sf * sizeof(float), "conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, sf * sizeof(float));
+      return mcdseg_internal_wgrad_pp3_launch(d, math, x_cb, x_bound, dy_cb, dy_bound, dw, (float*)workspace, (hipStream_t)stream);
     }
   }
   const bool tr64 = tr64_applies(d, math, x_cb, dy_cb, make_plan(d).cfg);

@@ -334,6 +334,260 @@ __global__ __launch_bounds__(256) void wgrad_reduce_sk_kernel(const float* __res
   for (int i = threadIdx.x; i < nci * T; i += 256) out[i] = stage[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same structure for the 128-CHANNEL layers (round 5): a tile is 128 (co) x 384 = the THREE taps of one
+// kernel row (ky; kx = 0, 1, 2) x 128 (ci).  The three taps of a row contract the same dZ pixels against X at three column shifts, so
+// one staged dZ block serves three times the products: per 16-pixel stage a wave issues 20 transposing reads for 18 matrix
+// instructions where conv_wgrad_split_tr_kernel's 128 x 128 one-tap tile needs 16 for 12, and the nine taps are three tiles, not nine
+// (three times fewer passes over dZ through L2).  The eight LDS-DMA roles of a stage are the same eight 128-channel blocks as above --
+// (dZ, piece 0), (dZ, piece 1) and (X at shift kx, piece) for kx = 0, 1, 2 -- so the stage image, the DMA shape, the bank layout
+// and the transposed-read addresses are the 256 x 256 kernel's.  Waves: the two groups split the 128 rows (64 each: two 32-row
+// blocks), the four waves of a group the 384 columns (96 each: three 32-column blocks, which may lie in two taps).  K is cut by the
+// slab plan only; a slab item writes its raw 128 x 384 sums, wgrad_reduce_rt_kernel adds a tile's slabs in K order in fp64.
+template <class P>
+__global__ __launch_bounds__(512) void conv_wgrad_split_pp3_kernel(WgradPpParams p) {
+  static_assert(P::NP == 2, "two-piece policies");
+  constexpr int WM = 2, WN = 3;
+  constexpr int NP = P::NP;
+  typedef typename P::frag frag;
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  constexpr int NDMA = 4;
+  constexpr int DSTR = 1024 + 64;
+  constexpr int BLKB = NDMA * DSTR;     // one 128-channel block of one piece
+  constexpr int STAGE = 8 * BLKB;       // [dZ piece 0][dZ piece 1][X piece 0: kx 0, 1, 2][X piece 1: kx 0, 1, 2]
+  constexpr int NS = 3;
+  static_assert(NS * STAGE <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp_id = wave >> 2;  // SIMD partners are waves w and w + 4
+  const int wm = grp_id, wn = wave & 3;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int w_id = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (w_id >= p.nwg) return;
+  const int tiles_all = p.co_tiles * p.ci_tiles * p.KH;
+
+  // ---- DMA role of this wave (wave-uniform): waves 0, 1 = dZ pieces 0, 1; wave 2 + i = X, piece i & 1, tap column kx = i >> 1
+  const bool isx = wave >= 2;
+  const int piece = isx ? ((wave - 2) & 1) : wave;
+  const int kxs = isx ? ((wave - 2) >> 1) : 0;
+  const int px = lane & 15;
+  const int cgl = lane >> 4;
+  const int sH = isx ? p.H : p.Ho;
+  const int sW = isx ? p.W : p.Wo;
+  const int sS = isx ? p.stride : 1;
+  const int sC8 = (isx ? p.Cin : p.Cout) >> 3;
+  const int sHW = sH * sW;
+  const int bias = p.pad * 16 + 16;
+  const char* sptr = (const char*)(isx ? p.x_cb : p.dy_cb) + piece * (isx ? p.x_piece_stride : p.dy_piece_stride) - bias;
+  const int sbytes = (isx ? p.x_cb_bytes : p.dy_cb_bytes) + bias;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sptr, 0, sbytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  const int lane_x = px * sS;
+  unsigned char* const unit_lds = smem + (isx ? (2 + piece * 3 + kxs) : piece) * BLKB;
+  const bool dma_on = piece < P::NPU;
+  const int ntiles = p.tiles_x * p.tiles_y;
+
+  const int gl = lane & 15;
+  const int tq = gl >> 2, tpp = gl & 3;
+  const int trow = ((((lane >> 4) & 1) * 2 + (tpp >> 1)) * DSTR) + tq * 16 + 8 * (tpp & 1) + (2 * lh) * 64;
+  const int a_lane = (wm * 2) * 256 + trow;  // the wave's 64 dZ channels = 32-row blocks 2 wm, 2 wm + 1 of the block
+  int b_lane[WN];                            // its 96 columns: 32-column block j lies in tap (column / 128), ci block (column % 128) / 32
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int col0 = wn * 96 + j * 32;
+    b_lane[j] = (2 + (col0 >> 7)) * BLKB + ((col0 & 127) >> 5) * 256 + trow;
+  }
+
+  auto tr_read_at = [&](unsigned base, auto off_c) -> s16x4 {
+    s16x4 v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(decltype(off_c)::value) : "memory");
+#else
+    (void)base;
+    v = s16x4{};
+#endif
+    return v;
+  };
+  auto frag_of = [&](unsigned base, auto lo_c, auto hi_c) -> frag {
+    const s16x4 lo = tr_read_at(base, lo_c);
+    const s16x4 hi = tr_read_at(base, hi_c);
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(frag, v);
+  };
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+#else
+  const unsigned smem_lds = 0;
+#endif
+
+  for (int item = w_id; item < p.items; item += p.nwg) {  // slab plan: item = (K slab item / tiles, tile item % tiles)
+    const int sl = item / tiles_all;
+    const int tile = item - sl * tiles_all;
+    const int k0 = sl * p.L;
+    const int k1 = k0 + p.L < p.kt ? k0 + p.L : p.kt;
+    const int ky = tile % p.KH;
+    const int tile_ci = (tile / p.KH) % p.ci_tiles;
+    const int tile_co = tile / (p.KH * p.ci_tiles);
+    const int shy = isx ? ky * p.dil - p.pad : 0;
+    const int shx = isx ? kxs * p.dil - p.pad : 0;
+    const int cg0 = (isx ? tile_ci : tile_co) * 16;  // first channel group of this wave's 128-channel block
+    unsigned vconst[NDMA];
+#pragma unroll
+    for (int d = 0; d < NDMA; ++d) vconst[d] = (cg0 + d + 4 * cgl) < sC8 ? (unsigned)((d + 4 * cgl) * sHW + px * sS) * 16u : OOB;
+
+    int l_n = k0 / ntiles;
+    int l_ty = (k0 - l_n * ntiles) / p.tiles_x;
+    int l_tx = k0 - l_n * ntiles - l_ty * p.tiles_x;
+    auto issue = [&](int stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (dma_on) {
+        const int sbase = (l_n * sC8 + cg0) * sHW;
+        const int iy = l_ty * sS + shy;
+        const int ux = l_tx * 16 * sS + shx;
+        const bool colok = (unsigned)(ux + lane_x) < (unsigned)sW;
+        const int soff = ((unsigned)iy < (unsigned)sH) ? (sbase + iy * sW + ux) * 16 + bias : 0x7FFFFFFF;
+#pragma unroll
+        for (int d = 0; d < NDMA; ++d)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(unit_lds + stage * STAGE + d * DSTR), 16,
+                                                   colok ? vconst[d] : OOB, soff, 0, 0);
+      }
+#else
+      (void)stage;
+#endif
+    };
+    auto advance = [&]() {
+      if (++l_tx == p.tiles_x) {
+        l_tx = 0;
+        if (++l_ty == p.tiles_y) {
+          l_ty = 0;
+          ++l_n;
+        }
+      }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nsteps = k1 - k0;
+    issue(0);
+    if (nsteps > 1) {
+      advance();
+      issue(1);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (grp_id == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1 runs one barrier behind group 0 to the end of the K loop
+
+    frag fa[NP][WM], fb[NP][WN];
+    int cur = 0, nxt2 = 2;
+    for (int s = 0; s < nsteps; ++s) {
+      // ---- read phase (the partner group multiplies meanwhile)
+      const unsigned base_a = smem_lds + (unsigned)(cur * STAGE + a_lane);
+      const unsigned base_b0 = smem_lds + (unsigned)(cur * STAGE + b_lane[0]), base_b1 = smem_lds + (unsigned)(cur * STAGE + b_lane[1]),
+                     base_b2 = smem_lds + (unsigned)(cur * STAGE + b_lane[2]);
+#define MCD_A3_FRAG(PC, I) \
+      if constexpr ((PC) < P::NPU) \
+        fa[PC][I] = frag_of(base_a, std::integral_constant<int, (PC) * BLKB + (I) * 256>{}, std::integral_constant<int, (PC) * BLKB + (I) * 256 + 64>{});
+#define MCD_B3_FRAG(PC, J, BASE) \
+      if constexpr ((PC) < P::NPU) \
+        fb[PC][J] = frag_of(BASE, std::integral_constant<int, (PC) * 3 * BLKB>{}, std::integral_constant<int, (PC) * 3 * BLKB + 64>{});
+      MCD_A3_FRAG(0, 0) MCD_A3_FRAG(0, 1) MCD_B3_FRAG(0, 0, base_b0) MCD_B3_FRAG(0, 1, base_b1) MCD_B3_FRAG(0, 2, base_b2)
+      MCD_A3_FRAG(1, 0) MCD_A3_FRAG(1, 1) MCD_B3_FRAG(1, 0, base_b0) MCD_B3_FRAG(1, 1, base_b1) MCD_B3_FRAG(1, 2, base_b2)
+#undef MCD_A3_FRAG
+#undef MCD_B3_FRAG
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < nsteps) {
+        advance();
+        issue(nxt2);
+        if (dma_on)
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA) : "memory");
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+#pragma unroll
+      for (int pc = 0; pc < P::NPU; ++pc) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) asm volatile("" : "+v"(fa[pc][i]));
+#pragma unroll
+        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(fb[pc][j]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- matrix phase: term-major, the sums and their order per 32 x 32 tile of conv_wgrad_split_tr_kernel
+#pragma unroll
+      for (int tm = 0; tm < P::NTERMS; ++tm)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[i][j] = P::mfma(fa[P::TA[tm]][i], fb[P::TB[tm]][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" ::: "memory");
+      cur = cur == 2 ? 0 : cur + 1;
+      nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+    }
+    if (grp_id == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's last matrix-phase barrier: the groups are level again
+
+    // ---- the item's raw sums (scaled units): slab[item][co 128][kx 3][ci 128]
+    float* out = p.slab + (size_t)item * (128 * 384);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) out[row * 384 + wn * 96 + j * 32 + l31] = acc[i][j][r];
+      }
+  }
+}
+
+// dw[co][ci][tap] = scale * sum over the tile's slabs in K order (fp64); tile = (128 co, 128 ci, kernel row ky), slab item = slab * tiles +
+// tile.  A block owns 64 consecutive ci of one co for all taps (wave w: taps w, w + 4, ...); the T values of a (co, ci) pair leave
+// through LDS as one contiguous run of dw [Cout][Cin][T].
+__global__ __launch_bounds__(256) void wgrad_reduce_rt_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int KH,
+                                                             int ci_tiles, int slabs, int tiles_all, const float* __restrict__ x_bound,
+                                                             const float* __restrict__ dy_bound) {
+  __shared__ float stage[64 * 33];
+  const int T = KH * 3;
+  const int co = blockIdx.y;
+  const int ci0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ci = ci0 + lane;
+  const double sc = x_bound != nullptr ? (double)mcd_scale_of_bound(*x_bound) * (double)mcd_scale_of_bound(*dy_bound) : 1.0;
+  const int nci = Cin - ci0 < 64 ? Cin - ci0 : 64;
+  const size_t SL = (size_t)tiles_all * (128 * 384);
+  for (int tap = wave; tap < T; tap += 4) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int tile = ((co >> 7) * ci_tiles + (ci0 >> 7)) * KH + ky;
+    double s = 0.0;
+    if (ci < Cin) {
+      const float* src = slab + ((size_t)tile * 128 + (co & 127)) * 384 + kx * 128 + (ci & 127);
+      int k = 0;
+      for (; k + 8 <= slabs; k += 8, src += 8 * SL) {  // eight loads in flight, added in slab order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[u * SL];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
+      }
+      for (; k < slabs; ++k, src += SL) s += (double)*src;
+    }
+    stage[lane * T + tap] = (float)(s * sc);
+  }
+  __syncthreads();
+  float* out = dw + ((size_t)co * Cin + ci0) * T;
+  for (int i = threadIdx.x; i < nci * T; i += 256) out[i] = stage[i];
+}
+
 int pp_compute_units() {
   static const int n = [] {
     const char* w = getenv("MCDSEG_WGRAD_PP_CUS");  // development knob: plan the weight gradient for fewer CUs than the chip has
@@ -439,5 +693,77 @@ int mcdseg_internal_wgrad_pp_launch(const mcdseg_conv_desc* d, int math, const v
   hipLaunchKernelGGL(wgrad_reduce_sk_kernel, dim3((unsigned)ceil_div(d->Cin, 64), (unsigned)d->Cout), dim3(256), 0, st, (const float*)slab, dw, d->Cout,
                      d->Cin, T, p.ci_tiles, p.kt, L, slabs, p.co_tiles * p.ci_tiles * T, x_bound, dy_bound);
   MCD_LAUNCH_CHECK("wgrad_reduce_sk");
+  return 0;
+}
+
+// The slab plan of the row-of-taps kernel: workgroups (0 when it does not apply), K-steps per slab, slabs, slab floats.  It takes the
+// 3 x KH kernels whose channel counts leave the 256 x 256 kernel out -- more than 64 channels on both sides, at most 128 on one -- when
+// the 128-channel tiles are at least three quarters full.  MCDSEG_WGRAD_PP3=0 turns it off (read per call: tests).
+int mcdseg_internal_wgrad_pp3_plan(const mcdseg_conv_desc* d, int math, int* L, size_t* slab_floats, int* slabs_out) {
+  const char* e = getenv("MCDSEG_WGRAD_PP3");
+  if (e != nullptr && atoi(e) == 0) return 0;
+  if (slabs_out) *slabs_out = 0;
+  if (mcd_storage_math(math) != MCDSEG_MATH_F16X3 || (d->Cin & 7) || (d->Cout & 7)) return 0;
+  const int lo = d->Cin < d->Cout ? d->Cin : d->Cout;
+  if (lo <= 64 || (d->Cin >= 129 && d->Cout >= 129)) return 0;
+  if (d->KW != 3 || d->KH > 10 || d->pad > 128) return 0;
+  const int64_t co_tiles = ceil_div(d->Cout, 128), ci_tiles = ceil_div(d->Cin, 128);
+  if (4 * (int64_t)d->Cout * d->Cin < 3 * (co_tiles * 128) * (ci_tiles * 128)) return 0;  // (tiles less than three quarters full)
+  const int64_t kt = (int64_t)d->N * ceil_div(d->Wo, 16) * d->Ho;
+  const int64_t tiles = co_tiles * ci_tiles * d->KH, total = tiles * kt;
+  const int64_t nwg = pp_compute_units();
+  if (total < nwg * 32) return 0;
+  int64_t best_r = 0, best_ls = 0, best_ns = 0;
+  double best_eff = 0.0;
+  for (int64_t r = 1; r <= 4; ++r) {
+    int64_t ns = r * nwg / tiles;
+    if (ns < 1) continue;
+    if (ns > kt / 32) ns = kt / 32;
+    if (ns < 1) continue;
+    const int64_t ls = ceil_div64(kt, ns);
+    ns = ceil_div64(kt, ls);
+    const double eff = (double)total / ((double)nwg * (double)(ceil_div64(ns * tiles, nwg) * ls));
+    if (eff > best_eff + 0.02 || best_r == 0) best_r = r, best_ls = ls, best_ns = ns, best_eff = eff;
+    if (best_eff >= 0.95) break;
+  }
+  if (best_r == 0 || best_eff < 0.80) return 0;
+  const int64_t items = best_ns * tiles;
+  const int64_t rounds = ceil_div64(items, nwg);
+  if (items * 128 * 384 >= (1ll << 31)) return 0;
+  if (L) *L = (int)best_ls;
+  if (slabs_out) *slabs_out = (int)best_ns;
+  if (slab_floats) *slab_floats = (size_t)items * 128 * 384;
+  return (int)ceil_div64(items, rounds);
+}
+
+int mcdseg_internal_wgrad_pp3_launch(const mcdseg_conv_desc* d, int math, const void* x_cb, const float* x_bound, const void* dy_cb,
+                                     const float* dy_bound, float* dw, float* slab, hipStream_t st) {
+  WgradPpParams p;
+  int L = 0, slabs = 0;
+  const int nwg = mcdseg_internal_wgrad_pp3_plan(d, math, &L, nullptr, &slabs);
+  MCD_REQUIRE(nwg > 0 && slabs > 0, "conv_wgrad_split_pp3: the geometry has no plan");
+  const int64_t xb = (int64_t)d->N * d->Cin * d->H * d->W * 2, yb = (int64_t)d->N * d->Cout * d->Ho * d->Wo * 2;
+  MCD_REQUIRE(xb + 4096 < (1ll << 31) && yb + 4096 < (1ll << 31) && (d->Ncb == 0 || d->Ncb >= d->N),
+              "conv_wgrad_split_pp3: pre-split operands need < 2 GiB per operand piece and Ncb >= N");
+  p.x_cb = x_cb; p.dy_cb = dy_cb; p.slab = slab;
+  p.N = d->N; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+  p.co_tiles = ceil_div(d->Cout, 128); p.ci_tiles = ceil_div(d->Cin, 128);
+  p.tiles_x = ceil_div(d->Wo, 16); p.tiles_y = d->Ho;
+  p.kt = d->N * p.tiles_x * p.tiles_y;
+  p.L = L; p.nwg = nwg;
+  p.slabs = slabs; p.items = slabs * p.co_tiles * p.ci_tiles * d->KH;
+  p.x_cb_bytes = (int)xb; p.dy_cb_bytes = (int)yb;
+  p.x_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cin * d->H * d->W * 2;
+  p.dy_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cout * d->Ho * d->Wo * 2;
+  const dim3 grid((unsigned)(8 * ceil_div(nwg, 8)));
+  if (math == MCDSEG_MATH_F16X1)
+    hipLaunchKernelGGL(conv_wgrad_split_pp3_kernel<SplitF16x1>, grid, dim3(512), 0, st, p);
+  else
+    hipLaunchKernelGGL(conv_wgrad_split_pp3_kernel<SplitF16x3>, grid, dim3(512), 0, st, p);
+  MCD_LAUNCH_CHECK("conv_wgrad_split_pp3");
+  hipLaunchKernelGGL(wgrad_reduce_rt_kernel, dim3((unsigned)ceil_div(d->Cin, 64), (unsigned)d->Cout), dim3(256), 0, st, (const float*)slab, dw, d->Cout,
+                     d->Cin, d->KH, p.ci_tiles, slabs, p.co_tiles * p.ci_tiles * d->KH, x_bound, dy_bound);
+  MCD_LAUNCH_CHECK("wgrad_reduce_rt");
   return 0;
 }

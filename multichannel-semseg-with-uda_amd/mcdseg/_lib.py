@@ -213,7 +213,7 @@ def packed_f32_opsel_sites(path=None):
     return sites
 
 
-def spills_inside_matrix_loops(path=None, prefix=("conv_gemm_split_pp_kernel", "conv_wgrad_split_pp_kernel")):
+def spills_inside_matrix_loops(path=None, prefix=("conv_gemm_split_pp_kernel", "conv_wgrad_split_pp_kernel", "conv_wgrad_split_pp3_kernel")):
     """[(kernel symbol, line offset)] of every scratch (spill) access that lies BETWEEN the first and the last matrix instruction of a
     ping-pong kernel, i.e. inside or between its K loops; must be empty.  (The 256 x 256 and 256 x 128 forward tiles hold 10 / 13
     spilled registers -- values parked before the K loop and fetched back in the epilogue, which costs a few scratch accesses per

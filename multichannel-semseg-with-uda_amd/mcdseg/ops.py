@@ -654,7 +654,7 @@ def split_companion_padded(x, bound=None):
 _WGRAD_NAMES = {10: "conv_wgrad_split_kernel<%s>", 11: "conv_wgrad_split_cb_kernel<%s>", 12: "conv_wgrad_split_tr_kernel<%s, 2, 2, 3, false>",
                 13: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3, false>", 14: "conv_wgrad_split_tr64_kernel<%s>",
                 16: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3, true>",
-                17: "conv_wgrad_split_pp_kernel<%s>"}
+                17: "conv_wgrad_split_pp_kernel<%s>", 18: "conv_wgrad_split_pp3_kernel<%s>"}
 WGRAD_TR64 = os.environ.get("MCDSEG_WGRAD_TR64", "1") != "0"
 
 

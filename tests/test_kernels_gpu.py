@@ -1746,6 +1746,62 @@ def test_conv_wgrad_pingpong_stream_k(case, monkeypatch):
         _assert_close(dw, gw_ref, 2e-5, "wgrad (ping-pong, stream-K)")
 
 
+# (Cin, Cout, k, stride, dil, H, W, N, math): 3 x 3 kernels with more than 64 channels on both sides and at most 128 on one
+WGRAD_PP3_CASES = [
+    (128, 128, 3, 1, 1, 60, 80, 16, "f16x3"),   # base.4.{0 conv2, 1, 2, 3}: BASELINE config 2's own shape, 3 tiles x 85 slabs
+    (128, 256, 3, 1, 2, 60, 80, 6, "f16x3"),    # base.5.0 conv1 (two co tiles), dilation 2
+    (96, 128, 3, 1, 1, 45, 50, 16, "f16x3"),    # ragged channel groups (the ci tile three quarters full), ragged 16-pixel stages
+    (128, 128, 3, 2, 1, 121, 163, 16, "f16x3"),  # stride 2: X is gathered through the convolution geometry
+    (128, 128, 3, 1, 1, 60, 80, 16, "f16x1"),   # the reduced-precision arithmetic (the piece-1 waves move nothing)
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_PP3_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_wgrad_row_of_taps(case, monkeypatch):
+    """``conv_wgrad_split_pp3_kernel`` (csrc/conv_wgrad_split_pp.hip; round 5): the weight gradient of the 128-channel layers on tiles
+    of 128 (co) x one kernel row of three taps x 128 (ci) -- the ping-pong kernel's structure, one staged dZ block serving three taps --
+    over the slab plan, one fp32 slab per item, summed in K order in fp64.  Named through ``mcdseg_conv_wgrad_variant == 18``; within
+    2e-5 of fp64; two runs agree bit for bit; and it equals the 4-wave transposed-read kernel (MCDSEG_WGRAD_PP3=0) to the last bits --
+    the same products, grouped into other partial sums."""
+    dev = _dev()
+    import ctypes
+    from mcdseg import ops
+    cin, cout, k, s, d, h, w, n, math = case
+    monkeypatch.setattr(ops, "CONV_MATH", math)
+    monkeypatch.delenv("MCDSEG_WGRAD_PP3", raising=False)
+    x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, s, d, h, w, n, False), 53)
+    desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
+    L, mid = ops.lib(), ops.MATH_ID[math]
+    assert L.mcdseg_conv_wgrad_variant(ctypes.byref(desc), mid, 1) == 18
+    gy = torch.randn(n, cout, desc.Ho, desc.Wo, generator=torch.Generator().manual_seed(54))
+    xg, gyg = x.to(dev), gy.to(dev)
+    x_cb, x_bound = ops.split_companion(xg)
+    gy_cb, gy_bound = ops.split_companion(gyg)
+    names = []
+
+    class _Names:
+        def wants(self, name):
+            names.append(name)
+            return False
+    prev, ops.LAUNCH_TIMER = ops.LAUNCH_TIMER, _Names()
+    try:
+        dw = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
+    finally:
+        ops.LAUNCH_TIMER = prev
+    assert names == ["conv_wgrad_split_pp3_kernel<%s>" % ops.POLICY[math]], names
+    assert torch.equal(dw, ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)), "two runs differ"
+    monkeypatch.setenv("MCDSEG_WGRAD_PP3", "0")
+    assert L.mcdseg_conv_wgrad_variant(ctypes.byref(desc), mid, 1) in (12, 13)
+    dw_tr = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
+    scale = float(dw_tr.abs().max())
+    assert float((dw - dw_tr).abs().max()) <= 4e-6 * scale, float((dw - dw_tr).abs().max()) / scale
+    if math == "f16x3":
+        x64, w64 = x.double(), wt.double().requires_grad_()
+        ref = F.conv2d(x64, w64, None, stride=s, padding=pad, dilation=d)
+        (gw_ref,) = torch.autograd.grad(ref, [w64], gy.double())
+        _assert_close(dw, gw_ref, 2e-5, "wgrad (row of taps)")
+
+
 @pytest.mark.parametrize("case", [(128, 128, 3, 1, 1, 12, 16, 2), (136, 200, 3, 1, 2, 13, 19, 2), (256, 128, 3, 1, 4, 9, 10, 1), (128, 128, 3, 2, 1, 15, 17, 2),
                                   (72, 80, 3, 1, 1, 8, 8, 3), (128, 256, 3, 1, 2, 30, 40, 4), (128, 136, 5, 1, 1, 9, 11, 1)], ids=lambda c: "x".join(map(str, c)))
 def test_conv_wgrad_two_taps_per_workgroup(case, monkeypatch):

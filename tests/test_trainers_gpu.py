@@ -299,6 +299,30 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path):
         assert out[1][k] == out[2][k], k
 
 
+def test_two_ranks_bucketed_overlap_with_rank_local_arrival_orders(tmp_path):
+    """ADVICE r4 (medium) through the real kernels: MCDSEG_DP_OVERLAP=1 with small buckets on two ranks whose gradients reach the
+    buckets at DIFFERENT times -- rank 0 defers its weight gradients to the side stream (early deliveries through the sink), rank 1
+    keeps them on the main stream (DP_SKEW).  Started "when complete", the buckets' collectives would be issued in different orders
+    on the two ranks (gloo pairs them by order: wrong sums or a hang); started in bucket order they match, and -- same batch on both
+    ranks -- the step equals the single-process step bit for bit."""
+    _need_gpu()
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    worker = os.path.join(here, "dp_worker.py")
+    out = {}
+    for world in (1, 2):
+        fn = str(tmp_path / ("fp%d.json" % world))
+        r = _run_ranks(world, worker, [fn], extra_env={"MCDSEG_DP_OVERLAP": "1", "MCDSEG_DP_BUCKET_MB": "4", "DP_SKEW": "1",
+                                                       "MCDSEG_DIST_FORCE": "1"}, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        out[world] = json.load(open(fn))
+    assert out[1].pop("world") == 1 and out[2].pop("world") == 2
+    assert out[1].pop("deferred") > 0 and out[2].pop("deferred") > 0  # (rank 0 of either run deferred: the early path was exercised)
+    assert out[1].keys() == out[2].keys() and len(out[1]) > 200
+    for k in out[1]:
+        assert out[1][k] == out[2][k], k
+
+
 def test_bench_with_two_ranks_on_one_gpu():
     """``bench.py --gpus 2`` under a launcher, both ranks on cuda:0 over gloo: the multi-rank branch of the benchmark (per-rank
     batches, barrier + MAX-over-ranks timing, rank 0's single JSON line with the whole-job rate) on the real step."""
