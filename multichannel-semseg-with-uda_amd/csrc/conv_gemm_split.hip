@@ -491,7 +491,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
 #if !defined(MCD_ABLATE) || !(MCD_ABLATE & 1)  // MCD_ABLATE: timing-only variant builds (tools/build_variant.py), never shipped
         dma_weights(nxt2);
 #endif
-#if !defined(MCD_ABLATE) || !(MCD_ABLATE & 2)
+#if defined(MCD_ABLATE) && (MCD_ABLATE & 64)  // timing only: the pixel operand moved for ONE tap of a channel chunk (what a staged window would move)
+        if (l_tap == 0) dma_b(nxt2);
+#elif !defined(MCD_ABLATE) || !(MCD_ABLATE & 2)
         dma_b(nxt2);
 #endif
       }

@@ -166,6 +166,9 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
       if (LANEHALF) ok = ok && (l_c0 >> 3) + khalf[x] < C8;  // (the ragged last chunk's second k-half)
       voff[x] = ok ? (vbase[x] + (unsigned)rel) * 16u : OOB;
     }
+#if defined(MCD_ABLATE) && (MCD_ABLATE & 64)  // timing only (never shipped): the pixel operand moved for ONE tap of a channel chunk
+    if (l_tap == 0)
+#endif
 #pragma unroll
     for (int i = 0; i < B_DMAS; ++i) {
       const int unit0 = wave * 64 + i * NT;  // this wave's first unit of the stage: wave-uniform, and so is its plane (LANEHALF: its piece)
