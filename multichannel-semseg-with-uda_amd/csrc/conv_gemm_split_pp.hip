@@ -44,10 +44,9 @@ namespace {
 //   <1, 5, 2, 2>  128 x 320, waves of 32 x 160: the same for the 128-channel layers.
 //   <1, 5, 4, 1>  256 x 160, waves of 32 x 160: for HALF the pixels (N = 8: 38400 = 240 tiles of 160).
 // (Round 5 built <1, 5, 1, 4> too -- 64 x 640 for the 64-channel layers, 307200 pixels = 480 tiles -- and measured it SLOWER than the
-// 4-wave 64 x 256 tiles: forward 0.115 against 0.091 ms, data gradient 0.105 against 0.088, the step + 1.4 ms.  With 64 output rows a
-// K-step moves 12 KB of operands per executed MFLOP through L2 whatever the tile's width -- three times the big tiles' -- and the
-// 4-wave kernel, three workgroups to a CU, keeps more of those loads in flight than one 8-wave workgroup does; what would help these
-// layers is re-using a staged pixel window across the nine taps, not a wider tile.  DESIGN.md section 4.1f.)
+// 4-wave 64 x 256 tiles: forward 0.115 against 0.091 ms, data gradient 0.105 against 0.088, the step + 1.4 ms.  An ablation that moves
+// the pixel operand once per channel chunk instead of once per tap (MCD_ABLATE & 64 below) leaves the 64-row layers unchanged: they pay
+// per K-step -- barrier, counted wait, DMA look-ahead -- against 12 matrix instructions per wave, not per byte.  DESIGN.md section 4.1f.)
 //   <2, 5, 2, 2>  256 x 320, waves of 64 x 160, one workgroup per CU (120 KB): the tile WIDTH is the knob against round quantisation --
 //                 76800 pixels (BASELINE config 2, 1/8 resolution) are 300 tiles of 256 (1.17 rounds of 256 CUs: the last 44 tiles
 //                 cost a whole round) but 240 tiles of 320 (0.94 of ONE round).  A wave's 160 pixels are one BatchNorm partial row.
