@@ -509,6 +509,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMA_PER_STEP) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#elif defined(MCD_ABLATE) && (MCD_ABLATE & 128)  // timing only: a workgroup barrier and a DMA wait every SECOND K-step (wrong results)
+      if (s & 1) {
+        if (more2)
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DMA_PER_STEP) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
 #else
       if (more2)
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DMA_PER_STEP) : "memory");
