@@ -105,6 +105,62 @@ def test_weight_gradient_batch_pieces_respect_the_library_limit(monkeypatch, mat
     assert ops._batch_pieces(d, wgrad_cb=True) == ops._batch_pieces(d) == [(0, 2), (2, 4), (4, 5)]
 
 
+def test_weight_gradient_plan_of_every_config2_layer():
+    """Which kernel ``mcdseg_conv_split_wgrad`` launches for each convolution of drn_d_38 at BASELINE config 2 (N = 16, 6 x 480 x 640;
+    SURVEY.md appendix A) when both companions are passed -- host-side arithmetic of the library (``mcdseg_conv_wgrad_variant``), so the
+    dispatch table is pinned without a GPU: 15 the thin-layer window kernel, 14 the 64-wide tap pairs (from 24 channels up: round 5),
+    18 the row-of-taps ping-pong kernel of the 128-channel layers (round 5), 17 the 256 x 256 ping-pong kernel, 12 the 4-wave 128 x 128
+    tiles (what is left: the 1 x 1 projection 128 -> 256), 1 the f32 64 x 64 plan (the 41-channel seg head)."""
+    import ctypes
+    from mcdseg import ops
+    L = ops.lib()
+    layers = [  # (Cin, Cout, k, stride, dil, H, W) -> variant
+        ((16, 16, 3, 1, 1, 480, 640), 15), ((16, 32, 3, 2, 1, 480, 640), 15),
+        ((32, 64, 3, 2, 1, 240, 320), 14), ((32, 64, 1, 2, 1, 240, 320), 14), ((64, 64, 3, 1, 1, 120, 160), 14),
+        ((64, 128, 3, 2, 1, 120, 160), 14), ((64, 128, 1, 2, 1, 120, 160), 14),
+        ((128, 128, 3, 1, 1, 60, 80), 18), ((128, 256, 3, 1, 2, 60, 80), 18), ((128, 256, 1, 1, 1, 60, 80), 12),
+        ((256, 256, 3, 1, 2, 60, 80), 17), ((256, 512, 3, 1, 4, 60, 80), 17), ((256, 512, 1, 1, 1, 60, 80), 17),
+        ((512, 512, 3, 1, 4, 60, 80), 17), ((512, 512, 3, 1, 2, 60, 80), 17), ((512, 512, 3, 1, 1, 60, 80), 17),
+        ((512, 41, 1, 1, 1, 60, 80), 1),
+    ]
+    for (cin, cout, k, s, d, h, w), want in layers:
+        desc = ops.conv_desc((16, cin, h, w), (cout, cin, k, k), s, d * (k // 2), d)
+        got = L.mcdseg_conv_wgrad_variant(ctypes.byref(desc), ops.MATH_ID["f16x3"], 1)
+        assert got == want, ((cin, cout, k, s, d, h, w), got, want)
+        # the workspace the entry point asks for covers the plan's slabs, and one launch addresses these operands
+        assert L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(desc)) > 0
+        assert L.mcdseg_conv_wgrad_fits(ctypes.byref(desc), ops.MATH_ID["f16x3"], 1) == 1
+
+
+def test_forward_and_data_gradient_plan_of_every_config2_layer():
+    """The same for forward and data gradient (``mcdseg_conv_split_wide_pingpong`` / ``_window_ok`` / ``_direct_ok`` /
+    ``_tile_config``; host-side arithmetic, 256 CUs assumed off the GPU): the 256- and 512-row problems on the 256 x 320 ping-pong tile
+    (1), the 128-row ones on its 128 x 320 form (2), the stem's forward on the direct kernel, the 16 -> 16 layer on the LDS-window
+    kernels, everything else on the 4-wave tiles (64 x 256 for 64 rows, 32 x 256 below)."""
+    import ctypes
+    from mcdseg import ops
+    L, mid = ops.lib(), ops.MATH_ID["f16x3"]
+    # (Cin, Cout, k, stride, dil, H, W) -> (wide forward, wide dgrad, window forward, window dgrad, direct, 4-wave tile fwd, 4-wave tile dgrad)
+    layers = [
+        ((6, 16, 7, 1, 1, 480, 640), (0, 0, 1, 0, 1, 1214, 1214)), ((16, 16, 3, 1, 1, 480, 640), (0, 0, 1, 1, 0, 1214, 1214)),
+        ((16, 32, 3, 2, 1, 480, 640), (0, 0, 0, 0, 0, 1214, 1214)), ((32, 64, 3, 2, 1, 240, 320), (0, 0, 0, 0, 0, 2214, 1214)),
+        ((64, 64, 3, 1, 1, 120, 160), (0, 0, 0, 0, 0, 2214, 2214)), ((64, 128, 3, 2, 1, 120, 160), (2, 0, 0, 0, 0, 2222, 2214)),
+        ((128, 128, 3, 1, 1, 60, 80), (2, 2, 0, 0, 0, 2222, 2222)), ((128, 256, 3, 1, 2, 60, 80), (1, 2, 0, 0, 0, 2222, 2222)),
+        ((256, 256, 3, 1, 2, 60, 80), (1, 1, 0, 0, 0, 2222, 2222)), ((256, 512, 3, 1, 4, 60, 80), (1, 1, 0, 0, 0, 4222, 2222)),
+        ((512, 512, 3, 1, 4, 60, 80), (1, 1, 0, 0, 0, 4222, 4222)), ((512, 41, 1, 1, 1, 60, 80), (0, 0, 0, 0, 0, 2214, 4222)),
+    ]
+    for (cin, cout, k, s, d, h, w), want in layers:
+        desc = ops.conv_desc((16, cin, h, w), (cout, cin, k, k), s, d * (k // 2), d)
+        got = (L.mcdseg_conv_split_wide_pingpong(ctypes.byref(desc), mid, 1, 0), L.mcdseg_conv_split_wide_pingpong(ctypes.byref(desc), mid, 1, 1),
+               L.mcdseg_conv_split_window_ok(ctypes.byref(desc), mid, 1, 0), L.mcdseg_conv_split_window_ok(ctypes.byref(desc), mid, 1, 1),
+               L.mcdseg_conv_split_direct_ok(ctypes.byref(desc)), L.mcdseg_conv_split_tile_config(cout, 16 * desc.Ho * desc.Wo, 1),
+               L.mcdseg_conv_split_tile_config(cin, 16 * h * w, 1))
+        assert got == want, ((cin, cout, k, s, d, h, w), got, want)
+        if want[0]:  # a wide tile takes the whole convolution, and its BatchNorm partial rows are one per 160 pixels
+            assert L.mcdseg_conv_split_parts(ctypes.byref(desc), mid, 1, 0) == 16 * desc.Ho * desc.Wo
+            assert L.mcdseg_conv_split_stat_rows_for(ctypes.byref(desc), mid, 1) == 2 * ((16 * desc.Ho * desc.Wo + 319) // 320)
+
+
 def test_grad_box_protocol_and_kernel_names():
     """Host logic of round 4 that needs no GPU: ``ops.GradBox`` (every producer of a shared gradient but the last leaves its tensor and
     reports None, the last returns what was left -- over several backward passes through one graph), the ping-pong kernel names the
