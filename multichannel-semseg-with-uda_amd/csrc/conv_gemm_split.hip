@@ -42,7 +42,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
   // B_DMA: the pre-split operand also goes global -> LDS by DMA (see dma_b); that K loop keeps NSTAGE LDS stages: with three,
   // the DMAs of step s+2 are in flight while step s multiplies -- a K-step of the three-term arithmetic is only ~400-800
   // cycles, less than a round trip beyond the XCD's L2
-  constexpr bool B_DMA = PRESPLIT && A_DMA && (B_ITEMS == 1 || (BM == 128 && BN == 256));  // (the 128 x 256 tile: two k-halves per thread)
+  // (the 128 x 256 tile: two k-halves per thread.  The 64 x 256 tile of the 64-channel layers stays on the register-staged two-stage
+  // loop: on the all-DMA loop it is SLOWER -- forward 0.086 -> 0.094 ms, data gradient 0.105 -> 0.123 in the step; round 5)
+  constexpr bool B_DMA = PRESPLIT && A_DMA && (B_ITEMS == 1 || (BM == 128 && BN == 256));
   constexpr int NSTAGE = (B_DMA && 3 * (A_BYTES + B_BYTES) <= 80 * 1024) ? 3 : 2;  // two workgroups per CU must still fit 160 KiB
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * (A_BYTES + B_BYTES)];
