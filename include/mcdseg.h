@@ -239,6 +239,22 @@ int mcdseg_bn_bwd_reduce_zmask(const float* dy, const float* z, const float* mea
 int mcdseg_bn_bwd_apply_cb_zmask(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                                  const float* beta, const float* dgamma, const float* dbeta, float* dz, void* dz_cb,
                                  const float* dz_bound, int32_t math, int32_t N, int32_t C, int32_t HW, int32_t train, void* stream);
+/* The same economy for a ReLU group WITH a residual branch (models/drn.py:48-57: out = relu(bn2(conv2(out)) + residual)), whose mask
+ * cannot be recomputed from z: the forward apply kernel also writes the mask as a bit-plane -- per (image, channel) and block of 256
+ * pixels four 64-bit words, bit l of word j = (y > 0) of pixel 256 blk + 4 l + j; mcdseg_bn_relu_mask_bytes gives its size, 0 when the
+ * geometry has none (HW not a multiple of 4) -- and the backward pair reads 1 bit per element where mcdseg_bn_bwd_reduce /
+ * mcdseg_bn_bwd_apply_cb read the 32 of the fp32 y: 8 instead of 12 and 16 instead of 20 bytes per element.  y > 0 is evaluated once, on
+ * the value that was stored: the same mask, the same results bit for bit.  Tensors 16-byte aligned, the mask 8-byte aligned. */
+size_t mcdseg_bn_relu_mask_bytes(int32_t N, int32_t C, int32_t HW);
+int mcdseg_bn_apply_cb_mask(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            const float* residual, float* y, void* y_cb, const float* y_bound, void* relu_mask, int32_t math, int32_t N,
+                            int32_t C, int32_t HW, void* stream);
+int mcdseg_bn_bwd_reduce_mask(const float* dy, const void* relu_mask, const float* z, const float* mean, const float* rstd,
+                              const float* gamma, float* dgamma, float* dbeta, float* dz_bound, int32_t train, int32_t N, int32_t C,
+                              int32_t HW, void* workspace, size_t workspace_bytes, void* stream);
+int mcdseg_bn_bwd_apply_cb_mask(const float* dy, const void* relu_mask, const float* z, const float* mean, const float* rstd,
+                                const float* gamma, const float* dgamma, const float* dbeta, float* dz, float* dres, void* dz_cb,
+                                const float* dz_bound, int32_t math, int32_t N, int32_t C, int32_t HW, int32_t train, void* stream);
 /* Backward.  dy is the gradient w.r.t. y; y (the saved forward output) -- or, when y == NULL, its companion y_cb of
  * arithmetic `math` -- supplies the ReLU mask when relu != 0.  reduce: dgamma[c] = sum dy_m*xhat, dbeta[c] = sum dy_m.
  * With z == NULL only dbeta is produced (used for the conv bias gradient, models/dilated_fcn.py:227).

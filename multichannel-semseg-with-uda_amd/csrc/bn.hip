@@ -288,7 +288,7 @@ BwdPlan bwd_plan(int N, int C, int HW) {
   if (cpp > max_cpp) cpp = max_cpp;
   if (cpp < 1) cpp = 1;
   int chunk = ceil_div(HW, cpp);
-  chunk = round_up(chunk, 4);
+  chunk = round_up(chunk, 256);  // (whole 256-pixel blocks: a wave of the float4 loop then walks exactly one block of the ReLU bit-plane)
   pl.cpp = ceil_div(HW, chunk);
   pl.chunk = chunk;
   int64_t items = (int64_t)N * pl.cpp;
@@ -297,13 +297,25 @@ BwdPlan bwd_plan(int N, int C, int HW) {
   return pl;
 }
 
+// ReLU bit-plane of a group WITH residual (round 5).  Such a group's backward pass needs y > 0 and cannot recompute it from z (the
+// residual enters), so until round 5 both backward kernels read the fp32 y for it: 4 of their 12 / 20 bytes per element.  The forward
+// apply kernel now also writes the mask -- per (image, channel) and block of 256 pixels four 64-bit words, bit l of word j = (y > 0) of
+// pixel 256 blk + 4 l + j: the ballots of a wave of the four-pixel kernels, whose lane l owns pixels 4 l .. 4 l + 3 of the block -- and
+// the backward kernels read 1 bit where they read 32.  The same mask, bit for bit: y > 0 evaluated once, on the value that was stored.
+__device__ __forceinline__ unsigned long long mcd_readlane64(unsigned long long v, int src_lane) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xFFFFFFFFull), src_lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src_lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                             const float* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ part, int N,
                                                             int C, int HW, int relu, int cpp, int chunk,
                                                             float* __restrict__ dz_bound, const float* __restrict__ mgamma,
-                                                            const float* __restrict__ mbeta) {
+                                                            const float* __restrict__ mbeta,
+                                                            const unsigned long long* __restrict__ rmask = nullptr, int nblk = 0) {
   const int c = blockIdx.x;
   const int S = gridDim.y;
   if (dz_bound != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *dz_bound = 0.f;  // finalize: atomic max
@@ -327,11 +339,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       const float4* dy4 = reinterpret_cast<const float4*>(dy + base);
       const float4* y4 = reinterpret_cast<const float4*>(y ? y + base : nullptr);
       const float4* z4 = reinterpret_cast<const float4*>(z ? z + base : nullptr);
-      for (int i = (e0 >> 2) + threadIdx.x; i < (e1 >> 2); i += 256) {
+      const int lane = threadIdx.x & 63;
+      // (stepped per WAVE: ib is the wave's first float4 -- a multiple of 64, chunks being whole 256-pixel blocks -- so that the four
+      // words of the wave's block of the ReLU bit-plane are loaded once, by lanes 0-3; per thread the same elements in the same order
+      // as a plain strided loop)
+      for (int ib = (e0 >> 2) + (threadIdx.x & ~63); ib < (e1 >> 2); ib += 256) {
+        unsigned long long w0 = 0ull, w1 = 0ull, w2 = 0ull, w3 = 0ull;
+        if (rmask != nullptr) {  // (wave-uniform control flow up to here: every lane takes part in the broadcasts)
+          unsigned long long mw = 0ull;
+          if (lane < 4) mw = rmask[(((size_t)n * C + c) * nblk + (ib >> 6)) * 4 + lane];
+          w0 = mcd_readlane64(mw, 0); w1 = mcd_readlane64(mw, 1); w2 = mcd_readlane64(mw, 2); w3 = mcd_readlane64(mw, 3);
+        }
+        const int i = ib + lane;
+        if (i >= (e1 >> 2)) continue;
         float4 g = dy4[i];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (z) v = z4[i];
-        if (zm) {
+        if (rmask != nullptr) {
+          g.x = ((w0 >> lane) & 1ull) ? g.x : 0.f; g.y = ((w1 >> lane) & 1ull) ? g.y : 0.f;
+          g.z = ((w2 >> lane) & 1ull) ? g.z : 0.f; g.w = ((w3 >> lane) & 1ull) ? g.w : 0.f;
+        } else if (zm) {
           g.x = fmaf(v.x, ma, mb) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, ma, mb) > 0.f ? g.y : 0.f;
           g.z = fmaf(v.z, ma, mb) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, ma, mb) > 0.f ? g.w : 0.f;
         } else if (relu) {
@@ -581,7 +608,8 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_apply_cb_v4_kernel(const float* _
                                                              const typename P::elem* __restrict__ res_cb,
                                                              const float* __restrict__ res_bound, float* __restrict__ y,
                                                              typename P::elem* __restrict__ cb, const float* __restrict__ y_bound, int N,
-                                                             int C, int HW, int relu, int rev) {
+                                                             int C, int HW, int relu, int rev,
+                                                             unsigned long long* __restrict__ rmask = nullptr) {
   __shared__ typename P::frag lds[BN_V4_NT / 64][256];
   const int C8 = C >> 3;
   // rev: walk the tensor from its END -- the convolution that has just written z did so front to back, so the tail is what the
@@ -631,8 +659,22 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_apply_cb_v4_kernel(const float* _
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
   }
-  if (pix_wave < HW)  // wave-uniform
+  if (pix_wave < HW) {  // wave-uniform
+    if (rmask != nullptr) {  // the ReLU bit-plane (see mcd_readlane64): lane 4 e + j keeps the ballot of (channel e, pixel slot j)
+      const int lane = threadIdx.x & 63;
+      unsigned long long mine = 0ull;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned long long b = __ballot(v[j][e] > 0.f);
+          if (lane == 4 * e + j) mine = b;
+        }
+      const int nblk = (HW + 255) >> 8;
+      if (lane < 32) rmask[(((size_t)n * C + 8 * g + (lane >> 2)) * nblk + (pix_wave >> 8)) * 4 + (lane & 3)] = mine;
+    }
     split_store_x4<P>(v, inv_scale, cb, (size_t)N * C * HW, (size_t)ng * HW + pix_wave, HW - pix_wave < 256 ? HW - pix_wave : 256, lds[wave]);
+  }
 }
 
 template <class P>
@@ -696,7 +738,8 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_bwd_apply_cb_v4_kernel(const floa
                                                                  float* __restrict__ dz, float* __restrict__ dres,
                                                                  typename P::elem* __restrict__ cb, const float* __restrict__ dz_bound,
                                                                  const typename P::elem* __restrict__ y_cb, int N, int C, int HW,
-                                                                 int relu, int train, const float* __restrict__ mbeta, int rev) {
+                                                                 int relu, int train, const float* __restrict__ mbeta, int rev,
+                                                                 const unsigned long long* __restrict__ rmask = nullptr) {
   __shared__ typename P::frag lds[BN_V4_NT / 64][256];
   const int C8 = C >> 3;
   // rev: walk the tensor from its END -- the reduce pass that ran just before read dy and z front to back, so their tails are what the
@@ -722,11 +765,16 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_bwd_apply_cb_v4_kernel(const floa
   const int wave = threadIdx.x >> 6;
   const int pix_wave = (bx * BN_V4_NT + 64 * wave) * 4;
   const int pix = pix_wave + 4 * (threadIdx.x & 63);
+  // the ReLU bit-plane of a group with residual: the wave's 32 words (8 channels x 4 pixel slots), word 4 e + j in lane 4 e + j
+  const bool bm = relu && !zm && rmask != nullptr;
+  unsigned long long mw = 0ull;
+  if (bm && pix_wave < HW && (threadIdx.x & 63) < 32)
+    mw = rmask[(((size_t)n * C + 8 * g + ((threadIdx.x & 63) >> 2)) * ((HW + 255) >> 8) + (pix_wave >> 8)) * 4 + (threadIdx.x & 3)];
   float v[4][8];
   if (pix < HW) {
     const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
     unsigned ymask[4] = {0xFFu, 0xFFu, 0xFFu, 0xFFu};
-    if (relu && !zm && y == nullptr) {  // compact activation storage: the mask from the leading piece of y's companion
+    if (relu && !zm && !bm && y == nullptr) {  // compact activation storage: the mask from the leading piece of y's companion
 #pragma unroll
       for (int j = 0; j < 4; ++j) ymask[j] = mask_load<P>(y_cb, (size_t)ng * HW + pix + j);
     }
@@ -736,7 +784,11 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_bwd_apply_cb_v4_kernel(const floa
       const float4 z4 = *reinterpret_cast<const float4*>(z + base + (size_t)e * HW);
       float gv[4] = {g4.x, g4.y, g4.z, g4.w};
       const float zv[4] = {z4.x, z4.y, z4.z, z4.w};
-      if (zm) {
+      if (bm) {  // (v_readlane reads its source lane whatever the execution mask: lanes 0-31 loaded their words above, unconditionally)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!((mcd_readlane64(mw, 4 * e + j) >> (threadIdx.x & 63)) & 1ull)) gv[j] = 0.f;
+      } else if (zm) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (!(fmaf(zv[j], ca[e], cmb[e]) > 0.f)) gv[j] = 0.f;
@@ -1064,18 +1116,64 @@ extern "C" int mcdseg_unsplit_cb(const void* x_cb, const float* x_bound, int32_t
 
 static bool bwd_apply_v4(const float* dy, const float* y, const void* y_cb, const float* z, const float* mean, const float* rstd,
                          const float* gamma, const float* dgamma, const float* dbeta, float* dz, float* dres, void* dz_cb,
-                         const float* dz_bound, int math, int N, int C, int HW, int relu, int train, const float* mbeta, hipStream_t st) {
+                         const float* dz_bound, int math, int N, int C, int HW, int relu, int train, const float* mbeta, hipStream_t st,
+                         const unsigned long long* rmask = nullptr) {
   if (!bn_v4_on() || (HW & 3) != 0) return false;
   if ((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)dres) & 15) != 0) return false;
   const dim3 grid(ceil_div(HW, 4 * BN_V4_NT), N * (C / 8));
   const int rev = bn_reverse_walk();
   if (math == MCDSEG_MATH_F16X3)
     hipLaunchKernelGGL(bn_bwd_apply_cb_v4_kernel<SplitF16x3>, grid, dim3(BN_V4_NT), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres,
-                       (_Float16*)dz_cb, dz_bound, (const _Float16*)y_cb, N, C, HW, relu, train, mbeta, rev);
+                       (_Float16*)dz_cb, dz_bound, (const _Float16*)y_cb, N, C, HW, relu, train, mbeta, rev, rmask);
   else
     hipLaunchKernelGGL(bn_bwd_apply_cb_v4_kernel<SplitBf16x6>, grid, dim3(BN_V4_NT), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres,
-                       (__bf16*)dz_cb, dz_bound, (const __bf16*)y_cb, N, C, HW, relu, train, mbeta, rev);
+                       (__bf16*)dz_cb, dz_bound, (const __bf16*)y_cb, N, C, HW, relu, train, mbeta, rev, rmask);
   return true;
+}
+
+// ---- the ReLU bit-plane of a group with residual (round 5; see mcd_readlane64 above): three entry points beside the fp32-y forms
+extern "C" size_t mcdseg_bn_relu_mask_bytes(int32_t N, int32_t C, int32_t HW) {
+  // (the bit-plane is written and read by the four-pixel kernels only: HW a multiple of 4, channel groups of 8)
+  if (N <= 0 || C <= 0 || HW <= 0 || (C & 7) != 0 || (HW & 3) != 0 || !bn_v4_on()) return 0;
+  return (size_t)N * C * ((HW + 255) >> 8) * 32;
+}
+
+extern "C" int mcdseg_bn_apply_cb_mask(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                       const float* residual, float* y, void* y_cb, const float* y_bound, void* relu_mask, int32_t math,
+                                       int32_t N, int32_t C, int32_t HW, void* stream) {
+  math = mcd_storage_math(math);
+  MCD_REQUIRE(z && mean && rstd && gamma && beta && y_cb && relu_mask, "bn_apply_cb_mask: null pointer");
+  if (int rc = cb_check("bn_apply_cb_mask", math, y_bound, N, C, HW)) return rc;
+  MCD_REQUIRE(mcdseg_bn_relu_mask_bytes(N, C, HW) > 0 && (((uintptr_t)z | (uintptr_t)y | (uintptr_t)residual) & 15) == 0 &&
+                  ((uintptr_t)relu_mask & 7) == 0,
+              "bn_apply_cb_mask: needs HW %% 4 == 0, 16-byte aligned tensors and an 8-byte aligned mask (mcdseg_bn_relu_mask_bytes)");
+  const dim3 grid4(ceil_div(HW, 4 * BN_V4_NT), N * (C / 8));
+  const int rev = bn_reverse_walk();
+  if (math == MCDSEG_MATH_F16X3)
+    hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitF16x3>, grid4, dim3(BN_V4_NT), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
+                       (const _Float16*)nullptr, (const float*)nullptr, y, (_Float16*)y_cb, y_bound, N, C, HW, 1, rev,
+                       (unsigned long long*)relu_mask);
+  else
+    hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitBf16x6>, grid4, dim3(BN_V4_NT), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
+                       (const __bf16*)nullptr, (const float*)nullptr, y, (__bf16*)y_cb, y_bound, N, C, HW, 1, rev, (unsigned long long*)relu_mask);
+  MCD_LAUNCH_CHECK("bn_apply_cb_mask");
+  return 0;
+}
+
+extern "C" int mcdseg_bn_bwd_apply_cb_mask(const float* dy, const void* relu_mask, const float* z, const float* mean, const float* rstd,
+                                           const float* gamma, const float* dgamma, const float* dbeta, float* dz, float* dres, void* dz_cb,
+                                           const float* dz_bound, int32_t math, int32_t N, int32_t C, int32_t HW, int32_t train,
+                                           void* stream) {
+  math = mcd_storage_math(math);
+  MCD_REQUIRE(dy && relu_mask && z && mean && rstd && gamma && dz_cb, "bn_bwd_apply_cb_mask: null pointer");
+  MCD_REQUIRE(!train || (dgamma && dbeta), "bn_bwd_apply_cb_mask: train mode needs dgamma/dbeta");
+  if (int rc = cb_check("bn_bwd_apply_cb_mask", math, dz_bound, N, C, HW)) return rc;
+  MCD_REQUIRE(mcdseg_bn_relu_mask_bytes(N, C, HW) > 0, "bn_bwd_apply_cb_mask: no bit-plane exists for this geometry");
+  MCD_REQUIRE(bwd_apply_v4(dy, nullptr, nullptr, z, mean, rstd, gamma, dgamma, dbeta, dz, dres, dz_cb, dz_bound, math, N, C, HW, 1, train, nullptr,
+                           (hipStream_t)stream, (const unsigned long long*)relu_mask),
+              "bn_bwd_apply_cb_mask: tensors must be 16-byte aligned");
+  MCD_LAUNCH_CHECK("bn_bwd_apply_cb_mask");
+  return 0;
 }
 
 extern "C" int mcdseg_bn_bwd_apply_cb(const float* dy, const float* y, const void* y_cb, const float* z, const float* mean,
@@ -1204,6 +1302,27 @@ extern "C" int mcdseg_bn_bwd_reduce_zmask(const float* dy, const float* z, const
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, st, dy, (const float*)nullptr, z, mean, rstd, (float*)workspace, N, C,
                        HW, 1, pl.cpp, pl.chunk, dz_bound, gamma, beta);
   MCD_LAUNCH_CHECK("bn_bwd_reduce_zmask");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, pl.S, C, dgamma, dbeta, gamma,
+                     rstd, (float)N * (float)HW, train, dz_bound);
+  MCD_LAUNCH_CHECK("bn_bwd_finalize");
+  return 0;
+}
+
+// backward reduce of a ReLU group WITH residual from its bit-plane: 8 instead of 12 bytes per element
+extern "C" int mcdseg_bn_bwd_reduce_mask(const float* dy, const void* relu_mask, const float* z, const float* mean, const float* rstd,
+                                         const float* gamma, float* dgamma, float* dbeta, float* dz_bound, int32_t train, int32_t N, int32_t C,
+                                         int32_t HW, void* workspace, size_t workspace_bytes, void* stream) {
+  MCD_REQUIRE(dy && relu_mask && z && mean && rstd && dgamma && dbeta && workspace, "bn_bwd_reduce_mask: null pointer");
+  MCD_REQUIRE(dz_bound == nullptr || gamma, "bn_bwd_reduce_mask: the dz bound needs gamma");
+  MCD_REQUIRE(mcdseg_bn_relu_mask_bytes(N, C, HW) > 0 && aligned16(dy) && aligned16(z), "bn_bwd_reduce_mask: no bit-plane exists for this geometry");
+  MCD_REQUIRE(workspace_bytes >= mcdseg_bn_bwd_workspace_bytes(N, C, HW), "bn_bwd_reduce_mask: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const BwdPlan pl = bwd_plan(N, C, HW);
+  MCD_REQUIRE(pl.S <= 65535, "bn_bwd_reduce_mask: too many splits");
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(C, pl.S), dim3(256), 0, st, dy, (const float*)nullptr, z, mean, rstd, (float*)workspace, N, C,
+                     HW, 1, pl.cpp, pl.chunk, dz_bound, (const float*)nullptr, (const float*)nullptr, (const unsigned long long*)relu_mask,
+                     (HW + 255) >> 8);
+  MCD_LAUNCH_CHECK("bn_bwd_reduce_mask");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, pl.S, C, dgamma, dbeta, gamma,
                      rstd, (float)N * (float)HW, train, dz_bound);
   MCD_LAUNCH_CHECK("bn_bwd_finalize");

@@ -60,6 +60,10 @@ _SIGNATURES = {
     "mcdseg_bn_bwd_apply_cb": (c_int, [c_void_p] * 13 + [c_i32] * 6 + [c_void_p]),
     "mcdseg_bn_bwd_reduce_zmask": (c_int, [c_void_p] * 9 + [c_i32] * 4 + [c_void_p, c_size_t, c_void_p]),
     "mcdseg_bn_bwd_apply_cb_zmask": (c_int, [c_void_p] * 11 + [c_i32] * 5 + [c_void_p]),
+    "mcdseg_bn_relu_mask_bytes": (c_size_t, [c_i32] * 3),
+    "mcdseg_bn_apply_cb_mask": (c_int, [c_void_p] * 10 + [c_i32] * 4 + [c_void_p]),
+    "mcdseg_bn_bwd_reduce_mask": (c_int, [c_void_p] * 9 + [c_i32] * 4 + [c_void_p, c_size_t, c_void_p]),
+    "mcdseg_bn_bwd_apply_cb_mask": (c_int, [c_void_p] * 12 + [c_i32] * 5 + [c_void_p]),
     "mcdseg_conv_split_wgrad": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 8 + [c_size_t, c_void_p]),
     "mcdseg_conv_dgrad": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcdseg_conv_wgrad_variant": (c_i32, [_P(ConvDesc), c_i32, c_i32]),

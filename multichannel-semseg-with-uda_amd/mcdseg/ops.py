@@ -321,6 +321,9 @@ GROUP_PACK = os.environ.get("MCDSEG_GROUP_PACK", "1") != "0"
 FUSED_UP_LOSS = os.environ.get("MCDSEG_FUSED_UP_LOSS", "1") != "0"  # MCDSolver: up-sampler folded into the loss kernel
 # BatchNorm backward of a ReLU group without residual: the mask y > 0 recomputed from z (bit-identical), y never read
 BN_ZMASK = os.environ.get("MCDSEG_BN_ZMASK", "1") != "0"
+# BatchNorm backward of a ReLU group WITH residual: the mask y > 0 from a bit-plane the forward apply kernel wrote (1 bit per element)
+# instead of from the fp32 y (32): the same mask, bit for bit; "0": read y (round 4's form)
+RELU_MASK = os.environ.get("MCDSEG_RELU_MASK", "1") != "0"
 # the gradient of a residual block's input has two producers (the first convolution's data gradient and the shortcut); autograd would
 # add them with an element-wise kernel -- 80 adds of 40-160 MB tensors per MCD step, 7.3 ms at BASELINE config 2.  With this on the
 # one that runs second folds the other's tensor into its own epilogue (``GradBox``); "0": autograd's add (same bits, tests compare)
@@ -995,7 +998,7 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_
     return dx, dw
 
 
-def _channel_reduce(dy, y, z, mean, rstd, relu, gamma=None, want_bound=False, train=True, y_cb=None, zmask_beta=None):
+def _channel_reduce(dy, y, z, mean, rstd, relu, gamma=None, want_bound=False, train=True, y_cb=None, zmask_beta=None, rmask=None):
     """(dgamma, dbeta) of a BN (z given) or just the per-channel sum of dy (z None); with ``want_bound`` also the device
     scalar bounding |dz| of the tensor bn_bwd_apply will write from these sums (include/mcdseg.h).  ``zmask_beta``: the group
     has a ReLU and no residual, so the mask is recomputed from z and ``y`` is not read."""
@@ -1006,6 +1009,12 @@ def _channel_reduce(dy, y, z, mean, rstd, relu, gamma=None, want_bound=False, tr
     dgamma = torch.empty(c, dtype=torch.float32, device=dy.device) if z is not None else None
     dbeta = torch.empty(c, dtype=torch.float32, device=dy.device)
     bound = torch.empty(1, dtype=torch.float32, device=dy.device) if want_bound else None
+    if rmask is not None:  # a ReLU group with residual: the mask from its bit-plane (``RELU_MASK``), y is not read
+        with _timed("bn_bwd_reduce", (0, 4 * n * c * hw * 2)):
+            check(L.mcdseg_bn_bwd_reduce_mask(_p(dy), _p(rmask), _p(z), _p(mean), _p(rstd), _p(gamma) if want_bound else None, _p(dgamma),
+                                              _p(dbeta), _p(bound), int(train), n, c, hw, _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()),
+                  "bn_bwd_reduce_mask")
+        return dgamma, dbeta, bound
     if zmask_beta is not None:
         with _timed("bn_bwd_reduce", (0, 4 * n * c * hw * 2)):
             check(L.mcdseg_bn_bwd_reduce_zmask(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(zmask_beta), _p(dgamma), _p(dbeta), _p(bound),
@@ -1092,7 +1101,18 @@ class _ConvBNAct(torch.autograd.Function):
         y = _virtual(z.shape, z.device) if compact else torch.empty_like(z)
         y_cb = None
         elems = desc.N * c * hw
-        if want_cb:
+        rmask = None
+        if (want_cb and RELU_MASK and relu and has_res and training and not compact and res_cb is None and any(ctx.needs_input_grad)
+                and (z.data_ptr() | y.data_ptr() | residual.data_ptr()) % 16 == 0):
+            nbytes = L.mcdseg_bn_relu_mask_bytes(desc.N, c, hw)
+            if nbytes > 0:  # the ReLU bit-plane for this group's backward pass (see RELU_MASK)
+                rmask = torch.empty(nbytes // 8, dtype=torch.int64, device=z.device)
+        if rmask is not None:
+            y_cb = _cb_alloc(desc.N, c, hw, z.device)
+            with _timed("bn_apply_cb", (0, elems * (4 + 4 + 2 * PIECES[CONV_MATH] + 4) + rmask.numel() * 8)):
+                check(L.mcdseg_bn_apply_cb_mask(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), _p(y), _p(y_cb), _p(y_bound),
+                                                _p(rmask), MATH_ID[CONV_MATH], desc.N, c, hw, _stream()), "bn_apply_cb_mask")
+        elif want_cb:
             y_cb = _cb_alloc(desc.N, c, hw, z.device)
             with _timed("bn_apply_cb", (0, elems * (4 + (0 if compact else 4) + 2 * PIECES[CONV_MATH] + (4 if has_res else 0)))):
                 check(L.mcdseg_bn_apply_cb(_p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual) if res_cb is None else None,
@@ -1113,6 +1133,7 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.has_bias = conv_bias is not None
         ctx.x_cb, ctx.x_bound = x_cb, x_bound  # wgrad reads the input's split companion too (an input of this node: safe to hold)
         ctx.x_virtual, ctx.compact = x_virtual, compact
+        ctx.rmask = rmask
         ctx.save_for_backward(x, z, y, mean, rstd, gamma, y_cb if compact else None, y_bound if compact else None, beta)
         ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the non-differentiable companions
         for t in (y_cb, y_bound):
@@ -1150,9 +1171,11 @@ class _ConvBNAct(torch.autograd.Function):
         if ctx.compact and not use_cb:  # the plain backward kernels read the fp32 activation for the ReLU mask
             y, y_cb = materialize(y, y_cb, y_bound), None
         y_mask = (y if y_cb is None else None) if ctx.relu else None
+        # a ReLU group with residual: the mask from the bit-plane the forward pass wrote, where the four-pixel backward kernel will run
+        rmask = ctx.rmask if (ctx.relu and use_cb and not zmask and dy.data_ptr() % 16 == 0) else None
         dgamma, dbeta, dz_bound = _channel_reduce(dy, y_mask, z, mean, rstd, ctx.relu, gamma,
                                                   want_bound=_scaled() and (split_d or stem_tr or _wgrad_split_plan(desc)), train=ctx.training,
-                                                  y_cb=y_cb if ctx.relu else None, zmask_beta=beta if zmask else None)
+                                                  y_cb=y_cb if ctx.relu else None, zmask_beta=beta if zmask else None, rmask=rmask)
         dz = None
         dres = None
         if ctx.has_res and ctx.needs_input_grad[4]:
@@ -1174,6 +1197,12 @@ class _ConvBNAct(torch.autograd.Function):
                 check(L.mcdseg_bn_bwd_apply_cb_zmask(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dgamma), _p(dbeta), _p(dz),
                                                      _p(dz_cb), _p(dz_bound), MATH_ID[CONV_MATH], n, c, hw, int(ctx.training), _stream()),
                       "bn_bwd_apply_cb_zmask")
+        elif use_cb and rmask is not None:
+            dz_cb = _cb_alloc(n, c, hw, dy.device)
+            with _timed("bn_bwd_apply_cb", (0, rd - 4 * n * c * hw + 2 * PIECES[CONV_MATH] * n * c * hw)):
+                check(L.mcdseg_bn_bwd_apply_cb_mask(_p(dy), _p(rmask), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dz),
+                                                    _p(dres) if dres is not None else None, _p(dz_cb), _p(dz_bound), MATH_ID[CONV_MATH], n, c,
+                                                    hw, int(ctx.training), _stream()), "bn_bwd_apply_cb_mask")
         elif use_cb:
             dz_cb = _cb_alloc(n, c, hw, dy.device)
             with _timed("bn_bwd_apply_cb", (0, rd + 2 * PIECES[CONV_MATH] * n * c * hw)):

@@ -1472,6 +1472,64 @@ def test_bn_backward_mask_from_z_is_bitwise(cin, cout, hw, n, monkeypatch):
         assert (a is None and b is None) or torch.equal(a, b)
 
 
+@pytest.mark.parametrize("block,planes,stride,dil,hw,n", [("basic", 64, 1, 1, (12, 20), 2), ("basic", 128, 2, 1, (28, 40), 2),
+                                                          ("basic", 256, 1, 2, (60, 80), 3), ("bottleneck", 64, 1, 1, (10, 14), 2),
+                                                          ("basic", 64, 1, 1, (120, 160), 3)])
+def test_relu_bit_plane_is_bitwise_the_fp32_mask(block, planes, stride, dil, hw, n, monkeypatch):
+    """BatchNorm backward of a ReLU group WITH residual (the block's last group) takes its mask from the bit-plane the forward apply
+    kernel wrote (round 5: ``mcdseg_bn_apply_cb_mask`` / ``_bn_bwd_reduce_mask`` / ``_bn_bwd_apply_cb_mask``, 1 bit per element)
+    instead of from the fp32 y: block output and every gradient are bit-identical to the y-reading form (MCDSEG_RELU_MASK=0) -- ragged
+    256-pixel blocks, several 256-pixel blocks per reduce chunk and channel counts from 64 to 256 included -- and the mask entry
+    points are the ones that ran."""
+    dev = _dev()
+    from mcdseg import ops
+    from models import drn
+    g = torch.Generator().manual_seed(15)
+    inpl = planes * (4 if block == "bottleneck" else 1) if stride == 1 else planes // 2
+    x = torch.randn(n, inpl, *hw, generator=g).to(dev)
+    assert hw[0] * hw[1] % 4 == 0
+
+    def run(on):
+        monkeypatch.setattr(ops, "RELU_MASK", on)
+        torch.manual_seed(4)
+        cls = drn.BasicBlock if block == "basic" else drn.Bottleneck
+        outpl = planes * cls.expansion
+        down = None
+        if stride != 1 or inpl != outpl:
+            down = drn.ConvBN(drn.Conv2d(inpl, outpl, kernel_size=1, stride=stride, bias=False), drn.BatchNorm2d(outpl))
+        blk = cls(inpl, planes, stride, down, dilation=(dil, dil)).to(dev).train()
+        pre_c, pre_b = drn.Conv2d(inpl, inpl, 3, padding=1, bias=False).to(dev), drn.BatchNorm2d(inpl).to(dev).train()
+        xin = x.clone().requires_grad_()
+        h0 = ops.conv_bn_act(xin, pre_c, pre_b)
+        calls = []
+        L = ops.lib()
+        real = {k: getattr(L, k) for k in ("mcdseg_bn_apply_cb_mask", "mcdseg_bn_bwd_reduce_mask", "mcdseg_bn_bwd_apply_cb_mask")}
+
+        class Spy:  # (ctypes function objects cannot be patched in place: wrap the handle ops.lib() returns)
+            def __getattr__(self, name):
+                fn = getattr(L, name)
+                if name in real:
+                    def wrapped(*a, **kw):
+                        calls.append(name)
+                        return fn(*a, **kw)
+                    return wrapped
+                return fn
+        monkeypatch.setattr(ops, "lib", lambda: Spy())
+        out = blk(h0)
+        gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(16)).to(dev)
+        out.backward(gy)
+        monkeypatch.setattr(ops, "lib", lambda: L)
+        grads = [xin.grad] + [p.grad for p in blk.parameters()] + [pre_c.weight.grad, pre_b.weight.grad]
+        return out.detach(), grads, calls
+
+    o1, g1, c1 = run(True)
+    o0, g0, c0 = run(False)
+    assert sorted(set(c1)) == ["mcdseg_bn_apply_cb_mask", "mcdseg_bn_bwd_apply_cb_mask", "mcdseg_bn_bwd_reduce_mask"] and c0 == [], (c1, c0)
+    assert torch.equal(o1, o0)
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("block,planes,stride,dil,hw", [("basic", 64, 1, 1, (12, 20)), ("basic", 128, 2, 1, (13, 19)),
                                                         ("basic", 256, 1, 2, (9, 12)), ("bottleneck", 64, 1, 1, (10, 14))])
 def test_internal_groups_skip_the_fp32_output_bitwise(block, planes, stride, dil, hw, monkeypatch):
