@@ -237,6 +237,13 @@ def _compact_now():
 # (Taken for more than 32 channels and un-cut batches only: there the consumer's forward, data and weight gradient all run on the
 # split kernels.  A consumer that needs fp32 after all reconstructs it from the companion, 22 bits, as in compact storage.)
 INTERNAL_SKIP_Y = os.environ.get("MCDSEG_INTERNAL_SKIP_Y", "1") != "0"
+# ... and so need the groups of a trunk's plain convolution chains (models/drn.py:195-205: the stem, layer1, layer2, layer7) whose output
+# only the next stage's convolutions read (round 5; models/drn.py run_fused / _reads_companions_only decide, "0": they write fp32 too).
+# These include the 16- and 32-channel layers: their consumers' forward, data and weight gradients all read companions since the thin
+# layers' window kernels (round 2) and the tap-pair weight gradient from 24 channels up (round 5).
+INTERNAL_STAGES = os.environ.get("MCDSEG_INTERNAL_STAGES", "1") != "0"
+# a block's 1x1 projection shortcut is read as a residual only (fp32): its companion is not written ("0": it is, as before round 5)
+SHORTCUT_NO_CB = os.environ.get("MCDSEG_SHORTCUT_NO_CB", "1") != "0"
 
 
 def _virtual(shape, device):
@@ -1067,9 +1074,9 @@ class _ConvBNAct(torch.autograd.Function):
         rstd = torch.empty(c, dtype=torch.float32, device=z.device)
         # the pre-split companion of y: the scaled arithmetic needs |y|'s bound BEFORE y is written -- train-mode statistics
         # give one (Samuelson), eval-mode running statistics do not (the consumer then measures y)
-        want_cb = _cb_wanted(c) and desc.N * (c // 8) <= 65535 and (training or not _scaled())
+        want_cb = _cb_wanted(c) and desc.N * (c // 8) <= 65535 and (training or not _scaled()) and not aux.get("no_cb")
         compact = aux["compact"] and want_cb and training
-        if compact and aux.get("single_piece_only") and c <= 32:
+        if compact and aux.get("single_piece_only") and c <= 32 and not (aux.get("thin_ok") and c >= 16 and len(_batch_pieces(desc)) == 1):
             compact = False  # the consumer would run its weight gradient on the f32 kernels and read fp32
         res_cb = aux["res_cb"] if aux["res_virtual"] else None
         if aux["res_virtual"] and not want_cb:
@@ -1275,9 +1282,11 @@ def _conv_bn_act_inference(x, conv, bn, relu, residual):
     return y
 
 
-def conv_bn_act(x, conv, bn, relu=True, residual=None, internal=False, in_box=None, res_box=None):
+def conv_bn_act(x, conv, bn, relu=True, residual=None, internal=False, in_box=None, res_box=None, thin_ok=False, shortcut_only=False):
     """y = act(bn(conv(x)) + residual) with the HIP kernels; ``conv``/``bn`` are the parameter-holding modules.
     ``internal``: the caller promises that only the next fused group reads the result (see INTERNAL_SKIP_Y).
+    ``shortcut_only``: the caller promises that the result is only ever read as the ``residual`` of another group (a block's 1x1
+    projection shortcut): no convolution gathers it, so its pre-split companion is not written (fp32 storage; round 5).
     ``in_box`` / ``res_box``: the ``GradBox`` through which the gradient of ``x`` / of ``residual`` is summed with its other producer."""
     geom = (conv.stride[0], conv.padding[0], conv.dilation[0])
     training = bn.training
@@ -1292,7 +1301,8 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, internal=False, in_box=No
     skip_y = internal and INTERNAL_SKIP_Y and BN_ZMASK and relu and residual is None and _scaled()
     grads = torch.is_grad_enabled()
     aux = dict(x_virtual=is_virtual(x), res_virtual=is_virtual(residual), res_cb=res_cb, compact=_compact_now() or skip_y,
-               single_piece_only=skip_y and not _compact_now(),
+               single_piece_only=skip_y and not _compact_now(), thin_ok=thin_ok,
+               no_cb=bool(shortcut_only and SHORTCUT_NO_CB and not relu and residual is None and not _compact_now()),
                in_box=in_box.attach() if (in_box is not None and grads and x.requires_grad) else None,
                res_box=res_box.attach() if (res_box is not None and grads and residual is not None and residual.requires_grad) else None)
     y, y_cb, y_bound = _ConvBNAct.apply(x, _take_late(conv), bn.weight, bn.bias, residual, conv.bias, bn.running_mean if track else None,

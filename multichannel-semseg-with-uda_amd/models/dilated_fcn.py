@@ -43,7 +43,7 @@ class Trunk(FusedSequential):
         # runs as one fused group like everywhere else
         with ops.late_weight_grads(self):  # (the weight gradients of these layers may stay on the side stream, mcdseg/ops.py)
             with ops.trunk_internal():
-                x = run_fused(mods[:-1], x)
+                x = run_fused(mods[:-1], x, following=mods[-1])
             return run_fused(mods[-1:], x)
 
 

@@ -56,19 +56,51 @@ class FusedSequential(nn.Sequential):
         return run_fused(list(self.children()), x)
 
 
-def run_fused(mods, x):
-    """the fusing walk over a list of modules: (Conv2d, BatchNorm2d[, ReLU]) runs become one fused group each"""
+def run_fused(mods, x, internal_last=False, following=None):
+    """the fusing walk over a list of modules: (Conv2d, BatchNorm2d[, ReLU]) runs become one fused group each.  A ReLU group followed by
+    another fused group of the same list feeds that convolution only, and so does the last one when the caller says so
+    (``internal_last``: the next stage's convolutions are its only readers): such a group need not write its fp32 output
+    (``ops.conv_bn_act(..., internal=True)``; the same bits).  A child that is itself a convolution chain (the stages of a DRN as
+    children of ``models.dilated_fcn.Trunk``) is walked the same way, its last group internal when the child behind it --
+    ``following`` for the last of ``mods`` -- reads it through convolutions only."""
     i = 0
     while i < len(mods):
         m = mods[i]
         if isinstance(m, Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], BatchNorm2d):
             relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
-            x = ops.conv_bn_act(x, m, mods[i + 1], relu=relu)
-            i += 3 if relu else 2
+            nxt = i + (3 if relu else 2)
+            feeds_conv = (nxt + 1 < len(mods) and isinstance(mods[nxt], Conv2d) and isinstance(mods[nxt + 1], BatchNorm2d)) \
+                or (nxt >= len(mods) and internal_last)
+            x = ops.conv_bn_act(x, m, mods[i + 1], relu=relu, internal=bool(relu and feeds_conv and ops.INTERNAL_STAGES), thin_ok=True)
+            i = nxt
+        elif type(m) is FusedSequential:  # a stage of plain convolutions
+            nxt_stage = mods[i + 1] if i + 1 < len(mods) else following
+            x = run_fused(list(m.children()), x, internal_last=nxt_stage is not None and _reads_companions_only(nxt_stage))
+            i += 1
         else:
             x = m(x)
             i += 1
     return x
+
+
+def _reads_companions_only(stage):
+    """the stage that follows a convolution chain reads the chain's output through convolutions only (never as an identity shortcut, never
+    as a tensor it hands on): another convolution chain, or residual blocks whose first block projects its shortcut"""
+    if isinstance(stage, FusedSequential):
+        mods = list(stage.children())
+        return len(mods) >= 2 and isinstance(mods[0], Conv2d) and isinstance(mods[1], BatchNorm2d) and _companion_conv(mods[0])
+    if isinstance(stage, nn.Sequential) and len(stage) > 0 and isinstance(stage[0], (BasicBlock, Bottleneck)):
+        b = stage[0]
+        ds = list(b.downsample.children()) if isinstance(b.downsample, FusedSequential) else []
+        return (len(ds) == 2 and isinstance(ds[0], Conv2d) and isinstance(ds[1], BatchNorm2d) and _companion_conv(ds[0])
+                and _companion_conv(b.conv1))
+    return False
+
+
+def _companion_conv(conv):
+    """forward, data and weight gradient of this convolution all read the pre-split companion of its input (16 channels on the thin
+    layers' window kernels, 24 and more on the tap-pair / 128-wide / ping-pong plans)"""
+    return conv.in_channels >= 16 and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0 and conv.groups == 1
 
 
 ConvBNReLU = FusedSequential
@@ -83,7 +115,7 @@ def _project(downsample, x, box):
     """the 1x1 projection shortcut of a block (a ``ConvBN``): as a fused group whose input gradient goes through the block's GradBox"""
     mods = list(downsample.children()) if isinstance(downsample, FusedSequential) else []
     if box is not None and len(mods) == 2 and isinstance(mods[0], Conv2d) and isinstance(mods[1], BatchNorm2d):
-        return ops.conv_bn_act(x, mods[0], mods[1], relu=False, in_box=box)
+        return ops.conv_bn_act(x, mods[0], mods[1], relu=False, in_box=box, shortcut_only=True)
     return downsample(x)
 
 
@@ -219,10 +251,15 @@ class DRN(nn.Module):
         else:
             x = self.layer0(x)
             stages = (self.layer1, self.layer2, self.layer3, self.layer4, self.layer5, self.layer6, self.layer7, self.layer8)
-        for st in stages:
-            if st is not None:
+        live = [st for st in stages if st is not None]
+        for k, st in enumerate(live):
+            if isinstance(st, FusedSequential):
+                # a convolution chain whose output only the next stage's convolutions read hands on its companion alone
+                last_internal = (not self.out_middle and k + 1 < len(live) and _reads_companions_only(live[k + 1]))
+                x = run_fused(list(st.children()), x, internal_last=last_internal)
+            else:
                 x = st(x)
-                feats.append(x)
+            feats.append(x)
         if not hasattr(self, "fc"):
             return (x, feats) if self.out_middle else x
         if self.out_map:

@@ -346,6 +346,51 @@ def test_residual_gradient_fold_is_bitwise_autograd(net, cut, monkeypatch):
         assert torch.equal(a, b), "%s: folded and accumulated gradients differ (max %.3e)" % (k, float((a - b).abs().max()))
 
 
+@pytest.mark.parametrize("net", ["drn_d_38", "drn_d_22"])
+def test_conv_chain_stages_hand_on_companions_bitwise(net, monkeypatch):
+    """Round 5: the plain convolution chains of a DRN-D trunk (the 7 x 7 stem, layer1, layer2, layer7; models/drn.py:195-205) feed nothing
+    but the next stage's convolutions, which read companions -- so their groups write no fp32 output (``ops.INTERNAL_STAGES``), the 16-
+    and 32-channel ones included.  Features, logits and every parameter gradient are bit-identical to the form that writes them
+    (MCDSEG_INTERNAL_STAGES=0), and four more groups hand on the 4-byte stand-in."""
+    dev = _dev()
+    from loss import CrossEntropyLoss2d
+    from mcdseg import ops
+    from models.model_util import get_models
+    src, lbl, _ = make_batch(33, 2, 6, 64, 96, NC)
+    cw = torch.ones(NC)
+    cw[NC - 1] = 0
+    out = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "INTERNAL_STAGES", on)
+        monkeypatch.setattr(ops, "SHORTCUT_NO_CB", on)  # (and the 1x1 projection shortcuts write no companion: read as residuals only)
+        g, f1, f2 = get_models(net, 6, NC)
+        for m, seed in ((g, 11), (f1, 12), (f2, 13)):
+            fill_state_(m, seed)
+            m.to(dev).train()
+        virtual = []
+        orig = ops.conv_bn_act
+
+        def spy(*a, **kw):
+            y = orig(*a, **kw)
+            virtual.append(ops.is_virtual(y))
+            if kw.get("shortcut_only"):
+                shortcuts.append(ops._cb_of(y)[0] is not None)
+            return y
+        shortcuts = []
+        monkeypatch.setattr(ops, "conv_bn_act", spy)
+        feat = g(src.to(dev))
+        monkeypatch.setattr(ops, "conv_bn_act", orig)
+        logits = f1(feat)
+        crit = CrossEntropyLoss2d(cw.to(dev))
+        (crit(logits, lbl.to(dev)) + crit(f2(feat), lbl.to(dev))).backward()
+        out[on] = (feat.detach().clone(), logits.detach().clone(), {k: v.grad.clone() for k, v in g.named_parameters()}, sum(virtual))
+        assert len(shortcuts) == 4 and all(c != on for c in shortcuts), shortcuts  # four projection shortcuts, with / without a companion
+    assert out[True][3] == out[False][3] + 4, (out[True][3], out[False][3])  # the stem, layer1, layer2, layer7
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    for k, v in out[True][2].items():
+        assert torch.equal(v, out[False][2][k]), k
+
+
 @pytest.mark.parametrize("reuse", [True, False])
 def test_solver_step_b_forward_fork_is_bitwise_the_serial_step(golden, monkeypatch, reuse):
     """Step B's two generator passes (source, target: same weights) side by side on two streams (``ops.ForwardFork``; every BatchNorm's
