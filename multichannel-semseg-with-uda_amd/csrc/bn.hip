@@ -308,14 +308,17 @@ __device__ __forceinline__ unsigned long long mcd_readlane64(unsigned long long 
   return ((unsigned long long)hi << 32) | lo;
 }
 
-template <bool VEC>
+// MASK (compile-time: with the four forms behind run-time branches in one loop the compiler carries the register hazards of one
+// form's loads into the others and waits for every load where it is issued): 0 no ReLU, 1 y > 0 from the fp32 y, 2 from z
+// (mgamma / mbeta: a group without residual), 3 from the bit-plane (rmask).
+template <bool VEC, int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                             const float* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ part, int N,
                                                             int C, int HW, int relu, int cpp, int chunk,
                                                             float* __restrict__ dz_bound, const float* __restrict__ mgamma,
                                                             const float* __restrict__ mbeta,
-                                                            const unsigned long long* __restrict__ rmask = nullptr, int nblk = 0) {
+                                                            const unsigned long long* __restrict__ rmask, int nblk) {
   const int c = blockIdx.x;
   const int S = gridDim.y;
   if (dz_bound != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *dz_bound = 0.f;  // finalize: atomic max
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   const float rs = z ? rstd[c] : 0.f;
   // ReLU mask without reading y (mbeta != NULL; a group WITHOUT residual): y > 0 <=> fma(z, a, b) > 0 with the forward kernels'
   // own a = gamma rstd, b = beta - mean a (bn_apply_kernel / bn_apply_cb_kernel: the same expressions, bit for bit)
-  const bool zm = relu && mbeta != nullptr;
+  constexpr bool zm = MASK == 2;
   const float ma = zm ? mgamma[c] * rs : 0.f;
   const float mb = zm ? mbeta[c] - mu * ma : 0.f;
   float s_dy = 0.f, s_dyx = 0.f, m_g = 0.f;
@@ -343,41 +346,62 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       // (stepped per WAVE: ib is the wave's first float4 -- a multiple of 64, chunks being whole 256-pixel blocks -- so that the four
       // words of the wave's block of the ReLU bit-plane are loaded once, by lanes 0-3; per thread the same elements in the same order
       // as a plain strided loop)
-      for (int ib = (e0 >> 2) + (threadIdx.x & ~63); ib < (e1 >> 2); ib += 256) {
-        unsigned long long w0 = 0ull, w1 = 0ull, w2 = 0ull, w3 = 0ull;
-        if (rmask != nullptr) {  // (wave-uniform control flow up to here: every lane takes part in the broadcasts)
-          unsigned long long mw = 0ull;
-          if (lane < 4) mw = rmask[(((size_t)n * C + c) * nblk + (ib >> 6)) * 4 + lane];
-          w0 = mcd_readlane64(mw, 0); w1 = mcd_readlane64(mw, 1); w2 = mcd_readlane64(mw, 2); w3 = mcd_readlane64(mw, 3);
+      // Four steps of the strided loop at a time, every load of the four issued before the first sum: a thread has 2 x 4 float4 in
+      // flight instead of 2 (a 256-channel layer of the benchmark gives a thread ten steps in all).  Worth 2 % of the kernel in the
+      // benchmark step -- at 8 waves per SIMD the other waves already covered most of the latency.  Same elements in the same order per
+      // thread: the same sums, bit for bit.
+      const int nq = e1 >> 2;
+      for (int ib = (e0 >> 2) + (threadIdx.x & ~63); ib < nq; ib += 4 * 256) {
+        float4 gq[4], vq[4], oq[4];
+        unsigned long long mq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          // (no divergent branch around a load -- the compiler waits at the join of each: clamped addresses instead; steps past the
+          // end repeat the last element and are skipped below)
+          const int ibu = ib + u * 256 < nq ? ib + u * 256 : ((nq - 1) & ~63);  // wave-uniform
+          const int i = ibu + lane < nq ? ibu + lane : nq - 1;
+          vq[u] = oq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          mq[u] = 0ull;
+          if (MASK == 3) mq[u] = rmask[(((size_t)n * C + c) * nblk + (ibu >> 6)) * 4 + (lane & 3)];
+          gq[u] = dy4[i];
+          if (z) vq[u] = z4[i];
+          if (MASK == 1) oq[u] = y4[i];
         }
-        const int i = ib + lane;
-        if (i >= (e1 >> 2)) continue;
-        float4 g = dy4[i];
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (z) v = z4[i];
-        if (rmask != nullptr) {
-          g.x = ((w0 >> lane) & 1ull) ? g.x : 0.f; g.y = ((w1 >> lane) & 1ull) ? g.y : 0.f;
-          g.z = ((w2 >> lane) & 1ull) ? g.z : 0.f; g.w = ((w3 >> lane) & 1ull) ? g.w : 0.f;
-        } else if (zm) {
-          g.x = fmaf(v.x, ma, mb) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, ma, mb) > 0.f ? g.y : 0.f;
-          g.z = fmaf(v.z, ma, mb) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, ma, mb) > 0.f ? g.w : 0.f;
-        } else if (relu) {
-          const float4 o = y4[i];
-          g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
-          g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
-        }
-        s_dy += (g.x + g.y) + (g.z + g.w);
-        m_g = fmaxf(m_g, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
-        if (z) {
-          s_dyx += (g.x * ((v.x - mu) * rs) + g.y * ((v.y - mu) * rs)) + (g.z * ((v.z - mu) * rs) + g.w * ((v.w - mu) * rs));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ibu = ib + u * 256;
+          if (ibu >= nq) break;  // wave-uniform
+          unsigned long long w0 = 0ull, w1 = 0ull, w2 = 0ull, w3 = 0ull;
+          if (MASK == 3) {  // (wave-uniform control flow up to here: every lane takes part in the broadcasts)
+            w0 = mcd_readlane64(mq[u], 0); w1 = mcd_readlane64(mq[u], 1); w2 = mcd_readlane64(mq[u], 2); w3 = mcd_readlane64(mq[u], 3);
+          }
+          if (ibu + lane >= nq) continue;
+          float4 g = gq[u];
+          const float4 v = vq[u];
+          if (MASK == 3) {
+            g.x = ((w0 >> lane) & 1ull) ? g.x : 0.f; g.y = ((w1 >> lane) & 1ull) ? g.y : 0.f;
+            g.z = ((w2 >> lane) & 1ull) ? g.z : 0.f; g.w = ((w3 >> lane) & 1ull) ? g.w : 0.f;
+          } else if (MASK == 2) {
+            g.x = fmaf(v.x, ma, mb) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, ma, mb) > 0.f ? g.y : 0.f;
+            g.z = fmaf(v.z, ma, mb) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, ma, mb) > 0.f ? g.w : 0.f;
+          } else if (MASK == 1) {
+            const float4 o = oq[u];
+            g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
+            g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+          }
+          s_dy += (g.x + g.y) + (g.z + g.w);
+          m_g = fmaxf(m_g, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
+          if (z) {
+            s_dyx += (g.x * ((v.x - mu) * rs) + g.y * ((v.y - mu) * rs)) + (g.z * ((v.z - mu) * rs) + g.w * ((v.w - mu) * rs));
+          }
         }
       }
     } else {
       for (int i = e0 + threadIdx.x; i < e1; i += 256) {
         float g = dy[base + i];
-        if (zm) {
+        if (MASK == 2) {
           if (!(fmaf(z[base + i], ma, mb) > 0.f)) g = 0.f;
-        } else if (relu && !(y[base + i] > 0.f)) {
+        } else if (MASK == 1 && !(y[base + i] > 0.f)) {
           g = 0.f;
         }
         s_dy += g;
@@ -401,6 +425,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     part[((size_t)blockIdx.y * 3 + 1) * C + c] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
     part[((size_t)blockIdx.y * 3 + 2) * C + c] = fmaxf(fmaxf(sh[2][0], sh[2][1]), fmaxf(sh[2][2], sh[2][3]));
   }
+}
+
+// the instantiation for (vectorised?, mask form)
+template <typename... A>
+void launch_bwd_reduce(bool vec, int mask, dim3 grid, hipStream_t st, A... a) {
+#define MCD_RED(V, M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, M>), grid, dim3(256), 0, st, a...)
+  if (vec) {
+    if (mask == 0) MCD_RED(true, 0); else if (mask == 1) MCD_RED(true, 1); else if (mask == 2) MCD_RED(true, 2); else MCD_RED(true, 3);
+  } else {
+    if (mask == 0) MCD_RED(false, 0); else if (mask == 1) MCD_RED(false, 1); else MCD_RED(false, 2);
+  }
+#undef MCD_RED
 }
 
 // dgamma / dbeta from the S partial rows (fp64) and, when asked, the bound of the dz tensor bn_bwd_apply is about to write
@@ -601,7 +637,10 @@ __device__ __forceinline__ void split_store_x4(const float (&v)[4][8], float inv
   }
 }
 
-template <class P>
+// RES (compile-time: behind a run-time branch the residual's loads are issued one channel at a time, each waited for where it is
+// issued -- eight HBM round trips in a row per thread; with all 16 loads issued first the forward apply kernels of a benchmark step take
+// 6 % less): 0 no residual, 1 fp32 residual, 2 the residual as its companion.
+template <class P, int RES>
 __global__ __launch_bounds__(BN_V4_NT) void bn_apply_cb_v4_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ res,
@@ -609,7 +648,7 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_apply_cb_v4_kernel(const float* _
                                                              const float* __restrict__ res_bound, float* __restrict__ y,
                                                              typename P::elem* __restrict__ cb, const float* __restrict__ y_bound, int N,
                                                              int C, int HW, int relu, int rev,
-                                                             unsigned long long* __restrict__ rmask = nullptr) {
+                                                             unsigned long long* __restrict__ rmask) {
   __shared__ typename P::frag lds[BN_V4_NT / 64][256];
   const int C8 = C >> 3;
   // rev: walk the tensor from its END -- the convolution that has just written z did so front to back, so the tail is what the
@@ -633,22 +672,28 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_apply_cb_v4_kernel(const float* _
   if (pix < HW) {
     const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
     float r[4][8];
-    if (res_cb != nullptr) {  // compact activation storage: the residual exists only as its companion
+    if (RES == 2) {  // compact activation storage: the residual exists only as its companion
       const float rscale = operand_scale<P>(res_bound);
 #pragma unroll
       for (int j = 0; j < 4; ++j) join_load<P>(res_cb, rscale, (size_t)N * C * HW, (size_t)ng * HW + pix + j, r[j]);
     }
+    float4 zq[8], rq[8];  // every load of the thread in flight before the first use
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float4 zv = *reinterpret_cast<const float4*>(z + base + (size_t)e * HW);
+      zq[e] = *reinterpret_cast<const float4*>(z + base + (size_t)e * HW);
+      if (RES == 1) rq[e] = *reinterpret_cast<const float4*>(res + base + (size_t)e * HW);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float4 zv = zq[e];
       float4 t;
       t.x = fmaf(zv.x, ca[e], cbeta[e]); t.y = fmaf(zv.y, ca[e], cbeta[e]);
       t.z = fmaf(zv.z, ca[e], cbeta[e]); t.w = fmaf(zv.w, ca[e], cbeta[e]);
-      if (res) {
-        const float4 rv = *reinterpret_cast<const float4*>(res + base + (size_t)e * HW);
+      if (RES == 1) {
+        const float4 rv = rq[e];
         t.x += rv.x; t.y += rv.y; t.z += rv.z; t.w += rv.w;
       }
-      if (res_cb != nullptr) { t.x += r[0][e]; t.y += r[1][e]; t.z += r[2][e]; t.w += r[3][e]; }
+      if (RES == 2) { t.x += r[0][e]; t.y += r[1][e]; t.z += r[2][e]; t.w += r[3][e]; }
       if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
       v[0][e] = t.x; v[1][e] = t.y; v[2][e] = t.z; v[3][e] = t.w;
       if (y != nullptr) *reinterpret_cast<float4*>(y + base + (size_t)e * HW) = t;
@@ -729,8 +774,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cb_kernel(const float* __res
   }
 }
 
-// four adjacent pixels per thread (see bn_apply_cb_v4_kernel); the ReLU mask comes from z (mbeta) or from the fp32 y
-template <class P>
+// four adjacent pixels per thread (see bn_apply_cb_v4_kernel).  MASK (compile-time, for the reason given at bn_bwd_reduce_kernel): where
+// y > 0 comes from -- 0 no ReLU, 1 the fp32 y, 2 z (mbeta: a group without residual), 3 the bit-plane (rmask), 4 y's companion.
+template <class P, int MASK>
 __global__ __launch_bounds__(BN_V4_NT) void bn_bwd_apply_cb_v4_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                  const float* __restrict__ z, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -739,7 +785,7 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_bwd_apply_cb_v4_kernel(const floa
                                                                  typename P::elem* __restrict__ cb, const float* __restrict__ dz_bound,
                                                                  const typename P::elem* __restrict__ y_cb, int N, int C, int HW,
                                                                  int relu, int train, const float* __restrict__ mbeta, int rev,
-                                                                 const unsigned long long* __restrict__ rmask = nullptr) {
+                                                                 const unsigned long long* __restrict__ rmask) {
   __shared__ typename P::frag lds[BN_V4_NT / 64][256];
   const int C8 = C >> 3;
   // rev: walk the tensor from its END -- the reduce pass that ran just before read dy and z front to back, so their tails are what the
@@ -750,7 +796,7 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_bwd_apply_cb_v4_kernel(const floa
   const int n = ng / C8;
   const float inv_scale = 1.f / operand_scale<P>(dz_bound);
   const float inv_n = 1.f / ((float)N * (float)HW);
-  const bool zm = relu && mbeta != nullptr;
+  constexpr bool zm = MASK == 2;
   float cmu[8], crs[8], ca[8], k1[8], k2[8], cmb[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -766,7 +812,7 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_bwd_apply_cb_v4_kernel(const floa
   const int pix_wave = (bx * BN_V4_NT + 64 * wave) * 4;
   const int pix = pix_wave + 4 * (threadIdx.x & 63);
   // the ReLU bit-plane of a group with residual: the wave's 32 words (8 channels x 4 pixel slots), word 4 e + j in lane 4 e + j
-  const bool bm = relu && !zm && rmask != nullptr;
+  constexpr bool bm = MASK == 3;
   unsigned long long mw = 0ull;
   if (bm && pix_wave < HW && (threadIdx.x & 63) < 32)
     mw = rmask[(((size_t)n * C + 8 * g + ((threadIdx.x & 63) >> 2)) * ((HW + 255) >> 8) + (pix_wave >> 8)) * 4 + (threadIdx.x & 3)];
@@ -774,14 +820,21 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_bwd_apply_cb_v4_kernel(const floa
   if (pix < HW) {
     const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
     unsigned ymask[4] = {0xFFu, 0xFFu, 0xFFu, 0xFFu};
-    if (relu && !zm && !bm && y == nullptr) {  // compact activation storage: the mask from the leading piece of y's companion
+    if (MASK == 4) {  // compact activation storage: the mask from the leading piece of y's companion
 #pragma unroll
       for (int j = 0; j < 4; ++j) ymask[j] = mask_load<P>(y_cb, (size_t)ng * HW + pix + j);
     }
+    float4 gq[8], zq[8], yq[8];  // every load of the thread in flight before the first use
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float4 g4 = *reinterpret_cast<const float4*>(dy + base + (size_t)e * HW);
-      const float4 z4 = *reinterpret_cast<const float4*>(z + base + (size_t)e * HW);
+      gq[e] = *reinterpret_cast<const float4*>(dy + base + (size_t)e * HW);
+      zq[e] = *reinterpret_cast<const float4*>(z + base + (size_t)e * HW);
+      if (MASK == 1) yq[e] = *reinterpret_cast<const float4*>(y + base + (size_t)e * HW);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float4 g4 = gq[e];
+      const float4 z4 = zq[e];
       float gv[4] = {g4.x, g4.y, g4.z, g4.w};
       const float zv[4] = {z4.x, z4.y, z4.z, z4.w};
       if (bm) {  // (v_readlane reads its source lane whatever the execution mask: lanes 0-31 loaded their words above, unconditionally)
@@ -792,13 +845,13 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_bwd_apply_cb_v4_kernel(const floa
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (!(fmaf(zv[j], ca[e], cmb[e]) > 0.f)) gv[j] = 0.f;
-      } else if (relu && y != nullptr) {
-        const float4 y4 = *reinterpret_cast<const float4*>(y + base + (size_t)e * HW);
+      } else if (MASK == 1) {
+        const float4 y4 = yq[e];
         const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (!(yv[j] > 0.f)) gv[j] = 0.f;
-      } else if (relu) {
+      } else if (MASK == 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (!((ymask[j] >> e) & 1u)) gv[j] = 0.f;
@@ -1069,6 +1122,23 @@ static bool bn_v4_on() {
   return on;
 }
 
+template <class P, typename... A>
+static void launch_apply_v4(const float* res, const void* res_cb, dim3 grid, hipStream_t st, A... a) {
+  if (res != nullptr)
+    hipLaunchKernelGGL((bn_apply_cb_v4_kernel<P, 1>), grid, dim3(BN_V4_NT), 0, st, a...);
+  else if (res_cb != nullptr)
+    hipLaunchKernelGGL((bn_apply_cb_v4_kernel<P, 2>), grid, dim3(BN_V4_NT), 0, st, a...);
+  else
+    hipLaunchKernelGGL((bn_apply_cb_v4_kernel<P, 0>), grid, dim3(BN_V4_NT), 0, st, a...);
+}
+
+template <class P, typename... A>
+static void launch_bwd_apply_v4(int mask, dim3 grid, hipStream_t st, A... a) {
+#define MCD_BA(M) hipLaunchKernelGGL((bn_bwd_apply_cb_v4_kernel<P, M>), grid, dim3(BN_V4_NT), 0, st, a...)
+  if (mask == 0) MCD_BA(0); else if (mask == 1) MCD_BA(1); else if (mask == 2) MCD_BA(2); else if (mask == 3) MCD_BA(3); else MCD_BA(4);
+#undef MCD_BA
+}
+
 extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                   const float* residual, const void* res_cb, const float* res_bound, float* y, void* y_cb,
                                   const float* y_bound, int32_t math, int32_t N, int32_t C, int32_t HW, int32_t relu, void* stream) {
@@ -1081,11 +1151,11 @@ extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float
     const dim3 grid4(ceil_div(HW, 4 * BN_V4_NT), N * (C / 8));
     const int rev = bn_reverse_walk();
     if (math == MCDSEG_MATH_F16X3)
-      hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitF16x3>, grid4, dim3(BN_V4_NT), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
-                         (const _Float16*)res_cb, res_bound, y, (_Float16*)y_cb, y_bound, N, C, HW, relu, rev);
+      launch_apply_v4<SplitF16x3>(residual, res_cb, grid4, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual, (const _Float16*)res_cb,
+                                  res_bound, y, (_Float16*)y_cb, y_bound, N, C, HW, relu, rev, (unsigned long long*)nullptr);
     else
-      hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitBf16x6>, grid4, dim3(BN_V4_NT), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
-                         (const __bf16*)res_cb, res_bound, y, (__bf16*)y_cb, y_bound, N, C, HW, relu, rev);
+      launch_apply_v4<SplitBf16x6>(residual, res_cb, grid4, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual, (const __bf16*)res_cb,
+                                   res_bound, y, (__bf16*)y_cb, y_bound, N, C, HW, relu, rev, (unsigned long long*)nullptr);
     MCD_LAUNCH_CHECK("bn_apply_cb");
     return 0;
   }
@@ -1122,12 +1192,13 @@ static bool bwd_apply_v4(const float* dy, const float* y, const void* y_cb, cons
   if ((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)dres) & 15) != 0) return false;
   const dim3 grid(ceil_div(HW, 4 * BN_V4_NT), N * (C / 8));
   const int rev = bn_reverse_walk();
+  const int mask = !relu ? 0 : (mbeta != nullptr ? 2 : (rmask != nullptr ? 3 : (y != nullptr ? 1 : 4)));  // (the kernel's own order of preference)
   if (math == MCDSEG_MATH_F16X3)
-    hipLaunchKernelGGL(bn_bwd_apply_cb_v4_kernel<SplitF16x3>, grid, dim3(BN_V4_NT), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres,
-                       (_Float16*)dz_cb, dz_bound, (const _Float16*)y_cb, N, C, HW, relu, train, mbeta, rev, rmask);
+    launch_bwd_apply_v4<SplitF16x3>(mask, grid, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres, (_Float16*)dz_cb, dz_bound,
+                                    (const _Float16*)y_cb, N, C, HW, relu, train, mbeta, rev, rmask);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_cb_v4_kernel<SplitBf16x6>, grid, dim3(BN_V4_NT), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres,
-                       (__bf16*)dz_cb, dz_bound, (const __bf16*)y_cb, N, C, HW, relu, train, mbeta, rev, rmask);
+    launch_bwd_apply_v4<SplitBf16x6>(mask, grid, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres, (__bf16*)dz_cb, dz_bound,
+                                     (const __bf16*)y_cb, N, C, HW, relu, train, mbeta, rev, rmask);
   return true;
 }
 
@@ -1150,12 +1221,11 @@ extern "C" int mcdseg_bn_apply_cb_mask(const float* z, const float* mean, const 
   const dim3 grid4(ceil_div(HW, 4 * BN_V4_NT), N * (C / 8));
   const int rev = bn_reverse_walk();
   if (math == MCDSEG_MATH_F16X3)
-    hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitF16x3>, grid4, dim3(BN_V4_NT), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
-                       (const _Float16*)nullptr, (const float*)nullptr, y, (_Float16*)y_cb, y_bound, N, C, HW, 1, rev,
-                       (unsigned long long*)relu_mask);
+    launch_apply_v4<SplitF16x3>(residual, nullptr, grid4, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual, (const _Float16*)nullptr,
+                                (const float*)nullptr, y, (_Float16*)y_cb, y_bound, N, C, HW, 1, rev, (unsigned long long*)relu_mask);
   else
-    hipLaunchKernelGGL(bn_apply_cb_v4_kernel<SplitBf16x6>, grid4, dim3(BN_V4_NT), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
-                       (const __bf16*)nullptr, (const float*)nullptr, y, (__bf16*)y_cb, y_bound, N, C, HW, 1, rev, (unsigned long long*)relu_mask);
+    launch_apply_v4<SplitBf16x6>(residual, nullptr, grid4, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual, (const __bf16*)nullptr,
+                                 (const float*)nullptr, y, (__bf16*)y_cb, y_bound, N, C, HW, 1, rev, (unsigned long long*)relu_mask);
   MCD_LAUNCH_CHECK("bn_apply_cb_mask");
   return 0;
 }
@@ -1270,12 +1340,8 @@ extern "C" int mcdseg_bn_bwd_reduce(const float* dy, const float* y, const void*
     S = pl.S;
     const bool vec = (HW % 4 == 0) && aligned16(dy) && (!y || aligned16(y)) && (!z || aligned16(z));
     dim3 grid(C, pl.S);
-    if (vec)
-      hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, (float*)workspace, N, C, HW, relu,
-                         pl.cpp, pl.chunk, dz_bound, (const float*)nullptr, (const float*)nullptr);
-    else
-      hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, (float*)workspace, N, C, HW,
-                         relu, pl.cpp, pl.chunk, dz_bound, (const float*)nullptr, (const float*)nullptr);
+    launch_bwd_reduce(vec, relu ? 1 : 0, grid, st, dy, y, z, mean, rstd, (float*)workspace, N, C, HW, relu, pl.cpp, pl.chunk, dz_bound,
+                      (const float*)nullptr, (const float*)nullptr, (const unsigned long long*)nullptr, 0);
   }
   MCD_LAUNCH_CHECK("bn_bwd_reduce");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, S, C,
@@ -1295,12 +1361,8 @@ extern "C" int mcdseg_bn_bwd_reduce_zmask(const float* dy, const float* z, const
   MCD_REQUIRE(pl.S <= 65535, "bn_bwd_reduce_zmask: too many splits");
   const bool vec = (HW % 4 == 0) && aligned16(dy) && aligned16(z);
   dim3 grid(C, pl.S);
-  if (vec)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, st, dy, (const float*)nullptr, z, mean, rstd, (float*)workspace, N, C,
-                       HW, 1, pl.cpp, pl.chunk, dz_bound, gamma, beta);
-  else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, st, dy, (const float*)nullptr, z, mean, rstd, (float*)workspace, N, C,
-                       HW, 1, pl.cpp, pl.chunk, dz_bound, gamma, beta);
+  launch_bwd_reduce(vec, 2, grid, st, dy, (const float*)nullptr, z, mean, rstd, (float*)workspace, N, C, HW, 1, pl.cpp, pl.chunk, dz_bound,
+                    gamma, beta, (const unsigned long long*)nullptr, 0);
   MCD_LAUNCH_CHECK("bn_bwd_reduce_zmask");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, pl.S, C, dgamma, dbeta, gamma,
                      rstd, (float)N * (float)HW, train, dz_bound);
@@ -1319,9 +1381,8 @@ extern "C" int mcdseg_bn_bwd_reduce_mask(const float* dy, const void* relu_mask,
   hipStream_t st = (hipStream_t)stream;
   const BwdPlan pl = bwd_plan(N, C, HW);
   MCD_REQUIRE(pl.S <= 65535, "bn_bwd_reduce_mask: too many splits");
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(C, pl.S), dim3(256), 0, st, dy, (const float*)nullptr, z, mean, rstd, (float*)workspace, N, C,
-                     HW, 1, pl.cpp, pl.chunk, dz_bound, (const float*)nullptr, (const float*)nullptr, (const unsigned long long*)relu_mask,
-                     (HW + 255) >> 8);
+  launch_bwd_reduce(true, 3, dim3(C, pl.S), st, dy, (const float*)nullptr, z, mean, rstd, (float*)workspace, N, C, HW, 1, pl.cpp, pl.chunk,
+                    dz_bound, (const float*)nullptr, (const float*)nullptr, (const unsigned long long*)relu_mask, (HW + 255) >> 8);
   MCD_LAUNCH_CHECK("bn_bwd_reduce_mask");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, pl.S, C, dgamma, dbeta, gamma,
                      rstd, (float)N * (float)HW, train, dz_bound);

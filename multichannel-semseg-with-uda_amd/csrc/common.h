@@ -72,3 +72,33 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
   return v;
 }
+
+typedef int mcd_i32x4 __attribute__((ext_vector_type(4)));
+
+// A raw buffer resource over [base, base + bytes) (what __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000) builds), as
+// the four dwords an inline-asm operand can take.
+__device__ __forceinline__ mcd_i32x4 mcd_raw_rsrc(const void* base, int bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  mcd_i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffffu));
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000;
+  return r;
+}
+
+// LDS-DMA the compiler does not see.  Issued through the builtin, every LDS read that follows -- in every basic block -- gets a
+// compiler-made `s_waitcnt vmcnt(0)` in front (it cannot tell the buffer being filled from the one being read), which drains
+// the very prefetch (and, the counter being one for loads and stores, every store in flight); the caller places the waits.
+// lds = the wave's destination (byte address in LDS, wave-uniform); lane l writes SIZE bytes at lds + l * SIZE.
+template <int SIZE>
+__device__ __forceinline__ void mcd_hidden_dma(mcd_i32x4 rs, unsigned lds, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (SIZE == 4)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rs) : "memory");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rs) : "memory");
+#else
+  (void)rs; (void)lds; (void)voff;
+#endif
+}

@@ -174,23 +174,21 @@ __global__ __launch_bounds__(256) void up8_bwd_band_kernel(const float* __restri
   const int iy1 = iy0 + p.rows_per_band < Hi ? iy0 + p.rows_per_band : Hi;
   const int slot_bytes = 8 * p.row_stride;
   const float* g = dy + (size_t)plane * Ho * Wo;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, Ho * Wo * 4, 0x00020000);
+  const mcd_i32x4 rs = mcd_raw_rsrc(g, Ho * Wo * 4);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ub_smem;
   const int chunk_insts = 8 * p.row_insts;
   const int row_bytes = 4 * Wo;
 
+  // (hidden from the compiler: through the builtin, the first LDS read of every row waits vmcnt(0) for the chunk issued a moment
+  // before it -- no look-ahead at all; see mcd_hidden_dma)
   auto issue = [&](int k) {  // chunk k -> slot k % 3
-    unsigned char* slot = ub_smem + (k % 3) * slot_bytes;
+    const unsigned slot = lds0 + (unsigned)((k % 3) * slot_bytes);
     for (int q = wave; q < chunk_insts; q += 4) {  // wave-uniform
       const int r = q / p.row_insts, j = q - r * p.row_insts;
       const int oy = 8 * k - 4 + r;
       const int cb = j * 1024 + lane * 16;
       const unsigned voff = ((unsigned)oy < (unsigned)Ho && cb < row_bytes) ? (unsigned)(oy * row_bytes + cb) : UB_OOB;
-#if defined(__HIP_DEVICE_COMPILE__)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(slot + r * p.row_stride + j * 1024), 16, voff,
-                                               0, 0, 0);
-#else
-      (void)voff; (void)slot;
-#endif
+      mcd_hidden_dma<16>(rs, __builtin_amdgcn_readfirstlane(slot + (unsigned)(r * p.row_stride + j * 1024)), voff);
     }
   };
 
@@ -200,6 +198,10 @@ __global__ __launch_bounds__(256) void up8_bwd_band_kernel(const float* __restri
   if (DX) {
 #pragma unroll
     for (int ky = 0; ky < 16; ++ky) wq[ky] = *reinterpret_cast<const float4*>(w + c * 256 + ky * 16 + 4 * v4);
+    // arrived HERE: left to the compiler, the wait for these loads sits in front of their first use -- inside the row loop, where
+    // a vmcnt(0) also drains the chunk just issued, every row
+#pragma unroll
+    for (int ky = 0; ky < 16; ++ky) asm volatile("" : "+v"(wq[ky].x), "+v"(wq[ky].y), "+v"(wq[ky].z), "+v"(wq[ky].w));
   }
   // dw: this thread's tap
   const int ky_t = tid >> 4, kx_t = tid & 15;
@@ -221,10 +223,16 @@ __global__ __launch_bounds__(256) void up8_bwd_band_kernel(const float* __restri
         const bool ok = !((ix == 0 && v4 == 0) || (ix == Wi - 1 && v4 == 3));
         float a = 0.f;
         if (ok) {
+          // all 16 reads in flight before the first multiply-add (left alone, the compiler re-uses one register quad and waits
+          // out the LDS latency 16 times per item)
+          f32x4 gv[16];
+#pragma unroll
+          for (int ky = 0; ky < 16; ++ky) gv[ky] = *reinterpret_cast<const f32x4*>((ky < 8 ? sa : sb) + (ky & 7) * p.row_stride + colb);
+          asm volatile("" : "+v"(gv[0]), "+v"(gv[1]), "+v"(gv[2]), "+v"(gv[3]), "+v"(gv[4]), "+v"(gv[5]), "+v"(gv[6]), "+v"(gv[7]), "+v"(gv[8]),
+                            "+v"(gv[9]), "+v"(gv[10]), "+v"(gv[11]), "+v"(gv[12]), "+v"(gv[13]), "+v"(gv[14]), "+v"(gv[15]));
 #pragma unroll
           for (int ky = 0; ky < 16; ++ky) {
-            const float4 gv = *reinterpret_cast<const float4*>((ky < 8 ? sa : sb) + (ky & 7) * p.row_stride + colb);
-            a = fmaf(gv.x, wq[ky].x, a); a = fmaf(gv.y, wq[ky].y, a); a = fmaf(gv.z, wq[ky].z, a); a = fmaf(gv.w, wq[ky].w, a);
+            a = fmaf(gv[ky].x, wq[ky].x, a); a = fmaf(gv[ky].y, wq[ky].y, a); a = fmaf(gv[ky].z, wq[ky].z, a); a = fmaf(gv[ky].w, wq[ky].w, a);
           }
         }
         a += __shfl_xor(a, 1);
@@ -244,6 +252,18 @@ __global__ __launch_bounds__(256) void up8_bwd_band_kernel(const float* __restri
         }
       }
       int ix = 1;
+      // 16 columns at a time: their LDS reads and the one scalar load of x in flight together (the empty asm is what holds the
+      // compiler to that: left alone it waits for each group of four on its own); same accumulators in the same order
+      for (; ix + 16 <= Wi - 1; ix += 16) {
+        typedef float f32x16u __attribute__((ext_vector_type(16), aligned(4)));
+        f32x16u xv = *reinterpret_cast<const f32x16u*>(xr + ix);
+        f32x4 gq[4];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gq[j >> 2][j & 3] = *reinterpret_cast<const float*>(row + 32 * (ix + j));
+        asm volatile("" : "+s"(xv), "+v"(gq[0]), "+v"(gq[1]), "+v"(gq[2]), "+v"(gq[3]));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j & 3] = fmaf(xv[j], gq[j >> 2][j & 3], acc[j & 3]);
+      }
       for (; ix + 4 <= Wi - 1; ix += 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = fmaf(xr[ix + j], *reinterpret_cast<const float*>(row + 32 * (ix + j)), acc[j]);

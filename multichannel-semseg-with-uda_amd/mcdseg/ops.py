@@ -1575,6 +1575,18 @@ def mcd_losses(z1, z2, labels, class_weight, ignore_index=-100, ce_coef=0.0, dif
     return losses, g1, g2
 
 
+def up8_loss_kernel_name(n, c, hi, wi, two, labelled):
+    """The kernel ``mcdseg_up8_softmax_ce_l1`` launches for this problem, as rocprofv3 prints it (csrc/loss.hip: the LDS-DMA kernel unless
+    MCDSEG_UP8_LOSS_DMA=0 or a tensor outgrows a 32-bit buffer resource; the benchmark's 41 classes have an instantiation of their own)."""
+    two = "true" if two else "false"
+    dma = (os.environ.get("MCDSEG_UP8_LOSS_DMA", "1").strip() != "0" and 4 * n * c * hi * wi < 2 ** 31
+           and (not labelled or 8 * 64 * n * hi * wi < 2 ** 31))
+    if dma:
+        nc = 16 if c <= 16 else (24 if c <= 24 else (41 if c == 41 else 48))
+        return "up8_softmax_ce_l1_dma_kernel<%d, %s, %s>" % (nc, two, "true" if c == nc else "false")
+    return "up8_softmax_ce_l1_kernel<%d, %s>" % (16 if c <= 16 else (24 if c <= 24 else 48), two)
+
+
 def up8_mcd_losses(s1, w1, s2, w2, labels, class_weight, ignore_index=-100, ce_coef=0.0, diff_coef=0.0, want_grad=True, wsum=None):
     """``mcd_losses(up8(s1, w1), up8(s2, w2), ...)`` without the full-resolution logits: the kernel forms each pixel's logits
     from the score maps [N,C,Hi,Wi] on the fly.  Returns (losses[4], g1, g2) with g_k [N,C,8Hi,8Wi] = the gradient w.r.t.
@@ -1604,8 +1616,7 @@ def up8_mcd_losses(s1, w1, s2, w2, labels, class_weight, ignore_index=-100, ce_c
     ws = _ws(L.mcdseg_up8_loss_workspace_bytes(n, hi, wi), s1.device)
     heads = 1 if s2 is None else 2
     byts = 4 * heads * n * c * h * w * (1 if want_grad else 0) + 4 * heads * n * c * hi * wi + (8 * n * h * w if labels is not None else 0)
-    with _timed("up8_softmax_ce_l1_kernel<48, %s>" % ("true" if s2 is not None else "false") if c > 24 else "up8_softmax_ce_l1_kernel",
-                (0, byts)):
+    with _timed(up8_loss_kernel_name(n, c, hi, wi, s2 is not None, labels is not None), (0, byts)):
         check(L.mcdseg_up8_softmax_ce_l1(_p(s1), _p(w1), _p(s2), _p(w2), _p(labels), _p(class_weight), int(ignore_index),
                                          float(ce_coef), float(diff_coef), _p(wsum), _p(g1), _p(g2), _p(losses), n, c, hi, wi,
                                          _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()), "up8_softmax_ce_l1")

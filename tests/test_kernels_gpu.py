@@ -262,14 +262,19 @@ def test_up8_backward_band_kernel(shape):
     assert ops._up8_bwd(gg, wg, xg, False, False) == (None, None)
 
 
-@pytest.mark.parametrize("shape", [(2, 41, 5, 7), (1, 12, 3, 20), (2, 20, 4, 33), (1, 41, 2, 80)])
+@pytest.mark.parametrize("shape", [(2, 41, 5, 7), (1, 12, 3, 20), (2, 20, 4, 33), (1, 41, 2, 80), (5, 41, 30, 24), (3, 30, 33, 17)])
 @pytest.mark.parametrize("mode", ["ce+diff", "diff", "ce-single", "shared-scores"])
-def test_up8_loss_fused_equals_two_pass(shape, mode):
+@pytest.mark.parametrize("dma", ["1", "0"])
+def test_up8_loss_fused_equals_two_pass(shape, mode, dma, monkeypatch):
     """The loss kernel that forms the up-sampled logits on the fly (mcdseg_up8_softmax_ce_l1) against up8 followed by the
     plain loss kernel: identical logit gradients (bitwise), loss values up to the order of the block partial sums; ragged
-    row segments (8 Wi not a multiple of 128), the image border and ignore_index pixels included."""
+    row segments (8 Wi not a multiple of 128), the image border and ignore_index pixels included.  Both forms of the kernel:
+    inputs prefetched by LDS-DMA behind a counted wait (the default; the last two shapes give every workgroup several
+    patches, i.e. gradient stores still in flight when the next patch's inputs are waited for) and staged through registers."""
     dev = _dev()
     from mcdseg import ops
+    monkeypatch.setenv("MCDSEG_UP8_LOSS_DMA", dma)
+    assert ("_dma_" in ops.up8_loss_kernel_name(*shape, mode != "ce-single", mode != "diff")) == (dma == "1")
     n, c, hi, wi = shape
     g = torch.Generator().manual_seed(11)
     s1 = (2 * torch.randn(n, c, hi, wi, generator=g)).to(dev)
@@ -294,6 +299,11 @@ def test_up8_loss_fused_equals_two_pass(shape, mode):
     vals, _, _ = ops.up8_mcd_losses(s1, w1, None if single else s2, None if single else w2, labels,
                                     cw if labels is not None else None, want_grad=False, **kw)
     assert torch.equal(vals, got_l)
+    if dma == "1":  # the two forms against each other: same arithmetic, same patch order, same sums -- the loss values bit for bit too
+        monkeypatch.setenv("MCDSEG_UP8_LOSS_DMA", "0")
+        reg_l, reg_g1, reg_g2 = ops.up8_mcd_losses(s1, w1, None if single else s2, None if single else w2, labels,
+                                                   cw if labels is not None else None, **kw)
+        assert torch.equal(reg_l, got_l) and torch.equal(reg_g1, got_g1) and (single or torch.equal(reg_g2, got_g2))
 
 
 def test_loss_kernel_against_golden_and_closed_forms(golden):
