@@ -829,11 +829,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr64_kernel(WgradCbPa
   const int sHW = sH * sW;
   const char* sptr = (const char*)(opnd ? p.x_cb : p.dy_cb) + piece * (opnd ? p.x_piece_stride : p.dy_piece_stride);  // this wave's piece
   const int sbytes = opnd ? p.x_cb_bytes : p.dy_cb_bytes;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sptr, 0, sbytes, 0x00020000);
+  // (LDS-DMA the compiler does not see -- mcd_hidden_dma: through the builtin, the transposed reads of fragments kk >= 1 of the CURRENT
+  // stage wait vmcnt(0) for the next stage's DMA issued a moment before them: no look-ahead at all)
+  const mcd_i32x4 rs = mcd_raw_rsrc(sptr, sbytes);
   constexpr unsigned OOB = 0x80000000u;
   const bool cg_ok = (cg0 + cg) < sC8 && tap_ok;
   const int lbase = (n * sC8 + cg0 + cg) * sHW;  // 16-B units inside the piece, per lane
   unsigned char* const unit_lds = smem + (opnd ? NP * A_UNIT + piece * B_UNIT : piece * A_UNIT);
+  const unsigned unit_lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)unit_lds;
 
   auto issue_dma = [&](int tt, int stage) {
     const int ty = tt / p.tiles_x;
@@ -847,8 +850,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr64_kernel(WgradCbPa
         const int ix = tx * 8 + 4 * (j / R) + ps;
         const bool ok = cg_ok && iy < sH && ix < sW;
         const unsigned voff = ok ? (unsigned)(lbase + iy * sW + ix) * 16u : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(unit_lds + stage * STAGE + i * 2 * AQ), 16,
-                                                 voff, 0, 0, 0);
+        mcd_hidden_dma<16>(rs, __builtin_amdgcn_readfirstlane(unit_lds_addr + (unsigned)(stage * STAGE + i * 2 * AQ)), voff);
       }
     } else {  // X: instruction j carries quad j of tap 2 tp (lower half-wave) and of tap 2 tp + 1 (upper)
 #pragma unroll
@@ -857,8 +859,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr64_kernel(WgradCbPa
         const int ix = (tx * 8 + 4 * (j / R) + ps) * sS + shx;
         const bool ok = cg_ok && (unsigned)iy < (unsigned)sH && (unsigned)ix < (unsigned)sW;
         const unsigned voff = ok ? (unsigned)(lbase + iy * sW + ix) * 16u : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(unit_lds + stage * STAGE + j * BQ), 16, voff,
-                                                 0, 0, 0);
+        mcd_hidden_dma<16>(rs, __builtin_amdgcn_readfirstlane(unit_lds_addr + (unsigned)(stage * STAGE + j * BQ)), voff);
       }
     }
 #else
