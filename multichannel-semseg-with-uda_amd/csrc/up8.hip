@@ -139,8 +139,19 @@ __global__ __launch_bounds__(256) void up8_bwd_weight_kernel(const float* __rest
 __global__ void up8_bwd_weight_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int C, int slabs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C * 256) return;
+  // 16 loads in flight, added in slab order (one at a time this was a chain of N x bands dependent HBM round trips: 35 us for 96 slabs)
   double s = 0.0;
-  for (int k = 0; k < slabs; ++k) s += (double)part[(size_t)k * C * 256 + i];
+  const size_t SL = (size_t)C * 256;
+  const float* src = part + i;
+  int k = 0;
+  for (; k + 16 <= slabs; k += 16, src += 16 * SL) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = src[(size_t)j * SL];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += (double)v[j];
+  }
+  for (; k < slabs; ++k, src += SL) s += (double)*src;
   dw[i] = (float)s;
 }
 
