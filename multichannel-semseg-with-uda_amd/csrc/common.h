@@ -91,6 +91,8 @@ __device__ __forceinline__ mcd_i32x4 mcd_raw_rsrc(const void* base, int bytes) {
 // compiler-made `s_waitcnt vmcnt(0)` in front (it cannot tell the buffer being filled from the one being read), which drains
 // the very prefetch (and, the counter being one for loads and stores, every store in flight); the caller places the waits.
 // lds = the wave's destination (byte address in LDS, wave-uniform); lane l writes SIZE bytes at lds + l * SIZE.
+// M0 is written without the compiler's knowledge (it is a reserved register: naming it as a clobber is refused as undefined behaviour),
+// so a kernel that uses this must not ALSO use the builtin LDS-DMA, whose M0 set-up the compiler may hoist out of a loop.
 template <int SIZE>
 __device__ __forceinline__ void mcd_hidden_dma(mcd_i32x4 rs, unsigned lds, unsigned voff) {
 #if defined(__HIP_DEVICE_COMPILE__)
