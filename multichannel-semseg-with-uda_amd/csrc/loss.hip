@@ -332,7 +332,8 @@ __global__ __launch_bounds__(UP_NT) void up8_softmax_ce_l1_kernel(const float* _
 // loads the compiler tracks.  The counter that tracks them (vmcnt) also counts the item's 2 C gradient stores, in issue order, so
 // the wait in front of the first use of any of those loads -- `s_waitcnt vmcnt(0)`, the stores sit behind data-dependent branches the
 // compiler cannot count -- drains every store of the previous item: the workgroup, the only one on its CU, alternates between
-// computing and writing (0.66 ms per launch at the benchmark's shape for 0.33 ms of arithmetic and 0.34 ms of HBM writes).
+// computing and writing (at the benchmark's shape 0.75 ms per launch with the gradients, 0.50 ms without them, for 0.34 ms of HBM writes at
+// the rate a copy reaches; this kernel: 0.58 / 0.38 ms -- tools/probes/up8_loss_probe.py).
 // Here every input of the loop arrives by LDS-DMA, which the compiler does not track, into two buffers: the next item's scores
 // (one dword per lane, the staging layout as it is), its labels (16 B per lane: one row segment of 64 labels per wave) -- issued
 // BEFORE the current item's stores, so that a counted `s_waitcnt vmcnt(63)` at the top of the next item proves them complete
