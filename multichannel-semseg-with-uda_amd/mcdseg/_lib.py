@@ -244,6 +244,35 @@ def spills_inside_matrix_loops(path=None, prefix=("conv_gemm_split_pp_kernel", "
     return out
 
 
+def drains_inside_store_loops(path=None, prefix=("up8_softmax_ce_l1_dma_kernel", "up8_bwd_band_kernel")):
+    """[(kernel symbol, instruction)] of every ``s_waitcnt vmcnt(0)`` of these kernels that lies between an LDS-DMA issue and the last
+    global store behind it; must be empty.  gfx950 counts loads, stores and LDS-DMA in ONE in-order counter: a ``vmcnt(0)`` there -- the
+    compiler puts one in front of any load it tracks whose first use is inside the loop, and in front of LDS reads behind an LDS-DMA issued
+    through the builtin -- makes every iteration wait for the prefetch it has just issued (and, in the loss kernel, would sit between the
+    DMA and the stores whose count the hand-written ``vmcnt(63)`` relies on).  DESIGN.md section 4.1g."""
+    import re
+    out, sym, body = [], None, []
+
+    def close():
+        if sym is None or not any(p in sym for p in prefix):
+            return
+        dma = [i for i, ln in enumerate(body) if re.search(r"buffer_load_dword(x4)? .* lds", ln)]
+        st = [i for i, ln in enumerate(body) if "global_store_dword" in ln]
+        if not dma or not st:
+            return
+        out.extend((sym, ln.strip()) for i, ln in enumerate(body) if dma[-1] < i < st[-1] and re.search(r"s_waitcnt.*vmcnt\(0\)", ln))
+
+    for line in device_disassembly(path).splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+        if m:
+            close()
+            sym, body = m.group(1), []
+        else:
+            body.append(line)
+    close()
+    return out
+
+
 def lib():
     """The loaded library; raises if it has not been built (no fallback exists)."""
     global _lib

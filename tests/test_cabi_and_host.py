@@ -29,6 +29,26 @@ def test_no_packed_fp32_instruction_with_op_sel_in_the_library():
     # the register spills of the 256 x 256 / 256 x 128 forward tiles (BASELINE config 5's plan) sit in the prologue and
     # the epilogue -- no scratch access between the first and the last matrix instruction of any ping-pong kernel
     assert _lib.spills_inside_matrix_loops() == []
+    # round 5: loads, stores and LDS-DMA share one in-order counter, and a compiler-made `s_waitcnt vmcnt(0)` between an
+    # LDS-DMA issue and the stores behind it drains the prefetch every iteration -- none in the fused loss kernel's item loop (whose
+    # hand-written vmcnt(63) counts on it) nor in the up-sampler's backward
+    assert text.count("up8_softmax_ce_l1_dma_kernel") >= 8, "the LDS-DMA loss kernels are missing from the library"
+    assert _lib.drains_inside_store_loops() == []
+
+
+def test_fused_loss_kernel_name_follows_the_library_rule(monkeypatch):
+    """ops.up8_loss_kernel_name restates csrc/loss.hip's dispatch (the launch timer and bench.py's counter lookup go by this name)"""
+    from mcdseg import ops
+    monkeypatch.delenv("MCDSEG_UP8_LOSS_DMA", raising=False)
+    assert ops.up8_loss_kernel_name(16, 41, 60, 80, True, True) == "up8_softmax_ce_l1_dma_kernel<41, true, true>"
+    assert ops.up8_loss_kernel_name(16, 41, 60, 80, False, True) == "up8_softmax_ce_l1_dma_kernel<41, false, true>"
+    assert ops.up8_loss_kernel_name(2, 14, 8, 8, True, False) == "up8_softmax_ce_l1_dma_kernel<16, true, false>"
+    assert ops.up8_loss_kernel_name(2, 24, 8, 8, True, False) == "up8_softmax_ce_l1_dma_kernel<24, true, true>"
+    assert ops.up8_loss_kernel_name(2, 40, 8, 8, True, False) == "up8_softmax_ce_l1_dma_kernel<48, true, false>"
+    # a tensor past a 32-bit buffer resource, or the switch: the register-staged kernel
+    assert ops.up8_loss_kernel_name(64, 41, 360, 640, True, True) == "up8_softmax_ce_l1_kernel<48, true>"
+    monkeypatch.setenv("MCDSEG_UP8_LOSS_DMA", "0")
+    assert ops.up8_loss_kernel_name(16, 41, 60, 80, True, True) == "up8_softmax_ce_l1_kernel<48, true>"
 
 
 def test_library_exports_every_header_symbol():
