@@ -169,6 +169,7 @@ constexpr unsigned UB_OOB = 0x80000000u;
 struct Up8BandParams {
   int N, C, Hi, Wi, bands, rows_per_band;
   int row_insts, row_stride;  // 1 KB DMA units per dy row; LDS row stride in bytes
+  int x_off, xrow_bytes;      // the weight gradient's ring of input rows behind the three dy slots: offset and slot size in bytes
 };
 
 template <bool DX, bool DW>
@@ -189,6 +190,9 @@ __global__ __launch_bounds__(256) void up8_bwd_band_kernel(const float* __restri
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ub_smem;
   const int chunk_insts = 8 * p.row_insts;
   const int row_bytes = 4 * Wo;
+  // (the weight gradient's input values: wave-uniform, and until round 5 scalar loads inside the row loop -- five dependent round trips to
+  // the scalar cache per row of 80, 1.5 us of the row's 2; now a row ahead in LDS, read as broadcasts)
+  const mcd_i32x4 xrs = mcd_raw_rsrc(DW ? x + (size_t)plane * Hi * Wi : dy, DW ? Hi * Wi * 4 : 0);
 
   // (hidden from the compiler: through the builtin, the first LDS read of every row waits vmcnt(0) for the chunk issued a moment
   // before it -- no look-ahead at all; see mcd_hidden_dma)
@@ -200,6 +204,14 @@ __global__ __launch_bounds__(256) void up8_bwd_band_kernel(const float* __restri
       const int cb = j * 1024 + lane * 16;
       const unsigned voff = ((unsigned)oy < (unsigned)Ho && cb < row_bytes) ? (unsigned)(oy * row_bytes + cb) : UB_OOB;
       mcd_hidden_dma<16>(rs, __builtin_amdgcn_readfirstlane(slot + (unsigned)(r * p.row_stride + j * 1024)), voff);
+    }
+    if (DW) {  // input row k - 1 travels with chunk k: row iy is read with chunks iy, iy + 1 (one dword per lane; instruction j by wave j & 3)
+      const int rx = k - 1;
+      for (int j = wave; j * 64 < Wi; j += 4) {
+        const int col = j * 64 + lane;
+        const unsigned voff = ((unsigned)rx < (unsigned)Hi && col < Wi) ? (unsigned)((rx * Wi + col) * 4) : UB_OOB;
+        mcd_hidden_dma<4>(xrs, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(p.x_off + (k % 3) * p.xrow_bytes + j * 256)), voff);
+      }
     }
   };
 
@@ -217,7 +229,6 @@ __global__ __launch_bounds__(256) void up8_bwd_band_kernel(const float* __restri
   // dw: this thread's tap
   const int ky_t = tid >> 4, kx_t = tid & 15;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const float* xin = DW ? x + (size_t)plane * Hi * Wi : nullptr;
 
   issue(iy0);
   issue(iy0 + 1);
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(256) void up8_bwd_band_kernel(const float* __restri
     }
     if (DW) {
       const unsigned char* row = (ky_t < 8 ? sa : sb) + (ky_t & 7) * p.row_stride + (kx_t - 4) * 4;
-      const float* xr = xin + iy * Wi;
+      const float* xr = reinterpret_cast<const float*>(ub_smem + p.x_off + ((iy + 1) % 3) * p.xrow_bytes);
       {  // first and last input column: part of the window lies outside the row
         const float g0 = (kx_t >= 4 && (Wi > 1 || kx_t < 12)) ? *reinterpret_cast<const float*>(row) : 0.f;
         acc[0] = fmaf(xr[0], g0, acc[0]);
@@ -263,17 +274,18 @@ __global__ __launch_bounds__(256) void up8_bwd_band_kernel(const float* __restri
         }
       }
       int ix = 1;
-      // 16 columns at a time: their LDS reads and the one scalar load of x in flight together (the empty asm is what holds the
-      // compiler to that: left alone it waits for each group of four on its own); same accumulators in the same order
+      // 16 columns at a time: their 32 LDS reads in flight together (the empty asm is what holds the compiler to that: left alone it
+      // waits for each group of four on its own); same accumulators in the same order
       for (; ix + 16 <= Wi - 1; ix += 16) {
-        typedef float f32x16u __attribute__((ext_vector_type(16), aligned(4)));
-        f32x16u xv = *reinterpret_cast<const f32x16u*>(xr + ix);
-        f32x4 gq[4];
+        f32x4 xq[4], gq[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) gq[j >> 2][j & 3] = *reinterpret_cast<const float*>(row + 32 * (ix + j));
-        asm volatile("" : "+s"(xv), "+v"(gq[0]), "+v"(gq[1]), "+v"(gq[2]), "+v"(gq[3]));
+        for (int j = 0; j < 16; ++j) {
+          xq[j >> 2][j & 3] = xr[ix + j];
+          gq[j >> 2][j & 3] = *reinterpret_cast<const float*>(row + 32 * (ix + j));
+        }
+        asm volatile("" : "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]), "+v"(gq[0]), "+v"(gq[1]), "+v"(gq[2]), "+v"(gq[3]));
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j & 3] = fmaf(xv[j], gq[j >> 2][j & 3], acc[j & 3]);
+        for (int j = 0; j < 16; ++j) acc[j & 3] = fmaf(xq[j >> 2][j & 3], gq[j >> 2][j & 3], acc[j & 3]);
       }
       for (; ix + 4 <= Wi - 1; ix += 4) {
 #pragma unroll
@@ -299,7 +311,7 @@ Up8BandPlan up8_band_plan(int N, int C, int Hi, int Wi) {
   if (knob == 0) return pl;
   pl.row_insts = ceil_div(32 * Wi, 1024);
   pl.row_stride = pl.row_insts * 1024 + 64;
-  pl.lds = 3 * 8 * pl.row_stride;
+  pl.lds = 3 * 8 * pl.row_stride + 3 * round_up(Wi, 64) * 4;  // + the weight gradient's three input rows
   if (pl.lds > 160 * 1024 - 1024 || (int64_t)Hi * Wi * 256 >= (1ll << 31)) return pl;
   pl.rows_per_band = knob > 0 ? knob : (Hi >= 20 ? 10 : Hi);
   if (pl.rows_per_band > Hi) pl.rows_per_band = Hi;
@@ -393,6 +405,7 @@ extern "C" int mcdseg_up8_bwd(const float* dy, const float* w, const float* x, f
   Up8BandParams p;
   p.N = N; p.C = C; p.Hi = Hi; p.Wi = Wi; p.bands = pl.bands; p.rows_per_band = pl.rows_per_band;
   p.row_insts = pl.row_insts; p.row_stride = pl.row_stride;
+  p.x_off = 3 * 8 * pl.row_stride; p.xrow_bytes = round_up(Wi, 64) * 4;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(N * C, pl.bands), block(256);
   static const bool attr = [] {
