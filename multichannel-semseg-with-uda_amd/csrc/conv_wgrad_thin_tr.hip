@@ -234,8 +234,18 @@ __global__ __launch_bounds__(256) void wgrad_thin_tr_reduce_kernel(const float* 
   const int ol = threadIdx.x & 15, part = threadIdx.x >> 4;
   const int o = blockIdx.x * 16 + ol;
   double s = 0.0;
-  if (o < nraw)
-    for (int k = part; k < partials; k += 16) s += (double)slab[(size_t)k * nraw + o];
+  if (o < nraw) {
+    // eight loads in flight, added in the same order (one at a time the thread's partials / 16 loads were a chain of dependent round trips)
+    int k = part;
+    for (; k + 7 * 16 < partials; k += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = slab[(size_t)(k + 16 * j) * nraw + o];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (double)v[j];
+    }
+    for (; k < partials; k += 16) s += (double)slab[(size_t)k * nraw + o];
+  }
   sh[part][ol] = s;
   __syncthreads();
   if (part != 0 || o >= nraw) return;

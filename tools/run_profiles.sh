@@ -4,7 +4,7 @@
 # reduced-precision mode.  Usage: bash tools/run_profiles.sh r05z [quick]    (raw output under gpurun_out/, summaries via
 # tools/summarize_profiles.py <tag> afterwards)
 set -u
-TAG=${1:-r05zd}
+TAG=${1:-r05ze}
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
