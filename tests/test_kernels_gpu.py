@@ -306,6 +306,46 @@ def test_up8_loss_fused_equals_two_pass(shape, mode, dma, monkeypatch):
         assert torch.equal(reg_l, got_l) and torch.equal(reg_g1, got_g1) and (single or torch.equal(reg_g2, got_g2))
 
 
+def test_up8_loss_and_backward_at_the_benchmark_size(monkeypatch):
+    """BASELINE config 2's own loss problem (16 x 41 x 60 x 80 scores -> 480 x 640 logits, 38 patches per workgroup): the LDS-DMA form of
+    the fused kernel against the register-staged form, bit for bit in both gradients and in the loss values; size-independent properties
+    of the result (a cross-entropy gradient sums to zero over the classes of a pixel, ignored pixels have none; the discrepancy's two
+    gradients are orthogonal to the constant vector); and the up-sampler's one-pass backward of that gradient against the two separate
+    kernels."""
+    dev = _dev()
+    from mcdseg import ops
+    n, c, hi, wi = 16, 41, 60, 80
+    g = torch.Generator().manual_seed(23)
+    s1 = (2 * torch.randn(n, c, hi, wi, generator=g)).to(dev)
+    s2 = (2 * torch.randn(n, c, hi, wi, generator=g)).to(dev)
+    w1 = (torch.randn(c, 1, 16, 16, generator=g) * 0.2).to(dev)
+    w2 = (torch.randn(c, 1, 16, 16, generator=g) * 0.2).to(dev)
+    lab = torch.randint(0, c, (n, 8 * hi, 8 * wi), generator=g)
+    lab[:, :7, :] = -100
+    lab = lab.to(dev)
+    cw = (0.5 + torch.rand(c, generator=g)).to(dev)
+    out = {}
+    for dma in ("1", "0"):
+        monkeypatch.setenv("MCDSEG_UP8_LOSS_DMA", dma)
+        out[dma] = (ops.up8_mcd_losses(s1, w1, s2, w2, lab, cw, ce_coef=1.0, diff_coef=0.0),
+                    ops.up8_mcd_losses(s1, w1, s2, w2, None, None, ce_coef=0.0, diff_coef=-1.0))
+    for a, b in zip(out["1"], out["0"]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    (l_ce, g1, g2), (l_d, d1, d2) = out["1"]
+    scale = float(g1.abs().max())
+    assert float(g1.sum(dim=1).abs().max()) <= 2e-5 * scale and float(g2.sum(dim=1).abs().max()) <= 2e-5 * scale
+    assert float(g1[:, :, :7, :].abs().max()) == 0.0  # ignore_index rows
+    assert float(d1.sum(dim=1).abs().max()) <= 2e-5 * float(d1.abs().max()) and float(d2.sum(dim=1).abs().max()) <= 2e-5 * float(d2.abs().max())
+    assert float(l_ce[0]) > 0 and float(l_d[2]) > 0
+    del out, g2, d1, d2
+    dx, dw = ops._up8_bwd(g1, w1, s1, True, True)
+    _assert_close(dx, ops._up8_bwd_input(g1, w1, n, c, hi, wi), 2e-5, "band kernel dx at full size")
+    _assert_close(dw, ops._up8_bwd_weight(g1, s1, n, c, hi, wi), 2e-5, "band kernel dw at full size")
+    dx1, _ = ops._up8_bwd(g1, w1, s1, True, False)
+    _, dw1 = ops._up8_bwd(g1, w1, s1, False, True)
+    assert torch.equal(dx1, dx) and torch.equal(dw1, dw)
+
+
 def test_loss_kernel_against_golden_and_closed_forms(golden):
     dev = _dev()
     from mcdseg import ops
