@@ -126,8 +126,12 @@ def build_hip(args, dev):
 ARITHMETIC_NOTE = {
     "cfg5": "f16x3, the fp32-grade arithmetic of the judged line (22-bit operands, fp32 accumulation).  BASELINE config 5 says 'bf16': the "
             "reduced-precision counterpart is the cfg5_f16 entry",
-    "cfg5_f16": "f16x1 = the stand-in for BASELINE config 5's 'bf16': operands rounded to ONE scaled fp16 piece (11 significant bits where bf16 "
-                "keeps 8), fp32 accumulation / BatchNorm / loss / optimizer; gfx950 runs fp16 and bf16 MFMA at the same rate",
+    "cfg5_f16": "f16x1 with 2-byte activation storage = BASELINE config 5's 'bf16': every trunk tensor is ONE 16-bit value per element -- "
+                "activations, pre-BatchNorm z and dz as per-tensor-scaled fp16 (11 significant bits where bf16 keeps 8; the scale comes from a "
+                "bound known before the tensor is written: Samuelson's inequality for BatchNorm outputs, K max|x| max|w| for z), the gradients "
+                "between the groups as bf16 (they span more binades than one scale covers and have no a-priori bound); the convolutions multiply "
+                "the one fp16 piece (gfx950 runs fp16 and bf16 MFMA at the same rate) and accumulate in fp32, BatchNorm statistics come from the "
+                "fp32 accumulators, BatchNorm / loss / optimizer arithmetic is fp32",
     "cfg2_bf16x6": "strict fp32: three bf16 pieces per operand (24 bits), six cross terms, no per-tensor scale",
     "cfg2_f32": "strict fp32: v_mfma_f32_32x32x2_f32, the exact k-ordered fp32 FMA chain",
 }
@@ -174,7 +178,9 @@ def other_config(tag, dev, steps, n_class=41, want_roofline=False):
             for m in (g, f1, f2):
                 m.to(dev).train()
             solver = MCDSolver(g, f1, f2, opt(g.parameters()), opt(list(f1.parameters()) + list(f2.parameters())), crit, crit_d, num_k=4)
-            what = ("adapt_trainer MCD drn_d_105, activations kept as 2 x fp16 companions (MCDSEG_ACT_STORAGE=compact)" if tag.startswith("cfg5")
+            what = (("adapt_trainer MCD drn_d_105, 2-byte activation storage (one scaled fp16 piece per activation / z / dz, bf16 gradients)"
+                     if (tag == "cfg5_f16" and ops.HALF_STORAGE) else
+                     "adapt_trainer MCD drn_d_105, activations kept as 2 x fp16 companions (MCDSEG_ACT_STORAGE=compact)") if tag.startswith("cfg5")
                     else "adapt_trainer MCD early-fusion drn_d_38 6-ch (the judged configuration in another arithmetic)")
         gen = torch.Generator(device=dev).manual_seed(1234)
         src = torch.randn(n, 6, h, w, generator=gen, device=dev)

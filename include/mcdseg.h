@@ -32,6 +32,15 @@ extern "C" {
 int mcdseg_version(void);
 const char* mcdseg_last_error(void);
 
+/* Plan / development options (tile choices, launch plans, kernel forms: csrc/options.h lists them with their defaults).  The library
+ * never reads the process environment: whoever wants another plan says so through this call.  The table is process-wide (a backward
+ * pass runs on other threads than the forward pass that built its graph) and read at every launch; a name may carry the "MCDSEG_"
+ * prefix of the environment variable the Python host side translates (mcdseg/_lib.py).  Unknown names are rejected. */
+int32_t mcdseg_option_count(void);
+const char* mcdseg_option_name(int32_t index);
+int mcdseg_set_option(const char* name, int64_t value);
+int mcdseg_get_option(const char* name, int64_t* value, int64_t* default_value);
+
 /* ------------------------------------------------------------------------------------------------
  * Convolution  (nn.Conv2d call sites: models/drn.py:21-23,127,177,199; models/dilated_fcn.py:227)
  * groups = 1, square kernel, symmetric stride / padding / dilation.
@@ -383,6 +392,44 @@ int mcdseg_normalize_u8(const uint8_t* src, float* dst, const float* mean, const
                         int32_t Cs, int32_t C, int32_t c_off, void* stream);
 int mcdseg_relabel_u8(const uint8_t* src, int64_t* dst, int64_t count, int32_t olabel, int32_t nlabel, void* stream);
 int mcdseg_confusion_hist(const int64_t* gt, const int64_t* pred, int64_t count, int32_t n, int64_t* hist, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2-byte activation storage (round 6): BASELINE config 5 ("drn_d_105 ... bf16 ... HBM-bound stress"; the network is the reference's
+ * Bottleneck trunk, models/drn.py:62-100, 344-348, trained by adapt_trainer.py:155-220).  In the one-term arithmetic MCDSEG_MATH_F16X1
+ * a fused conv + BatchNorm (+ residual) + ReLU group inside a trunk keeps ONE 16-bit value per element of every tensor it moves, all in
+ * the companions' unit layout [N][C/8][H*W][8 x 16 bit] (one 16-byte unit = 8 channels of one pixel):
+ *   z16    the convolution's output: fp16 of z / scale(z_bound), z_bound = KH KW Cin x_bound w_bound written by the convolution (|z| cannot
+ *          exceed it; scale(b) = 2^(e-15), 2^e >= b, as for every F16X3 / F16X1 tensor).  fp16 rather than bf16: 11 significant bits
+ *          against 8 where the per-tensor scale keeps the values in range, which a bound known before the tensor is written does;
+ *   y_cb   the activation: the leading piece of the F16X3 companion, alone -- it IS the next convolution's operand;
+ *   dy16   the gradient arriving from the consumers: bf16 -- gradients span more binades than one scale covers and have no a-priori
+ *          bound; written by mcdseg_conv_split_dgrad_half (+ addend16: the other gradient of a residual block's input, same layout);
+ *   dz_cb  the leading piece of dz's companion (scale from dz_bound, as in mcdseg_bn_bwd_reduce); dres16: dy16 under the ReLU mask.
+ * mean / rstd / running statistics come from the convolution's fp32 accumulators through mcdseg_bn_stats_finalize as always; all
+ * BatchNorm arithmetic is fp32.  mask_kind: 0 no ReLU; 2 y > 0 recomputed from z16 (a group without residual: the forward kernel's own
+ * expression on the same stored z, so the same mask); 4 from y_cb (a group with residual).
+ * F16X1 reads the LEADING piece of every companion only (piece stride 0), so one- and two-piece companions mix freely.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t mcdseg_conv_split_half_ok(const mcdseg_conv_desc* d, int32_t math, int32_t dgrad);
+int mcdseg_conv_split_fprop_half(const mcdseg_conv_desc* d, int32_t math, const void* x_cb, const float* x_bound, const void* wp_fprop,
+                                 const float* w_bound, void* z16, float* z_bound, float* stat_partials, int32_t part, void* stream);
+int mcdseg_conv_split_dgrad_half(const mcdseg_conv_desc* d, int32_t math, const void* dy_cb, const float* dy_bound, const void* wp_dgrad,
+                                 const float* w_bound, const void* addend16, void* dx16, int32_t part, void* stream);
+int mcdseg_bn_apply_half(const void* z16, const float* z_bound, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                         const void* res_cb, const float* res_bound, void* y_cb, const float* y_bound, int32_t N, int32_t C, int32_t HW,
+                         int32_t relu, void* stream);
+size_t mcdseg_bn_bwd_half_workspace_bytes(int32_t N, int32_t C, int32_t HW);
+int mcdseg_bn_bwd_reduce_half(const void* dy16, const void* y_cb, const void* z16, const float* z_bound, const float* mean,
+                              const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* dz_bound,
+                              int32_t mask_kind, int32_t train, int32_t N, int32_t C, int32_t HW, void* workspace, size_t workspace_bytes,
+                              void* stream);
+int mcdseg_bn_bwd_apply_half(const void* dy16, const void* y_cb, const void* z16, const float* z_bound, const float* mean,
+                             const float* rstd, const float* gamma, const float* beta, const float* dgamma, const float* dbeta, void* dz_cb,
+                             const float* dz_bound, void* dres16, int32_t mask_kind, int32_t train, int32_t N, int32_t C, int32_t HW,
+                             void* stream);
+/* fp32 NCHW <-> bf16 units: a gradient crossing the border of the 2-byte chain through a kernel without the 16-bit epilogue */
+int mcdseg_pack_bf16_units(const float* x, void* out16, int32_t N, int32_t C, int32_t HW, void* stream);
+int mcdseg_unpack_bf16_units(const void* in16, float* x, int32_t N, int32_t C, int32_t HW, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SGD with momentum + weight decay on flat buffers (torch.optim.SGD via models/model_util.py:289-292)

@@ -8,6 +8,7 @@
 // Reference semantics: nn.BatchNorm2d(eps=1e-5, momentum=0.1) in train mode normalises with the biased
 // batch variance and moves running_var with the unbiased one (models/drn.py:34,38,129,179,202);
 // ReLU is in place after the residual add (models/drn.py:48,55-57).
+#include "options.h"
 #include "split.h"
 
 namespace {
@@ -205,11 +206,8 @@ __global__ __launch_bounds__(256) void bn_stats_one_kernel(const float* __restri
   }
 }
 
-// rows up to which the one-launch form is used (MCDSEG_BN_STATS_ONE, read per call: tests compare the two forms; 0 = never)
-int64_t stats_one_rows() {
-  const char* e = getenv("MCDSEG_BN_STATS_ONE");
-  return e ? atoll(e) : 1024;
-}
+// rows up to which the one-launch form is used (option BN_STATS_ONE: tests compare the two forms; 0 = never)
+int64_t stats_one_rows() { return mcd_opt(MCD_OPT_BN_STATS_ONE); }
 
 __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int C, float eps,
                                      float* __restrict__ mean, float* __restrict__ rstd) {
@@ -538,17 +536,20 @@ __device__ __forceinline__ void split_store(const float (&v)[8], float inv_scale
 
 // the inverse: 8 channels of one pixel back from the companion, value = scale * (sum of the pieces) -- exact for the bf16
 // split, the 22 leading bits for the fp16 one
+// (piece_stride == 0: the caller reads the leading piece only -- MCDSEG_MATH_F16X1, whose companions may be stored as ONE piece)
 template <class P>
 __device__ __forceinline__ void join_load(const typename P::elem* __restrict__ cb, float scale, size_t piece_stride, size_t idx16,
                                           float (&v)[8]) {
   typename P::frag pieces[P::NP];
 #pragma unroll
   for (int pc = 0; pc < P::NP; ++pc) pieces[pc] = *reinterpret_cast<const typename P::frag*>(cb + pc * piece_stride + idx16 * 8);
+  const bool lead_only = piece_stride == 0;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     float t = 0.f;
 #pragma unroll
-    for (int pc = P::NP - 1; pc >= 0; --pc) t += (float)pieces[pc][e];  // smallest piece first: exact
+    for (int pc = P::NP - 1; pc >= 1; --pc) t += lead_only ? 0.f : (float)pieces[pc][e];  // smallest piece first: exact
+    t += (float)pieces[0][e];
     v[e] = t * scale;
   }
 }
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(256) void bn_apply_cb_kernel(const float* __restric
                                                           const typename P::elem* __restrict__ res_cb,
                                                           const float* __restrict__ res_bound, float* __restrict__ y,
                                                           typename P::elem* __restrict__ cb, const float* __restrict__ y_bound, int N,
-                                                          int C, int HW, int relu) {
+                                                          int C, int HW, int relu, int res_lead_only) {
   const int C8 = C >> 3;
   const int ng = blockIdx.y;  // n * C8 + g
   const int g = ng % C8;
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(256) void bn_apply_cb_kernel(const float* __restric
     if (pix >= HW) continue;
     const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
     float r[8];
-    if (res_cb != nullptr) join_load<P>(res_cb, operand_scale<P>(res_bound), (size_t)N * C * HW, (size_t)ng * HW + pix, r);
+    if (res_cb != nullptr) join_load<P>(res_cb, operand_scale<P>(res_bound), res_lead_only ? (size_t)0 : (size_t)N * C * HW, (size_t)ng * HW + pix, r);
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_apply_cb_v4_kernel(const float* _
                                                              const float* __restrict__ res_bound, float* __restrict__ y,
                                                              typename P::elem* __restrict__ cb, const float* __restrict__ y_bound, int N,
                                                              int C, int HW, int relu, int rev,
-                                                             unsigned long long* __restrict__ rmask) {
+                                                             unsigned long long* __restrict__ rmask, int res_lead_only) {
   __shared__ typename P::frag lds[BN_V4_NT / 64][256];
   const int C8 = C >> 3;
   // rev: walk the tensor from its END -- the convolution that has just written z did so front to back, so the tail is what the
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(BN_V4_NT) void bn_apply_cb_v4_kernel(const float* _
     if (RES == 2) {  // compact activation storage: the residual exists only as its companion
       const float rscale = operand_scale<P>(res_bound);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) join_load<P>(res_cb, rscale, (size_t)N * C * HW, (size_t)ng * HW + pix + j, r[j]);
+      for (int j = 0; j < 4; ++j) join_load<P>(res_cb, rscale, res_lead_only ? (size_t)0 : (size_t)N * C * HW, (size_t)ng * HW + pix + j, r[j]);
     }
     float4 zq[8], rq[8];  // every load of the thread in flight before the first use
 #pragma unroll
@@ -939,7 +940,7 @@ int bwd_cb_slices(int N, int C, int HW) {
 // companion -> fp32 NCHW (an activation kept only as its companion, for a consumer outside the split kernels)
 template <class P>
 __global__ __launch_bounds__(256) void unsplit_cb_kernel(const typename P::elem* __restrict__ cb, const float* __restrict__ bound,
-                                                         float* __restrict__ x, int N, int C, int HW) {
+                                                         float* __restrict__ x, int N, int C, int HW, int lead_only) {
   const int C8 = C >> 3;
   const int ng = blockIdx.y;
   const int g = ng % C8;
@@ -947,7 +948,7 @@ __global__ __launch_bounds__(256) void unsplit_cb_kernel(const typename P::elem*
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= HW) return;
   float v[8];
-  join_load<P>(cb, operand_scale<P>(bound), (size_t)N * C * HW, (size_t)ng * HW + pix, v);
+  join_load<P>(cb, operand_scale<P>(bound), lead_only ? (size_t)0 : (size_t)N * C * HW, (size_t)ng * HW + pix, v);
   const size_t base = ((size_t)n * C + 8 * g) * HW + pix;
 #pragma unroll
   for (int e = 0; e < 8; ++e) x[base + (size_t)e * HW] = v[e];
@@ -1001,10 +1002,7 @@ int plane_chunks(int HW, bool vec) {
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // the four-pixel apply kernels walk their tensors back to front (see the kernels); MCDSEG_BN_REVERSE=0: front to back (development knob)
-int bn_reverse_walk() {
-  const char* e = getenv("MCDSEG_BN_REVERSE");
-  return e ? atoi(e) : 1;
-}
+int bn_reverse_walk() { return (int)mcd_opt(MCD_OPT_BN_REVERSE); }
 
 }  // namespace
 
@@ -1114,13 +1112,7 @@ extern "C" int mcdseg_split_cb_padded(const float* x, void* x_cb, const float* x
 }
 
 // the four-pixels-per-thread forms of the two companion-writing apply kernels (MCDSEG_BN_V4=0: the one-pixel forms)
-static bool bn_v4_on() {
-  static const bool on = [] {
-    const char* e = getenv("MCDSEG_BN_V4");
-    return e == nullptr || atoi(e) != 0;
-  }();
-  return on;
-}
+static bool bn_v4_on() { return mcd_opt(MCD_OPT_BN_V4) != 0; }
 
 template <class P, typename... A>
 static void launch_apply_v4(const float* res, const void* res_cb, dim3 grid, hipStream_t st, A... a) {
@@ -1142,6 +1134,7 @@ static void launch_bwd_apply_v4(int mask, dim3 grid, hipStream_t st, A... a) {
 extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                   const float* residual, const void* res_cb, const float* res_bound, float* y, void* y_cb,
                                   const float* y_bound, int32_t math, int32_t N, int32_t C, int32_t HW, int32_t relu, void* stream) {
+  const int lead = math == MCDSEG_MATH_F16X1;  // (F16X1 reads the leading piece of a companion only)
   math = mcd_storage_math(math);  // F16X1 shares F16X3's storage
   MCD_REQUIRE(z && mean && rstd && gamma && beta && y_cb, "bn_apply_cb: null pointer");
   MCD_REQUIRE(!(residual && res_cb), "bn_apply_cb: the residual comes either as fp32 or as its companion, not both");
@@ -1152,34 +1145,35 @@ extern "C" int mcdseg_bn_apply_cb(const float* z, const float* mean, const float
     const int rev = bn_reverse_walk();
     if (math == MCDSEG_MATH_F16X3)
       launch_apply_v4<SplitF16x3>(residual, res_cb, grid4, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual, (const _Float16*)res_cb,
-                                  res_bound, y, (_Float16*)y_cb, y_bound, N, C, HW, relu, rev, (unsigned long long*)nullptr);
+                                  res_bound, y, (_Float16*)y_cb, y_bound, N, C, HW, relu, rev, (unsigned long long*)nullptr, lead);
     else
       launch_apply_v4<SplitBf16x6>(residual, res_cb, grid4, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual, (const __bf16*)res_cb,
-                                   res_bound, y, (__bf16*)y_cb, y_bound, N, C, HW, relu, rev, (unsigned long long*)nullptr);
+                                   res_bound, y, (__bf16*)y_cb, y_bound, N, C, HW, relu, rev, (unsigned long long*)nullptr, lead);
     MCD_LAUNCH_CHECK("bn_apply_cb");
     return 0;
   }
   const dim3 grid(ceil_div(HW, 256 * BN_PIX_ITERS), N * (C / 8));
   if (math == MCDSEG_MATH_F16X3)
     hipLaunchKernelGGL(bn_apply_cb_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
-                       (const _Float16*)res_cb, res_bound, y, (_Float16*)y_cb, y_bound, N, C, HW, relu);
+                       (const _Float16*)res_cb, res_bound, y, (_Float16*)y_cb, y_bound, N, C, HW, relu, lead);
   else
     hipLaunchKernelGGL(bn_apply_cb_kernel<SplitBf16x6>, grid, dim3(256), 0, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual,
-                       (const __bf16*)res_cb, res_bound, y, (__bf16*)y_cb, y_bound, N, C, HW, relu);
+                       (const __bf16*)res_cb, res_bound, y, (__bf16*)y_cb, y_bound, N, C, HW, relu, lead);
   MCD_LAUNCH_CHECK("bn_apply_cb");
   return 0;
 }
 
 extern "C" int mcdseg_unsplit_cb(const void* x_cb, const float* x_bound, int32_t math, int32_t N, int32_t C, int32_t HW, float* x,
                                  void* stream) {
+  const int lead = math == MCDSEG_MATH_F16X1;  // (the leading piece only: an F16X1 companion may be stored as one piece)
   math = mcd_storage_math(math);  // F16X1 shares F16X3's storage
   MCD_REQUIRE(x_cb && x, "unsplit_cb: null pointer");
   if (int rc = cb_check("unsplit_cb", math, x_bound, N, C, HW)) return rc;
   const dim3 grid(ceil_div(HW, 256), N * (C / 8));
   if (math == MCDSEG_MATH_F16X3)
-    hipLaunchKernelGGL(unsplit_cb_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x_cb, x_bound, x, N, C, HW);
+    hipLaunchKernelGGL(unsplit_cb_kernel<SplitF16x3>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x_cb, x_bound, x, N, C, HW, lead);
   else
-    hipLaunchKernelGGL(unsplit_cb_kernel<SplitBf16x6>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)x_cb, x_bound, x, N, C, HW);
+    hipLaunchKernelGGL(unsplit_cb_kernel<SplitBf16x6>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)x_cb, x_bound, x, N, C, HW, lead);
   MCD_LAUNCH_CHECK("unsplit_cb");
   return 0;
 }
@@ -1222,10 +1216,10 @@ extern "C" int mcdseg_bn_apply_cb_mask(const float* z, const float* mean, const 
   const int rev = bn_reverse_walk();
   if (math == MCDSEG_MATH_F16X3)
     launch_apply_v4<SplitF16x3>(residual, nullptr, grid4, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual, (const _Float16*)nullptr,
-                                (const float*)nullptr, y, (_Float16*)y_cb, y_bound, N, C, HW, 1, rev, (unsigned long long*)relu_mask);
+                                (const float*)nullptr, y, (_Float16*)y_cb, y_bound, N, C, HW, 1, rev, (unsigned long long*)relu_mask, 0);
   else
     launch_apply_v4<SplitBf16x6>(residual, nullptr, grid4, (hipStream_t)stream, z, mean, rstd, gamma, beta, residual, (const __bf16*)nullptr,
-                                 (const float*)nullptr, y, (__bf16*)y_cb, y_bound, N, C, HW, 1, rev, (unsigned long long*)relu_mask);
+                                 (const float*)nullptr, y, (__bf16*)y_cb, y_bound, N, C, HW, 1, rev, (unsigned long long*)relu_mask, 0);
   MCD_LAUNCH_CHECK("bn_apply_cb_mask");
   return 0;
 }
@@ -1408,5 +1402,347 @@ extern "C" int mcdseg_bn_bwd_apply(const float* dy, const float* y, const float*
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, st, dy, y, z, mean, rstd, gamma, dgamma, dbeta, dz, dres, N,
                        C, HW, relu, train);
   MCD_LAUNCH_CHECK("bn_bwd_apply");
+  return 0;
+}
+
+// ================================================================================================
+// 2-byte activation storage (round 6; BASELINE config 5 "bf16", reference network models/drn.py:62-100, 344-348).  Inside a trunk run in
+// the one-term arithmetic (MCDSEG_MATH_F16X1) every tensor a BatchNorm pass touches is ONE 16-bit value per element, all in the
+// companions' unit layout [N][C/8][HW][8]:
+//   z     the convolution's output, fp16 of z / scale(z_bound)      written by the convolution's epilogue (conv_gemm_split*.hip), after
+//                                                                   it took the BatchNorm partial sums from its fp32 accumulators
+//   y     the activation, fp16 of y / scale(y_bound): ONE piece     it IS the next convolution's operand (SplitF16x1 stages one piece)
+//   dy    the incoming gradient, bf16                               written by the next convolution's data gradient
+//   dz    fp16 of dz / scale(dz_bound): one piece                   the operand of this convolution's data and weight gradient
+//   dres  the residual's gradient, bf16 (= dy under the ReLU mask: exact)
+// so a thread of these kernels owns whole 16-byte units -- 8 channels of one pixel -- of every tensor: no plane-to-unit transposition,
+// every load and store instruction of a wave covers 1 KB of consecutive bytes, and the passes move 4-6 (forward) / 4-6 (reduce) /
+// 6-10 (backward apply) bytes per element where the fp32 forms move 8-12 / 8-10 / 12-18.  All arithmetic is fp32: mean, rstd, the
+// running statistics and the bounds come from the same finalize kernels as ever.
+namespace {
+
+// the forward map of one channel, shared by the forward kernel and the backward kernels' ReLU mask (y > 0 recomputed from z: the same
+// expression on the same 16-bit z, so the same mask, bit for bit): y = fma(zh, a zs, b), a = gamma rstd, b = beta - mean a, zh the stored
+// half, zs the (power-of-two) scale of z -- a zs is exact
+struct HalfAffine {
+  float a[8], b[8];
+  __device__ __forceinline__ void load(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, int c0, float zs) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float ca = gamma[c0 + e] * rstd[c0 + e];
+      b[e] = beta[c0 + e] - mean[c0 + e] * ca;
+      a[e] = ca * zs;
+    }
+  }
+};
+
+#ifndef BN_H_UNITS
+#define BN_H_UNITS 2  // units (pixels) per thread of the two streaming kernels, 256 apart
+#endif
+
+// RES: 0 none, 2 the residual as its (leading) companion piece
+template <int RES>
+__global__ __launch_bounds__(256) void bn_apply_h_kernel(const f16x8* __restrict__ z, const float* __restrict__ z_bound,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const f16x8* __restrict__ res_cb, const float* __restrict__ res_bound,
+                                                         f16x8* __restrict__ y_cb, const float* __restrict__ y_bound, int C8, int HW, int relu) {
+  const int ng = blockIdx.y;  // n * C8 + g
+  const int g = ng % C8;
+  HalfAffine f;
+  f.load(gamma, beta, mean, rstd, 8 * g, mcd_scale_of_bound(*z_bound));
+  const float inv_ys = 1.f / mcd_scale_of_bound(*y_bound);
+  const float rs = RES == 2 ? mcd_scale_of_bound(*res_bound) : 0.f;
+  const size_t base = (size_t)ng * HW;
+  f16x8 zq[BN_H_UNITS], rq[BN_H_UNITS];
+  int pix[BN_H_UNITS];
+#pragma unroll
+  for (int u = 0; u < BN_H_UNITS; ++u) {  // every load of the thread in flight before the first use (clamped: no branch around a load)
+    pix[u] = (blockIdx.x * BN_H_UNITS + u) * 256 + threadIdx.x;
+    const int pc = pix[u] < HW ? pix[u] : HW - 1;
+    zq[u] = z[base + pc];
+    if (RES == 2) rq[u] = res_cb[base + pc];
+  }
+#pragma unroll
+  for (int u = 0; u < BN_H_UNITS; ++u) {
+    if (pix[u] >= HW) continue;
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = fmaf((float)zq[u][e], f.a[e], f.b[e]);
+      if (RES == 2) t += (float)rq[u][e] * rs;
+      if (relu) t = fmaxf(t, 0.f);
+      o[e] = (_Float16)(t * inv_ys);
+    }
+    y_cb[base + pix[u]] = o;
+  }
+}
+
+// ReLU mask of a unit.  MASK: 0 none, 2 recomputed from z (a group without residual), 4 from the activation's piece (y > 0 <=> its
+// fp16 image > 0, except 0 < y < 2^-25 of the scale, which the piece rounds to zero -- and which the next convolution multiplies as zero)
+template <int MASK>
+__device__ __forceinline__ unsigned half_mask(const f16x8& zq, const f16x8& yq, const HalfAffine& f) {
+  if (MASK == 0) return 0xFFu;
+  unsigned m = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bool on = MASK == 2 ? fmaf((float)zq[e], f.a[e], f.b[e]) > 0.f : (float)yq[e] > 0.f;
+    m |= (on ? 1u : 0u) << e;
+  }
+  return m;
+}
+
+// backward reduce: grid (slices, N * C8); a block strides over the pixels of its (image, channel group) slice, four units in flight per
+// thread, and writes one partial row per channel: part[((n * slices + slice) * 3 + {sum dy, sum dy xhat, max |dy|}) * C + c] -- the
+// rows bn_bwd_finalize_kernel merges in fp64
+template <int MASK>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_h_kernel(const bf16x8* __restrict__ dy, const f16x8* __restrict__ y_cb,
+                                                              const f16x8* __restrict__ z, const float* __restrict__ z_bound,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ part, int C, int HW, int per_slice,
+                                                              float* __restrict__ dz_bound) {
+  const int C8 = C >> 3;
+  const int ng = blockIdx.y;
+  const int g = ng % C8;
+  const int n = ng / C8;
+  if (dz_bound != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *dz_bound = 0.f;  // finalize: atomic max
+  const float zs = mcd_scale_of_bound(*z_bound);
+  HalfAffine f;
+  f.load(gamma, beta, mean, rstd, 8 * g, zs);
+  float mu[8], rs[8], s_dy[8], s_dyx[8], m_g[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mu[e] = mean[8 * g + e];
+    rs[e] = rstd[8 * g + e];
+    s_dy[e] = s_dyx[e] = m_g[e] = 0.f;
+  }
+  const size_t base = (size_t)ng * HW;
+  const int p0 = blockIdx.x * per_slice;
+  int p1 = p0 + per_slice;
+  if (p1 > HW) p1 = HW;
+  for (int pb = p0 + (int)threadIdx.x; pb < p1; pb += 4 * 256) {
+    bf16x8 gq[4];
+    f16x8 zq[4], yq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pc = pb + u * 256 < p1 ? pb + u * 256 : p1 - 1;
+      gq[u] = dy[base + pc];
+      zq[u] = z[base + pc];
+      if (MASK == 4) yq[u] = y_cb[base + pc];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (pb + u * 256 >= p1) break;
+      const unsigned m = half_mask<MASK>(zq[u], yq[u], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float gv = ((m >> e) & 1u) ? (float)gq[u][e] : 0.f;
+        s_dy[e] += gv;
+        m_g[e] = fmaxf(m_g[e], fabsf(gv));
+        s_dyx[e] += gv * (((float)zq[u][e] * zs - mu[e]) * rs[e]);
+      }
+    }
+  }
+  __shared__ float sh[3][8][4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float a = wave_sum(s_dy[e]), b = wave_sum(s_dyx[e]);
+    float m = m_g[e];
+    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) {
+      sh[0][e][threadIdx.x >> 6] = a;
+      sh[1][e][threadIdx.x >> 6] = b;
+      sh[2][e][threadIdx.x >> 6] = m;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 24) {
+    const int k = threadIdx.x >> 3, e = threadIdx.x & 7;
+    const float v = k == 2 ? fmaxf(fmaxf(sh[2][e][0], sh[2][e][1]), fmaxf(sh[2][e][2], sh[2][e][3]))
+                           : (sh[k][e][0] + sh[k][e][1]) + (sh[k][e][2] + sh[k][e][3]);
+    part[((size_t)(n * gridDim.x + blockIdx.x) * 3 + k) * C + 8 * g + e] = v;
+  }
+}
+
+// slices per (image, channel group): ~4096 blocks in all, at least 1024 pixels per block
+int bwd_h_slices(int N, int C, int HW) {
+  int s = (int)ceil_div64(4096, (int64_t)N * (C / 8));
+  const int most = ceil_div(HW, 1024);
+  if (s > most) s = most;
+  return s < 1 ? 1 : s;
+}
+
+template <int MASK>
+__global__ __launch_bounds__(256) void bn_bwd_apply_h_kernel(const bf16x8* __restrict__ dy, const f16x8* __restrict__ y_cb,
+                                                             const f16x8* __restrict__ z, const float* __restrict__ z_bound,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                             f16x8* __restrict__ dz_cb, const float* __restrict__ dz_bound,
+                                                             bf16x8* __restrict__ dres, int N, int C8, int HW, int train) {
+  const int ng = blockIdx.y;
+  const int g = ng % C8;
+  const float zs = mcd_scale_of_bound(*z_bound);
+  HalfAffine f;
+  f.load(gamma, beta, mean, rstd, 8 * g, zs);
+  const float inv_s = 1.f / mcd_scale_of_bound(*dz_bound);
+  const float inv_n = 1.f / ((float)N * (float)HW);
+  float cmu[8], crs[8], ca[8], k1[8], k2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = 8 * g + e;
+    cmu[e] = mean[c];
+    crs[e] = rstd[c];
+    ca[e] = gamma[c] * crs[e];
+    k1[e] = train ? dbeta[c] * inv_n : 0.f;
+    k2[e] = train ? dgamma[c] * inv_n : 0.f;
+  }
+  const size_t base = (size_t)ng * HW;
+  bf16x8 gq[BN_H_UNITS];
+  f16x8 zq[BN_H_UNITS], yq[BN_H_UNITS];
+  int pix[BN_H_UNITS];
+#pragma unroll
+  for (int u = 0; u < BN_H_UNITS; ++u) {
+    pix[u] = (blockIdx.x * BN_H_UNITS + u) * 256 + threadIdx.x;
+    const int pc = pix[u] < HW ? pix[u] : HW - 1;
+    gq[u] = dy[base + pc];
+    zq[u] = z[base + pc];
+    if (MASK == 4) yq[u] = y_cb[base + pc];
+  }
+#pragma unroll
+  for (int u = 0; u < BN_H_UNITS; ++u) {
+    if (pix[u] >= HW) continue;
+    const unsigned m = half_mask<MASK>(zq[u], yq[u], f);
+    f16x8 o;
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool on = ((m >> e) & 1u) != 0;
+      const float gv = on ? (float)gq[u][e] : 0.f;
+      r[e] = on ? gq[u][e] : (__bf16)0.f;
+      const float t = ca[e] * (gv - k1[e] - (((float)zq[u][e] * zs - cmu[e]) * crs[e]) * k2[e]);
+      o[e] = (_Float16)(t * inv_s);
+    }
+    dz_cb[base + pix[u]] = o;
+    if (dres != nullptr) dres[base + pix[u]] = r;
+  }
+}
+
+// fp32 NCHW -> bf16 units (a gradient a kernel without the 16-bit epilogue produced, for a consumer inside the 2-byte chain) and back
+__global__ __launch_bounds__(256) void pack_bf16_units_kernel(const float* __restrict__ x, bf16x8* __restrict__ out, int C, int HW) {
+  const int C8 = C >> 3;
+  const int ng = blockIdx.y;
+  const int g = ng % C8, n = ng / C8;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= HW) return;
+  const size_t src = ((size_t)n * C + 8 * g) * HW + pix;
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (__bf16)x[src + (size_t)e * HW];
+  out[(size_t)ng * HW + pix] = o;
+}
+
+__global__ __launch_bounds__(256) void unpack_bf16_units_kernel(const bf16x8* __restrict__ in, float* __restrict__ x, int C, int HW) {
+  const int C8 = C >> 3;
+  const int ng = blockIdx.y;
+  const int g = ng % C8, n = ng / C8;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= HW) return;
+  const bf16x8 v = in[(size_t)ng * HW + pix];
+  const size_t dst = ((size_t)n * C + 8 * g) * HW + pix;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[dst + (size_t)e * HW] = (float)v[e];
+}
+
+int half_check(const char* who, int32_t N, int32_t C, int32_t HW) {
+  MCD_REQUIRE(N > 0 && C > 0 && HW > 0 && (C % 8) == 0, "%s: C must be a positive multiple of 8", who);
+  MCD_REQUIRE((int64_t)N * (C / 8) <= 65535, "%s: N*C/8 exceeds the grid limit", who);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mcdseg_bn_apply_half(const void* z16, const float* z_bound, const float* mean, const float* rstd, const float* gamma,
+                                    const float* beta, const void* res_cb, const float* res_bound, void* y_cb, const float* y_bound, int32_t N,
+                                    int32_t C, int32_t HW, int32_t relu, void* stream) {
+  MCD_REQUIRE(z16 && z_bound && mean && rstd && gamma && beta && y_cb && y_bound, "bn_apply_half: null pointer");
+  MCD_REQUIRE(res_cb == nullptr || res_bound != nullptr, "bn_apply_half: the residual companion needs its bound");
+  if (int rc = half_check("bn_apply_half", N, C, HW)) return rc;
+  const dim3 grid(ceil_div(HW, 256 * BN_H_UNITS), N * (C / 8));
+  if (res_cb != nullptr)
+    hipLaunchKernelGGL(bn_apply_h_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const f16x8*)z16, z_bound, mean, rstd, gamma, beta,
+                       (const f16x8*)res_cb, res_bound, (f16x8*)y_cb, y_bound, C / 8, HW, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_h_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const f16x8*)z16, z_bound, mean, rstd, gamma, beta,
+                       (const f16x8*)nullptr, (const float*)nullptr, (f16x8*)y_cb, y_bound, C / 8, HW, relu);
+  MCD_LAUNCH_CHECK("bn_apply_half");
+  return 0;
+}
+
+extern "C" size_t mcdseg_bn_bwd_half_workspace_bytes(int32_t N, int32_t C, int32_t HW) {
+  if (N <= 0 || C <= 0 || HW <= 0 || (C & 7) != 0) return 0;
+  return (size_t)N * bwd_h_slices(N, C, HW) * 3 * C * sizeof(float);
+}
+
+// mask_kind: 0 no ReLU, 2 the mask recomputed from z (a ReLU group without residual: needs gamma / beta), 4 from the activation's piece y_cb
+extern "C" int mcdseg_bn_bwd_reduce_half(const void* dy16, const void* y_cb, const void* z16, const float* z_bound, const float* mean,
+                                         const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                                         float* dz_bound, int32_t mask_kind, int32_t train, int32_t N, int32_t C, int32_t HW, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  MCD_REQUIRE(dy16 && z16 && z_bound && mean && rstd && gamma && beta && dgamma && dbeta && workspace, "bn_bwd_reduce_half: null pointer");
+  MCD_REQUIRE(mask_kind == 0 || mask_kind == 2 || (mask_kind == 4 && y_cb != nullptr), "bn_bwd_reduce_half: mask_kind must be 0, 2 or 4 (with y_cb)");
+  if (int rc = half_check("bn_bwd_reduce_half", N, C, HW)) return rc;
+  MCD_REQUIRE(workspace_bytes >= mcdseg_bn_bwd_half_workspace_bytes(N, C, HW), "bn_bwd_reduce_half: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int sl = bwd_h_slices(N, C, HW);
+  const int per = round_up(ceil_div(HW, sl), 256);
+  const dim3 grid(ceil_div(HW, per), N * (C / 8));
+  const int S = N * (int)grid.x;
+#define MCD_RH(M)                                                                                                                       \
+  hipLaunchKernelGGL(bn_bwd_reduce_h_kernel<M>, grid, dim3(256), 0, st, (const bf16x8*)dy16, (const f16x8*)y_cb, (const f16x8*)z16, z_bound, \
+                     mean, rstd, gamma, beta, (float*)workspace, C, HW, per, dz_bound)
+  if (mask_kind == 0) MCD_RH(0); else if (mask_kind == 2) MCD_RH(2); else MCD_RH(4);
+#undef MCD_RH
+  MCD_LAUNCH_CHECK("bn_bwd_reduce_half");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)workspace, S, C, dgamma, dbeta, gamma, rstd,
+                     (float)N * (float)HW, train, dz_bound);
+  MCD_LAUNCH_CHECK("bn_bwd_finalize");
+  return 0;
+}
+
+extern "C" int mcdseg_bn_bwd_apply_half(const void* dy16, const void* y_cb, const void* z16, const float* z_bound, const float* mean,
+                                        const float* rstd, const float* gamma, const float* beta, const float* dgamma, const float* dbeta,
+                                        void* dz_cb, const float* dz_bound, void* dres16, int32_t mask_kind, int32_t train, int32_t N, int32_t C,
+                                        int32_t HW, void* stream) {
+  MCD_REQUIRE(dy16 && z16 && z_bound && mean && rstd && gamma && beta && dz_cb && dz_bound, "bn_bwd_apply_half: null pointer");
+  MCD_REQUIRE(!train || (dgamma && dbeta), "bn_bwd_apply_half: train mode needs dgamma/dbeta");
+  MCD_REQUIRE(mask_kind == 0 || mask_kind == 2 || (mask_kind == 4 && y_cb != nullptr), "bn_bwd_apply_half: mask_kind must be 0, 2 or 4 (with y_cb)");
+  if (int rc = half_check("bn_bwd_apply_half", N, C, HW)) return rc;
+  const dim3 grid(ceil_div(HW, 256 * BN_H_UNITS), N * (C / 8));
+  hipStream_t st = (hipStream_t)stream;
+#define MCD_AH(M)                                                                                                                      \
+  hipLaunchKernelGGL(bn_bwd_apply_h_kernel<M>, grid, dim3(256), 0, st, (const bf16x8*)dy16, (const f16x8*)y_cb, (const f16x8*)z16, z_bound, \
+                     mean, rstd, gamma, beta, dgamma, dbeta, (f16x8*)dz_cb, dz_bound, (bf16x8*)dres16, N, C / 8, HW, train)
+  if (mask_kind == 0) MCD_AH(0); else if (mask_kind == 2) MCD_AH(2); else MCD_AH(4);
+#undef MCD_AH
+  MCD_LAUNCH_CHECK("bn_bwd_apply_half");
+  return 0;
+}
+
+extern "C" int mcdseg_pack_bf16_units(const float* x, void* out16, int32_t N, int32_t C, int32_t HW, void* stream) {
+  MCD_REQUIRE(x && out16, "pack_bf16_units: null pointer");
+  if (int rc = half_check("pack_bf16_units", N, C, HW)) return rc;
+  hipLaunchKernelGGL(pack_bf16_units_kernel, dim3(ceil_div(HW, 256), N * (C / 8)), dim3(256), 0, (hipStream_t)stream, x, (bf16x8*)out16, C, HW);
+  MCD_LAUNCH_CHECK("pack_bf16_units");
+  return 0;
+}
+
+extern "C" int mcdseg_unpack_bf16_units(const void* in16, float* x, int32_t N, int32_t C, int32_t HW, void* stream) {
+  MCD_REQUIRE(x && in16, "unpack_bf16_units: null pointer");
+  if (int rc = half_check("unpack_bf16_units", N, C, HW)) return rc;
+  hipLaunchKernelGGL(unpack_bf16_units_kernel, dim3(ceil_div(HW, 256), N * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)in16, x, C, HW);
+  MCD_LAUNCH_CHECK("unpack_bf16_units");
   return 0;
 }

@@ -6,6 +6,7 @@
 #include <stdio.h>
 
 #include "mcdseg.h"
+#include "options.h"
 
 void mcdseg_set_error(const char* fmt, ...);
 

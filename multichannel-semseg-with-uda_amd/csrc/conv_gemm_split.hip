@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "conv_split_params.h"
+#include "options.h"
 
 namespace {
 
@@ -589,6 +590,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
   }
   bool colv[WN];
   size_t dbase[WN];
+  size_t ubase[std::is_same<P, SplitF16x1>::value ? WN : 1];  // (16-bit blocked output: the pixel's first unit)
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int pp = ltile * BN + wn * (32 * WN) + j * 32 + l31;  // pixel index inside the (class) ordering
@@ -603,7 +605,56 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
       }
     }
     dbase[j] = (size_t)n * p.M * HWd + rem;
+    if constexpr (std::is_same<P, SplitF16x1>::value) ubase[j] = (size_t)n * (p.M >> 3) * HWd + rem;
   }
+  // ---- 16-bit channel-blocked output (the one-term arithmetic only; see conv_gemm_split_pp.hip): registers r = 4 q .. 4 q + 3 of a
+  // tile are channels 8 q + 4 lh .. + 3 of one pixel, half of a 16-byte unit
+  bool half_out = false;
+  if constexpr (std::is_same<P, SplitF16x1>::value) half_out = p.dst16 != nullptr;
+  if constexpr (std::is_same<P, SplitF16x1>::value) {
+    if (half_out) {
+      float inv_zs = 1.f;
+      if (!DGRAD) {
+        const float zb = (float)(taps * p.Cs) * (*p.src_bound) * (*p.w_bound);  // |z| <= taps Cs max|x| max|w|
+        inv_zs = 1.f / mcd_scale_of_bound(zb);
+        if (blockIdx.x == 0 && t == 0 && p.dst_bound != nullptr) *p.dst_bound = zb;
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m0 = m_wave + i * 32 + 8 * q;
+          if (m0 < p.M) {  // (M is a multiple of 8: host)
+            const size_t gofs = (size_t)(m0 >> 3) * HWd;
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+              if (colv[j]) {
+                const size_t byte = (ubase[j] + gofs) * 16 + lh * 8;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * q + k];
+                if (DGRAD) {
+                  if (p.ep_res16 != nullptr) {
+                    const mcd_bf16x4 add = *reinterpret_cast<const mcd_bf16x4*>((const char*)p.ep_res16 + byte);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += (float)add[k];
+                  }
+                  mcd_bf16x4 o;
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) o[k] = (__bf16)v[k];
+                  *reinterpret_cast<mcd_bf16x4*>((char*)p.dst16 + byte) = o;
+                } else {
+                  mcd_f16x4 o;
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) o[k] = (_Float16)(v[k] * inv_zs);
+                  *reinterpret_cast<mcd_f16x4*>((char*)p.dst16 + byte) = o;
+                }
+              }
+          }
+        }
+    }
+  }
+  if (!half_out) {
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -624,6 +675,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
           }
       }
     }
+  }
   if (!DGRAD && p.stats != nullptr) {
     int cntw = p.P - p_wave;
     cntw = cntw < 0 ? 0 : (cntw > 32 * WN ? 32 * WN : cntw);
@@ -834,10 +886,7 @@ int64_t split_image_bytes(int math, int M, int K, int T) {
 }
 
 // development knob: number of tile slots from which the 256 x 128 tile is preferred (see launch<>)
-int big_tile_min_slots() {  // (read per call: a test runs one problem on several tiles)
-  const char* e = getenv("MCDSEG_BIGTILE_MIN_SLOTS");
-  return e ? atoi(e) : 1024;
-}
+int big_tile_min_slots() { return (int)mcd_opt(MCD_OPT_BIGTILE_MIN_SLOTS); }  // (a test runs one problem on several tiles)
 
 template <class P, int WM, int WN, int WAVES_M, int WAVES_N, bool DGRAD>
 void launch_cfg(const ConvSplitParams& p, int64_t pix0, hipStream_t st) {
@@ -859,7 +908,7 @@ void launch_cfg(const ConvSplitParams& p, int64_t pix0, hipStream_t st) {
     q.cls_tile0[4] = t0;
     n_tiles = t0;
     const int c0 = q.cls_tile0[1];
-    static const bool interleave = [] { const char* e = getenv("MCDSEG_DGRAD_INTERLEAVE"); return e == nullptr || atoi(e) != 0; }();
+    const bool interleave = mcd_opt(MCD_OPT_DGRAD_INTERLEAVE) != 0;
     if (interleave && q.cls_tile0[2] == 2 * c0 && q.cls_tile0[3] == 3 * c0 && t0 == 4 * c0) q.sub = 2;
   }
   dim3 grid(8 * ceil_div(n_tiles, 8) * (p.Mp / BM));
@@ -870,10 +919,7 @@ void launch_cfg(const ConvSplitParams& p, int64_t pix0, hipStream_t st) {
 }
 
 // development knob: number of 128 x 256 tiles from which that tile is preferred over 128 x 128 (see tile_config)
-int wide_tile_min_slots() {
-  const char* e = getenv("MCDSEG_WIDETILE_MIN_SLOTS");
-  return e ? atoi(e) : 1024;
-}
+int wide_tile_min_slots() { return (int)mcd_opt(MCD_OPT_WIDETILE_MIN_SLOTS); }
 
 // Workgroup tile of the implicit GEMM with M output rows (padded Mp) and P pixels, as WM WN WAVES_M WAVES_N packed into decimal
 // digits: 4222 = 256 x 128 (each wave 128 x 64), 4214 = 128 x 256 (each wave 128 x 64, four waves along the pixels), 2222 =
@@ -1057,10 +1103,7 @@ extern "C" int mcdseg_conv_split_pack_weights_multi(const int64_t* ptrs, const i
   hipStream_t st = (hipStream_t)stream;
   // workgroups per (convolution, image): a 512 -> 512 3 x 3 kernel is 512 tiles of 32 rows x 16 channels x 9 taps, and a workgroup walks
   // its tiles one after the other (stage, barrier, convert, store)
-  static const unsigned pack_blocks = [] {
-    const char* e = getenv("MCDSEG_PACK_BLOCKS");  // development knob
-    return (unsigned)(e && atoi(e) > 0 ? atoi(e) : 192);  // (96 -> 192: 0.194 -> 0.177 ms per optimizer step, round 5)
-  }();
+  const unsigned pack_blocks = (unsigned)(mcd_opt(MCD_OPT_PACK_BLOCKS) > 0 ? mcd_opt(MCD_OPT_PACK_BLOCKS) : 192);  // (96 -> 192: 0.194 -> 0.177 ms per optimizer step, round 5)
   if (math == MCDSEG_MATH_F16X3) {
     (void)hipMemsetAsync(bounds, 0, sizeof(float) * (size_t)n, st);
     hipLaunchKernelGGL(absmax_multi_kernel, dim3(48, (unsigned)n), dim3(256), 0, st, ptrs, dims);
@@ -1074,7 +1117,9 @@ extern "C" int mcdseg_conv_split_pack_weights_multi(const int64_t* ptrs, const i
 }
 
 // one piece of the companion of this call's N images, and the distance between the pieces (the companion's own batch d->Ncb)
-static int split_cb_bytes(const mcdseg_conv_desc* d, int C, int HW, const void* cb, int* piece_bytes, long long* piece_stride) {
+// (F16X1 multiplies -- and therefore reads -- the leading piece only: its piece stride is 0, so that a companion stored as ONE piece,
+// the 2-byte activation storage of round 6, can never be read past its end by a kernel that addresses "piece 1")
+static int split_cb_bytes(const mcdseg_conv_desc* d, int math, int C, int HW, const void* cb, int* piece_bytes, long long* piece_stride) {
   *piece_bytes = 0;
   *piece_stride = 0;
   if (cb == nullptr) return 0;
@@ -1083,7 +1128,7 @@ static int split_cb_bytes(const mcdseg_conv_desc* d, int C, int HW, const void* 
   const int64_t b = (int64_t)d->N * C * HW * 2;
   MCD_REQUIRE(b < (1ll << 31), "conv_split: one piece of the pre-split operand exceeds 2 GiB; split the batch");
   *piece_bytes = (int)b;
-  *piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * C * HW * 2;
+  *piece_stride = math == MCDSEG_MATH_F16X1 ? 0 : (long long)(d->Ncb ? d->Ncb : d->N) * C * HW * 2;
   return 0;
 }
 
@@ -1091,9 +1136,16 @@ static int fill_fprop_params(const mcdseg_conv_desc* d, int math, const void* x_
 
 static int split_fprop_impl(const mcdseg_conv_desc* d, int math, const float* x, const void* x_cb, const float* x_bound, const void* wp,
                             const float* w_bound, const float* bias, float* y, float* stats, const float* ep_scale,
-                            const float* ep_shift, const float* ep_res, int ep_relu, void* stream, int part = 0) {
-  if (int rc = split_check(d, math, "conv_split_fprop")) return rc;
-  MCD_REQUIRE((x || x_cb) && wp && y, "conv_split_fprop: null pointer");
+                            const float* ep_shift, const float* ep_res, int ep_relu, void* stream, int part = 0, void* z16 = nullptr,
+                            float* z_bound = nullptr) {
+  if (int rc = split_check(d, math, "conv_split_fprop", z16 == nullptr)) return rc;
+  MCD_REQUIRE((x || x_cb) && wp && (y || z16), "conv_split_fprop: null pointer");
+  if (z16 != nullptr) {
+    MCD_REQUIRE(mcdseg_conv_split_half_ok(d, math, 0) && x_cb != nullptr && z_bound != nullptr && bias == nullptr && ep_scale == nullptr,
+                "conv_split_fprop_half: the 16-bit output needs f16x1, a pre-split input, channel counts divisible by 8, a bound scalar "
+                "to write and no bias / affine epilogue (mcdseg_conv_split_half_ok tells)");
+    MCD_REQUIRE((int64_t)d->N * d->Cout * d->Ho * d->Wo * 2 < (1ll << 32), "conv_split_fprop_half: output above 4 GiB; split the batch");
+  }
   const bool stem = mcdseg_internal_stem_ok(d);
   // the stem with a (zero-padded, 8-channel) companion of the network input runs on the window kernel; its fp32 form (and every
   // bias / affine epilogue) on the direct bf16x6 kernel
@@ -1118,6 +1170,7 @@ static int split_fprop_impl(const mcdseg_conv_desc* d, int math, const float* x,
   p.src_bound = x_bound; p.w_bound = w_bound;
   p.src = x; p.wp = wp; p.bias = bias; p.dst = y; p.stats = stats;
   p.ep_scale = ep_scale; p.ep_shift = ep_shift; p.ep_res = ep_res; p.ep_relu = ep_relu;
+  p.dst16 = z16; p.dst_bound = z_bound;
   if (int rc = launch_math<false>(math, p, part, (hipStream_t)stream)) return rc;
   MCD_LAUNCH_CHECK("conv_split_fprop");
   return 0;
@@ -1125,7 +1178,7 @@ static int split_fprop_impl(const mcdseg_conv_desc* d, int math, const float* x,
 
 // geometry of the forward implicit GEMM (everything but the data pointers)
 static int fill_fprop_params(const mcdseg_conv_desc* d, int math, const void* x_cb, ConvSplitParams& p) {
-  if (int rc = split_cb_bytes(d, d->Cin, d->H * d->W, x_cb, &p.cb_bytes, &p.cb_piece_stride)) return rc;
+  if (int rc = split_cb_bytes(d, math, d->Cin, d->H * d->W, x_cb, &p.cb_bytes, &p.cb_piece_stride)) return rc;
   p.src_cb = x_cb;
   p.N = d->N;
   p.Cs = d->Cin; p.Hs = d->H; p.Ws = d->W;
@@ -1140,6 +1193,7 @@ static int fill_fprop_params(const mcdseg_conv_desc* d, int math, const void* x_
   p.wp_bytes = (int)wb;
   p.sub = 0; p.tile_n0 = 0; p.tile_n1 = 0;
   p.ep_res_lds = 0; p.ep_res_bytes = 0;
+  p.dst16 = nullptr; p.dst_bound = nullptr; p.ep_res16 = nullptr;
   return 0;
 }
 
@@ -1157,7 +1211,7 @@ extern "C" int mcdseg_conv_split_fprop_affine(const mcdseg_conv_desc* d, int32_t
 }
 
 static int fill_dgrad_params(const mcdseg_conv_desc* d, int math, const void* dy_cb, ConvSplitParams& p) {
-  if (int rc = split_cb_bytes(d, d->Cout, d->Ho * d->Wo, dy_cb, &p.cb_bytes, &p.cb_piece_stride)) return rc;
+  if (int rc = split_cb_bytes(d, math, d->Cout, d->Ho * d->Wo, dy_cb, &p.cb_bytes, &p.cb_piece_stride)) return rc;
   p.src_cb = dy_cb;
   p.N = d->N;
   p.Cs = d->Cout; p.Hs = d->Ho; p.Ws = d->Wo;
@@ -1172,13 +1226,21 @@ static int fill_dgrad_params(const mcdseg_conv_desc* d, int math, const void* dy
   p.wp_bytes = (int)wb;
   p.sub = 0; p.tile_n0 = 0; p.tile_n1 = 0;
   p.ep_res_lds = 0; p.ep_res_bytes = 0;
+  p.dst16 = nullptr; p.dst_bound = nullptr; p.ep_res16 = nullptr;
   return 0;
 }
 
 static int split_dgrad_impl(const mcdseg_conv_desc* d, int32_t math, const float* dy, const void* dy_cb, const float* dy_bound,
-                            const void* wp_dgrad, const float* w_bound, float* dx, void* stream, int part, const float* addend = nullptr) {
-  if (int rc = split_check(d, math, "conv_split_dgrad")) return rc;
-  MCD_REQUIRE((dy || dy_cb) && wp_dgrad && dx, "conv_split_dgrad: null pointer");
+                            const void* wp_dgrad, const float* w_bound, float* dx, void* stream, int part, const float* addend = nullptr,
+                            void* dx16 = nullptr, const void* addend16 = nullptr) {
+  if (int rc = split_check(d, math, "conv_split_dgrad", dx16 == nullptr)) return rc;
+  MCD_REQUIRE((dy || dy_cb) && wp_dgrad && (dx || dx16), "conv_split_dgrad: null pointer");
+  if (dx16 != nullptr) {
+    MCD_REQUIRE(mcdseg_conv_split_half_ok(d, math, 1) && dy_cb != nullptr && addend == nullptr,
+                "conv_split_dgrad_half: the 16-bit output needs f16x1, a pre-split gradient and channel counts divisible by 8 "
+                "(mcdseg_conv_split_half_ok tells)");
+    MCD_REQUIRE((int64_t)d->N * d->Cin * d->H * d->W * 2 < (1ll << 32), "conv_split_dgrad_half: output above 4 GiB; split the batch");
+  }
   const int smath = mcd_storage_math(math);
   MCD_REQUIRE(smath != MCDSEG_MATH_F16X3 || (dy_bound && w_bound), "conv_split_dgrad: f16x3 needs the operand and weight bound scalars");
   MCD_REQUIRE(addend == nullptr || !(smath == MCDSEG_MATH_F16X3 && dy_cb != nullptr && mcdseg_internal_thin_window_ok(d, 1)),
@@ -1192,8 +1254,9 @@ static int split_dgrad_impl(const mcdseg_conv_desc* d, int32_t math, const float
   p.src_bound = dy_bound; p.w_bound = w_bound;
   p.src = dy; p.wp = wp_dgrad; p.bias = nullptr; p.dst = dx; p.stats = nullptr;
   p.ep_scale = nullptr; p.ep_shift = nullptr; p.ep_res = addend; p.ep_relu = 0;
+  p.dst16 = dx16; p.ep_res16 = addend16;
   if (addend != nullptr) {
-    static const bool stage = [] { const char* e = getenv("MCDSEG_DGRAD_ADD_LDS"); return e == nullptr || atoi(e) != 0; }();  // development knob
+    const bool stage = mcd_opt(MCD_OPT_DGRAD_ADD_LDS) != 0;  // development knob
     const int64_t bytes = (int64_t)d->N * d->Cin * d->H * d->W * 4;
     p.ep_res_lds = stage && ((d->H * d->W) & 3) == 0 && (reinterpret_cast<uintptr_t>(addend) & 15) == 0 && bytes < (1ll << 32) ? 1 : 0;
     p.ep_res_bytes = (unsigned)(bytes < (1ll << 32) ? bytes : 0);
@@ -1264,4 +1327,35 @@ extern "C" int mcdseg_conv_split_dgrad_part(const mcdseg_conv_desc* d, int32_t m
                                             const void* wp_dgrad, const float* w_bound, float* dx, int32_t part, void* stream) {
   MCD_REQUIRE(part >= 0 && part <= 2, "conv_split_dgrad_part: part must be 0 (whole), 1 (ping-pong tiles) or 2 (the rest)");
   return split_dgrad_impl(d, math, dy, dy_cb, dy_bound, wp_dgrad, w_bound, dx, stream, part);
+}
+
+// ---- 2-byte activation storage (round 6; BASELINE config 5 "bf16"): the same convolutions writing channel-blocked 16-bit tensors
+// [N][C/8][H*W][8] -- the unit layout of the companions -- instead of fp32 NCHW.  F16X1 only.
+//   forward        z as fp16 of z / scale(z_bound); the kernel writes z_bound = KH KW Cin * x_bound * w_bound (|z| cannot exceed it), the
+//                  BatchNorm partial rows come from the fp32 accumulators as always;
+//   data gradient  dx as bf16 (+ an addend in the same layout: the other gradient of a residual block's input).
+// 1 when these entry points take the geometry (`dgrad`: the data gradient): one-term arithmetic, both channel counts multiples of 8,
+// at least 16 contraction channels, not the thin layers' window kernels, not the stem.
+extern "C" int32_t mcdseg_conv_split_half_ok(const mcdseg_conv_desc* d, int32_t math, int32_t dgrad) {
+  if (d == nullptr || math != MCDSEG_MATH_F16X1) return 0;
+  if ((d->Cin & 7) != 0 || (d->Cout & 7) != 0 || (dgrad ? d->Cout : d->Cin) < 16) return 0;
+  if (mcdseg_internal_thin_window_ok(d, dgrad ? 1 : 0) || mcdseg_internal_stem_ok(d)) return 0;
+  return 1;
+}
+
+extern "C" int mcdseg_conv_split_fprop_half(const mcdseg_conv_desc* d, int32_t math, const void* x_cb, const float* x_bound,
+                                            const void* wp_fprop, const float* w_bound, void* z16, float* z_bound, float* stat_partials,
+                                            int32_t part, void* stream) {
+  MCD_REQUIRE(part >= 0 && part <= 2, "conv_split_fprop_half: part must be 0 (whole), 1 (ping-pong tiles) or 2 (the rest)");
+  MCD_REQUIRE(z16 != nullptr, "conv_split_fprop_half: null output");
+  return split_fprop_impl(d, math, nullptr, x_cb, x_bound, wp_fprop, w_bound, nullptr, nullptr, stat_partials, nullptr, nullptr, nullptr, 0,
+                          stream, part, z16, z_bound);
+}
+
+extern "C" int mcdseg_conv_split_dgrad_half(const mcdseg_conv_desc* d, int32_t math, const void* dy_cb, const float* dy_bound,
+                                            const void* wp_dgrad, const float* w_bound, const void* addend16, void* dx16, int32_t part,
+                                            void* stream) {
+  MCD_REQUIRE(part >= 0 && part <= 2, "conv_split_dgrad_half: part must be 0 (whole), 1 (ping-pong tiles) or 2 (the rest)");
+  MCD_REQUIRE(dx16 != nullptr && addend16 != dx16, "conv_split_dgrad_half: null output (or the addend aliases it)");
+  return split_dgrad_impl(d, math, nullptr, dy_cb, dy_bound, wp_dgrad, w_bound, nullptr, stream, part, nullptr, dx16, addend16);
 }

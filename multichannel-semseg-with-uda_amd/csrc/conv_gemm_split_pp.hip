@@ -34,6 +34,7 @@
 #include <type_traits>
 
 #include "conv_split_params.h"
+#include "options.h"
 
 namespace {
 
@@ -301,7 +302,72 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
     }
     dbase[j] = (size_t)n * p.M * HWd + rem;
   }
-  if (DGRAD && p.ep_res != nullptr && p.ep_res_lds) {
+  // ---- 16-bit channel-blocked output (the one-term arithmetic only: every other instantiation is compiled without this block).  The
+  // registers r = 4 q .. 4 q + 3 of an accumulator tile are channels 8 q + 4 lh .. + 3 of one pixel: half of a 16-byte unit, so a
+  // store instruction of the wave covers 32 whole units = 512 consecutive bytes (the fp32 planar form: two runs of 128 bytes).
+  bool half_out = false;
+  if constexpr (std::is_same<P, SplitF16x1>::value) half_out = p.dst16 != nullptr;
+  if constexpr (std::is_same<P, SplitF16x1>::value) {
+    if (half_out) {
+      float inv_zs = 1.f;
+      if (!DGRAD) {
+        const float zb = (float)(taps * p.Cs) * (*p.src_bound) * (*p.w_bound);  // |z| <= taps Cs max|x| max|w|
+        inv_zs = 1.f / mcd_scale_of_bound(zb);
+        if (blockIdx.x == 0 && t == 0 && p.dst_bound != nullptr) *p.dst_bound = zb;
+      }
+      const int M8 = p.M >> 3;
+      size_t ubase[WN];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int pp = p_wave + j * 32 + l31;
+        int n = 0, rem = 0;
+        if (colv[j]) {
+          n = pp / HWd;
+          rem = pp - n * HWd;
+        }
+        ubase[j] = (size_t)n * M8 * HWd + rem;
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m0 = m_wave + i * 32 + 8 * q;
+          if (m0 < p.M) {  // (M is a multiple of 8: host)
+            const size_t gofs = (size_t)(m0 >> 3) * HWd;
+            mcd_bf16x4 add[WN];
+            if (DGRAD && p.ep_res16 != nullptr) {
+#pragma unroll
+              for (int j = 0; j < WN; ++j)
+                if (colv[j]) add[j] = *reinterpret_cast<const mcd_bf16x4*>((const char*)p.ep_res16 + (ubase[j] + gofs) * 16 + lh * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+              if (colv[j]) {
+                char* dst = (char*)p.dst16 + (ubase[j] + gofs) * 16 + lh * 8;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * q + k];
+                if (DGRAD) {
+                  if (p.ep_res16 != nullptr) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += (float)add[j][k];
+                  }
+                  mcd_bf16x4 o;
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) o[k] = (__bf16)v[k];
+                  *reinterpret_cast<mcd_bf16x4*>(dst) = o;
+                } else {
+                  mcd_f16x4 o;
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) o[k] = (_Float16)(v[k] * inv_zs);
+                  *reinterpret_cast<mcd_f16x4*>(dst) = o;
+                }
+              }
+          }
+        }
+    }
+  }
+  if (!half_out && DGRAD && p.ep_res != nullptr && p.ep_res_lds) {
     // ---- data gradient + addend, the addend's tile staged through LDS.  With one workgroup per CU nothing hides the latency of
     // epilogue loads, and the accumulators leave ~20 registers to keep them in flight (measured: matrix pipe busy 0.78 -> 0.69 with
     // the addend loaded value by value).  A pass stages 16 rows of every wave row block -- rows i * 32 + 16 h .. + 15, what the
@@ -349,6 +415,7 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
 #endif
     return;
   }
+  if (!half_out) {
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -369,6 +436,7 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
           }
       }
     }
+  }
   if (!DGRAD && p.stats != nullptr) {
     int cntw = p.P - p_wave;
     cntw = cntw < 0 ? 0 : (cntw > 32 * WN ? 32 * WN : cntw);
@@ -409,16 +477,12 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
 // (N = 16, 60 x 80, same box, ms forward / data gradient, 4-wave tiles -> ping-pong): 512 -> 512 (600 tiles = 2.3 rounds) 0.892 / 0.894 ->
 // 0.816 / 0.800, 256 -> 512 0.476 / 0.477 -> 0.434 / 0.469; but 256 -> 256 (300 tiles = 1.2 rounds) 0.249 / 0.255 -> 0.253 / 0.246 and
 // 128 -> 256 0.135 -> 0.145: with one round the 15 % of the tiles left over take a third of the time.  (Read per call: tests lower it.)
-int pp_min_rounds() {
-  const char* e = getenv("MCDSEG_PP_MIN_ROUNDS");
-  return e ? atoi(e) : 2;
-}
+int pp_min_rounds() { return (int)mcd_opt(MCD_OPT_PP_MIN_ROUNDS); }
 
 int compute_units() {  // one workgroup per CU: a launch is worth whole rounds of this many tiles
-  // MCDSEG_PP_CUS (read per call): a test plans a small batch as if the chip had fewer CUs, which gives it the rounds -- and hence the
+  // option PP_CUS: a test plans a small batch as if the chip had fewer CUs, which gives it the rounds -- and hence the
   // launch plan -- of a batch that many times larger (BASELINE config 5's N = 32 plan at N = 2 with 16 "CUs")
-  const char* e = getenv("MCDSEG_PP_CUS");
-  if (e && atoi(e) > 0) return atoi(e);
+  if (mcd_opt(MCD_OPT_PP_CUS) > 0) return (int)mcd_opt(MCD_OPT_PP_CUS);
   static const int n = [] {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
@@ -431,10 +495,7 @@ int compute_units() {  // one workgroup per CU: a launch is worth whole rounds o
 // MCDSEG_PINGPONG (development knob, read per call: a test runs one problem several ways): 0 the 4-wave tiles only; 1 whole rounds of
 // 256 x 256 tiles + the rest on the 4-wave tiles; 2 the 256 x 128 ping-pong tile for everything; 3 (default) whole rounds of 256 x 256
 // tiles + the rest on the 256 x 128 ping-pong tile
-int pp_mode() {
-  const char* e = getenv("MCDSEG_PINGPONG");
-  return e == nullptr ? 3 : atoi(e);
-}
+int pp_mode() { return (int)mcd_opt(MCD_OPT_PINGPONG); }
 
 bool pp_applies(const ConvSplitParams& p, int math, bool dgrad, int bm = 256) {
   if (p.src_cb == nullptr || mcd_math_pieces(math) != 2 || (p.Mp % bm) != 0) return false;
@@ -479,13 +540,11 @@ int pp_wide(const ConvSplitParams& p, int math, bool dgrad) {
   if ((mode != 3 && mode != 4) || !pp_applies(p, math, dgrad, 128)) return 0;
   const int kind = (p.Mp % 256) == 0 ? 1 : 2;
   if (mode == 4) return kind;
-  const char* e = getenv("MCDSEG_PP_WIDE_FILL");
-  const int64_t fill = e ? atoi(e) : 80;
+  const int64_t fill = mcd_opt(MCD_OPT_PP_WIDE_FILL);
   if (fill > 100) return 0;
   const int64_t cus = compute_units();
   if (kind == 2) {
-    const char* e128 = getenv("MCDSEG_PP_WIDE128");  // development knob: 0 = the 128-row variant off
-    if (e128 && atoi(e128) == 0) return 0;
+    if (mcd_opt(MCD_OPT_PP_WIDE128) == 0) return 0;  // development knob: 0 = the 128-row variant off
     const int64_t tiles = ceil_div64(p.P, 320) * (p.Mp / 128), rounds_w = ceil_div64(tiles, cus);
     return tiles * 100 >= fill * rounds_w * cus ? 2 : 0;
   }

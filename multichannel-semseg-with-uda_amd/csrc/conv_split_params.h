@@ -37,4 +37,15 @@ struct ConvSplitParams {
   // quad never straddles two images and the tensor is 16-byte aligned
   int ep_res_lds;
   unsigned ep_res_bytes;
+  // 16-bit channel-blocked output (SplitF16x1 only; round 6: BASELINE config 5's 2-byte activation storage).  When dst16 is set the
+  // kernel writes NO fp32 dst: [N][M/8][Hd*Wd][8 x 16 bit] -- the companions' unit layout, one 16-byte unit per pixel and 8-channel
+  // group -- as fp16 of z / scale(dst_bound) in the forward pass (the kernel itself writes dst_bound = taps * Cs * src_bound * w_bound,
+  // an upper bound of |z| known before any z exists) and as bf16 in the data gradient (gradients span more binades than a per-tensor
+  // scale covers, and need no bound); ep_res16: the data gradient's addend in the same bf16 layout.
+  void* dst16;
+  float* dst_bound;
+  const void* ep_res16;
 };
+
+typedef _Float16 mcd_f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 mcd_bf16x4 __attribute__((ext_vector_type(4)));

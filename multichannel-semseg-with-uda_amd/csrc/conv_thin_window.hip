@@ -262,10 +262,7 @@ ThinWinPlan thin_win_plan(const mcdseg_conv_desc* d, bool dgrad) {
   ThinWinPlan pl{};
   pl.ok = false;
   if (d->Ncb != 0 && d->Ncb != d->N) return pl;  // a batch slice of a larger companion: its pieces are not adjacent (implicit GEMM handles it)
-  static const bool on = [] {
-    const char* e = getenv("MCDSEG_THIN_WINDOW");  // development knob: 0 = the implicit-GEMM kernels for these layers too
-    return e == nullptr || atoi(e) != 0;
-  }();
+  const bool on = mcd_opt(MCD_OPT_THIN_WINDOW) != 0;  // development knob: 0 = the implicit-GEMM kernels for these layers too
   if (!on || d->stride != 1) return pl;  // (a stride-2 form, 16 -> 32, measured no faster than the implicit GEMM: 0.134 vs 0.131 ms)
   const int T = d->KH * d->KW;
   const int ks = dgrad ? d->Cout : d->Cin, m = dgrad ? d->Cin : d->Cout;

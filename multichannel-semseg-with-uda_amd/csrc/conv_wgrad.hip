@@ -60,10 +60,7 @@ WgradPlan make_plan(const mcdseg_conv_desc* d) {
   pl.co_p = round_up(d->Cout, pl.bm);
   pl.ci_p = pl.cfg == 3 ? 32 : round_up(d->Cin, pl.bn);
   const int64_t tiles = (int64_t)(pl.co_p / pl.bm) * (pl.ci_p / pl.bn) * pl.groups;
-  static const int64_t tuned_wgs = [] {
-    const char* e = getenv("MCDSEG_WGRAD_WGS");  // development knob: target workgroup count of the 128/64-tile plans
-    return e ? (int64_t)atoll(e) : (int64_t)1024;
-  }();
+  const int64_t tuned_wgs = mcd_opt(MCD_OPT_WGRAD_WGS);  // development knob: target workgroup count of the 128/64-tile plans
   const int64_t want_wgs = (pl.cfg >= 2) ? 4096 : tuned_wgs;
   const int64_t want_splits = ceil_div64(want_wgs, tiles);
   const int hw = d->Ho * d->Wo;
@@ -485,19 +482,13 @@ int mcdseg_internal_wgrad_pp3_plan(const mcdseg_conv_desc* d, int math, int* L, 
 int mcdseg_internal_wgrad_pp3_launch(const mcdseg_conv_desc* d, int math, const void* x_cb, const float* x_bound, const void* dy_cb,
                                      const float* dy_bound, float* dw, float* slab, hipStream_t st);
 static bool thin_tr_applies(const mcdseg_conv_desc* d, int math, const void* x_cb, const void* dy_cb) {
-  static const bool on = [] {
-    const char* e = getenv("MCDSEG_WGRAD_THIN_TR");
-    return e == nullptr || atoi(e) != 0;
-  }();
+  const bool on = mcd_opt(MCD_OPT_WGRAD_THIN_TR) != 0;
   return on && mcd_storage_math(math) == MCDSEG_MATH_F16X3 && x_cb && dy_cb && mcdseg_internal_wgrad_thin_tr_ok(d);
 }
 
 // the 64 x 64 plan (32 < min(Cin, Cout) <= 64) from both pre-split companions: f16x3 only (MCDSEG_WGRAD_TR64=0 turns it off)
 static bool tr64_applies(const mcdseg_conv_desc* d, int math, const void* x_cb, const void* dy_cb, int cfg) {
-  static const bool on = [] {
-    const char* e = getenv("MCDSEG_WGRAD_TR64");
-    return e == nullptr || atoi(e) != 0;
-  }();
+  const bool on = mcd_opt(MCD_OPT_WGRAD_TR64) != 0;
   return on && cfg == 1 && mcd_storage_math(math) == MCDSEG_MATH_F16X3 && x_cb && dy_cb && (d->Cin & 7) == 0 && (d->Cout & 7) == 0;
 }
 

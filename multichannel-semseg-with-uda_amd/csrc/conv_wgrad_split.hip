@@ -948,13 +948,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_tr64_kernel(WgradCbPa
 // which pre-split kernel runs: 0 = register-transposing (three-piece policy, or MCDSEG_WGRAD_TR=0), 1 = transposed-read
 // 128x128 tiles, 2 = transposed-read 256x128 tiles
 int mcdseg_internal_wgrad_cb_variant(const mcdseg_conv_desc* d, int math, int co_p, int ci_p, int splits) {
-  // development / test knobs, read per call (a getenv costs nothing next to a launch) so that a test can run one problem on
-  // both tile shapes: MCDSEG_WGRAD_TR=0 = register-transposing kernel for the two-piece policy too, MCDSEG_WGRAD_BIG=0 = 128 x 128
+  // development / test knobs (options.h), read per call so that a test can run one problem on
+  // both tile shapes: WGRAD_TR=0 = register-transposing kernel for the two-piece policy too, MCDSEG_WGRAD_BIG=0 = 128 x 128
   // tiles only
-  const char* e_tr = getenv("MCDSEG_WGRAD_TR");
-  const char* e_big = getenv("MCDSEG_WGRAD_BIG");
-  const bool use_tr = e_tr == nullptr || atoi(e_tr) != 0;
-  const bool use_big = e_big == nullptr || atoi(e_big) != 0;
+  const bool use_tr = mcd_opt(MCD_OPT_WGRAD_TR) != 0;
+  const bool use_big = mcd_opt(MCD_OPT_WGRAD_BIG) != 0;
   if (!(mcd_storage_math(math) == MCDSEG_MATH_F16X3 && use_tr)) return 0;
   // 256 x 128 tiles (16-pixel stages) for the layers whose padded Cout is a multiple of 256 -- the plan was made for 128-row
   // tiles, so the number of workgroups halves; taken only while that still fills the chip twice over
@@ -963,8 +961,7 @@ int mcdseg_internal_wgrad_cb_variant(const mcdseg_conv_desc* d, int math, int co
   // the remaining 128-row layers with more than one tap: two taps per workgroup sharing the staged dY tile -- built, bit-identical,
   // and SLOWER at the benchmark's sizes (256 -> 256 at N = 16: 0.309-0.349 ms against 0.286: an odd tap count idles a tenth of the waves,
   // half as many workgroups, a transposed epilogue), so it runs only on request (MCDSEG_WGRAD_TWOTAP=1; tests)
-  const char* e_two = getenv("MCDSEG_WGRAD_TWOTAP");
-  return (d->KH * d->KW > 1 && e_two != nullptr && atoi(e_two) != 0) ? 3 : 1;
+  return (d->KH * d->KW > 1 && mcd_opt(MCD_OPT_WGRAD_TWOTAP) != 0) ? 3 : 1;
 }
 
 // pre-split operands (see conv_wgrad_split_cb_kernel); chunks_per_img / splits come from the shared plan, the pixel range
@@ -999,8 +996,8 @@ int mcdseg_internal_wgrad_split_cb_launch(const mcdseg_conv_desc* d, int math, c
   }
   p.x_cb_bytes = (int)xb;
   p.dy_cb_bytes = (int)yb;
-  p.x_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cin * d->H * d->W * 2;
-  p.dy_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cout * d->Ho * d->Wo * 2;
+  p.x_piece_stride = math == MCDSEG_MATH_F16X1 ? 0 : (long long)(d->Ncb ? d->Ncb : d->N) * d->Cin * d->H * d->W * 2;  // (F16X1 reads piece 0 only)
+  p.dy_piece_stride = math == MCDSEG_MATH_F16X1 ? 0 : (long long)(d->Ncb ? d->Ncb : d->N) * d->Cout * d->Ho * d->Wo * 2;
   const int64_t per_split = (int64_t)(co_p / (big ? 256 : 128)) * (ci_p / 128) * (two ? (d->KH * d->KW + 1) / 2 : d->KH * d->KW);
   const int64_t nwg = 8 * ceil_div64(splits, 8) * per_split;
   if (nwg >= (1ll << 31)) {
@@ -1049,8 +1046,8 @@ int mcdseg_internal_wgrad_split_tr64_launch(const mcdseg_conv_desc* d, int math,
   }
   p.x_cb_bytes = (int)xb;
   p.dy_cb_bytes = (int)yb;
-  p.x_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cin * d->H * d->W * 2;
-  p.dy_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cout * d->Ho * d->Wo * 2;
+  p.x_piece_stride = math == MCDSEG_MATH_F16X1 ? 0 : (long long)(d->Ncb ? d->Ncb : d->N) * d->Cin * d->H * d->W * 2;  // (F16X1 reads piece 0 only)
+  p.dy_piece_stride = math == MCDSEG_MATH_F16X1 ? 0 : (long long)(d->Ncb ? d->Ncb : d->N) * d->Cout * d->Ho * d->Wo * 2;
   const int64_t per_split = (int64_t)(co_p / 64) * (ci_p / 64) * ((d->KH * d->KW + 1) / 2);
   const int64_t nwg = 8 * ceil_div64(splits, 8) * per_split;
   if (nwg >= (1ll << 31)) {

@@ -589,11 +589,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_rt_kernel(const float* __res
 }
 
 int pp_compute_units() {
+  if (mcd_opt(MCD_OPT_WGRAD_PP_CUS) > 0) return (int)mcd_opt(MCD_OPT_WGRAD_PP_CUS);  // development knob: plan the weight gradient for fewer CUs than the chip has
+  if (mcd_opt(MCD_OPT_PP_CUS) > 0) return (int)mcd_opt(MCD_OPT_PP_CUS);              // development knob (shared with conv_gemm_split_pp.hip)
   static const int n = [] {
-    const char* w = getenv("MCDSEG_WGRAD_PP_CUS");  // development knob: plan the weight gradient for fewer CUs than the chip has
-    if (w && atoi(w) > 0) return atoi(w);
-    const char* e = getenv("MCDSEG_PP_CUS");  // development knob (shared with conv_gemm_split_pp.hip)
-    if (e && atoi(e) > 0) return atoi(e);
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       cus = 256;  // MI355X
@@ -617,9 +615,8 @@ int pp_compute_units() {
 //              workgroups of one XCD hold consecutive items, i.e. the tiles (taps, channel blocks) of ONE slab, walk the same pixels
 //              at the same time and share them through the XCD's L2.  252 of 256 CUs busy at BASELINE config 2 (36, 18 or 9 tiles).
 int mcdseg_internal_wgrad_pp_plan(const mcdseg_conv_desc* d, int math, int* L, size_t* slab_floats, int* slabs_out) {
-  const char* e = getenv("MCDSEG_WGRAD_PP");
-  if (e != nullptr && atoi(e) == 0) return 0;
-  const bool stream_k = e != nullptr && atoi(e) == 1;
+  if (mcd_opt(MCD_OPT_WGRAD_PP) == 0) return 0;
+  const bool stream_k = mcd_opt(MCD_OPT_WGRAD_PP) == 1;
   if (slabs_out) *slabs_out = 0;
   if (mcd_storage_math(math) != MCDSEG_MATH_F16X3 || (d->Cin & 7) || (d->Cout & 7) || d->Cin < 129 || d->Cout < 129) return 0;
   const int T = d->KH * d->KW;
@@ -680,8 +677,8 @@ int mcdseg_internal_wgrad_pp_launch(const mcdseg_conv_desc* d, int math, const v
   p.L = L; p.nwg = nwg;
   p.slabs = slabs; p.items = slabs * p.co_tiles * p.ci_tiles * d->KH * d->KW;
   p.x_cb_bytes = (int)xb; p.dy_cb_bytes = (int)yb;
-  p.x_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cin * d->H * d->W * 2;
-  p.dy_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cout * d->Ho * d->Wo * 2;
+  p.x_piece_stride = math == MCDSEG_MATH_F16X1 ? 0 : (long long)(d->Ncb ? d->Ncb : d->N) * d->Cin * d->H * d->W * 2;  // (F16X1 reads piece 0 only)
+  p.dy_piece_stride = math == MCDSEG_MATH_F16X1 ? 0 : (long long)(d->Ncb ? d->Ncb : d->N) * d->Cout * d->Ho * d->Wo * 2;
   const dim3 grid((unsigned)(8 * ceil_div(nwg, 8)));
   if (math == MCDSEG_MATH_F16X1)
     hipLaunchKernelGGL(conv_wgrad_split_pp_kernel<SplitF16x1>, grid, dim3(512), 0, st, p);
@@ -700,8 +697,7 @@ int mcdseg_internal_wgrad_pp_launch(const mcdseg_conv_desc* d, int math, const v
 // 3 x KH kernels whose channel counts leave the 256 x 256 kernel out -- more than 64 channels on both sides, at most 128 on one -- when
 // the 128-channel tiles are at least three quarters full.  MCDSEG_WGRAD_PP3=0 turns it off (read per call: tests).
 int mcdseg_internal_wgrad_pp3_plan(const mcdseg_conv_desc* d, int math, int* L, size_t* slab_floats, int* slabs_out) {
-  const char* e = getenv("MCDSEG_WGRAD_PP3");
-  if (e != nullptr && atoi(e) == 0) return 0;
+  if (mcd_opt(MCD_OPT_WGRAD_PP3) == 0) return 0;
   if (slabs_out) *slabs_out = 0;
   if (mcd_storage_math(math) != MCDSEG_MATH_F16X3 || (d->Cin & 7) || (d->Cout & 7)) return 0;
   const int lo = d->Cin < d->Cout ? d->Cin : d->Cout;
@@ -754,8 +750,8 @@ int mcdseg_internal_wgrad_pp3_launch(const mcdseg_conv_desc* d, int math, const 
   p.L = L; p.nwg = nwg;
   p.slabs = slabs; p.items = slabs * p.co_tiles * p.ci_tiles * d->KH;
   p.x_cb_bytes = (int)xb; p.dy_cb_bytes = (int)yb;
-  p.x_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cin * d->H * d->W * 2;
-  p.dy_piece_stride = (long long)(d->Ncb ? d->Ncb : d->N) * d->Cout * d->Ho * d->Wo * 2;
+  p.x_piece_stride = math == MCDSEG_MATH_F16X1 ? 0 : (long long)(d->Ncb ? d->Ncb : d->N) * d->Cin * d->H * d->W * 2;  // (F16X1 reads piece 0 only)
+  p.dy_piece_stride = math == MCDSEG_MATH_F16X1 ? 0 : (long long)(d->Ncb ? d->Ncb : d->N) * d->Cout * d->Ho * d->Wo * 2;
   const dim3 grid((unsigned)(8 * ceil_div(nwg, 8)));
   if (math == MCDSEG_MATH_F16X1)
     hipLaunchKernelGGL(conv_wgrad_split_pp3_kernel<SplitF16x1>, grid, dim3(512), 0, st, p);

@@ -662,8 +662,7 @@ int launch_up_loss_dma(bool two, int blocks, hipStream_t st, const float* s1, co
 int up_loss_dma_ncmax(int C) { return C <= 16 ? 16 : (C <= 24 ? 24 : (C == 41 ? 41 : 48)); }
 
 bool up_loss_dma_ok(int64_t N, int64_t C, int64_t Hi, int64_t Wi, bool labels) {
-  const char* e = getenv("MCDSEG_UP8_LOSS_DMA");  // 0: the register-staged kernel (A/B, and the parity test's other side); read per call
-  const bool on = !(e && atoi(e) == 0);
+  const bool on = mcd_opt(MCD_OPT_UP8_LOSS_DMA) != 0;  // 0: the register-staged kernel (A/B, and the parity test's other side)
   // buffer resources address 32 bits (the DMA's offsets are formed in int)
   return on && N * C * Hi * Wi * 4 < (1ll << 31) && (!labels || N * Hi * Wi * 64 * 8 < (1ll << 31));
 }

@@ -304,10 +304,7 @@ struct Up8BandPlan {
 
 Up8BandPlan up8_band_plan(int N, int C, int Hi, int Wi) {
   Up8BandPlan pl{};
-  static const int knob = [] {
-    const char* e = getenv("MCDSEG_UP8_BAND_ROWS");  // development knob: 0 = the two separate kernels, n = rows per band
-    return e ? atoi(e) : -1;
-  }();
+  const int knob = (int)mcd_opt(MCD_OPT_UP8_BAND_ROWS);  // development knob: 0 = the two separate kernels, n = rows per band
   if (knob == 0) return pl;
   pl.row_insts = ceil_div(32 * Wi, 1024);
   pl.row_stride = pl.row_insts * 1024 + 64;

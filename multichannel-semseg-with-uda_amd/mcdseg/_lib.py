@@ -27,6 +27,10 @@ _SIGNATURES = {
     # name: (restype, argtypes)   -- one entry per symbol declared in include/mcdseg.h
     "mcdseg_version": (c_int, []),
     "mcdseg_last_error": (ctypes.c_char_p, []),
+    "mcdseg_option_count": (c_i32, []),
+    "mcdseg_option_name": (ctypes.c_char_p, [c_i32]),
+    "mcdseg_set_option": (c_int, [ctypes.c_char_p, c_i64]),
+    "mcdseg_get_option": (c_int, [ctypes.c_char_p, _P(c_i64), _P(c_i64)]),
     "mcdseg_conv_packed_dims": (c_int, [_P(ConvDesc), _P(c_i32), _P(c_i32), _P(c_i32), _P(c_i32)]),
     "mcdseg_conv_pack_weights": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcdseg_conv_stat_rows": (c_i64, [_P(ConvDesc)]),
@@ -111,6 +115,16 @@ _SIGNATURES = {
     "mcdseg_confusion_hist": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p]),
     "mcdseg_scale_by_device_scalar": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "mcdseg_sgd_momentum_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_float, c_void_p]),
+    # 2-byte activation storage (round 6)
+    "mcdseg_conv_split_half_ok": (c_i32, [_P(ConvDesc), c_i32, c_i32]),
+    "mcdseg_conv_split_fprop_half": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 7 + [c_i32, c_void_p]),
+    "mcdseg_conv_split_dgrad_half": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 6 + [c_i32, c_void_p]),
+    "mcdseg_bn_apply_half": (c_int, [c_void_p] * 10 + [c_i32] * 4 + [c_void_p]),
+    "mcdseg_bn_bwd_half_workspace_bytes": (c_size_t, [c_i32] * 3),
+    "mcdseg_bn_bwd_reduce_half": (c_int, [c_void_p] * 11 + [c_i32] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "mcdseg_bn_bwd_apply_half": (c_int, [c_void_p] * 13 + [c_i32] * 5 + [c_void_p]),
+    "mcdseg_pack_bf16_units": (c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
+    "mcdseg_unpack_bf16_units": (c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -273,6 +287,69 @@ def drains_inside_store_loops(path=None, prefix=("up8_softmax_ce_l1_dma_kernel",
     return out
 
 
+def _kernel_bodies(path=None):
+    """[(kernel symbol, [instruction lines])] of the built library"""
+    import re
+    out, sym, body = [], None, []
+    for line in device_disassembly(path).splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+        if m:
+            if sym is not None:
+                out.append((sym, body))
+            sym, body = m.group(1), []
+        else:
+            body.append(line)
+    if sym is not None:
+        out.append((sym, body))
+    return out
+
+
+HIDDEN_DMA_KERNELS = ("up8_softmax_ce_l1_dma_kernel", "up8_bwd_band_kernel", "conv_wgrad_split_tr64_kernel")  # users of mcd_hidden_dma
+
+
+def hidden_dma_hazards(path=None):
+    """[(kernel symbol, instruction)] that break the contract of ``mcd_hidden_dma`` (csrc/common.h): that inline assembly writes M0 -- the
+    LDS base of the DMA behind it -- without the compiler's knowledge, so a kernel that uses it must contain NO other use of M0: in the
+    kernels of HIDDEN_DMA_KERNELS every instruction that names M0 and every LDS-DMA must belong to one triple
+    `s_mov_b32 m0, sN; s_nop 0; buffer_load_dword[x4] ... lds` -- an LDS-DMA outside a triple is one whose M0 set-up the compiler hoisted
+    (a builtin DMA beside the hidden ones), any other M0 instruction (`s_add_i32 m0`, `v_movrel*`, an `s_mov_b32 sN, m0` spill) is a
+    compiler-made use the asm would clobber.  Must be empty.  (Whether a wait separates a DMA from the LDS reads of its buffer cannot be
+    read off the text -- the wait sits at the head of the NEXT loop iteration, and the reads right behind a DMA are those of the other
+    buffer: that is what the bitwise A/B tests against the register kernels and tools/op_contention.py's soak establish.)"""
+    import re
+    bad, seen = [], set()
+    for sym, body in _kernel_bodies(path):
+        if not any(k in sym for k in HIDDEN_DMA_KERNELS):
+            continue
+        ins = [ln.split("//")[0].strip() for ln in body]
+        ins = [i for i in ins if i]
+        trip = set()
+        for i in range(len(ins) - 2):
+            if re.match(r"s_mov_b32 m0, s\d+$", ins[i]) and ins[i + 1] == "s_nop 0" and re.match(r"buffer_load_dword(x4)? .* lds$", ins[i + 2]):
+                trip.update((i, i + 2))
+        if trip:
+            seen.add([k for k in HIDDEN_DMA_KERNELS if k in sym][0])
+        for i, t in enumerate(ins):
+            if (re.search(r"\bm0\b", t) or re.match(r"buffer_load_dword(x4)? .* lds$", t)) and i not in trip:
+                bad.append((sym, t))
+    bad.extend((k, "no hidden DMA found in this kernel: is HIDDEN_DMA_KERNELS stale?") for k in HIDDEN_DMA_KERNELS if k not in seen)
+    return bad
+
+
+def loss_dma_store_counts(path=None):
+    """{(classes, heads): global stores} of the LDS-DMA loss kernels: the hand-counted `s_waitcnt vmcnt(63)` of csrc/loss.hip relies on a
+    wave issuing its item's heads x C gradient stores BEHIND the next item's DMAs (`behind = nst`)"""
+    import re
+    out = {}
+    for sym, body in _kernel_bodies(path):
+        m = re.search(r"up8_softmax_ce_l1_dma_kernelILi(\d+)ELb([01])ELb[01]E", sym)
+        if m:
+            n = sum(1 for ln in body if re.search(r"\bglobal_store_dword\b", ln))
+            key = (int(m.group(1)), 2 if m.group(2) == "1" else 1)
+            out[key] = min(n, out.get(key, n))
+    return out
+
+
 def lib():
     """The loaded library; raises if it has not been built (no fallback exists)."""
     global _lib
@@ -296,8 +373,69 @@ def lib():
                     fn.argtypes = args
                 if handle.mcdseg_version() != 101:
                     raise RuntimeError("libmcdseg.so version mismatch: %d" % handle.mcdseg_version())
+                _options_from_env(handle)
                 _lib = handle
     return _lib
+
+
+def option_names():
+    """names of the library's plan / development options (csrc/options.h)"""
+    L = lib()
+    return [L.mcdseg_option_name(i).decode() for i in range(L.mcdseg_option_count())]
+
+
+def _options_from_env(handle):
+    """The library never reads the environment (include/mcdseg.h, mcdseg_set_option): the MCDSEG_<OPTION> variables are translated HERE,
+    once, when the library is loaded.  A value that is not an integer is an error, not a silent default."""
+    for i in range(handle.mcdseg_option_count()):
+        name = handle.mcdseg_option_name(i).decode()
+        raw = os.environ.get("MCDSEG_" + name)
+        if raw is None or raw.strip() == "":
+            continue
+        try:
+            value = int(raw.strip())
+        except ValueError:
+            raise ValueError("MCDSEG_%s must be an integer, got %r" % (name, raw))
+        if handle.mcdseg_set_option(name.encode(), value) != 0:
+            raise RuntimeError("mcdseg_set_option(%s) failed" % name)
+
+
+def get_option(name):
+    """current value of a library option"""
+    v = c_i64()
+    check(lib().mcdseg_get_option(name.encode(), ctypes.byref(v), None), "get_option")
+    return v.value
+
+
+def option_default(name):
+    d = c_i64()
+    check(lib().mcdseg_get_option(name.encode(), None, ctypes.byref(d)), "get_option")
+    return d.value
+
+
+def set_option(name, value):
+    """set a library option (process-wide; read by the launchers at every call); returns the previous value"""
+    prev = get_option(name)
+    check(lib().mcdseg_set_option(name.encode(), int(value)), "set_option")
+    return prev
+
+
+class options:
+    """``with mcdseg.options(PINGPONG=0, PP_CUS=16): ...`` -- library options for the duration of a block (also usable from a test
+    fixture: ``enter()`` / ``restore()``)"""
+
+    def __init__(self, **values):
+        self.values, self.prev = values, {}
+
+    def __enter__(self):
+        for k, v in self.values.items():
+            self.prev[k] = set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            set_option(k, v)
+        self.prev = {}
 
 
 def check(rc, what):

@@ -20,7 +20,7 @@ import weakref
 
 import torch
 
-from ._lib import ConvDesc, check, lib
+from ._lib import ConvDesc, check, get_option, lib
 
 # bumped by the optimizer after every in-place parameter update (the kernels write through raw
 # pointers, so torch's own version counters do not move)
@@ -92,13 +92,13 @@ def pingpong_kernel_name(dgrad, math=None, small=False, wide=0):
     return "conv_gemm_split_pp_kernel<%s, %s, %s>" % (POLICY[math or CONV_MATH], "true" if dgrad else "false", tile)
 
 
-def _split_launches(d, presplit, dgrad, name, call):
+def _split_launches(d, presplit, dgrad, name, call, work=None):
     """One split-arithmetic convolution as the library would launch it, each kernel bracketed by its own timer: the pixels
     ``mcdseg_conv_split_parts`` gives to the ping-pong kernel (part 1) and the rest on the 4-wave tiles (part 2); ``call(part)``
     invokes the ``_part`` entry point.  Work is shared out by pixels."""
     pixels = d.N * (d.H * d.W if dgrad else d.Ho * d.Wo)
     pp = lib().mcdseg_conv_split_parts(ctypes.byref(d), MATH_ID[CONV_MATH], int(presplit), int(dgrad)) if presplit else 0
-    flops, byts = conv_work(d)
+    flops, byts = (work or conv_work)(d)
     if pp > 0:
         wide = lib().mcdseg_conv_split_wide_pingpong(ctypes.byref(d), MATH_ID[CONV_MATH], 1, int(dgrad))
         with _timed(pingpong_kernel_name(dgrad, wide=wide), (flops * pp / pixels, byts * pp / pixels)):
@@ -192,7 +192,6 @@ if CONV_MATH not in ("f16x3", "bf16x6", "f32", "f16x1"):
     raise ValueError("MCDSEG_CONV_MATH must be f16x3, bf16x6, f32 or f16x1, got %r" % CONV_MATH)
 MATH_ID = {"f16x3": 3, "bf16x6": 6, "f16x1": 1}   # MCDSEG_MATH_F16X3 / _BF16X6 / _F16X1 of include/mcdseg.h
 PIECES = {"f16x3": 2, "bf16x6": 3, "f16x1": 2}    # (f16x1 stores what f16x3 stores)
-BIGTILE_MIN_SLOTS = int(os.environ.get("MCDSEG_BIGTILE_MIN_SLOTS", "1024"))  # launch<> rule of csrc/conv_gemm_split.hip
 
 
 # the stem's training forward on the LDS-window kernel (f16x3, 0.20 instead of 0.35 ms per launch at 14 x 480 x 640).  OFF by
@@ -230,6 +229,41 @@ def _compact_now():
     return ACT_STORAGE == "compact" and _TRUNK_DEPTH > 0 and _scaled()
 
 
+# 2-byte activation storage (round 6; BASELINE config 5 "bf16"): in the one-term arithmetic f16x1 a compact group keeps ONE 16-bit value per
+# element of everything its BatchNorm passes move -- the convolution writes z as scaled fp16 units (after taking the BatchNorm partial sums
+# from its fp32 accumulators), the activation is the leading piece of the companion alone, the gradients between the groups travel as bf16
+# units (include/mcdseg.h, "2-byte activation storage").  Such a group's output is a VIRTUAL tensor of dtype bfloat16: the dtype is the
+# contract with autograd -- whoever consumes it owes its gradient as a bf16 tensor of the same logical shape whose BYTES are in the unit
+# layout [N][C/8][HW][8] (element-wise sums of two such tensors, which is all autograd ever does to them, do not care).
+# MCDSEG_HALF_STORAGE=0: f16x1 stores what f16x3 stores (round 5's form).
+HALF_STORAGE = os.environ.get("MCDSEG_HALF_STORAGE", "1") != "0"
+
+
+def _half_now():
+    return HALF_STORAGE and CONV_MATH == "f16x1" and _compact_now()
+
+
+def is_half(t):
+    """an activation of the 2-byte chain (see HALF_STORAGE): virtual, dtype bfloat16"""
+    return t is not None and t.dtype == torch.bfloat16 and is_virtual(t)
+
+
+def pack_bf16_units(g):
+    """fp32 NCHW gradient -> the bf16 unit layout (a gradient entering the 2-byte chain from a kernel without the 16-bit epilogue)"""
+    n, c, h, w = g.shape
+    out = torch.empty((n, c, h, w), dtype=torch.bfloat16, device=g.device)
+    check(lib().mcdseg_pack_bf16_units(_p(_req(g, "gradient")), _p(out), n, c, h * w, _stream()), "pack_bf16_units")
+    return out
+
+
+def unpack_bf16_units(g):
+    """the inverse of ``pack_bf16_units``"""
+    n, c, h, w = g.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=g.device)
+    check(lib().mcdseg_unpack_bf16_units(_p(_req(g, "gradient", torch.bfloat16)), _p(out), n, c, h * w, _stream()), "unpack_bf16_units")
+    return out
+
+
 # A fused ReLU group WITHOUT residual whose output only the next split convolution consumes (conv1 of a BasicBlock, conv1 / conv2
 # of a Bottleneck: ``conv_bn_act(..., internal=True)``) need not write its fp32 output at all, in ANY storage mode and without
 # changing a bit: the consumer's forward and weight gradient read the companion either way, and the group's own backward
@@ -246,9 +280,9 @@ INTERNAL_STAGES = os.environ.get("MCDSEG_INTERNAL_STAGES", "1") != "0"
 SHORTCUT_NO_CB = os.environ.get("MCDSEG_SHORTCUT_NO_CB", "1") != "0"
 
 
-def _virtual(shape, device):
+def _virtual(shape, device, dtype=torch.float32):
     """stand-in for an activation that exists only as its companion: right shape / device / dtype, 4 bytes of storage"""
-    return torch.empty(1, dtype=torch.float32, device=device).expand(shape)
+    return torch.empty(1, dtype=dtype, device=device).expand(shape)
 
 
 # how many times a train-mode BatchNorm forward applies its running-statistics update (solvers/solver.py: one generator
@@ -375,9 +409,15 @@ class GradBox:
         self.g = g
 
 
+# (a private torch hook, resolved once: on a build without it the residual sums go back to autograd's own add -- same bits)
+_GRAPH_TASK_ID = getattr(torch._C, "_current_graph_task_id", None)
+if _GRAPH_TASK_ID is None:
+    FUSE_RES_ADD = False
+
+
 def _graph_task_id():
     """id of the backward pass the calling autograd node runs in (-1 outside one)"""
-    return torch._C._current_graph_task_id()
+    return _GRAPH_TASK_ID()
 
 
 def grad_box(x):
@@ -621,6 +661,66 @@ def _conv_dgrad(desc, dy, wd, dy_cb=None, dy_bound=None, w_bound=None, addend=No
     return dx
 
 
+def _batch_pieces_half(desc):
+    """[(first image, end)] of the launches of a convolution of the 2-byte chain: a launch addresses one piece of its pre-split operand
+    through a 32-bit buffer resource (< 2 GiB, 2 bytes per element); the 16-bit output is addressed with 64-bit pointers"""
+    step = desc.N
+    for c, hw in ((desc.Cin, desc.H * desc.W), (desc.Cout, desc.Ho * desc.Wo)):
+        step = min(step, max(1, MAX_CONV_BYTES // (2 * c * hw)))
+    if step >= desc.N:
+        return [(0, desc.N)]
+    return [(i, min(i + step, desc.N)) for i in range(0, desc.N, step)]
+
+
+def half_conv_work(d):
+    """(algorithmic FLOPs, algorithmic bytes) of one conv pass of the 2-byte chain: 16-bit operand in, 16-bit result out"""
+    flops, byts = conv_work(d)
+    return flops, byts // 2
+
+
+def _unit_slice(t, a, channels, hw):
+    """pointer to image ``a`` of a 16-bit tensor in the unit layout [N][C/8][HW][8]"""
+    return None if t is None else ctypes.c_void_p(t.data_ptr() + a * channels * hw * 2)
+
+
+def _conv_fprop_half(desc, x_cb, x_bound, wf, w_bound, mpf):
+    """forward convolution of the 2-byte chain: (z16 units [int16], z_bound scalar, BatchNorm partial rows, row count)"""
+    L = lib()
+    dev = x_cb.device
+    z16 = torch.empty(desc.N * desc.Cout * desc.Ho * desc.Wo, dtype=torch.int16, device=dev)
+    z_bound = torch.empty(1, dtype=torch.float32, device=dev)
+    pieces = _batch_pieces_half(desc)
+    descs = [desc if len(pieces) == 1 else _sub_desc(desc, b - a, desc.N) for a, b in pieces]
+    row_off = [0]
+    for d in descs:
+        row_off.append(row_off[-1] + L.mcdseg_conv_split_stat_rows_for(ctypes.byref(d), MATH_ID[CONV_MATH], 1))
+    rows = row_off[-1]
+    part = torch.empty(rows * 3 * mpf, dtype=torch.float32, device=dev)
+    for i, ((a, b), d) in enumerate(zip(pieces, descs)):
+        pp = ctypes.c_void_p(part.data_ptr() + 4 * row_off[i] * 3 * mpf)
+        name = gemm_kernel_name(desc.Cout, desc.Cin, False, True, True, False, d.N * d.Ho * d.Wo)
+        _split_launches(d, True, False, name, lambda part_no: check(L.mcdseg_conv_split_fprop_half(
+            ctypes.byref(d), MATH_ID[CONV_MATH], _cb_slice(x_cb, a, desc.Cin, desc.H * desc.W), _p(x_bound), _p(wf), _p(w_bound),
+            _unit_slice(z16, a, desc.Cout, desc.Ho * desc.Wo), _p(z_bound), pp, part_no, _stream()), "conv_split_fprop_half"), work=half_conv_work)
+    return z16, z_bound, part, rows
+
+
+def _conv_dgrad_half(desc, dy_cb, dy_bound, wd, w_bound, addend16=None):
+    """data gradient of the 2-byte chain: bf16 units (+ the other gradient of the same tensor, same layout, in the kernel's epilogue)"""
+    L = lib()
+    dx = torch.empty((desc.N, desc.Cin, desc.H, desc.W), dtype=torch.bfloat16, device=dy_cb.device)
+    if addend16 is not None:
+        addend16 = _req(addend16, "gradient addend", torch.bfloat16)
+    for a, b in _batch_pieces_half(desc):
+        d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a, desc.N)
+        name = gemm_kernel_name(desc.Cin, desc.Cout, True, True, True, False, d.N * d.H * d.W)
+        _split_launches(d, True, True, name, lambda part_no: check(L.mcdseg_conv_split_dgrad_half(
+            ctypes.byref(d), MATH_ID[CONV_MATH], _cb_slice(dy_cb, a, desc.Cout, desc.Ho * desc.Wo), _p(dy_bound), _p(wd), _p(w_bound),
+            _unit_slice(addend16, a, desc.Cin, desc.H * desc.W), _unit_slice(dx, a, desc.Cin, desc.H * desc.W), part_no, _stream()),
+            "conv_split_dgrad_half"), work=half_conv_work)
+    return dx
+
+
 def _cb_wanted(channels):
     """Emit the pre-split (channel-blocked) companion of a tensor with this many channels?  Only when the conv that gathers
     it runs on the split path (contraction >= 16 channels) and the layout applies (multiple of 8)."""
@@ -665,7 +765,6 @@ _WGRAD_NAMES = {10: "conv_wgrad_split_kernel<%s>", 11: "conv_wgrad_split_cb_kern
                 13: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3, false>", 14: "conv_wgrad_split_tr64_kernel<%s>",
                 16: "conv_wgrad_split_tr_kernel<%s, 4, 2, 3, true>",
                 17: "conv_wgrad_split_pp_kernel<%s>", 18: "conv_wgrad_split_pp3_kernel<%s>"}
-WGRAD_TR64 = os.environ.get("MCDSEG_WGRAD_TR64", "1") != "0"
 
 
 def wgrad_split_kernel_name(d, have_cb):
@@ -692,7 +791,7 @@ def _wgrad_split_plan(desc, have_cb=False):
     lo = min(desc.Cout, desc.Cin)
     if lo > 64:
         return True
-    return WGRAD_TR64 and have_cb and _scaled() and lo > 16 and desc.Cin % 8 == 0 and desc.Cout % 8 == 0
+    return get_option("WGRAD_TR64") != 0 and have_cb and _scaled() and lo > 16 and desc.Cin % 8 == 0 and desc.Cout % 8 == 0
 
 
 def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None, x_bound=None, dy_bound=None):
@@ -949,8 +1048,19 @@ def _room_to_defer(device):
             and torch.cuda.memory_reserved(key) < DEFER_RESERVED_FRACTION * _TOTAL_MEM[key])
 
 
+def _dgrad_any(desc, dy, wd, dy_cb, dy_bound, w_bound, addend, dx16):
+    """the data gradient in the format its consumer is owed: fp32 NCHW, or -- ``dx16``: the convolution's input is an activation of the
+    2-byte chain -- bf16 units, straight from the kernel's epilogue where it has one, converted otherwise"""
+    if not dx16:
+        return _conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound, addend)
+    if dy_cb is not None and _is_split(wd) and lib().mcdseg_conv_split_half_ok(ctypes.byref(desc), MATH_ID.get(CONV_MATH, 0), 1):
+        return _conv_dgrad_half(desc, dy_cb, dy_bound, wd, w_bound, addend)
+    dx = pack_bf16_units(_conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound, None))
+    return dx if addend is None else dx + addend
+
+
 def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_bound=None, x_bound=None, w_bound=None, defer=False, param=None,
-                   dx_addend=None):
+                   dx_addend=None, dx16=False):
     """(dx, dw).  ``defer``: dw goes to a ``_LateGrad`` node, so mode "2" may leave it on the side stream.  ``param``: the parameter
     behind that node; when its optimizer has left a ``_mcd_grad_sink`` on it (FlatSGD's bucketed all-reduce, MCDSEG_DP_OVERLAP=1) a
     deferred gradient is handed to the sink ON THE SIDE STREAM, right behind its kernels -- the exchange of a bucket then starts when
@@ -961,15 +1071,16 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_
         mode = "0"  # (without companions the weight gradient measures bounds and caches them on tensors the main stream reads)
     if mode != "0" and LAUNCH_TIMER is not None and LAUNCH_TIMER.wants("conv_wgrad"):
         mode = "0"  # a step whose launches are bracketed by HIP events runs every kernel alone, so that the pairs time kernels
-    # (a weight whose optimizer exchanges gradients in buckets is deferred whatever the allocator holds: WHICH gradients arrive early
-    # must not depend on one rank's memory -- the held operands are bounded by MAX_LAG launches)
-    if mode == "2" and sink is None and not _room_to_defer(x.device):
+    # (nothing is deferred while the allocator is close to its limit -- BASELINE config 5 -- also for a weight whose optimizer exchanges
+    # gradients in buckets: its gradient then reaches the sink as "not early" (below), which spoils the bucket's early start on THIS rank
+    # only; the collectives still start in bucket order on every rank, FlatSGD._drain)
+    if mode == "2" and not _room_to_defer(x.device):
         mode = "0"
         WGRAD_STREAM_STATS["no_room"] += 1
     if not (need_dx and need_dw and mode != "0"):
         if sink is not None and need_dw:
             sink(param, None)  # this contribution to the weight's gradient reaches p.grad WITHOUT passing through the sink
-        return ((_conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound, dx_addend) if need_dx else None),
+        return ((_dgrad_any(desc, dy, wd, dy_cb, dy_bound, w_bound, dx_addend, dx16) if need_dx else None),
                 (_conv_wgrad(desc, x, dy, x_cb, dy_cb, x_bound, dy_bound) if need_dw else None))
     main = torch.cuda.current_stream()
     side = _side_stream(x.device)
@@ -984,7 +1095,7 @@ def _conv_backward(desc, x, dy, wd, need_dx, need_dw, dy_cb=None, x_cb=None, dy_
         dw = _conv_wgrad(desc, x, dy, x_cb, dy_cb, x_bound, dy_bound)
     finally:
         keep, _LAUNCH.stream, _LAUNCH.keep = _LAUNCH.keep, None, None
-    dx = _conv_dgrad(desc, dy, wd, dy_cb, dy_bound, w_bound, dx_addend)
+    dx = _dgrad_any(desc, dy, wd, dy_cb, dy_bound, w_bound, dx_addend, dx16)
     if mode == "1":
         main.wait_stream(side)
         if sink is not None:
@@ -1052,6 +1163,7 @@ class _ConvBNAct(torch.autograd.Function):
         wf, wd, mpf = packed.get(getattr(weight, "_mcd_param", weight), desc)
         w_bound = packed.w_bound
         x_virtual = aux["x_virtual"]
+        x_half = bool(aux.get("x_half"))  # (decided on the tensor autograd knows, before a consumer of fp32 materializes it below)
         # (a batch cut along N keeps its companions -- the split kernels take slices, mcdseg.h Ncb -- except on the thin layers'
         # window kernels, Cin <= 16)
         uncut = len(_batch_pieces(desc)) == 1
@@ -1067,9 +1179,17 @@ class _ConvBNAct(torch.autograd.Function):
             # the stem: forward on the LDS-window kernel from the zero-padded companion of the network input (cached on the
             # tensor: the same batch goes through the stem several times per MCD step, forward and weight gradient)
             f_cb, x_bound = split_companion_padded(x, x_bound)
-        z, part, rows = _conv_fprop(desc, x, wf, _req(conv_bias, "conv bias"), training, mpf, f_cb, x_bound, w_bound)
         c = desc.Cout
         hw = desc.Ho * desc.Wo
+        # the 2-byte chain (HALF_STORAGE): this group keeps z, y, dz and the gradients it hands on as one 16-bit value per element
+        half = bool(aux.get("half") and training and _is_split(wf) and x_cb is not None and conv_bias is None and _cb_wanted(c)
+                    and desc.N * (c // 8) <= 65535 and not aux.get("no_cb")
+                    and (residual is None or (aux["res_virtual"] and aux["res_cb"] is not None and residual.dtype == torch.bfloat16))
+                    and L.mcdseg_conv_split_half_ok(ctypes.byref(desc), MATH_ID[CONV_MATH], 0) and _wgrad_split_plan(desc, True))
+        if half:
+            return _ConvBNAct._forward_half(ctx, L, desc, x, weight, gamma, beta, residual, running_mean, running_var, nbt, packed, wf, wd, mpf,
+                                            w_bound, momentum, eps, relu, x_cb, x_bound, res_bound, aux)
+        z, part, rows = _conv_fprop(desc, x, wf, _req(conv_bias, "conv bias"), training, mpf, f_cb, x_bound, w_bound)
         mean = torch.empty(c, dtype=torch.float32, device=z.device)
         rstd = torch.empty(c, dtype=torch.float32, device=z.device)
         # the pre-split companion of y: the scaled arithmetic needs |y|'s bound BEFORE y is written -- train-mode statistics
@@ -1141,6 +1261,9 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.x_cb, ctx.x_bound = x_cb, x_bound  # wgrad reads the input's split companion too (an input of this node: safe to hold)
         ctx.x_virtual, ctx.compact = x_virtual, compact
         ctx.rmask = rmask
+        ctx.half = False
+        ctx.x_half = x_half        # the gradients owed to activations of the 2-byte chain: bf16 units
+        ctx.res_half = bool(aux.get("res_half"))
         ctx.save_for_backward(x, z, y, mean, rstd, gamma, y_cb if compact else None, y_bound if compact else None, beta)
         ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the non-differentiable companions
         for t in (y_cb, y_bound):
@@ -1149,10 +1272,113 @@ class _ConvBNAct(torch.autograd.Function):
         return y, y_cb, y_bound
 
     @staticmethod
+    def _forward_half(ctx, L, desc, x, weight, gamma, beta, residual, running_mean, running_var, nbt, packed, wf, wd, mpf, w_bound, momentum,
+                      eps, relu, x_cb, x_bound, res_bound, aux):
+        """the group in the 2-byte chain (HALF_STORAGE; include/mcdseg.h "2-byte activation storage"): train mode, pre-split input"""
+        c, hw = desc.Cout, desc.Ho * desc.Wo
+        dev = x_cb.device
+        has_res = residual is not None
+        z16, z_bound, part, rows = _conv_fprop_half(desc, x_cb, x_bound, wf, w_bound, mpf)
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        rstd = torch.empty(c, dtype=torch.float32, device=dev)
+        y_bound = torch.empty(1, dtype=torch.float32, device=dev)
+        track = running_mean is not None
+        ws = torch.empty(L.mcdseg_bn_stats_workspace_bytes(rows, c) // 8 + 1, dtype=torch.float64, device=dev)
+        with _timed("bn_stats_finalize", (0, 12 * rows * mpf)):
+            check(L.mcdseg_bn_stats_finalize(_p(part), rows, c, mpf, _p(mean), _p(rstd), _p(running_mean) if track else None,
+                                             _p(running_var) if track else None, _p(nbt) if track else None, float(momentum), float(eps),
+                                             _p(gamma), _p(beta), _p(res_bound) if has_res else None, _p(y_bound),
+                                             int(BN_RUNNING_REPEAT if track else 1), _p(ws), ctypes.c_size_t(ws.numel() * 8), _stream()),
+                  "bn_stats_finalize")
+        if _FWD_SYNC == "lead":
+            _fwd_sync_record(gamma)
+        y_cb = torch.empty(desc.N * c * hw, dtype=torch.int16, device=dev)   # ONE piece: the activation
+        with _timed("bn_apply_half", (0, desc.N * c * hw * (4 + (2 if has_res else 0)))):
+            check(L.mcdseg_bn_apply_half(_p(z16), _p(z_bound), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(aux["res_cb"]) if has_res else None,
+                                         _p(res_bound) if has_res else None, _p(y_cb), _p(y_bound), desc.N, c, hw, int(relu), _stream()),
+                  "bn_apply_half")
+        y = _virtual((desc.N, c, desc.Ho, desc.Wo), dev, torch.bfloat16)
+        ctx.desc, ctx.wd, ctx.relu, ctx.training, ctx.has_res = desc, wd, relu, True, has_res
+        ctx.w_bound = w_bound
+        ctx.packed, ctx.pack_key = packed, packed.key
+        ctx.defer_ok = hasattr(weight, "_mcd_param")
+        ctx.w_param = getattr(weight, "_mcd_param", None)
+        if ctx.w_param is None and getattr(weight, "_mcd_grad_sink", None) is not None:
+            ctx.w_param = weight
+        ctx.in_box, ctx.res_box = aux.get("in_box"), aux.get("res_box")
+        ctx.has_bias = False
+        ctx.x_cb, ctx.x_bound = x_cb, x_bound
+        ctx.x_virtual, ctx.compact = aux["x_virtual"], True
+        ctx.rmask = None
+        ctx.half = True
+        ctx.x_half = bool(aux.get("x_half"))
+        ctx.res_half = has_res
+        ctx.z_bound = z_bound
+        ctx.save_for_backward(x, z16, y, mean, rstd, gamma, y_cb, y_bound, beta)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(y_cb, y_bound)
+        return y, y_cb, y_bound
+
+    @staticmethod
+    def _backward_half(ctx, dy):
+        """backward of a group of the 2-byte chain: ``dy`` bf16 units -> dz as the leading companion piece, the residual's gradient as bf16
+        units, then the convolution's gradients from companions alone"""
+        L = lib()
+        x, z16, y, mean, rstd, gamma, y_cb, y_bound, beta = ctx.saved_tensors
+        desc = ctx.desc
+        if ctx.packed.key != ctx.pack_key:
+            raise RuntimeError("mcdseg: a convolution weight was modified between a forward pass and its backward pass "
+                               "(an optimizer stepped the generator while its graph was still alive)")
+        dy = _req(dy, "grad_output", torch.bfloat16)
+        n, c, hw = desc.N, desc.Cout, desc.Ho * desc.Wo
+        dev = dy.device
+        mask = 0 if not ctx.relu else (4 if ctx.has_res else 2)
+        ws = _ws(L.mcdseg_bn_bwd_half_workspace_bytes(n, c, hw), dev)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        dz_bound = torch.empty(1, dtype=torch.float32, device=dev)
+        elems = n * c * hw
+        with _timed("bn_bwd_reduce_half", (0, elems * (4 + (2 if mask == 4 else 0)))):
+            check(L.mcdseg_bn_bwd_reduce_half(_p(dy), _p(y_cb) if mask == 4 else None, _p(z16), _p(ctx.z_bound), _p(mean), _p(rstd), _p(gamma),
+                                              _p(beta), _p(dgamma), _p(dbeta), _p(dz_bound), mask, 1, n, c, hw, _p(ws),
+                                              ctypes.c_size_t(ws.numel() * 4), _stream()), "bn_bwd_reduce_half")
+        dz_cb = torch.empty(elems, dtype=torch.int16, device=dev)
+        dres = None
+        if ctx.has_res and ctx.needs_input_grad[4]:
+            dres = torch.empty_like(dy) if ctx.relu else dy
+        with _timed("bn_bwd_apply_half", (0, elems * (6 + (2 if mask == 4 else 0) + (2 if (dres is not None and ctx.relu) else 0)))):
+            check(L.mcdseg_bn_bwd_apply_half(_p(dy), _p(y_cb) if mask == 4 else None, _p(z16), _p(ctx.z_bound), _p(mean), _p(rstd), _p(gamma),
+                                             _p(beta), _p(dgamma), _p(dbeta), _p(dz_cb), _p(dz_bound),
+                                             _p(dres) if (dres is not None and ctx.relu) else None, mask, 1, n, c, hw, _stream()),
+                  "bn_bwd_apply_half")
+        if ctx.res_box is not None and dres is not None:
+            other, last = ctx.res_box.arrive()
+            if last:
+                dres = dres if other is None else dres + other
+            else:
+                ctx.res_box.leave(dres if other is None else dres + other)
+                dres = None
+        addend, dx_last = (None, True)
+        if ctx.in_box is not None and ctx.needs_input_grad[0]:
+            addend, dx_last = ctx.in_box.arrive()
+        if ctx.needs_input_grad[1] and not (_wgrad_split_plan(desc, True) and desc.Cin % 8 == 0 and desc.Cout % 8 == 0):
+            raise RuntimeError("mcdseg: a group of the 2-byte chain needs a weight-gradient plan that reads companions (%d -> %d channels)"
+                               % (desc.Cin, desc.Cout))
+        dx, dw = _conv_backward(desc, x, None, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz_cb, ctx.x_cb, dz_bound,
+                                ctx.x_bound, ctx.w_bound, defer=ctx.defer_ok, param=ctx.w_param, dx_addend=addend, dx16=ctx.x_half)
+        if not dx_last:
+            ctx.in_box.leave(dx)
+            dx = None
+        return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres, None,
+                None, None, None, None, None, None, None, None, None, None, None, None, None)
+
+    @staticmethod
     def backward(ctx, dy, _dcb=None, _dbound=None):
         L = lib()
         if dy is None:
             return (None,) * 19
+        if ctx.half:
+            return _ConvBNAct._backward_half(ctx, dy)
         x, z, y, mean, rstd, gamma, y_cb, y_bound, beta = ctx.saved_tensors
         desc = ctx.desc
         if ctx.packed.key != ctx.pack_key:
@@ -1230,6 +1456,8 @@ class _ConvBNAct(torch.autograd.Function):
                                    y=y_mask, mean=mean, rstd=rstd, gamma=gamma, beta=beta, zmask=zmask))
         # the gradients this group shares with another producer (GradBox): the shortcut's goes into its box -- or comes back summed when
         # this group happens to be the last -- and the data gradient takes the box's tensor into its epilogue
+        if dres is not None and ctx.res_half:
+            dres = pack_bf16_units(dres)  # (the residual is an activation of the 2-byte chain: its gradient is owed as bf16 units)
         if ctx.res_box is not None and dres is not None:
             other, last = ctx.res_box.arrive()
             if last:
@@ -1241,7 +1469,7 @@ class _ConvBNAct(torch.autograd.Function):
         if ctx.in_box is not None and ctx.needs_input_grad[0]:
             addend, dx_last = ctx.in_box.arrive()
         dx, dw = _conv_backward(desc, x, dz, ctx.wd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz_cb, x_cb, dz_bound,
-                                x_bound, ctx.w_bound, defer=ctx.defer_ok, param=ctx.w_param, dx_addend=addend)
+                                x_bound, ctx.w_bound, defer=ctx.defer_ok, param=ctx.w_param, dx_addend=addend, dx16=ctx.x_half)
         if not dx_last:
             ctx.in_box.leave(dx)
             dx = None
@@ -1303,6 +1531,7 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, internal=False, in_box=No
     aux = dict(x_virtual=is_virtual(x), res_virtual=is_virtual(residual), res_cb=res_cb, compact=_compact_now() or skip_y,
                single_piece_only=skip_y and not _compact_now(), thin_ok=thin_ok,
                no_cb=bool(shortcut_only and SHORTCUT_NO_CB and not relu and residual is None and not _compact_now()),
+               half=_half_now(), x_half=is_half(x), res_half=is_half(residual),
                in_box=in_box.attach() if (in_box is not None and grads and x.requires_grad) else None,
                res_box=res_box.attach() if (res_box is not None and grads and residual is not None and residual.requires_grad) else None)
     y, y_cb, y_bound = _ConvBNAct.apply(x, _take_late(conv), bn.weight, bn.bias, residual, conv.bias, bn.running_mean if track else None,
@@ -1330,8 +1559,8 @@ def _cb_of(x):
     cb, bound, version, ptr = rec
     if x._version != version or x.data_ptr() != ptr or not (x.is_contiguous() or is_virtual(x)):
         return None, None
-    if cb is not None and cb.numel() != PIECES.get(CONV_MATH, 0) * x.numel():
-        cb = None
+    if cb is not None and cb.numel() != PIECES.get(CONV_MATH, 0) * x.numel() and not (CONV_MATH == "f16x1" and cb.numel() == x.numel()):
+        cb = None  # (f16x1 reads the leading piece only: a one-piece companion of the 2-byte chain serves every consumer)
     return cb, (bound if _scaled() else None)
 
 
@@ -1577,9 +1806,9 @@ def mcd_losses(z1, z2, labels, class_weight, ignore_index=-100, ce_coef=0.0, dif
 
 def up8_loss_kernel_name(n, c, hi, wi, two, labelled):
     """The kernel ``mcdseg_up8_softmax_ce_l1`` launches for this problem, as rocprofv3 prints it (csrc/loss.hip: the LDS-DMA kernel unless
-    MCDSEG_UP8_LOSS_DMA=0 or a tensor outgrows a 32-bit buffer resource; the benchmark's 41 classes have an instantiation of their own)."""
+    the library option UP8_LOSS_DMA is 0 or a tensor outgrows a 32-bit buffer resource; the benchmark's 41 classes have an instantiation of their own)."""
     two = "true" if two else "false"
-    dma = (os.environ.get("MCDSEG_UP8_LOSS_DMA", "1").strip() != "0" and 4 * n * c * hi * wi < 2 ** 31
+    dma = (get_option("UP8_LOSS_DMA") != 0 and 4 * n * c * hi * wi < 2 ** 31
            and (not labelled or 8 * 64 * n * hi * wi < 2 ** 31))
     if dma:
         nc = 16 if c <= 16 else (24 if c <= 24 else (41 if c == 41 else 48))

@@ -73,7 +73,7 @@ def run_fused(mods, x, internal_last=False, following=None):
                 or (nxt >= len(mods) and internal_last)
             x = ops.conv_bn_act(x, m, mods[i + 1], relu=relu, internal=bool(relu and feeds_conv and ops.INTERNAL_STAGES), thin_ok=True)
             i = nxt
-        elif type(m) is FusedSequential:  # a stage of plain convolutions
+        elif type(m) is FusedSequential and not _has_hooks(m):  # a stage of plain convolutions (one with hooks is CALLED: below)
             nxt_stage = mods[i + 1] if i + 1 < len(mods) else following
             x = run_fused(list(m.children()), x, internal_last=nxt_stage is not None and _reads_companions_only(nxt_stage))
             i += 1
@@ -81,6 +81,12 @@ def run_fused(mods, x, internal_last=False, following=None):
             x = m(x)
             i += 1
     return x
+
+
+def _has_hooks(module):
+    """forward (pre-)hooks registered on a stage: such a stage is called as a module -- its hooks fire and see a real fp32 output -- instead
+    of being walked group by group with a companion-only hand-over"""
+    return bool(module._forward_hooks or module._forward_pre_hooks)
 
 
 def _reads_companions_only(stage):
@@ -253,8 +259,9 @@ class DRN(nn.Module):
             stages = (self.layer1, self.layer2, self.layer3, self.layer4, self.layer5, self.layer6, self.layer7, self.layer8)
         live = [st for st in stages if st is not None]
         for k, st in enumerate(live):
-            if isinstance(st, FusedSequential):
+            if type(st) is FusedSequential and not _has_hooks(st):
                 # a convolution chain whose output only the next stage's convolutions read hands on its companion alone
+                # (a subclass, or a stage with forward hooks, is called like any module and writes its fp32 output)
                 last_internal = (not self.out_middle and k + 1 < len(live) and _reads_companions_only(live[k + 1]))
                 x = run_fused(list(st.children()), x, internal_last=last_internal)
             else:

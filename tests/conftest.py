@@ -52,3 +52,24 @@ def device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+LIB_OPTIONS = ("BN_STATS_ONE", "BN_REVERSE", "BN_V4", "BIGTILE_MIN_SLOTS", "WIDETILE_MIN_SLOTS", "DGRAD_INTERLEAVE", "DGRAD_ADD_LDS", "PACK_BLOCKS",
+               "PP_MIN_ROUNDS", "PP_CUS", "PINGPONG", "PP_WIDE_FILL", "PP_WIDE128", "THIN_WINDOW", "WGRAD_WGS", "WGRAD_THIN_TR", "WGRAD_TR64",
+               "WGRAD_TR", "WGRAD_BIG", "WGRAD_TWOTAP", "WGRAD_PP_CUS", "WGRAD_PP", "WGRAD_PP3", "UP8_LOSS_DMA", "UP8_BAND_ROWS")
+
+
+@pytest.fixture
+def libopt():
+    """``libopt(PINGPONG=0, PP_CUS=16)``: library options through the ABI (mcdseg_set_option -- the library reads no environment
+    variable); whatever a test set is restored when it ends"""
+    import mcdseg
+    first = {}
+
+    def set_(**values):
+        for k, v in values.items():
+            prev = mcdseg.set_option(k, int(v))
+            first.setdefault(k, prev)
+    yield set_
+    for k, v in first.items():
+        mcdseg.set_option(k, v)

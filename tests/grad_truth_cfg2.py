@@ -101,8 +101,10 @@ def main():
         NET, SEEDS, SIZE = "drn_d_105", (71, 72, 73), (720, 1280)
         if args.n == 16:
             args.n = 2
-        os.environ["MCDSEG_PP_CUS"] = str(8 * args.n)  # 256 CUs at N = 32: the same rounds of tiles, hence the same launch plan
+    import mcdseg
     from mcdseg import ops
+    if args.cfg5:
+        mcdseg.set_option("PP_CUS", 8 * args.n)  # 256 CUs at N = 32: the same rounds of tiles, hence the same launch plan
     if args.math:
         ops.CONV_MATH = args.math
     if args.cfg5:

@@ -34,12 +34,17 @@ def test_no_packed_fp32_instruction_with_op_sel_in_the_library():
     # hand-written vmcnt(63) counts on it) nor in the up-sampler's backward
     assert text.count("up8_softmax_ce_l1_dma_kernel") >= 8, "the LDS-DMA loss kernels are missing from the library"
     assert _lib.drains_inside_store_loops() == []
+    # mcd_hidden_dma writes M0 behind the compiler's back -- in the kernels that use it nothing else may touch M0 and no
+    # builtin LDS-DMA may sit beside it; and the loss kernel's counted vmcnt(63) needs the item's heads x C stores in the loop's text
+    assert _lib.hidden_dma_hazards() == []
+    counts = _lib.loss_dma_store_counts()
+    assert (41, 2) in counts and all(n >= c * h for (c, h), n in counts.items()), counts
 
 
-def test_fused_loss_kernel_name_follows_the_library_rule(monkeypatch):
+def test_fused_loss_kernel_name_follows_the_library_rule(monkeypatch, libopt):
     """ops.up8_loss_kernel_name restates csrc/loss.hip's dispatch (the launch timer and bench.py's counter lookup go by this name)"""
     from mcdseg import ops
-    monkeypatch.delenv("MCDSEG_UP8_LOSS_DMA", raising=False)
+    libopt(UP8_LOSS_DMA=1)  # (the default)
     assert ops.up8_loss_kernel_name(16, 41, 60, 80, True, True) == "up8_softmax_ce_l1_dma_kernel<41, true, true>"
     assert ops.up8_loss_kernel_name(16, 41, 60, 80, False, True) == "up8_softmax_ce_l1_dma_kernel<41, false, true>"
     assert ops.up8_loss_kernel_name(2, 14, 8, 8, True, False) == "up8_softmax_ce_l1_dma_kernel<16, true, false>"
@@ -47,7 +52,7 @@ def test_fused_loss_kernel_name_follows_the_library_rule(monkeypatch):
     assert ops.up8_loss_kernel_name(2, 40, 8, 8, True, False) == "up8_softmax_ce_l1_dma_kernel<48, true, false>"
     # a tensor past a 32-bit buffer resource, or the switch: the register-staged kernel
     assert ops.up8_loss_kernel_name(64, 41, 360, 640, True, True) == "up8_softmax_ce_l1_kernel<48, true>"
-    monkeypatch.setenv("MCDSEG_UP8_LOSS_DMA", "0")
+    libopt(UP8_LOSS_DMA=0)
     assert ops.up8_loss_kernel_name(16, 41, 60, 80, True, True) == "up8_softmax_ce_l1_kernel<48, true>"
 
 
@@ -448,3 +453,24 @@ def test_drn_c_generator_has_the_reference_state_dict_layout(golden):
     want = json.loads(str(golden.npz("drnc_small.npz")["keys"]))
     g = get_models("drn_c_26", 6, 41)[0]
     assert [[k, list(v.shape)] for k, v in g.state_dict().items()] == want
+
+
+def test_library_reads_no_environment_variable():
+    """no hidden inputs.  Plan selection is an explicit table behind mcdseg_set_option (csrc/options.h); neither the
+    sources nor the built library refer to getenv, and the table round-trips through the ABI."""
+    import subprocess
+    import mcdseg
+    from mcdseg import _lib
+    for src in _lib.sources() + [os.path.join(_lib.CSRC, h) for h in os.listdir(_lib.CSRC) if h.endswith(".h")]:
+        assert "getenv" not in open(src).read(), src
+    syms = subprocess.run(["nm", "-D", "--undefined-only", mcdseg.build()], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms
+    names = mcdseg.option_names()
+    assert len(names) == len(set(names)) >= 25 and "PINGPONG" in names and "PP_CUS" in names
+    for nm in names:
+        assert mcdseg.get_option(nm) == mcdseg.option_default(nm), "a test left %s set" % nm
+    with mcdseg.options(PP_CUS=16, PINGPONG=0):
+        assert (mcdseg.get_option("PP_CUS"), mcdseg.get_option("MCDSEG_PINGPONG")) == (16, 0)
+    assert (mcdseg.get_option("PP_CUS"), mcdseg.get_option("PINGPONG")) == (0, 3)
+    with pytest.raises(RuntimeError, match="unknown option"):
+        mcdseg.set_option("NO_SUCH_OPTION", 1)

@@ -265,7 +265,7 @@ def test_up8_backward_band_kernel(shape):
 @pytest.mark.parametrize("shape", [(2, 41, 5, 7), (1, 12, 3, 20), (2, 20, 4, 33), (1, 41, 2, 80), (5, 41, 30, 24), (3, 30, 33, 17)])
 @pytest.mark.parametrize("mode", ["ce+diff", "diff", "ce-single", "shared-scores"])
 @pytest.mark.parametrize("dma", ["1", "0"])
-def test_up8_loss_fused_equals_two_pass(shape, mode, dma, monkeypatch):
+def test_up8_loss_fused_equals_two_pass(shape, mode, dma, monkeypatch, libopt):
     """The loss kernel that forms the up-sampled logits on the fly (mcdseg_up8_softmax_ce_l1) against up8 followed by the
     plain loss kernel: identical logit gradients (bitwise), loss values up to the order of the block partial sums; ragged
     row segments (8 Wi not a multiple of 128), the image border and ignore_index pixels included.  Both forms of the kernel:
@@ -273,7 +273,7 @@ def test_up8_loss_fused_equals_two_pass(shape, mode, dma, monkeypatch):
     patches, i.e. gradient stores still in flight when the next patch's inputs are waited for) and staged through registers."""
     dev = _dev()
     from mcdseg import ops
-    monkeypatch.setenv("MCDSEG_UP8_LOSS_DMA", dma)
+    libopt(UP8_LOSS_DMA=int(dma))
     assert ("_dma_" in ops.up8_loss_kernel_name(*shape, mode != "ce-single", mode != "diff")) == (dma == "1")
     n, c, hi, wi = shape
     g = torch.Generator().manual_seed(11)
@@ -300,13 +300,13 @@ def test_up8_loss_fused_equals_two_pass(shape, mode, dma, monkeypatch):
                                     cw if labels is not None else None, want_grad=False, **kw)
     assert torch.equal(vals, got_l)
     if dma == "1":  # the two forms against each other: same arithmetic, same patch order, same sums -- the loss values bit for bit too
-        monkeypatch.setenv("MCDSEG_UP8_LOSS_DMA", "0")
+        libopt(UP8_LOSS_DMA=0)
         reg_l, reg_g1, reg_g2 = ops.up8_mcd_losses(s1, w1, None if single else s2, None if single else w2, labels,
                                                    cw if labels is not None else None, **kw)
         assert torch.equal(reg_l, got_l) and torch.equal(reg_g1, got_g1) and (single or torch.equal(reg_g2, got_g2))
 
 
-def test_up8_loss_and_backward_at_the_benchmark_size(monkeypatch):
+def test_up8_loss_and_backward_at_the_benchmark_size(monkeypatch, libopt):
     """BASELINE config 2's own loss problem (16 x 41 x 60 x 80 scores -> 480 x 640 logits, 38 patches per workgroup): the LDS-DMA form of
     the fused kernel against the register-staged form, bit for bit in both gradients and in the loss values; size-independent properties
     of the result (a cross-entropy gradient sums to zero over the classes of a pixel, ignored pixels have none; the discrepancy's two
@@ -326,7 +326,7 @@ def test_up8_loss_and_backward_at_the_benchmark_size(monkeypatch):
     cw = (0.5 + torch.rand(c, generator=g)).to(dev)
     out = {}
     for dma in ("1", "0"):
-        monkeypatch.setenv("MCDSEG_UP8_LOSS_DMA", dma)
+        libopt(UP8_LOSS_DMA=int(dma))
         out[dma] = (ops.up8_mcd_losses(s1, w1, s2, w2, lab, cw, ce_coef=1.0, diff_coef=0.0),
                     ops.up8_mcd_losses(s1, w1, s2, w2, None, None, ce_coef=0.0, diff_coef=-1.0))
     for a, b in zip(out["1"], out["0"]):
@@ -1101,7 +1101,7 @@ def test_conv_large_tile_kernels(case):
 
 
 @pytest.mark.parametrize("rows,c,mp", [(480, 512, 512), (480, 128, 128), (7, 16, 32), (1000, 41, 64), (1024, 2048, 2048), (333, 24, 32)])
-def test_bn_statistics_in_one_launch_are_bitwise_the_two_stage_result(rows, c, mp, monkeypatch):
+def test_bn_statistics_in_one_launch_are_bitwise_the_two_stage_result(rows, c, mp, monkeypatch, libopt):
     """``bn_stats_one_kernel`` (csrc/bn.hip): the merge of the convolution epilogue's partial rows into mean / rstd /
     running statistics / output bound as ONE launch for layers with few partial rows (<= 1024: the 1/8-resolution maps) -- the same fp64
     sums in the same order as ``bn_stats_partial_kernel`` + ``bn_stats_finalize_kernel`` (MCDSEG_BN_STATS_ONE=0), so every output is
@@ -1121,9 +1121,9 @@ def test_bn_statistics_in_one_launch_are_bitwise_the_two_stage_result(rows, c, m
     out = {}
     for mode in ("0", None):
         if mode is None:
-            monkeypatch.delenv("MCDSEG_BN_STATS_ONE", raising=False)
+            libopt(BN_STATS_ONE=1024)  # (the default)
         else:
-            monkeypatch.setenv("MCDSEG_BN_STATS_ONE", mode)
+            libopt(BN_STATS_ONE=int(mode))
         mean, rstd = torch.empty(c, device=dev), torch.empty(c, device=dev)
         rm, rv = torch.full((c,), 0.25, device=dev), torch.full((c,), 1.5, device=dev)
         nbt = torch.full((1,), 5, dtype=torch.int64, device=dev)
@@ -1157,7 +1157,7 @@ PINGPONG_CASES = [
 
 
 @pytest.mark.parametrize("case", PINGPONG_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_conv_pingpong_tile(case, monkeypatch):
+def test_conv_pingpong_tile(case, monkeypatch, libopt):
     """``conv_gemm_split_pp_kernel`` (csrc/conv_gemm_split_pp.hip: eight waves in two groups half a K-step apart) takes whole rounds of
     one 256 x 256 tile per CU and, with its 256 x 128 tile, the remaining pixels.  Forward (+ fused BatchNorm partial rows) and data
     gradient of such a two-launch convolution against fp64, and BIT FOR BIT against the same convolution on the 4-wave tiles
@@ -1168,8 +1168,8 @@ def test_conv_pingpong_tile(case, monkeypatch):
     from mcdseg import ops
     cin, cout, k, stride, d, n, h, w, math = case
     monkeypatch.setattr(ops, "CONV_MATH", math)
-    monkeypatch.setenv("MCDSEG_PP_MIN_ROUNDS", "1")  # (by default the kernels take a convolution from two whole rounds of tiles on)
-    monkeypatch.setenv("MCDSEG_PP_WIDE_FILL", "101")  # (... and the 256 x 320 tile takes it whole where that is cheaper: below, forced)
+    libopt(PP_MIN_ROUNDS=1)  # (by default the kernels take a convolution from two whole rounds of tiles on)
+    libopt(PP_WIDE_FILL=101)  # (... and the 256 x 320 tile takes it whole where that is cheaper: below, forced)
     x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, stride, d, h, w, n, False), 41)
     desc = ops.conv_desc(x.shape, wt.shape, stride, pad, d)
     pk = ops.PackedWeights()
@@ -1183,7 +1183,7 @@ def test_conv_pingpong_tile(case, monkeypatch):
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
     outs = {}
     for tag in ("pp", "off"):
-        monkeypatch.setenv("MCDSEG_PINGPONG", "3" if tag == "pp" else "0")
+        libopt(PINGPONG=int("3" if tag == "pp" else "0"))
         names = []
 
         class _Names:
@@ -1223,14 +1223,14 @@ def test_conv_pingpong_tile(case, monkeypatch):
         assert torch.equal(dx_add, dx + addend), "dgrad + addend differs from the separate add (max %.3e)" % float((dx_add - dx - addend).abs().max())
     # the 256 x 128 ping-pong tile alone (mode 2) and the 256 x 256 tile with the 4-wave tiles for the rest (mode 1): the same bits
     for mode in ("2", "1"):
-        monkeypatch.setenv("MCDSEG_PINGPONG", mode)
+        libopt(PINGPONG=int(mode))
         y_m, part_m, rows_m = ops._conv_fprop(desc, xg, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)
         assert torch.equal(y_m, y) and rows_m == rows and torch.equal(part_m, part), "mode %s differs" % mode
         if dx is not None:
             assert torch.equal(ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound), dx), "data gradient, mode %s" % mode
     # the 256 x 320 tile (mode 4 forces it; by default it takes a convolution with fewer than two rounds of 256 x 256 tiles whose 320-pixel
     # tiles fill their rounds): the same output bits; its BatchNorm partial rows are one per 160 pixels -- the same moments, regrouped
-    monkeypatch.setenv("MCDSEG_PINGPONG", "4")
+    libopt(PINGPONG=4)
     names = []
 
     class _Names4:
@@ -1265,7 +1265,7 @@ def test_conv_pingpong_tile(case, monkeypatch):
     assert float((mean - y64.mean(1)).abs().max()) <= 1e-6 * float(y64.abs().max())
     assert float((var - y64.var(1, unbiased=False)).abs().max()) <= 1e-6 * float(y64.var(1, unbiased=False).max())
     # parts 1 + 2 of the C ABI write exactly what part 0 writes (poisoned output, two calls)
-    monkeypatch.setenv("MCDSEG_PINGPONG", "3")
+    libopt(PINGPONG=3)
     y2 = torch.full_like(y, float("nan"))
     part2 = torch.full_like(part, float("nan"))
     for prt in (2, 1):
@@ -1276,7 +1276,7 @@ def test_conv_pingpong_tile(case, monkeypatch):
 
 @pytest.mark.parametrize("case", [(128, 128, 3, 1, 2, 45, 67), (128, 256, 3, 2, 2, 33, 40), (256, 128, 3, 2, 1, 47, 30), (136, 200, 1, 1, 3, 29, 31)],
                          ids=lambda c: "x".join(map(str, c)))
-def test_conv_wide_tile_kernels(case, monkeypatch):
+def test_conv_wide_tile_kernels(case, monkeypatch, libopt):
     """The 128 x 256 tile (``conv_gemm_split_kernel<P, 4, 2, 1, 4, ...>``: the 128- and 256-channel layers at BASELINE batch sizes, all-DMA
     K loop with two k-halves per thread) forced onto small problems with MCDSEG_WIDETILE_MIN_SLOTS: forward (+ fused BatchNorm partial
     rows) and data gradient against fp64 and bit for bit against the 128 x 128 tile (same K order, same 64-pixel statistic rows)."""
@@ -1299,7 +1299,7 @@ def test_conv_wide_tile_kernels(case, monkeypatch):
     gy_cb, gy_bound = ops.split_companion(gyg)
     outs = {}
     for tag, slots in (("wide", "1"), ("square", "1000000000")):
-        monkeypatch.setenv("MCDSEG_WIDETILE_MIN_SLOTS", slots)
+        libopt(WIDETILE_MIN_SLOTS=int(slots))
         names = []
 
         class _Names:
@@ -1685,7 +1685,7 @@ def test_conv_wgrad_presplit_operands(case, math, monkeypatch):
 
 @pytest.mark.parametrize("case", [(256, 512, 3, 1, 4, 30, 40, 6), (512, 512, 3, 1, 2, 24, 32, 6), (264, 512, 3, 1, 4, 29, 37, 6)],
                          ids=lambda c: "x".join(map(str, c)))
-def test_conv_wgrad_large_tile_kernel(case, monkeypatch):
+def test_conv_wgrad_large_tile_kernel(case, monkeypatch, libopt):
     """``conv_wgrad_split_tr_kernel<SplitF16x3, 4, 2, 3>`` -- the 256 x 128 weight-gradient tile, 14 % of the benchmark step -- on
     problems small enough for an fp64 reference but with enough split-K work that the launcher takes it (it was
     only reached at the benchmark's size): named through ``mcdseg_conv_wgrad_variant == 13``, <= 2e-5 of the scale against fp64, and
@@ -1694,8 +1694,8 @@ def test_conv_wgrad_large_tile_kernel(case, monkeypatch):
     import ctypes
     from mcdseg import ops
     monkeypatch.setattr(ops, "CONV_MATH", "f16x3")
-    monkeypatch.delenv("MCDSEG_WGRAD_BIG", raising=False)
-    monkeypatch.setenv("MCDSEG_WGRAD_PP", "0")  # (the ping-pong / stream-K kernel takes these layers when the problem is large enough: next test)
+    libopt(WGRAD_BIG=1)  # (the default)
+    libopt(WGRAD_PP=0)  # (the ping-pong / stream-K kernel takes these layers when the problem is large enough: next test)
     cin, cout, k, s, d, h, w, n = case
     x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, s, d, h, w, n, False), 41)
     desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
@@ -1709,7 +1709,7 @@ def test_conv_wgrad_large_tile_kernel(case, monkeypatch):
     gy_cb, gy_bound = ops.split_companion(gyg)
     dw_big = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
     _assert_close(dw_big, gw_ref, 2e-5, "wgrad (256 x 128 tiles)")
-    monkeypatch.setenv("MCDSEG_WGRAD_BIG", "0")
+    libopt(WGRAD_BIG=0)
     assert ops.lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), ops.MATH_ID["f16x3"], 1) == 12
     dw_small = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
     _assert_close(dw_small, gw_ref, 2e-5, "wgrad (128 x 128 tiles)")
@@ -1717,7 +1717,7 @@ def test_conv_wgrad_large_tile_kernel(case, monkeypatch):
 
 
 @pytest.mark.parametrize("math", ["f16x3", "f16x1"])
-def test_conv_pingpong_wide_tile_by_default(math, monkeypatch):
+def test_conv_pingpong_wide_tile_by_default(math, monkeypatch, libopt):
     """What the launcher chooses BY DEFAULT at BASELINE config 2's pixel count (76800 = 240 tiles of 320 pixels on 256 CUs): the
     256 x 320 ping-pong tile for a 256-row problem, its 128 x 320 form for the 128-channel layers -- forward (+ partial rows of 160
     pixels) and data gradient bit for bit those of the 4-wave tiles (MCDSEG_PINGPONG=0), the statistics the same moments, fp64 parity
@@ -1726,7 +1726,7 @@ def test_conv_pingpong_wide_tile_by_default(math, monkeypatch):
     import ctypes
     from mcdseg import ops
     monkeypatch.setattr(ops, "CONV_MATH", math)
-    monkeypatch.delenv("MCDSEG_PINGPONG", raising=False)
+    libopt(PINGPONG=3)  # (the default)
     L, mid = ops.lib(), ops.MATH_ID[math]
     # (Cin, Cout, N, forward tile, data-gradient tile): 76800 pixels = 240 tiles of 320; 38400 pixels (half: BASELINE config 4's N = 8)
     # = 240 tiles of 160 for a 256-row problem, and nothing for a 128-row one (0: the 4-wave tiles keep it)
@@ -1758,10 +1758,10 @@ def test_conv_pingpong_wide_tile_by_default(math, monkeypatch):
         assert names[0] == ops.pingpong_kernel_name(False, wide=kind_f) and len(names) == 2, names
         assert names[1] == ops.pingpong_kernel_name(True, wide=kind_d) if kind_d else "conv_gemm_split_pp_kernel" not in names[1], names
         assert rows == (pixels // 160 if kind_f == 3 else 2 * (pixels // 320))
-        monkeypatch.setenv("MCDSEG_PINGPONG", "0")
+        libopt(PINGPONG=0)
         y0, part0, rows0 = ops._conv_fprop(desc, xg, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)
         dx0 = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound)
-        monkeypatch.delenv("MCDSEG_PINGPONG")
+        libopt(PINGPONG=3)  # (the default)
         assert torch.equal(y, y0) and torch.equal(dx, dx0), "the wide tile's results differ from the 4-wave tiles'"
         # data gradient + addend (a residual block's other gradient; the tile of the addend goes through LDS): the bits of dgrad-then-add
         addend = torch.randn(dx.shape, generator=torch.Generator().manual_seed(45)).to(dev)
@@ -1799,7 +1799,7 @@ WGRAD_PP_CASES = [
 
 
 @pytest.mark.parametrize("case", WGRAD_PP_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_conv_wgrad_pingpong_stream_k(case, monkeypatch):
+def test_conv_wgrad_pingpong_stream_k(case, monkeypatch, libopt):
     """``conv_wgrad_split_pp_kernel`` (csrc/conv_wgrad_split_pp.hip): the weight gradient of the 256-channel-and-wider layers on
     256 x 256 tiles, eight waves in two groups half a K-step apart, over a split of the pixel range -- by default K slabs whose tiles run
     side by side on one XCD, or (MCDSEG_WGRAD_PP=1) stream-K: one equal piece of the flattened (tile, K-step) range per CU -- with one
@@ -1811,7 +1811,7 @@ def test_conv_wgrad_pingpong_stream_k(case, monkeypatch):
     from mcdseg import ops
     cin, cout, k, s, d, h, w, n, math = case
     monkeypatch.setattr(ops, "CONV_MATH", math)
-    monkeypatch.delenv("MCDSEG_WGRAD_PP", raising=False)
+    libopt(WGRAD_PP=2)  # (the default)
     x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, s, d, h, w, n, False), 43)
     desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
     L, mid = ops.lib(), ops.MATH_ID[math]
@@ -1835,14 +1835,14 @@ def test_conv_wgrad_pingpong_stream_k(case, monkeypatch):
     dw_b = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
     assert torch.equal(dw, dw_b), "two runs differ"
     # the default decomposition is the slab plan (K slabs whose tiles run side by side on one XCD); MCDSEG_WGRAD_PP=1 is stream-K
-    monkeypatch.setenv("MCDSEG_WGRAD_PP", "1")
+    libopt(WGRAD_PP=1)
     assert L.mcdseg_conv_wgrad_variant(ctypes.byref(desc), mid, 1) == 17
     dw_sk = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
     assert torch.equal(dw_sk, ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)), "two stream-K runs differ"
     # (fp32 accumulation inside a slab / a stream-K piece: the two plans cut K = N Ho Wo pixels differently, and at the benchmark's 76800
     # pixels a slab sums ~11 000 products per accumulator -- 2.1e-6 of the scale measured there, 1e-6 at the smaller cases)
     assert float((dw - dw_sk).abs().max()) <= 4e-6 * float(dw.abs().max()), "the two decompositions differ by more than their rounding"
-    monkeypatch.setenv("MCDSEG_WGRAD_PP", "0")
+    libopt(WGRAD_PP=0)
     assert L.mcdseg_conv_wgrad_variant(ctypes.byref(desc), mid, 1) in (12, 13)
     dw_tr = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
     scale = float(dw_tr.abs().max())
@@ -1865,7 +1865,7 @@ WGRAD_PP3_CASES = [
 
 
 @pytest.mark.parametrize("case", WGRAD_PP3_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_conv_wgrad_row_of_taps(case, monkeypatch):
+def test_conv_wgrad_row_of_taps(case, monkeypatch, libopt):
     """``conv_wgrad_split_pp3_kernel`` (csrc/conv_wgrad_split_pp.hip; round 5): the weight gradient of the 128-channel layers on tiles
     of 128 (co) x one kernel row of three taps x 128 (ci) -- the ping-pong kernel's structure, one staged dZ block serving three taps --
     over the slab plan, one fp32 slab per item, summed in K order in fp64.  Named through ``mcdseg_conv_wgrad_variant == 18``; within
@@ -1876,7 +1876,7 @@ def test_conv_wgrad_row_of_taps(case, monkeypatch):
     from mcdseg import ops
     cin, cout, k, s, d, h, w, n, math = case
     monkeypatch.setattr(ops, "CONV_MATH", math)
-    monkeypatch.delenv("MCDSEG_WGRAD_PP3", raising=False)
+    libopt(WGRAD_PP3=1)  # (the default)
     x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, s, d, h, w, n, False), 53)
     desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
     L, mid = ops.lib(), ops.MATH_ID[math]
@@ -1898,7 +1898,7 @@ def test_conv_wgrad_row_of_taps(case, monkeypatch):
         ops.LAUNCH_TIMER = prev
     assert names == ["conv_wgrad_split_pp3_kernel<%s>" % ops.POLICY[math]], names
     assert torch.equal(dw, ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)), "two runs differ"
-    monkeypatch.setenv("MCDSEG_WGRAD_PP3", "0")
+    libopt(WGRAD_PP3=0)
     assert L.mcdseg_conv_wgrad_variant(ctypes.byref(desc), mid, 1) in (12, 13)
     dw_tr = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
     scale = float(dw_tr.abs().max())
@@ -1912,7 +1912,7 @@ def test_conv_wgrad_row_of_taps(case, monkeypatch):
 
 @pytest.mark.parametrize("case", [(128, 128, 3, 1, 1, 12, 16, 2), (136, 200, 3, 1, 2, 13, 19, 2), (256, 128, 3, 1, 4, 9, 10, 1), (128, 128, 3, 2, 1, 15, 17, 2),
                                   (72, 80, 3, 1, 1, 8, 8, 3), (128, 256, 3, 1, 2, 30, 40, 4), (128, 136, 5, 1, 1, 9, 11, 1)], ids=lambda c: "x".join(map(str, c)))
-def test_conv_wgrad_two_taps_per_workgroup(case, monkeypatch):
+def test_conv_wgrad_two_taps_per_workgroup(case, monkeypatch, libopt):
     """``conv_wgrad_split_tr_kernel<SplitF16x3, 4, 2, 3, true>``: the 128-row weight-gradient layers with two taps per workgroup (X at both
     tap shifts on the "A" side, one shared dY tile on the "B" side, transposed output tile; odd tap counts leave the last pair half empty):
     named through ``mcdseg_conv_wgrad_variant == 16``, <= 2e-5 of the scale against fp64, and bit for bit the one-tap kernel
@@ -1921,7 +1921,7 @@ def test_conv_wgrad_two_taps_per_workgroup(case, monkeypatch):
     import ctypes
     from mcdseg import ops
     monkeypatch.setattr(ops, "CONV_MATH", "f16x3")
-    monkeypatch.setenv("MCDSEG_WGRAD_TWOTAP", "1")  # (off by default: slower at the benchmark's sizes)
+    libopt(WGRAD_TWOTAP=1)  # (off by default: slower at the benchmark's sizes)
     cin, cout, k, s, d, h, w, n = case
     x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, s, d, h, w, n, False), 43)
     desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
@@ -1938,7 +1938,7 @@ def test_conv_wgrad_two_taps_per_workgroup(case, monkeypatch):
     gy_cb, gy_bound = ops.split_companion(gyg)
     dw2 = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
     _assert_close(dw2, gw_ref, 2e-5, "wgrad (two taps per workgroup)")
-    monkeypatch.setenv("MCDSEG_WGRAD_TWOTAP", "0")
+    libopt(WGRAD_TWOTAP=0)
     assert ops.lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), ops.MATH_ID["f16x3"], 1) == 12
     dw1 = ops._conv_wgrad(desc, xg, gyg, x_cb, gy_cb, x_bound, gy_bound)
     assert torch.equal(dw2, dw1)

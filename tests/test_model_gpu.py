@@ -1212,7 +1212,7 @@ def test_d105_bottleneck_vs_reference(golden, storage, k, monkeypatch):
         assert e <= max(k * nz, 1e-3 * float(g64[name].abs().max())), "%s: err %.3e noise %.3e" % (name, e, nz)
 
 
-def test_cfg5_geometry_vs_oracle(monkeypatch):
+def test_cfg5_geometry_vs_oracle(monkeypatch, libopt):
     """BASELINE config 5's network at ITS geometry against the CPU oracle: drn_d_105 (Bottleneck blocks,
     models/drn.py:62-100, 344-348), 2 x 6 x 720 x 1280, train-mode BatchNorm, compact activation storage -- with the launch plan of the
     stated N = 32 batch: MCDSEG_PP_CUS = 16 gives the 28800 pixels of the 90 x 160 maps the rounds of tiles 460800 pixels have on 256
@@ -1229,7 +1229,7 @@ def test_cfg5_geometry_vs_oracle(monkeypatch):
     if ops.CONV_MATH != "f16x3":
         pytest.skip("the configuration's arithmetic is f16x3")
     n = 2
-    monkeypatch.setenv("MCDSEG_PP_CUS", str(8 * n))
+    libopt(PP_CUS=8 * n)
     monkeypatch.setattr(ops, "ACT_STORAGE", "compact")
     monkeypatch.setattr(ops, "MAX_CONV_BYTES", 150 << 20)
     assert len(ops._batch_pieces(ops.conv_desc((n, 2048, 90, 160), (512, 2048, 1, 1), 1, 0, 1))) == 2  # (the cut path is reached ...)
