@@ -505,16 +505,19 @@ def _main():
     timer.enabled = False
     wgrad_stream = dict(ops.WGRAD_STREAM_STATS)
     collectives, mdist.COLLECTIVE_EVENTS = mdist.COLLECTIVE_EVENTS, None
-    coll = None
-    if collectives is not None:
-        ms = [a.elapsed_time(b) for _, a, b in collectives]
-        big = [(nb, m) for (nb, _, _), m in zip(collectives, ms) if nb >= (1 << 20)]
-        coll = {"collective_ms_per_step": round(sum(ms) / args.steps, 3), "collectives_per_step": round(len(ms) / args.steps, 1),
-                "bytes_per_step": int(sum(nb for nb, _, _ in collectives) / args.steps),
+
+    def coll_summary(records, steps):
+        if records is None:
+            return None
+        ms = [a.elapsed_time(b) for _, a, b in records]
+        big = [(nb, m) for (nb, _, _), m in zip(records, ms) if nb >= (1 << 20)]
+        return {"collective_ms_per_step": round(sum(ms) / steps, 3), "collectives_per_step": round(len(ms) / steps, 1),
+                "bytes_per_step": int(sum(nb for nb, _, _ in records) / steps),
                 "large_all_reduce_avg_ms": round(sum(m for _, m in big) / len(big), 3) if big else None,
                 "large_all_reduce_avg_mb": round(sum(nb for nb, _ in big) / len(big) / 1e6, 1) if big else None,
                 "note": "HIP events on the compute stream around every all-reduce (or around the wait for a bucketed one): the time that "
                         "stream stands still for the exchange, rank 0"}
+    coll = coll_summary(collectives, args.steps)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if mdist.is_distributed():
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
@@ -543,6 +546,39 @@ def _main():
                    "value": round(args.batch * world * args.literal_steps / float(lt), 3),
                    "note": "same build with solver.reuse_tgt = False (7 generator forwards + 5 backwards per step), measured after the "
                            "timed region; identical weights, statistics and losses"}
+
+    # N > 1, outside the timed region: the same step with the OTHER setting of MCDSEG_DP_OVERLAP (gradients exchanged in buckets during
+    # the backward pass instead of one all-reduce of the flat buffer in step(), or the reverse) -- one invocation decides the default
+    dp_other = None
+    if mdist.is_distributed() and args.literal_steps > 0:
+        from mcdseg import optim as moptim
+        was = moptim.DP_OVERLAP
+        opts = [o for o in (getattr(solver, "opt_g", None), getattr(solver, "opt_f", None)) if hasattr(o, "_setup_overlap")]
+        moptim.DP_OVERLAP = not was
+        for o in opts:
+            o._setup_overlap()
+        solver.step(*next_batch())
+        torch.cuda.synchronize()
+        mdist.barrier()
+        torch.cuda.synchronize()
+        mdist.COLLECTIVE_EVENTS = []
+        t3 = time.perf_counter()
+        for _ in range(args.literal_steps):
+            solver.step(*next_batch())
+        torch.cuda.synchronize()
+        mdist.barrier()
+        torch.cuda.synchronize()
+        dt3 = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(dt3, op=torch.distributed.ReduceOp.MAX)
+        recs, mdist.COLLECTIVE_EVENTS = mdist.COLLECTIVE_EVENTS, None
+        dp_other = {"MCDSEG_DP_OVERLAP": "1" if moptim.DP_OVERLAP else "0", "steps": args.literal_steps,
+                    "ms_per_step": round(1e3 * float(dt3) / args.literal_steps, 2),
+                    "value": round(args.batch * world * args.literal_steps / float(dt3), 3), "collectives": coll_summary(recs, args.literal_steps),
+                    "note": "same build and ranks with the other setting of MCDSEG_DP_OVERLAP, measured after the timed region (MAX over ranks); "
+                            "the timed line above ran with MCDSEG_DP_OVERLAP=%s" % ("1" if was else "0")}
+        moptim.DP_OVERLAP = was
+        for o in opts:
+            o._setup_overlap()
 
     # likewise outside the timed region: the same step with the weight gradients on the main stream, the same-box
     # price of the second stream
@@ -580,7 +616,7 @@ def _main():
         others = {}
         for tag in [t.strip() for t in args.other_configs.split(",") if t.strip()]:
             try:
-                others[tag] = other_config(tag, dev, max(1, args.other_steps), args.n_class, want_roofline=tag.startswith("cfg5"))
+                others[tag] = other_config(tag, dev, max(1, args.other_steps), args.n_class, want_roofline=tag.startswith("cfg"))
             except Exception as e:  # (a configuration that does not fit or fails must not take the judged line down)
                 others[tag] = {"error": "%s: %s" % (type(e).__name__, e)}
                 torch.cuda.empty_cache()
@@ -683,6 +719,7 @@ def _main():
             "one_stream": one_stream,
             "wgrad_stream": wgrad_stream,
             "collectives": coll,
+            "dp_overlap_other_setting": dp_other,
             "other_configs": others,
             "strict_fp32": strict,
             "roofline": roofline,

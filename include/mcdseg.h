@@ -411,6 +411,9 @@ int mcdseg_confusion_hist(const int64_t* gt, const int64_t* pred, int64_t count,
  * F16X1 reads the LEADING piece of every companion only (piece stride 0), so one- and two-piece companions mix freely.
  * ---------------------------------------------------------------------------------------------- */
 int32_t mcdseg_conv_split_half_ok(const mcdseg_conv_desc* d, int32_t math, int32_t dgrad);
+/* 1 when the 8-wave ping-pong launches of this convolution run with two K-steps of 16 channels per barrier interval (MCDSEG_MATH_F16X1 with
+ * an even number of K-steps; kernel policy SplitF16x1D in profiles): the same products in the same order as the one-step kernel. */
+int32_t mcdseg_conv_split_pp_deep(const mcdseg_conv_desc* d, int32_t math, int32_t dgrad);
 int mcdseg_conv_split_fprop_half(const mcdseg_conv_desc* d, int32_t math, const void* x_cb, const float* x_bound, const void* wp_fprop,
                                  const float* w_bound, void* z16, float* z_bound, float* stat_partials, int32_t part, void* stream);
 int mcdseg_conv_split_dgrad_half(const mcdseg_conv_desc* d, int32_t math, const void* dy_cb, const float* dy_bound, const void* wp_dgrad,

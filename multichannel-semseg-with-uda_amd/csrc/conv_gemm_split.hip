@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
   }
   bool colv[WN];
   size_t dbase[WN];
-  size_t ubase[std::is_same<P, SplitF16x1>::value ? WN : 1];  // (16-bit blocked output: the pixel's first unit)
+  size_t ubase[P::HALF_OUT ? WN : 1];  // (16-bit blocked output: the pixel's first unit)
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int pp = ltile * BN + wn * (32 * WN) + j * 32 + l31;  // pixel index inside the (class) ordering
@@ -605,13 +605,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
       }
     }
     dbase[j] = (size_t)n * p.M * HWd + rem;
-    if constexpr (std::is_same<P, SplitF16x1>::value) ubase[j] = (size_t)n * (p.M >> 3) * HWd + rem;
+    if constexpr (P::HALF_OUT) ubase[j] = (size_t)n * (p.M >> 3) * HWd + rem;
   }
   // ---- 16-bit channel-blocked output (the one-term arithmetic only; see conv_gemm_split_pp.hip): registers r = 4 q .. 4 q + 3 of a
   // tile are channels 8 q + 4 lh .. + 3 of one pixel, half of a 16-byte unit
   bool half_out = false;
-  if constexpr (std::is_same<P, SplitF16x1>::value) half_out = p.dst16 != nullptr;
-  if constexpr (std::is_same<P, SplitF16x1>::value) {
+  if constexpr (P::HALF_OUT) half_out = p.dst16 != nullptr;
+  if constexpr (P::HALF_OUT) {
     if (half_out) {
       float inv_zs = 1.f;
       if (!DGRAD) {
@@ -955,6 +955,7 @@ int64_t mcdseg_internal_conv_pp_pixels(const ConvSplitParams& p, int math, bool 
 int mcdseg_internal_conv_pp_launch(const ConvSplitParams& p, int math, bool dgrad, int64_t pixels, hipStream_t st);
 int mcdseg_internal_conv_pp_rest(const ConvSplitParams& p, int math, bool dgrad);
 int mcdseg_internal_conv_pp_wide(const ConvSplitParams& p, int math, bool dgrad);
+int mcdseg_internal_conv_pp_deep(const ConvSplitParams& p, int math);
 int mcdseg_internal_conv_pp_rest_launch(const ConvSplitParams& p, int math, bool dgrad, int64_t pix0, hipStream_t st);
 
 namespace {
@@ -1358,4 +1359,13 @@ extern "C" int mcdseg_conv_split_dgrad_half(const mcdseg_conv_desc* d, int32_t m
   MCD_REQUIRE(part >= 0 && part <= 2, "conv_split_dgrad_half: part must be 0 (whole), 1 (ping-pong tiles) or 2 (the rest)");
   MCD_REQUIRE(dx16 != nullptr && addend16 != dx16, "conv_split_dgrad_half: null output (or the addend aliases it)");
   return split_dgrad_impl(d, math, nullptr, dy_cb, dy_bound, wp_dgrad, w_bound, nullptr, stream, part, nullptr, dx16, addend16);
+}
+
+// 1 when the ping-pong launches of this convolution (forward, or `dgrad`) run with two K-steps per barrier interval (the policy name
+// rocprofv3 prints is then SplitF16x1D; the 256 x 128 tile never does)
+extern "C" int32_t mcdseg_conv_split_pp_deep(const mcdseg_conv_desc* d, int32_t math, int32_t dgrad) {
+  if (d == nullptr || !mcd_math_known(math)) return 0;
+  ConvSplitParams p;
+  if (dgrad ? fill_dgrad_params(d, math, d, p) : fill_fprop_params(d, math, d, p)) return 0;
+  return mcdseg_internal_conv_pp_deep(p, math);
 }

@@ -64,8 +64,15 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
   constexpr int A_DMAS = (A_UNITS + NT - 1) / NT;  // per thread (units past A_UNITS: out of range, zeros past the staged planes)
   constexpr int B_UNITS = 2 * NPU * BN;            // 16-byte units of the pixel operand per K-step: [piece][k-half][pixel]
   constexpr int B_DMAS = (B_UNITS + NT - 1) / NT;  // per thread (units past B_UNITS: an out-of-range DMA that deposits zeros past the planes)
-  constexpr int DMA_PER_STEP = A_DMAS + B_DMAS;
-  constexpr int A_BYTES = (NQ * BM > A_DMAS * NT ? NQ * BM : A_DMAS * NT) * 16, B_BYTES = (NQ * BN > B_DMAS * NT ? NQ * BN : B_DMAS * NT) * 16;
+  // KDEEP K-steps of 16 channels per barrier interval (SplitF16x1D: 2): sub-step d of an interval lies A_SUB / B_SUB units behind
+  // sub-step 0 in the stage -- for the one-term arithmetic with 256 / 128 pixels exactly where the second piece would lie
+  constexpr int KDEEP = P::KDEEP;
+  static_assert(KDEEP == 1 || NPU == 1, "deep K-steps use the slots of the pieces the policy does not stage");
+  constexpr int A_SUB = 2 * NPU * BM > A_DMAS * NT ? 2 * NPU * BM : A_DMAS * NT;
+  constexpr int B_SUB = 2 * NPU * BN > B_DMAS * NT ? 2 * NPU * BN : B_DMAS * NT;
+  constexpr int DMA_PER_STEP = KDEEP * (A_DMAS + B_DMAS);
+  constexpr int A_BYTES = KDEEP > 1 ? KDEEP * A_SUB * 16 : (NQ * BM > A_DMAS * NT ? NQ * BM : A_DMAS * NT) * 16;
+  constexpr int B_BYTES = KDEEP > 1 ? KDEEP * B_SUB * 16 : (NQ * BN > B_DMAS * NT ? NQ * BN : B_DMAS * NT) * 16;
   // a pixel tile that divides the workgroup gives every thread ONE gather pixel for all its units; otherwise (320) one per unit
   constexpr bool SAMEPX = (NT % BN) == 0;
   constexpr int NPX = SAMEPX ? 1 : B_DMAS;
@@ -151,10 +158,10 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
 
   // loader state: K order is channel-chunk outer, tap inner (the shifted re-reads of a 16-channel slab are back to back)
   int l_tap = 0, l_c0 = 0, l_ky = 0, l_kx = 0, l_kstep = 0;
-  auto issue = [&](int buf) {  // this wave's share of one K-step: A_DMAS KB of the weight slab, NPU x 1 KB of gathered pixel units
+  auto issue_sub = [&](int buf, int d) {  // this wave's share of one K-step: A_DMAS KB of the weight slab, NPU x 1 KB of gathered pixel units
 #if defined(__HIP_DEVICE_COMPILE__)  // the LDS address space does not exist in the host pass of this translation unit
     const int a_soff = (l_kstep * NQ * p.Mp + tile_m * BM) * 16;
-    unsigned char* adst = As + buf * A_BYTES + wave * 64 * 16;
+    unsigned char* adst = As + buf * A_BYTES + (d * A_SUB + wave * 64) * 16;
 #pragma unroll
     for (int i = 0; i < A_DMAS; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wp_rs, (__attribute__((address_space(3))) void*)(adst + i * NT * 16), 16, a_voff[i], a_soff, 0, 0);
@@ -176,12 +183,13 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
       const int grp = (l_c0 >> 3) + (plane & 1);
       // (a ragged last chunk, or a unit past the staged pieces: the range check deposits zeros)
       const int soff = (grp < C8 && plane < 2 * NPU) ? grp * HWs * 16 : 0x7FFFFFFF;
-      unsigned char* bdst = Bs + buf * B_BYTES + unit0 * 16;
+      unsigned char* bdst = Bs + buf * B_BYTES + (d * B_SUB + unit0) * 16;
       const __amdgpu_buffer_rsrc_t rs = (NPU > 1 && plane >= 2) ? cb_rs[NPU - 1] : cb_rs[0];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)bdst, 16, voff[SAMEPX ? 0 : i], soff, 0, 0);
     }
 #else
     (void)buf;
+    (void)d;
 #endif
   };
   auto advance = [&]() {
@@ -199,6 +207,17 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
     }
   };
 
+  auto issue = [&](int buf) {  // one barrier interval's operands: KDEEP consecutive K-steps
+    issue_sub(buf, 0);
+    if constexpr (KDEEP > 1) {
+#pragma unroll
+      for (int d = 1; d < KDEEP; ++d) {
+        advance();
+        issue_sub(buf, d);
+      }
+    }
+  };
+
   f32x16 acc[WM][WN];
 #pragma unroll
   for (int i = 0; i < WM; ++i)
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nsteps = taps * (p.Kp / 16);
+  const int nsteps = taps * (p.Kp / 16) / KDEEP;  // (KDEEP > 1: the host launches this instantiation for an even number of K-steps only)
   issue(0);
   if (nsteps > 1) {
     advance();
@@ -216,18 +235,28 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (grp_id == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1 runs one barrier behind group 0 from here to the end of the K loop
 
-  frag fa[NP][WM], fb[NP][WN];
+  frag fa[KDEEP > 1 ? KDEEP : NP][WM], fb[KDEEP > 1 ? KDEEP : NP][WN];
   int cur = 0, nxt2 = 2;
   for (int s = 0; s < nsteps; ++s) {
     // ---- read phase (the partner group multiplies meanwhile)
     const unsigned char* a_base = As + cur * A_BYTES + (lh * BM + wm * (32 * WM) + l31) * 16;
     const unsigned char* b_base = Bs + cur * B_BYTES + (lh * BN + wn * (32 * WN) + l31) * 16;
+    if constexpr (KDEEP > 1) {
+#pragma unroll
+      for (int d = 0; d < KDEEP; ++d) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) fa[d][i] = *reinterpret_cast<const frag*>(a_base + (d * A_SUB + i * 32) * 16);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) fb[d][j] = *reinterpret_cast<const frag*>(b_base + (d * B_SUB + j * 32) * 16);
+      }
+    } else {
 #pragma unroll
     for (int pc = 0; pc < NPU; ++pc) {
 #pragma unroll
       for (int i = 0; i < WM; ++i) fa[pc][i] = *reinterpret_cast<const frag*>(a_base + (pc * 2 * BM + i * 32) * 16);
 #pragma unroll
       for (int j = 0; j < WN; ++j) fb[pc][j] = *reinterpret_cast<const frag*>(b_base + (pc * 2 * BN + j * 32) * 16);
+    }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (s + 2 < nsteps) {
@@ -241,12 +270,21 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
     __builtin_amdgcn_sched_barrier(0);
     // ---- matrix phase (the partner group reads meanwhile): the policy's cross terms, smallest first, term-major -- consecutive
     // instructions go to different accumulator tiles; same sums in the same order per tile as conv_gemm_split_kernel
+    if constexpr (KDEEP > 1) {  // the interval's K-steps in K order (one term each): the sums of SplitF16x1's kernel, in its order
+#pragma unroll
+      for (int d = 0; d < KDEEP; ++d)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[i][j] = P::mfma(fa[d][i], fb[d][j], acc[i][j]);
+    } else {
 #pragma unroll
     for (int tm = 0; tm < P::NTERMS; ++tm)
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = P::mfma(fa[P::TA[tm]][i], fb[P::TB[tm]][j], acc[i][j]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_barrier" ::: "memory");
     cur = cur == 2 ? 0 : cur + 1;
@@ -306,8 +344,8 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
   // registers r = 4 q .. 4 q + 3 of an accumulator tile are channels 8 q + 4 lh .. + 3 of one pixel: half of a 16-byte unit, so a
   // store instruction of the wave covers 32 whole units = 512 consecutive bytes (the fp32 planar form: two runs of 128 bytes).
   bool half_out = false;
-  if constexpr (std::is_same<P, SplitF16x1>::value) half_out = p.dst16 != nullptr;
-  if constexpr (std::is_same<P, SplitF16x1>::value) {
+  if constexpr (P::HALF_OUT) half_out = p.dst16 != nullptr;
+  if constexpr (P::HALF_OUT) {
     if (half_out) {
       float inv_zs = 1.f;
       if (!DGRAD) {
@@ -509,8 +547,25 @@ void launch_tile(const ConvSplitParams& q, hipStream_t st) {
   hipLaunchKernelGGL((conv_gemm_split_pp_kernel<P, DGRAD, WM, WN, QM, QN>), grid, dim3(512), 0, st, q);
 }
 
+// SplitF16x1D (two K-steps per barrier interval) takes an even number of K-steps; not on the 256 x 128 tile, whose two workgroups per CU
+// would no longer fit the LDS side by side (option PP_DEEP = 0: never)
+template <int WM, int WN, int QM, int QN>
+bool deep_applies(const ConvSplitParams& q, int math) {
+  constexpr bool small = WM == 2 && WN == 2 && QM == 2 && QN == 2;
+  return math == MCDSEG_MATH_F16X1 && !small && mcd_opt(MCD_OPT_PP_DEEP) != 0 && ((q.KH * q.KW * (q.Kp / 16)) & 1) == 0;
+}
+
 template <int WM, int WN, int QM, int QN>
 void launch_math(const ConvSplitParams& q, int math, bool dgrad, hipStream_t st) {
+  if constexpr (!(WM == 2 && WN == 2 && QM == 2 && QN == 2)) {
+    if (deep_applies<WM, WN, QM, QN>(q, math)) {
+      if (dgrad)
+        launch_tile<SplitF16x1D, true, WM, WN, QM, QN>(q, st);
+      else
+        launch_tile<SplitF16x1D, false, WM, WN, QM, QN>(q, st);
+      return;
+    }
+  }
   if (math == MCDSEG_MATH_F16X1) {
     if (dgrad)
       launch_tile<SplitF16x1, true, WM, WN, QM, QN>(q, st);
@@ -568,6 +623,9 @@ int pp_wide(const ConvSplitParams& p, int math, bool dgrad) {
 
 // 1 when the whole convolution runs on the 256 x 320 ping-pong tile (BatchNorm partial rows of 160 pixels)
 int mcdseg_internal_conv_pp_wide(const ConvSplitParams& p, int math, bool dgrad) { return pp_wide(p, math, dgrad); }
+
+// 1 when the ping-pong launches of this problem (all but the 256 x 128 tile's) run as SplitF16x1D (kernel names for profilers)
+int mcdseg_internal_conv_pp_deep(const ConvSplitParams& p, int math) { return deep_applies<4, 2, 1, 4>(p, math) ? 1 : 0; }
 
 // Pixels (a multiple of 256, counted from pixel 0) of this problem that the 256 x 256 ping-pong tile takes: whole rounds of one tile
 // per CU; 0 when it does not apply (no pre-split operand, three-piece arithmetic, output rows not a multiple of 256, strided data

@@ -18,6 +18,7 @@
   X(PINGPONG, 3)              /* 0 4-wave tiles only; 1 / 3 whole rounds of 256 x 256 + rest on 4-wave / 256 x 128; 2 256 x 128 for all; 4 wide tile forced */ \
   X(PP_WIDE_FILL, 80)         /* per cent of its rounds the 320-pixel tile must fill (> 100 = never) */                      \
   X(PP_WIDE128, 1)            /* the 128 x 320 variant */                                                                    \
+  X(PP_DEEP, 1)               /* one-term arithmetic: two K-steps per barrier interval of the ping-pong kernels (SplitF16x1D) */ \
   X(THIN_WINDOW, 1)           /* LDS-window kernels of the thin 3x3 layers */                                                \
   X(WGRAD_WGS, 1024)          /* target workgroup count of the 128 / 64-tile weight-gradient plans */                        \
   X(WGRAD_THIN_TR, 1)         /* thin layers' window weight gradient */                                                      \

@@ -36,6 +36,8 @@ __host__ __device__ __forceinline__ float mcd_scale_of_bound(float bound) {
 }
 
 struct SplitBf16x6 {
+  static constexpr bool HALF_OUT = false;  // (16-bit channel-blocked epilogues: the one-term arithmetic only)
+  static constexpr int KDEEP = 1;          // (K-steps of 16 channels per barrier interval of the ping-pong kernels)
   static constexpr int NP = 3;
   static constexpr int NPU = 3;  // pieces a kernel stages into LDS (all of them)
   static constexpr int NTERMS = 6;
@@ -59,6 +61,8 @@ struct SplitBf16x6 {
 };
 
 struct SplitF16x3 {
+  static constexpr bool HALF_OUT = false;
+  static constexpr int KDEEP = 1;
   static constexpr int NP = 2;
   static constexpr int NPU = 2;
   static constexpr int NTERMS = 3;
@@ -82,10 +86,20 @@ struct SplitF16x3 {
 // as SplitF16x3 stores them (two scaled fp16 pieces -- same companions, weight images, bounds, producers), but a product keeps
 // only the leading term h1 h1': one MFMA instead of three, operands rounded to fp16's 11 significant bits (bf16 would keep 8).
 struct SplitF16x1 : SplitF16x3 {
+  static constexpr bool HALF_OUT = true;  // its convolutions can write 16-bit channel-blocked tensors (round 6: 2-byte activation storage)
   static constexpr int NPU = 1;  // pieces a kernel has to STAGE (the second piece is stored but never multiplied)
   static constexpr int NTERMS = 1;
   static constexpr int TA[1] = {0};
   static constexpr int TB[1] = {0};
+};
+
+// SplitF16x1D: the same arithmetic for the 8-wave ping-pong convolution with TWO K-steps of 16 channels per barrier interval.  A K-step
+// of the one-term arithmetic is 8 matrix instructions per wave (256 cycles) against the three-term form's 24, while its barriers, counted
+// waits and DMA issue cost what they cost: the kernels balanced for three terms reach 0.30 of the matrix peak with one (round 5).  Here
+// the LDS slots of the (never staged) second piece hold the NEXT K-step's operands: the stage image, the fragment reads and the DMA count
+// are the three-term kernel's, 16 matrix instructions per interval.  Same products in the same order: bit for bit SplitF16x1's results.
+struct SplitF16x1D : SplitF16x1 {
+  static constexpr int KDEEP = 2;
 };
 
 // split 8 values into NP fragments

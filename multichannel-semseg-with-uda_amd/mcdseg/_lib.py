@@ -117,6 +117,7 @@ _SIGNATURES = {
     "mcdseg_sgd_momentum_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_float, c_void_p]),
     # 2-byte activation storage (round 6)
     "mcdseg_conv_split_half_ok": (c_i32, [_P(ConvDesc), c_i32, c_i32]),
+    "mcdseg_conv_split_pp_deep": (c_i32, [_P(ConvDesc), c_i32, c_i32]),
     "mcdseg_conv_split_fprop_half": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 7 + [c_i32, c_void_p]),
     "mcdseg_conv_split_dgrad_half": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 6 + [c_i32, c_void_p]),
     "mcdseg_bn_apply_half": (c_int, [c_void_p] * 10 + [c_i32] * 4 + [c_void_p]),

@@ -85,11 +85,13 @@ def gemm_kernel_name(m, k, dgrad, split=False, presplit=False, direct=False, pix
     return "conv_gemm_kernel<%s, %d, %s>" % (cfg, 8 if k <= 8 else 16, "true" if dgrad else "false")
 
 
-def pingpong_kernel_name(dgrad, math=None, small=False, wide=0):
+def pingpong_kernel_name(dgrad, math=None, small=False, wide=0, deep=False):
     """rocprofv3's name of the 8-wave ping-pong kernel (csrc/conv_gemm_split_pp.hip): its 256 x 256 tile, the 256 x 128 one
-    (``small``), the 256 x 320 one (``wide`` = 1), the 128 x 320 one (2) or the 256 x 160 one (3: what ``mcdseg_conv_split_wide_pingpong`` returns)"""
+    (``small``), the 256 x 320 one (``wide`` = 1), the 128 x 320 one (2) or the 256 x 160 one (3: what ``mcdseg_conv_split_wide_pingpong`` returns).
+    ``deep`` (``mcdseg_conv_split_pp_deep``; never on the 256 x 128 tile): the one-term arithmetic with two K-steps per barrier interval"""
     tile = {0: "2, 2, 2, 2" if small else "4, 2, 1, 4", 1: "2, 5, 2, 2", 2: "1, 5, 2, 2", 3: "1, 5, 4, 1"}[int(wide)]
-    return "conv_gemm_split_pp_kernel<%s, %s, %s>" % (POLICY[math or CONV_MATH], "true" if dgrad else "false", tile)
+    policy = POLICY[math or CONV_MATH] + ("D" if (deep and not (small and not wide) and (math or CONV_MATH) == "f16x1") else "")
+    return "conv_gemm_split_pp_kernel<%s, %s, %s>" % (policy, "true" if dgrad else "false", tile)
 
 
 def _split_launches(d, presplit, dgrad, name, call, work=None):
@@ -101,7 +103,8 @@ def _split_launches(d, presplit, dgrad, name, call, work=None):
     flops, byts = (work or conv_work)(d)
     if pp > 0:
         wide = lib().mcdseg_conv_split_wide_pingpong(ctypes.byref(d), MATH_ID[CONV_MATH], 1, int(dgrad))
-        with _timed(pingpong_kernel_name(dgrad, wide=wide), (flops * pp / pixels, byts * pp / pixels)):
+        deep = bool(lib().mcdseg_conv_split_pp_deep(ctypes.byref(d), MATH_ID[CONV_MATH], int(dgrad)))
+        with _timed(pingpong_kernel_name(dgrad, wide=wide, deep=deep), (flops * pp / pixels, byts * pp / pixels)):
             call(1)
     if pp < pixels:
         if presplit and lib().mcdseg_conv_split_rest_pingpong(ctypes.byref(d), MATH_ID[CONV_MATH], 1, int(dgrad)):
@@ -1182,7 +1185,8 @@ class _ConvBNAct(torch.autograd.Function):
         c = desc.Cout
         hw = desc.Ho * desc.Wo
         # the 2-byte chain (HALF_STORAGE): this group keeps z, y, dz and the gradients it hands on as one 16-bit value per element
-        half = bool(aux.get("half") and training and _is_split(wf) and x_cb is not None and conv_bias is None and _cb_wanted(c)
+        # (not the thin layers, Cin <= 16: their window weight gradient multiplies BOTH pieces of dz's companion whatever the arithmetic)
+        half = bool(aux.get("half") and training and _is_split(wf) and x_cb is not None and conv_bias is None and _cb_wanted(c) and desc.Cin > 16
                     and desc.N * (c // 8) <= 65535 and not aux.get("no_cb")
                     and (residual is None or (aux["res_virtual"] and aux["res_cb"] is not None and residual.dtype == torch.bfloat16))
                     and L.mcdseg_conv_split_half_ok(ctypes.byref(desc), MATH_ID[CONV_MATH], 0) and _wgrad_split_plan(desc, True))
@@ -1525,6 +1529,10 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, internal=False, in_box=No
         raise NotImplementedError("mcdseg: eval-mode BatchNorm needs running statistics")
     momentum = 0.1 if bn.momentum is None else bn.momentum
     x_cb, x_bound = _cb_of(x)
+    if x_cb is not None and conv.in_channels <= 16 and x_cb.numel() == x.numel() and PIECES.get(CONV_MATH, 0) > 1:
+        # (the thin layers' window kernels multiply BOTH pieces of their operand whatever the arithmetic; no network of the reference
+        # feeds a 16-channel convolution from inside the 2-byte chain, whose groups all have more than 16 input channels)
+        raise RuntimeError("mcdseg: a convolution of %d input channels cannot consume a one-piece (2-byte chain) activation" % conv.in_channels)
     res_cb, res_bound = _cb_of(residual) if residual is not None else (None, None)
     skip_y = internal and INTERNAL_SKIP_Y and BN_ZMASK and relu and residual is None and _scaled()
     grads = torch.is_grad_enabled()

@@ -191,14 +191,18 @@ def _bottleneck_run(dev, half, seed=3, n=2, h=24, w=32):
     import torch.nn as nn
     torch.manual_seed(seed)
     ds = ConvBN(Conv2d(64, 256, kernel_size=1, stride=1, bias=False), BatchNorm2d(256))
-    net = nn.ModuleList([ConvBNReLU(Conv2d(32, 64, kernel_size=3, padding=1, bias=False), BatchNorm2d(64), nn.ReLU(inplace=True)),
+    # (the head of the chain as in a DRN-D trunk, models/drn.py:195-205: thin layers -- 16 input channels, their window kernels multiply both
+    # pieces of an operand whatever the arithmetic -- stay OUTSIDE the 2-byte chain; the 32 -> 64 convolution is its first group)
+    net = nn.ModuleList([ConvBNReLU(Conv2d(16, 16, kernel_size=3, padding=1, bias=False), BatchNorm2d(16), nn.ReLU(inplace=True),
+                                    Conv2d(16, 32, kernel_size=3, stride=2, padding=1, bias=False), BatchNorm2d(32), nn.ReLU(inplace=True),
+                                    Conv2d(32, 64, kernel_size=3, padding=1, bias=False), BatchNorm2d(64), nn.ReLU(inplace=True)),
                          Bottleneck(64, 64, 1, ds, dilation=(1, 1)), Bottleneck(256, 64, dilation=(2, 2)),
                          ConvBNReLU(Conv2d(256, 128, kernel_size=3, padding=1, bias=False), BatchNorm2d(128), nn.ReLU(inplace=True))]).to(dev).train()
     for m in net.modules():
         if isinstance(m, nn.BatchNorm2d):
             m.weight.data.uniform_(0.5, 1.5)
             m.bias.data.normal_(0, 0.2)
-    x = torch.randn(n, 32, h, w, generator=torch.Generator().manual_seed(seed + 1)).to(dev).requires_grad_()
+    x = torch.randn(n, 16, 2 * h, 2 * w, generator=torch.Generator().manual_seed(seed + 1)).to(dev).requires_grad_()
     prev = (ops.CONV_MATH, ops.ACT_STORAGE, ops.HALF_STORAGE)
     ops.CONV_MATH, ops.ACT_STORAGE, ops.HALF_STORAGE = "f16x1", "compact", half
     names = []
@@ -248,3 +252,50 @@ def test_bottleneck_blocks_through_the_half_chain():
     assert rel(gx1, gx0) <= 0.12, rel(gx1, gx0)    # measured 5.5e-2: eight roundings to bf16 between the groups, and the ReLU masks of a z kept to 11 bits
     assert worst[0] <= 0.15, worst
     assert cos >= 0.99, cos
+
+
+@pytest.mark.parametrize("case", [(256, 256, 3, 1, 2, 60, 80, 16), (1024, 256, 1, 1, 1, 90, 160, 4), (256, 1024, 1, 1, 1, 90, 160, 4), (48, 256, 1, 1, 1, 128, 129, 4)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_two_k_steps_per_interval_are_bitwise_the_one_step_kernel(case, monkeypatch, libopt):
+    """SplitF16x1D (csrc/split.h: the one-term ping-pong convolution with two K-steps of 16 channels per barrier interval) against
+    SplitF16x1's kernel (option PP_DEEP = 0): the same products in the same order -- forward output, BatchNorm partial rows, data gradient
+    and the 16-bit epilogues bit for bit; an odd number of K-steps (48 channels, 1 x 1) stays on the one-step kernel."""
+    dev = _dev()
+    import ctypes
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "CONV_MATH", "f16x1")
+    cin, cout, k, s, d, h, w, n = case
+    g = torch.Generator().manual_seed(67)
+    x = torch.randn(n, cin, h, w, generator=g).to(dev)
+    wt = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (k * k * cout)) ** 0.5).to(dev)
+    desc = ops.conv_desc(x.shape, wt.shape, s, d * (k // 2), d)
+    gy = torch.randn(n, cout, desc.Ho, desc.Wo, generator=g).to(dev)
+    pk = ops.PackedWeights()
+    wf, wd, mpf = pk.get(wt, desc)
+    x_cb, x_bound = ops.split_companion(x)
+    gy_cb, gy_bound = ops.split_companion(gy)
+    L = ops.lib()
+    even = (k * k * ((cin + 15) // 16)) % 2 == 0
+    outs = {}
+    for deep in (1, 0):
+        libopt(PP_DEEP=deep)
+        assert L.mcdseg_conv_split_pp_deep(ctypes.byref(desc), 1, 0) == (1 if (deep and even) else 0)
+        names = []
+
+        class _Names:
+            def wants(self, name):
+                names.append(name)
+                return False
+        prev, ops.LAUNCH_TIMER = ops.LAUNCH_TIMER, _Names()
+        try:
+            z, part, rows = ops._conv_fprop(desc, x, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)
+            dx = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound)
+            z16, zb, part16, _ = ops._conv_fprop_half(desc, x_cb, x_bound, wf, pk.w_bound, mpf)
+            dx16 = ops._conv_dgrad_half(desc, gy_cb, gy_bound, wd, pk.w_bound)
+        finally:
+            ops.LAUNCH_TIMER = prev
+        outs[deep] = (z, part, dx, z16, part16, dx16, names)
+    assert any("SplitF16x1D" in nm for nm in outs[1][6]) == even and not any("SplitF16x1D" in nm for nm in outs[0][6]), (outs[1][6], outs[0][6])
+    assert any("conv_gemm_split_pp_kernel" in nm for nm in outs[1][6]), outs[1][6]
+    for a, b, what in zip(outs[1][:6], outs[0][:6], ("forward", "partial rows", "data gradient", "z16", "partial rows (16-bit epilogue)", "dx16")):
+        assert torch.equal(a, b), what

@@ -1203,7 +1203,8 @@ def test_conv_pingpong_tile(case, monkeypatch, libopt):
             want = (tiles // cus) * cus // max(1, m // 256) * 256 if tag == "pp" else 0
             assert pp == min(want, pix // 256 * 256), (tag, dgrad, pp, want)
     y, dx, part, rows, names = outs["pp"]
-    assert any(nm in (ops.pingpong_kernel_name(False), ops.pingpong_kernel_name(True)) for nm in names), names
+    dp = math == "f16x1"  # (the one-term arithmetic: two K-steps per barrier interval where their number is even -- every case here)
+    assert any(nm in (ops.pingpong_kernel_name(False, deep=dp), ops.pingpong_kernel_name(True, deep=dp)) for nm in names), names
     assert any(nm in (ops.pingpong_kernel_name(False, small=True), ops.pingpong_kernel_name(True, small=True)) for nm in names), names
     assert not any("conv_gemm_split_pp_kernel" in nm for nm in outs["off"][4]), outs["off"][4]
     assert torch.equal(y, outs["off"][0]), "forward differs from the 4-wave tiles (max %.3e)" % float((y - outs["off"][0]).abs().max())
@@ -1244,9 +1245,9 @@ def test_conv_pingpong_tile(case, monkeypatch, libopt):
     finally:
         ops.LAUNCH_TIMER = prev
     if cout % 256 == 0:
-        assert ops.pingpong_kernel_name(False, wide=True) in names, names
+        assert ops.pingpong_kernel_name(False, wide=True, deep=dp) in names, names
     if dx is not None and cin % 256 == 0:  # (the data gradient has M = Cin output rows)
-        assert L.mcdseg_conv_split_wide_pingpong(ctypes.byref(desc), mid, 1, 1) == 1 and ops.pingpong_kernel_name(True, wide=True) in names, names
+        assert L.mcdseg_conv_split_wide_pingpong(ctypes.byref(desc), mid, 1, 1) == 1 and ops.pingpong_kernel_name(True, wide=True, deep=dp) in names, names
     pixels = n * desc.Ho * desc.Wo
     if cout % 256 == 0:
         assert L.mcdseg_conv_split_wide_pingpong(ctypes.byref(desc), mid, 1, 0) == 1
@@ -1755,8 +1756,13 @@ def test_conv_pingpong_wide_tile_by_default(math, monkeypatch, libopt):
             dx = ops._conv_dgrad(desc, None, wd, gy_cb, gy_bound, pk.w_bound)
         finally:
             ops.LAUNCH_TIMER = prev
-        assert names[0] == ops.pingpong_kernel_name(False, wide=kind_f) and len(names) == 2, names
-        assert names[1] == ops.pingpong_kernel_name(True, wide=kind_d) if kind_d else "conv_gemm_split_pp_kernel" not in names[1], names
+        # (the one-term arithmetic runs these -- an even number of K-steps -- two K-steps per barrier interval: policy SplitF16x1D, the
+        # same products in the same order, so the bitwise comparison with the 4-wave tiles below covers it)
+        deep = [bool(L.mcdseg_conv_split_pp_deep(ctypes.byref(desc), mid, g)) for g in (0, 1)]
+        assert deep == [math == "f16x1"] * 2
+        assert names[0] == ops.pingpong_kernel_name(False, wide=kind_f, deep=deep[0]) and len(names) == 2, names
+        assert names[1] == ops.pingpong_kernel_name(True, wide=kind_d, deep=deep[1]) if kind_d else "conv_gemm_split_pp_kernel" not in names[1], names
+        assert ("SplitF16x1D" in names[0]) == (math == "f16x1")
         assert rows == (pixels // 160 if kind_f == 3 else 2 * (pixels // 320))
         libopt(PINGPONG=0)
         y0, part0, rows0 = ops._conv_fprop(desc, xg, wf, None, True, mpf, x_cb, x_bound, pk.w_bound)

@@ -77,7 +77,7 @@ def main():
         for _ in range(args.steps):
             out = solver.step(s, l, t)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / max(args.steps, 1)
+        dt = max((time.perf_counter() - t0) / max(args.steps, 1), 1e-9)
         from mcdseg import ops
         print("%s %-10s N=%-2d 6x%dx%d [%s, activations %s]: %.1f ms/step, %.2f pairs/s, peak %.1f GB  (c_loss %.4f, d_loss %.6f)" % (
             cfg, net, n, h, w, ops.CONV_MATH, ops.ACT_STORAGE, 1e3 * dt, n / dt, torch.cuda.max_memory_allocated() / 2 ** 30,
