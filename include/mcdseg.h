@@ -411,6 +411,12 @@ int mcdseg_confusion_hist(const int64_t* gt, const int64_t* pred, int64_t count,
  * F16X1 reads the LEADING piece of every companion only (piece stride 0), so one- and two-piece companions mix freely.
  * ---------------------------------------------------------------------------------------------- */
 int32_t mcdseg_conv_split_half_ok(const mcdseg_conv_desc* d, int32_t math, int32_t dgrad);
+/* Which kernels a call will launch, for profilers and bench.py's per-kernel tables (the host side derives rocprofv3's kernel names from
+ * these instead of restating the dispatch): mcdseg_up8_loss_variant = the class count of mcdseg_up8_softmax_ce_l1's LDS-DMA instantiation
+ * (16, 24, 41, 48) or minus that of the register-staged kernel; mcdseg_conv_wgrad_thin_tr_config = the template arguments
+ * <cin8, mt, ntl, tr> of the thin layers' window weight gradient as cin8 * 1000000 + mt * 10000 + ntl * 100 + tr (0: not that kernel). */
+int32_t mcdseg_up8_loss_variant(int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t labelled);
+int32_t mcdseg_conv_wgrad_thin_tr_config(const mcdseg_conv_desc* d);
 /* 1 when the 8-wave ping-pong launches of this convolution run with two K-steps of 16 channels per barrier interval (MCDSEG_MATH_F16X1 with
  * an even number of K-steps; kernel policy SplitF16x1D in profiles): the same products in the same order as the one-step kernel. */
 int32_t mcdseg_conv_split_pp_deep(const mcdseg_conv_desc* d, int32_t math, int32_t dgrad);

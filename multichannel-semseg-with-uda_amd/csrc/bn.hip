@@ -349,50 +349,66 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       // benchmark step -- at 8 waves per SIMD the other waves already covered most of the latency.  Same elements in the same order per
       // thread: the same sums, bit for bit.
       const int nq = e1 >> 2;
-      for (int ib = (e0 >> 2) + (threadIdx.x & ~63); ib < nq; ib += 4 * 256) {
+      // one step of the strided loop for this wave's float4s ibu .. ibu + 63 (wave-uniform ibu < nq): mask, sums
+      auto step = [&](int ibu, const float4& gld, const float4& vld, const float4& old, unsigned long long mld) {
+        unsigned long long w0 = 0ull, w1 = 0ull, w2 = 0ull, w3 = 0ull;
+        if (MASK == 3) {  // (wave-uniform control flow up to here: every lane takes part in the broadcasts)
+          w0 = mcd_readlane64(mld, 0); w1 = mcd_readlane64(mld, 1); w2 = mcd_readlane64(mld, 2); w3 = mcd_readlane64(mld, 3);
+        }
+        if (ibu + lane >= nq) return;
+        float4 g = gld;
+        const float4 v = vld;
+        if (MASK == 3) {
+          g.x = ((w0 >> lane) & 1ull) ? g.x : 0.f; g.y = ((w1 >> lane) & 1ull) ? g.y : 0.f;
+          g.z = ((w2 >> lane) & 1ull) ? g.z : 0.f; g.w = ((w3 >> lane) & 1ull) ? g.w : 0.f;
+        } else if (MASK == 2) {
+          g.x = fmaf(v.x, ma, mb) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, ma, mb) > 0.f ? g.y : 0.f;
+          g.z = fmaf(v.z, ma, mb) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, ma, mb) > 0.f ? g.w : 0.f;
+        } else if (MASK == 1) {
+          const float4 o = old;
+          g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
+          g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+        }
+        s_dy += (g.x + g.y) + (g.z + g.w);
+        m_g = fmaxf(m_g, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
+        if (z) {
+          s_dyx += (g.x * ((v.x - mu) * rs) + g.y * ((v.y - mu) * rs)) + (g.z * ((v.z - mu) * rs) + g.w * ((v.w - mu) * rs));
+        }
+      };
+      auto load = [&](int ibu, float4& gld, float4& vld, float4& old, unsigned long long& mld) {
+        // (no divergent branch around a load -- the compiler waits at the join of each: a clamped address instead; lanes past the end
+        // repeat the last element and are skipped in `step`)
+        const int i = ibu + lane < nq ? ibu + lane : nq - 1;
+        vld = old = make_float4(0.f, 0.f, 0.f, 0.f);
+        mld = 0ull;
+        if (MASK == 3) mld = rmask[(((size_t)n * C + c) * nblk + (ibu >> 6)) * 4 + (lane & 3)];
+        gld = dy4[i];
+        if (z) vld = z4[i];
+        if (MASK == 1) old = y4[i];
+      };
+      int ib = (e0 >> 2) + (threadIdx.x & ~63);
+      // four steps at a time while all four lie inside the chunk (round 6: until now the LAST group of four was issued whole with
+      // clamped addresses -- at the benchmark's 60 x 80 maps a plane is 1200 float4s, i.e. one full group and one with 176 of its 1024
+      // slots in use: 41 % of the load instructions fetched nothing new, and the kernel ran at 4.2 TB/s beside siblings at 5.8) ...
+      for (; ib + 3 * 256 < nq; ib += 4 * 256) {
         float4 gq[4], vq[4], oq[4];
         unsigned long long mq[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          // (no divergent branch around a load -- the compiler waits at the join of each: clamped addresses instead; steps past the
-          // end repeat the last element and are skipped below)
-          const int ibu = ib + u * 256 < nq ? ib + u * 256 : ((nq - 1) & ~63);  // wave-uniform
-          const int i = ibu + lane < nq ? ibu + lane : nq - 1;
-          vq[u] = oq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          mq[u] = 0ull;
-          if (MASK == 3) mq[u] = rmask[(((size_t)n * C + c) * nblk + (ibu >> 6)) * 4 + (lane & 3)];
-          gq[u] = dy4[i];
-          if (z) vq[u] = z4[i];
-          if (MASK == 1) oq[u] = y4[i];
-        }
+        for (int u = 0; u < 4; ++u) load(ib + u * 256, gq[u], vq[u], oq[u], mq[u]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int ibu = ib + u * 256;
-          if (ibu >= nq) break;  // wave-uniform
-          unsigned long long w0 = 0ull, w1 = 0ull, w2 = 0ull, w3 = 0ull;
-          if (MASK == 3) {  // (wave-uniform control flow up to here: every lane takes part in the broadcasts)
-            w0 = mcd_readlane64(mq[u], 0); w1 = mcd_readlane64(mq[u], 1); w2 = mcd_readlane64(mq[u], 2); w3 = mcd_readlane64(mq[u], 3);
-          }
-          if (ibu + lane >= nq) continue;
-          float4 g = gq[u];
-          const float4 v = vq[u];
-          if (MASK == 3) {
-            g.x = ((w0 >> lane) & 1ull) ? g.x : 0.f; g.y = ((w1 >> lane) & 1ull) ? g.y : 0.f;
-            g.z = ((w2 >> lane) & 1ull) ? g.z : 0.f; g.w = ((w3 >> lane) & 1ull) ? g.w : 0.f;
-          } else if (MASK == 2) {
-            g.x = fmaf(v.x, ma, mb) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, ma, mb) > 0.f ? g.y : 0.f;
-            g.z = fmaf(v.z, ma, mb) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, ma, mb) > 0.f ? g.w : 0.f;
-          } else if (MASK == 1) {
-            const float4 o = oq[u];
-            g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
-            g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
-          }
-          s_dy += (g.x + g.y) + (g.z + g.w);
-          m_g = fmaxf(m_g, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
-          if (z) {
-            s_dyx += (g.x * ((v.x - mu) * rs) + g.y * ((v.y - mu) * rs)) + (g.z * ((v.z - mu) * rs) + g.w * ((v.w - mu) * rs));
-          }
-        }
+        for (int u = 0; u < 4; ++u) step(ib + u * 256, gq[u], vq[u], oq[u], mq[u]);
+      }
+      // ... then the steps that are left, all loads first again (at most three): the same elements in the same order per thread as the
+      // plain strided loop, so the same sums, bit for bit
+      {
+        float4 gq[3], vq[3], oq[3];
+        unsigned long long mq[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+          if (ib + u * 256 < nq) load(ib + u * 256, gq[u], vq[u], oq[u], mq[u]);  // wave-uniform
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+          if (ib + u * 256 < nq) step(ib + u * 256, gq[u], vq[u], oq[u], mq[u]);
       }
     } else {
       for (int i = e0 + threadIdx.x; i < e1; i += 256) {
@@ -1421,6 +1437,7 @@ extern "C" int mcdseg_bn_bwd_apply(const float* dy, const float* y, const float*
 // running statistics and the bounds come from the same finalize kernels as ever.
 namespace {
 
+// (the kernels take their 16-byte units as uint4: rocprofv3's demangler gives up on _Float16 / __bf16 vector types in a signature)
 // the forward map of one channel, shared by the forward kernel and the backward kernels' ReLU mask (y > 0 recomputed from z: the same
 // expression on the same 16-bit z, so the same mask, bit for bit): y = fma(zh, a zs, b), a = gamma rstd, b = beta - mean a, zh the stored
 // half, zs the (power-of-two) scale of z -- a zs is exact
@@ -1443,11 +1460,11 @@ struct HalfAffine {
 
 // RES: 0 none, 2 the residual as its (leading) companion piece
 template <int RES>
-__global__ __launch_bounds__(256) void bn_apply_h_kernel(const f16x8* __restrict__ z, const float* __restrict__ z_bound,
+__global__ __launch_bounds__(256) void bn_apply_h_kernel(const uint4* __restrict__ z, const float* __restrict__ z_bound,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         const f16x8* __restrict__ res_cb, const float* __restrict__ res_bound,
-                                                         f16x8* __restrict__ y_cb, const float* __restrict__ y_bound, int C8, int HW, int relu) {
+                                                         const uint4* __restrict__ res_cb, const float* __restrict__ res_bound,
+                                                         uint4* __restrict__ y_cb, const float* __restrict__ y_bound, int C8, int HW, int relu) {
   const int ng = blockIdx.y;  // n * C8 + g
   const int g = ng % C8;
   HalfAffine f;
@@ -1461,8 +1478,8 @@ __global__ __launch_bounds__(256) void bn_apply_h_kernel(const f16x8* __restrict
   for (int u = 0; u < BN_H_UNITS; ++u) {  // every load of the thread in flight before the first use (clamped: no branch around a load)
     pix[u] = (blockIdx.x * BN_H_UNITS + u) * 256 + threadIdx.x;
     const int pc = pix[u] < HW ? pix[u] : HW - 1;
-    zq[u] = z[base + pc];
-    if (RES == 2) rq[u] = res_cb[base + pc];
+    zq[u] = __builtin_bit_cast(f16x8, z[base + pc]);
+    if (RES == 2) rq[u] = __builtin_bit_cast(f16x8, res_cb[base + pc]);
   }
 #pragma unroll
   for (int u = 0; u < BN_H_UNITS; ++u) {
@@ -1475,7 +1492,7 @@ __global__ __launch_bounds__(256) void bn_apply_h_kernel(const f16x8* __restrict
       if (relu) t = fmaxf(t, 0.f);
       o[e] = (_Float16)(t * inv_ys);
     }
-    y_cb[base + pix[u]] = o;
+    y_cb[base + pix[u]] = __builtin_bit_cast(uint4, o);
   }
 }
 
@@ -1497,8 +1514,8 @@ __device__ __forceinline__ unsigned half_mask(const f16x8& zq, const f16x8& yq, 
 // thread, and writes one partial row per channel: part[((n * slices + slice) * 3 + {sum dy, sum dy xhat, max |dy|}) * C + c] -- the
 // rows bn_bwd_finalize_kernel merges in fp64
 template <int MASK>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_h_kernel(const bf16x8* __restrict__ dy, const f16x8* __restrict__ y_cb,
-                                                              const f16x8* __restrict__ z, const float* __restrict__ z_bound,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_h_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ y_cb,
+                                                              const uint4* __restrict__ z, const float* __restrict__ z_bound,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ part, int C, int HW, int per_slice,
@@ -1528,9 +1545,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_h_kernel(const bf16x8* __re
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int pc = pb + u * 256 < p1 ? pb + u * 256 : p1 - 1;
-      gq[u] = dy[base + pc];
-      zq[u] = z[base + pc];
-      if (MASK == 4) yq[u] = y_cb[base + pc];
+      gq[u] = __builtin_bit_cast(bf16x8, dy[base + pc]);
+      zq[u] = __builtin_bit_cast(f16x8, z[base + pc]);
+      if (MASK == 4) yq[u] = __builtin_bit_cast(f16x8, y_cb[base + pc]);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1575,13 +1592,13 @@ int bwd_h_slices(int N, int C, int HW) {
 }
 
 template <int MASK>
-__global__ __launch_bounds__(256) void bn_bwd_apply_h_kernel(const bf16x8* __restrict__ dy, const f16x8* __restrict__ y_cb,
-                                                             const f16x8* __restrict__ z, const float* __restrict__ z_bound,
+__global__ __launch_bounds__(256) void bn_bwd_apply_h_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ y_cb,
+                                                             const uint4* __restrict__ z, const float* __restrict__ z_bound,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                             f16x8* __restrict__ dz_cb, const float* __restrict__ dz_bound,
-                                                             bf16x8* __restrict__ dres, int N, int C8, int HW, int train) {
+                                                             uint4* __restrict__ dz_cb, const float* __restrict__ dz_bound,
+                                                             uint4* __restrict__ dres, int N, int C8, int HW, int train) {
   const int ng = blockIdx.y;
   const int g = ng % C8;
   const float zs = mcd_scale_of_bound(*z_bound);
@@ -1607,9 +1624,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h_kernel(const bf16x8* __res
   for (int u = 0; u < BN_H_UNITS; ++u) {
     pix[u] = (blockIdx.x * BN_H_UNITS + u) * 256 + threadIdx.x;
     const int pc = pix[u] < HW ? pix[u] : HW - 1;
-    gq[u] = dy[base + pc];
-    zq[u] = z[base + pc];
-    if (MASK == 4) yq[u] = y_cb[base + pc];
+    gq[u] = __builtin_bit_cast(bf16x8, dy[base + pc]);
+    zq[u] = __builtin_bit_cast(f16x8, z[base + pc]);
+    if (MASK == 4) yq[u] = __builtin_bit_cast(f16x8, y_cb[base + pc]);
   }
 #pragma unroll
   for (int u = 0; u < BN_H_UNITS; ++u) {
@@ -1625,13 +1642,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h_kernel(const bf16x8* __res
       const float t = ca[e] * (gv - k1[e] - (((float)zq[u][e] * zs - cmu[e]) * crs[e]) * k2[e]);
       o[e] = (_Float16)(t * inv_s);
     }
-    dz_cb[base + pix[u]] = o;
-    if (dres != nullptr) dres[base + pix[u]] = r;
+    dz_cb[base + pix[u]] = __builtin_bit_cast(uint4, o);
+    if (dres != nullptr) dres[base + pix[u]] = __builtin_bit_cast(uint4, r);
   }
 }
 
 // fp32 NCHW -> bf16 units (a gradient a kernel without the 16-bit epilogue produced, for a consumer inside the 2-byte chain) and back
-__global__ __launch_bounds__(256) void pack_bf16_units_kernel(const float* __restrict__ x, bf16x8* __restrict__ out, int C, int HW) {
+__global__ __launch_bounds__(256) void pack_bf16_units_kernel(const float* __restrict__ x, uint4* __restrict__ out, int C, int HW) {
   const int C8 = C >> 3;
   const int ng = blockIdx.y;
   const int g = ng % C8, n = ng / C8;
@@ -1641,16 +1658,16 @@ __global__ __launch_bounds__(256) void pack_bf16_units_kernel(const float* __res
   bf16x8 o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = (__bf16)x[src + (size_t)e * HW];
-  out[(size_t)ng * HW + pix] = o;
+  out[(size_t)ng * HW + pix] = __builtin_bit_cast(uint4, o);
 }
 
-__global__ __launch_bounds__(256) void unpack_bf16_units_kernel(const bf16x8* __restrict__ in, float* __restrict__ x, int C, int HW) {
+__global__ __launch_bounds__(256) void unpack_bf16_units_kernel(const uint4* __restrict__ in, float* __restrict__ x, int C, int HW) {
   const int C8 = C >> 3;
   const int ng = blockIdx.y;
   const int g = ng % C8, n = ng / C8;
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= HW) return;
-  const bf16x8 v = in[(size_t)ng * HW + pix];
+  const bf16x8 v = __builtin_bit_cast(bf16x8, in[(size_t)ng * HW + pix]);
   const size_t dst = ((size_t)n * C + 8 * g) * HW + pix;
 #pragma unroll
   for (int e = 0; e < 8; ++e) x[dst + (size_t)e * HW] = (float)v[e];
@@ -1672,11 +1689,11 @@ extern "C" int mcdseg_bn_apply_half(const void* z16, const float* z_bound, const
   if (int rc = half_check("bn_apply_half", N, C, HW)) return rc;
   const dim3 grid(ceil_div(HW, 256 * BN_H_UNITS), N * (C / 8));
   if (res_cb != nullptr)
-    hipLaunchKernelGGL(bn_apply_h_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const f16x8*)z16, z_bound, mean, rstd, gamma, beta,
-                       (const f16x8*)res_cb, res_bound, (f16x8*)y_cb, y_bound, C / 8, HW, relu);
+    hipLaunchKernelGGL(bn_apply_h_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const uint4*)z16, z_bound, mean, rstd, gamma, beta,
+                       (const uint4*)res_cb, res_bound, (uint4*)y_cb, y_bound, C / 8, HW, relu);
   else
-    hipLaunchKernelGGL(bn_apply_h_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const f16x8*)z16, z_bound, mean, rstd, gamma, beta,
-                       (const f16x8*)nullptr, (const float*)nullptr, (f16x8*)y_cb, y_bound, C / 8, HW, relu);
+    hipLaunchKernelGGL(bn_apply_h_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const uint4*)z16, z_bound, mean, rstd, gamma, beta,
+                       (const uint4*)nullptr, (const float*)nullptr, (uint4*)y_cb, y_bound, C / 8, HW, relu);
   MCD_LAUNCH_CHECK("bn_apply_half");
   return 0;
 }
@@ -1701,7 +1718,7 @@ extern "C" int mcdseg_bn_bwd_reduce_half(const void* dy16, const void* y_cb, con
   const dim3 grid(ceil_div(HW, per), N * (C / 8));
   const int S = N * (int)grid.x;
 #define MCD_RH(M)                                                                                                                       \
-  hipLaunchKernelGGL(bn_bwd_reduce_h_kernel<M>, grid, dim3(256), 0, st, (const bf16x8*)dy16, (const f16x8*)y_cb, (const f16x8*)z16, z_bound, \
+  hipLaunchKernelGGL(bn_bwd_reduce_h_kernel<M>, grid, dim3(256), 0, st, (const uint4*)dy16, (const uint4*)y_cb, (const uint4*)z16, z_bound, \
                      mean, rstd, gamma, beta, (float*)workspace, C, HW, per, dz_bound)
   if (mask_kind == 0) MCD_RH(0); else if (mask_kind == 2) MCD_RH(2); else MCD_RH(4);
 #undef MCD_RH
@@ -1723,8 +1740,8 @@ extern "C" int mcdseg_bn_bwd_apply_half(const void* dy16, const void* y_cb, cons
   const dim3 grid(ceil_div(HW, 256 * BN_H_UNITS), N * (C / 8));
   hipStream_t st = (hipStream_t)stream;
 #define MCD_AH(M)                                                                                                                      \
-  hipLaunchKernelGGL(bn_bwd_apply_h_kernel<M>, grid, dim3(256), 0, st, (const bf16x8*)dy16, (const f16x8*)y_cb, (const f16x8*)z16, z_bound, \
-                     mean, rstd, gamma, beta, dgamma, dbeta, (f16x8*)dz_cb, dz_bound, (bf16x8*)dres16, N, C / 8, HW, train)
+  hipLaunchKernelGGL(bn_bwd_apply_h_kernel<M>, grid, dim3(256), 0, st, (const uint4*)dy16, (const uint4*)y_cb, (const uint4*)z16, z_bound, \
+                     mean, rstd, gamma, beta, dgamma, dbeta, (uint4*)dz_cb, dz_bound, (uint4*)dres16, N, C / 8, HW, train)
   if (mask_kind == 0) MCD_AH(0); else if (mask_kind == 2) MCD_AH(2); else MCD_AH(4);
 #undef MCD_AH
   MCD_LAUNCH_CHECK("bn_bwd_apply_half");
@@ -1734,7 +1751,7 @@ extern "C" int mcdseg_bn_bwd_apply_half(const void* dy16, const void* y_cb, cons
 extern "C" int mcdseg_pack_bf16_units(const float* x, void* out16, int32_t N, int32_t C, int32_t HW, void* stream) {
   MCD_REQUIRE(x && out16, "pack_bf16_units: null pointer");
   if (int rc = half_check("pack_bf16_units", N, C, HW)) return rc;
-  hipLaunchKernelGGL(pack_bf16_units_kernel, dim3(ceil_div(HW, 256), N * (C / 8)), dim3(256), 0, (hipStream_t)stream, x, (bf16x8*)out16, C, HW);
+  hipLaunchKernelGGL(pack_bf16_units_kernel, dim3(ceil_div(HW, 256), N * (C / 8)), dim3(256), 0, (hipStream_t)stream, x, (uint4*)out16, C, HW);
   MCD_LAUNCH_CHECK("pack_bf16_units");
   return 0;
 }
@@ -1742,7 +1759,7 @@ extern "C" int mcdseg_pack_bf16_units(const float* x, void* out16, int32_t N, in
 extern "C" int mcdseg_unpack_bf16_units(const void* in16, float* x, int32_t N, int32_t C, int32_t HW, void* stream) {
   MCD_REQUIRE(x && in16, "unpack_bf16_units: null pointer");
   if (int rc = half_check("unpack_bf16_units", N, C, HW)) return rc;
-  hipLaunchKernelGGL(unpack_bf16_units_kernel, dim3(ceil_div(HW, 256), N * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)in16, x, C, HW);
+  hipLaunchKernelGGL(unpack_bf16_units_kernel, dim3(ceil_div(HW, 256), N * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const uint4*)in16, x, C, HW);
   MCD_LAUNCH_CHECK("unpack_bf16_units");
   return 0;
 }

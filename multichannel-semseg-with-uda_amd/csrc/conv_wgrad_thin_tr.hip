@@ -312,6 +312,14 @@ ThinTrPlan thin_tr_plan(const mcdseg_conv_desc* d) {
 
 int mcdseg_internal_wgrad_thin_tr_ok(const mcdseg_conv_desc* d) { return thin_tr_plan(d).ok ? 1 : 0; }
 
+// the instantiation conv_wgrad_thin_tr_kernel<cin8, mt, ntl, tr> this geometry runs on, as cin8 * 1000000 + mt * 10000 + ntl * 100 + tr
+// (0: the kernel does not take it) -- kernel names for profilers
+extern "C" int32_t mcdseg_conv_wgrad_thin_tr_config(const mcdseg_conv_desc* d) {
+  if (d == nullptr) return 0;
+  const ThinTrPlan pl = thin_tr_plan(d);
+  return pl.ok ? pl.cin8 * 1000000 + pl.mt * 10000 + pl.ntl * 100 + pl.tr : 0;
+}
+
 size_t mcdseg_internal_wgrad_thin_tr_ws(const mcdseg_conv_desc* d) {
   const ThinTrPlan pl = thin_tr_plan(d);
   return pl.ok ? (size_t)pl.blocks * pl.nraw * sizeof(float) : 0;

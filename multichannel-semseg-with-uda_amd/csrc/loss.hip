@@ -53,6 +53,12 @@ __global__ __launch_bounds__(256) void wsum_finalize_kernel(const float* __restr
   int name = 1;               \
   asm volatile("" : "+s"(name))
 
+// exp of a NON-POSITIVE argument (a logit minus the pixel's maximum): v_exp_f32(x log2 e), two instructions where expf spends fifteen on
+// a range reduction and a scaling that such an argument never needs (round 6: the fused loss kernel evaluates 82 of these per pixel and
+// was bound by them after round 5's wait fix).  Relative error: the instruction's 1 ulp plus |x| 2^-24 from rounding x log2 e -- below
+// 2e-7 for every class that carries probability (x > -3); exp(-inf) = 0 for the padding classes; results below 2^-126 flush to zero.
+__device__ __forceinline__ float exp_nonpos(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 template <int NCMAX, bool TWO>
 __device__ __forceinline__ void pixel_losses(float (&a)[NCMAX], float (&b)[NCMAX], int y, float wy, float ce_coef, float diff_coef,
                                              const float* __restrict__ losses_w, float* __restrict__ g1, float* __restrict__ g2,
@@ -75,10 +81,10 @@ __device__ __forceinline__ void pixel_losses(float (&a)[NCMAX], float (&b)[NCMAX
           zy1 = a[c];
           if (TWO) zy2 = b[c];
         }
-        a[c] = expf(a[c] - m1);
+        a[c] = exp_nonpos(a[c] - m1);
         s1 += a[c];
         if (TWO) {
-          b[c] = expf(b[c] - m2);
+          b[c] = exp_nonpos(b[c] - m2);
           s2 += b[c];
         }
       }
@@ -853,4 +859,13 @@ extern "C" int mcdseg_scale_by_device_scalar(float* buf, const float* scale, int
   hipLaunchKernelGGL(scale_by_device_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, buf, scale, n4, n);
   MCD_LAUNCH_CHECK("scale_by_device_scalar");
   return 0;
+}
+
+// Which kernel mcdseg_up8_softmax_ce_l1 launches for a problem (profilers, bench.py's per-kernel tables): the class count of the LDS-DMA
+// kernel's instantiation (16, 24, 41, 48), or MINUS that of the register-staged kernel (16, 24, 48) when the option UP8_LOSS_DMA is 0
+// or a tensor outgrows a 32-bit buffer resource.
+extern "C" int32_t mcdseg_up8_loss_variant(int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t labelled) {
+  if (N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0) return 0;
+  if (up_loss_dma_ok(N, C, Hi, Wi, labelled != 0)) return up_loss_dma_ncmax(C);
+  return -(C <= 16 ? 16 : (C <= 24 ? 24 : 48));
 }

@@ -118,6 +118,8 @@ _SIGNATURES = {
     # 2-byte activation storage (round 6)
     "mcdseg_conv_split_half_ok": (c_i32, [_P(ConvDesc), c_i32, c_i32]),
     "mcdseg_conv_split_pp_deep": (c_i32, [_P(ConvDesc), c_i32, c_i32]),
+    "mcdseg_up8_loss_variant": (c_i32, [c_i32] * 5),
+    "mcdseg_conv_wgrad_thin_tr_config": (c_i32, [_P(ConvDesc)]),
     "mcdseg_conv_split_fprop_half": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 7 + [c_i32, c_void_p]),
     "mcdseg_conv_split_dgrad_half": (c_int, [_P(ConvDesc), c_i32] + [c_void_p] * 6 + [c_i32, c_void_p]),
     "mcdseg_bn_apply_half": (c_int, [c_void_p] * 10 + [c_i32] * 4 + [c_void_p]),

@@ -774,7 +774,8 @@ def wgrad_split_kernel_name(d, have_cb):
     """rocprofv3's name of the split-arithmetic weight-gradient kernel the library launches for this geometry"""
     v = lib().mcdseg_conv_wgrad_variant(ctypes.byref(d), MATH_ID[CONV_MATH], int(have_cb))
     if v == 15:  # csrc/conv_wgrad_thin_tr.hip: <channel groups of the input, row tiles, column tiles, tile rows> (no policy argument)
-        return "conv_wgrad_thin_tr_kernel<%s>" % ("1, 1, 25, 8" if d.Cin <= 8 else ("2, 1, 9, 8" if d.Cout <= 16 else "2, 2, 9, 4"))
+        cfg = lib().mcdseg_conv_wgrad_thin_tr_config(ctypes.byref(d))  # (the library's own choice, not a restatement of it)
+        return "conv_wgrad_thin_tr_kernel<%d, %d, %d, %d>" % (cfg // 1000000, cfg // 10000 % 100, cfg // 100 % 100, cfg % 100)
     return _WGRAD_NAMES.get(v, "conv_wgrad<%s>") % POLICY[CONV_MATH]
 
 
@@ -1813,15 +1814,14 @@ def mcd_losses(z1, z2, labels, class_weight, ignore_index=-100, ce_coef=0.0, dif
 
 
 def up8_loss_kernel_name(n, c, hi, wi, two, labelled):
-    """The kernel ``mcdseg_up8_softmax_ce_l1`` launches for this problem, as rocprofv3 prints it (csrc/loss.hip: the LDS-DMA kernel unless
-    the library option UP8_LOSS_DMA is 0 or a tensor outgrows a 32-bit buffer resource; the benchmark's 41 classes have an instantiation of their own)."""
+    """The kernel ``mcdseg_up8_softmax_ce_l1`` launches for this problem, as rocprofv3 prints it -- from the library's own dispatch
+    (``mcdseg_up8_loss_variant``: the LDS-DMA kernel unless the option UP8_LOSS_DMA is 0 or a tensor outgrows a 32-bit buffer resource;
+    the benchmark's 41 classes have an instantiation of their own)."""
     two = "true" if two else "false"
-    dma = (get_option("UP8_LOSS_DMA") != 0 and 4 * n * c * hi * wi < 2 ** 31
-           and (not labelled or 8 * 64 * n * hi * wi < 2 ** 31))
-    if dma:
-        nc = 16 if c <= 16 else (24 if c <= 24 else (41 if c == 41 else 48))
-        return "up8_softmax_ce_l1_dma_kernel<%d, %s, %s>" % (nc, two, "true" if c == nc else "false")
-    return "up8_softmax_ce_l1_kernel<%d, %s>" % (16 if c <= 16 else (24 if c <= 24 else 48), two)
+    v = lib().mcdseg_up8_loss_variant(int(n), int(c), int(hi), int(wi), int(bool(labelled)))
+    if v > 0:
+        return "up8_softmax_ce_l1_dma_kernel<%d, %s, %s>" % (v, two, "true" if c == v else "false")
+    return "up8_softmax_ce_l1_kernel<%d, %s>" % (-v, two)
 
 
 def up8_mcd_losses(s1, w1, s2, w2, labels, class_weight, ignore_index=-100, ce_coef=0.0, diff_coef=0.0, want_grad=True, wsum=None):

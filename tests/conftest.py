@@ -14,7 +14,7 @@ PKG = os.path.join(ROOT, "multichannel-semseg-with-uda_amd")
 # The product mirrors the reference's flat script layout (``import loss``, ``from models.model_util
 # import get_models`` ...), so its directory goes first on sys.path -- ahead of site-packages, which
 # holds an unrelated HuggingFace ``datasets``.
-for p in (GOLDEN, ROOT, PKG):
+for p in (TESTS, GOLDEN, ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 for name in ("datasets", "loss", "util", "models"):

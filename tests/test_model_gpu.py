@@ -776,35 +776,16 @@ def test_full_resolution_vs_oracle_and_properties():
 def test_cfg2_full_batch_vs_oracle():
     """BASELINE config 2 at its stated size -- 16 x 6 x 480 x 640, train-mode BatchNorm, with a tape -- so that the kernels the
     benchmark times (the ping-pong and large-tile pre-split convolutions, selected only at this batch) are the ones compared: encoder
-    features and logits against the CPU oracle's N = 16 train-mode forward (<= 1e-3, north_star), then the cross-entropy
-    gradient of EVERY parameter against the oracle's backward (adapt_trainer.py:163-185): per tensor and over all of them."""
+    features and logits (<= 1e-3, north_star) and the cross-entropy gradient of EVERY parameter (adapt_trainer.py:163-185) against the CPU
+    oracle's fp64 run of the same pass, in units of the fp32 oracle's own distance from it (tests/golden/grad_truth_cfg2.npz, written by
+    tests/golden/make_grad_truth.py; ``_truth_check`` below).  Measured (profiles/r06_truth_report.txt): all gradients 1.11x the fp32
+    oracle's distance (9.4e-3 against 8.4e-3 of the norm), 90 % of the tensors within 1.21x, the worst 1.34x; features 4.2e-4."""
     dev = _dev()
-    import os
-    from loss import CrossEntropyLoss2d
+    import truth
     from mcdseg import ops
-    from oracle import ref_loss, ref_models
     n = 16
-    desc = ops.conv_desc((n, 512, 60, 80), (512, 512, 3, 3), 1, 4, 4)
     big = ops.gemm_kernel_name(512, 512, False, True, True, False, n * 60 * 80)
     assert ops.CONV_MATH == "f32" or ", 2, 2, 2, 2," not in big, "N=16 must select the large tile, got %s" % big
-    g, f1, f2 = _mcd_models(dev)
-    og, of1, of2 = ref_models.get_models("drn_d_38", 6, NC)
-    fill_state_(og, 11), fill_state_(of1, 12), fill_state_(of2, 13)
-    og.train(), of1.train(), of2.train()
-    src, lbl, _ = make_batch(78, n, 6, 480, 640, NC)
-    cw = ref_loss.class_weights(NC)
-    threads = _all_threads()
-    try:
-        ref_feat = og(src)
-        ref_logits = of1(ref_feat)
-        rcrit = ref_loss.CrossEntropyLoss2d(cw)
-        (rcrit(ref_logits, lbl) + rcrit(of2(ref_feat), lbl)).backward()
-    finally:
-        torch.set_num_threads(threads)
-    ref_gs = {k: v.grad.clone() for k, v in og.named_parameters()}
-    ref_fgs = [m.up.weight.grad.clone() for m in (of1, of2)]
-    ref_feat, ref_logits = ref_feat.detach(), ref_logits.detach()[:, :, ::8, ::8].clone()
-    del og, of1, of2
     names = []
     timer_prev = ops.LAUNCH_TIMER
 
@@ -814,10 +795,7 @@ def test_cfg2_full_batch_vs_oracle():
             return False
     ops.LAUNCH_TIMER = _Names()
     try:
-        feat = g(src.to(dev))
-        logits = f1(feat)
-        crit = CrossEntropyLoss2d(cw.to(dev))
-        (crit(logits, lbl.to(dev)) + crit(f2(feat), lbl.to(dev))).backward()
+        outs, grads = truth.hip_run("cfg2", dev)
     finally:
         ops.LAUNCH_TIMER = timer_prev
     if ops.CONV_MATH != "f32":
@@ -836,32 +814,14 @@ def test_cfg2_full_batch_vs_oracle():
                        "conv_wgrad_split_tr64_kernel<SplitF16x3>", "conv_wgrad_thin_tr_kernel<1, 1, 25, 8>",
                        "conv_wgrad_thin_tr_kernel<2, 1, 9, 8>", "conv_wgrad_thin_tr_kernel<2, 2, 9, 4>"):
                 assert wg in names, "the backward pass did not run %s: %s" % (wg, sorted(set(names)))
-    err = float((feat.detach().cpu() - ref_feat).abs().max())
-    assert err <= 1e-3, "feat err %.3e" % err
-    lerr = float((logits.detach()[:, :, ::8, ::8].cpu() - ref_logits).abs().max())
-    assert lerr <= 1e-3, "logit err %.3e" % lerr
-    # EVERY parameter gradient of the benchmarked pass against the oracle's backward.  Both sides compute in fp32 through 41
-    # train-mode BatchNorms, and at this random initialisation that is worth 1 % on EVERY trunk tensor, whoever computes it:
-    # tests/grad_truth_cfg2.py runs the oracle in fp64 beside both (same parameters, same batch; profiles/r04_grad_truth_cfg2.txt):
-    # oracle fp32 - fp64 8.4e-3 overall (worst tensor 1.2e-2), HIP - fp64 9.3e-3 (1.2e-2), HIP - oracle fp32 1.04e-2 (1.4e-2),
-    # while the two up-sampling kernels, whose gradients do not pass through the trunk's backward, agree to 2e-6.  The bounds are
-    # twice those distances: a kernel that mis-weights one layer by a few per cent is caught by its own fp64 test
-    # (tests/test_kernels_gpu.py, <= 2e-5), a wrong schedule or a dropped term here.
-    named = dict(g.named_parameters())
-    assert set(named) == set(ref_gs)
-    num = den = 0.0
-    worst = (0.0, None)
-    for k, rg in ref_gs.items():
-        got = named[k].grad.cpu()
-        dn, rn = float((got - rg).double().norm()), float(rg.double().norm())
-        num, den = num + dn * dn, den + rn * rn
-        worst = max(worst, (dn / rn, k))
-    assert worst[0] <= 3e-2, "%s: relative L2 difference %.3e" % (worst[1], worst[0])
-    overall = (num / den) ** 0.5
-    assert overall <= 2e-2, "all generator gradients: relative L2 difference %.3e (worst tensor %s %.3e)" % (overall, worst[1], worst[0])
-    for m, rg in zip((f1, f2), ref_fgs):
-        rel = float((m.up.weight.grad.cpu() - rg).norm() / rg.norm())
-        assert rel <= 1e-4, "up.weight: relative L2 difference %.3e" % rel
+    fx = _truth_check("cfg2", outs, grads)
+    for name in ("feat", "logits1"):  # north_star's absolute bound, against the truth
+        e, _, _ = truth.output_error(fx, name, outs[name])
+        assert e <= 1e-3, "%s err %.3e" % (name, e)
+    # the two up-sampling kernels' gradients never pass the trunk's BatchNorms: the kernels' own accuracy, 1e-4 of the norm
+    dist = truth.distances(fx, grads)
+    for k in ("f1.up.weight", "f2.up.weight"):
+        assert dist[k][0] <= 1e-4 * dist[k][2], "%s: %.3e of its norm" % (k, dist[k][0] / dist[k][2])
 
 
 def test_full_step_480x640_vs_oracle():
@@ -942,130 +902,39 @@ def _all_threads():
 
 def test_cfg3_full_batch_vs_oracle():
     """BASELINE config 3 at its stated per-GPU size -- MFNet-ScoreAddFusion, two drn_d_38 encoders (RGB / HHA), 16 x 6 x 480 x 640 --
-    against the CPU oracle: both encoders' score maps and the fused full-resolution logits (<= 1e-3, north_star), the two cross-entropy
-    values, the gradients of the four up-sampling kernels and the gradients handed back to the two encoders.  (The oracle's encoders
-    run with their tapes: every parameter gradient of BOTH is compared.)  What only
+    against the CPU oracle's fp64 run (tests/golden/grad_truth_cfg3.npz; ``_truth_check``): both encoders' score maps and the fused
+    full-resolution logits (<= 1e-3, north_star), the two cross-entropy values, and every gradient -- all parameters of both encoders, the
+    four up-sampling kernels, the gradients handed back to the two encoders -- in units of the fp32 oracle's own distance from the truth
+    [measured: all gradients 1.14x, 90 % of the 256 tensors within 1.23x, the worst (a 32-element BatchNorm bias) 1.60x].  What only
     this size reaches: the two-input up-sampling kernel and the stored-logit loss kernel on 16 x 41 x 480 x 640 tensors (806 MB each)."""
     dev = _dev()
-    from loss import CrossEntropyLoss2d
-    from models.model_util import get_models
-    from oracle import ref_loss, ref_models
-    n = 16
-    hip = get_models("drn_d_38", 6, NC, method="MFNet-ScoreAddFusion")
-    ora = ref_models.get_models("drn_d_38", 6, NC, method="MFNet-ScoreAddFusion")
-    for i, (a, b) in enumerate(zip(hip, ora)):
-        fill_state_(a, 51 + i), fill_state_(b, 51 + i)
-        a.to(dev).train(), b.train()
-    src, lbl, _ = make_batch(79, n, 6, 480, 640, NC)
-    cw = ref_loss.class_weights(NC)
-    prev = _all_threads()
-    try:
-        ra = ora[0](src[:, :3].contiguous())  # both encoders WITH their tapes: every parameter gradient of both is compared below
-        rb = ora[1](src[:, 3:].contiguous())
-        ra.retain_grad()
-        rb.retain_grad()
-        ro1, ro2 = ora[2](ra, rb), ora[3](ra, rb)
-        rcrit = ref_loss.CrossEntropyLoss2d(cw)
-        rl1, rl2 = rcrit(ro1, lbl), rcrit(ro2, lbl)
-        (rl1 + rl2).backward()
-    finally:
-        torch.set_num_threads(prev)
-    keys = [(2, "up1.weight"), (2, "up2.weight"), (3, "up1.weight"), (3, "up2.weight")]
-    ref_gs = {k: dict(ora[k[0]].named_parameters())[k[1]].grad.clone() for k in keys}
-    ref_enc_gs = [{k: v.grad.clone() for k, v in ora[e].named_parameters()} for e in (0, 1)]
-    rga, rgb_ = ra.grad.clone(), rb.grad.clone()
-    ra, rb, ro1s = ra.detach(), rb.detach(), ro1.detach()[:, :, ::8, ::8].clone()
-    rl1, rl2 = float(rl1.detach()), float(rl2.detach())
-    del ora, ro1, ro2
-    s = src.to(dev)
-    a, b = hip[0](s[:, :3].contiguous()), hip[1](s[:, 3:].contiguous())
-    a.retain_grad(), b.retain_grad()
-    o1, o2 = hip[2](a, b), hip[3](a, b)
-    crit = CrossEntropyLoss2d(cw.to(dev))
-    l1, l2 = crit(o1, lbl.to(dev)), crit(o2, lbl.to(dev))
-    (l1 + l2).backward()
-    assert float((a.detach().cpu() - ra).abs().max()) <= 1e-3 and float((b.detach().cpu() - rb).abs().max()) <= 1e-3
-    assert float((o1.detach()[:, :, ::8, ::8].cpu() - ro1s).abs().max()) <= 1e-3
-    assert abs(float(l1.detach()) - rl1) <= 1e-5 * rl1 and abs(float(l2.detach()) - rl2) <= 1e-5 * rl2
-    for (i, name), rg in ref_gs.items():
-        got = dict(hip[i].named_parameters())[name].grad.cpu()
-        rel = float((got - rg).norm() / rg.norm())
-        assert rel <= 2e-3, "%d.%s: relative L2 difference %.3e" % (i, name, rel)
-    for got, rg, what in ((a.grad, rga, "d/d(RGB score map)"), (b.grad, rgb_, "d/d(HHA score map)")):
-        rel = float((got.cpu() - rg).norm() / rg.norm())
-        assert rel <= 2e-3, "%s: relative L2 difference %.3e" % (what, rel)
-    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in hip[0].parameters())  # ... and the encoders did back-propagate
-    # every parameter gradient of BOTH encoders (bounds as in the cfg2 test: fp32 through 41 train-mode BatchNorms)
-    for e, what in ((0, "RGB"), (1, "HHA")):
-        named = dict(hip[e].named_parameters())
-        assert set(named) == set(ref_enc_gs[e])
-        num = den = 0.0
-        worst = (0.0, None)
-        for k, rg in ref_enc_gs[e].items():
-            dn, rn = float((named[k].grad.cpu() - rg).double().norm()), float(rg.double().norm())
-            num, den = num + dn * dn, den + rn * rn
-            worst = max(worst, (dn / rn, k))
-        assert worst[0] <= 4e-2, "%s encoder, %s: relative L2 difference %.3e" % (what, worst[1], worst[0])
-        assert (num / den) ** 0.5 <= 2.5e-2, "%s encoder gradients: relative L2 difference %.3e (worst %s %.3e)" % (what, (num / den) ** 0.5, worst[1], worst[0])
+    import truth
+    outs, grads = truth.hip_run("cfg3", dev)
+    fx = _truth_check("cfg3", outs, grads)
+    for name in ("score_rgb", "score_hha", "logits1"):
+        e, _, _ = truth.output_error(fx, name, outs[name])
+        assert e <= 1e-3, "%s err %.3e" % (name, e)
+    for got, ref in zip(outs["losses"], fx["losses64"]):
+        assert abs(got - float(ref)) <= 1e-5 * float(ref), (got, float(ref))
+    dist = truth.distances(fx, grads)
+    for k in ("2.up1.weight", "2.up2.weight", "3.up1.weight", "3.up2.weight", "d/d(RGB score map)", "d/d(HHA score map)"):
+        assert dist[k][0] <= 2e-3 * dist[k][2], "%s: relative L2 difference %.3e" % (k, dist[k][0] / dist[k][2])
 
 
 def test_cfg4_full_batch_vs_oracle():
     """BASELINE config 4 at its stated per-GPU size -- multitask, 8 x 6 x 480 x 640: RGB encoder, two segmentation decoders and the HHA
     regression decoder (conv + bias + BN + ReLU groups on 512 channels, bilinear x8 to 480 x 640, MSE, learned task weights) -- against
-    the CPU oracle: encoder features and the decoder outputs (<= 1e-3 of scale), the loss the trainer's step A forms (``get_loss``,
-    adapt_multitask_trainer.py:174-181), its gradients into the decoders' convolutions, the gradient handed back to the encoder and --
-    the oracle's encoder runs WITH its tape here (N = 8: 20 s of CPU) -- every encoder parameter gradient (bounds as in the cfg2 test:
-    fp32 through 41 train-mode BatchNorms is worth 1 % per tensor on either side)."""
+    the CPU oracle's fp64 run (tests/golden/grad_truth_cfg4.npz; ``_truth_check``): encoder features, the loss the trainer's step A forms
+    (``get_loss``, adapt_multitask_trainer.py:174-181), and every gradient -- encoder, decoders, the gradient handed back to the encoder
+    -- in units of the fp32 oracle's own distance from the truth [measured: 1.09x over all, worst tensor 1.29x; the six decoder biases in
+    front of a train-mode BatchNorm are zero up to rounding on both sides and are checked as such]."""
     dev = _dev()
-    from loss import CrossEntropyLoss2d, Diff2d
-    from models.model_util import get_multitask_models
-    from oracle import ref_loss, ref_multitask
-    n = 8
-    cw = ref_loss.class_weights(NC)
-    enc, dec = get_multitask_models("drn_d_38", 6, NC, CrossEntropyLoss2d(cw), Diff2d())
-    renc, rdec = ref_multitask.get_multitask_models("drn_d_38", 6, NC, ref_loss.CrossEntropyLoss2d(cw), ref_loss.Diff2d())
-    fill_state_(enc, 81), fill_state_(dec, 82), fill_state_(renc, 81), fill_state_(rdec, 82)
-    enc.to(dev).train(), dec.to(dev).train(), renc.train(), rdec.train()
-    src, lbl, _ = make_batch(80, n, 6, 480, 640, NC)
-    rgb, dep = src[:, :3].contiguous(), src[:, 3:].contiguous()
-    prev = _all_threads()
-    try:
-        rfet = renc(rgb)
-        rfet.retain_grad()
-        rloss = rdec.get_loss(rfet, lbl, dep)
-        rloss.backward()
-    finally:
-        torch.set_num_threads(prev)
-    ref_enc_gs = {k: v.grad.clone() for k, v in renc.named_parameters()}
-    names = ["semsegcls_dec1.cbr1.conv.weight", "semsegcls_dec2.cbr1.conv.weight", "deprgr_dec.cbr1.conv.weight", "semsegcls_dec1.conv3.weight",
-             "deprgr_dec.cbr2.bn.weight"]
-    rpar = dict(rdec.named_parameters())
-    ref_gs = {k: rpar[k].grad.clone() for k in names}
-    rgf, rl = rfet.grad.clone(), float(rloss.detach())
-    rfet = rfet.detach()
-    del renc, rdec
-    fet = enc(rgb.to(dev))
-    fet.retain_grad()
-    loss = dec.get_loss(fet, lbl.to(dev), dep.to(dev))
-    loss.backward()
-    assert float((fet.detach().cpu() - rfet).abs().max()) <= 1e-3 * max(1.0, float(rfet.abs().max()))
-    assert abs(float(loss.detach()) - rl) <= 1e-4 * abs(rl)
-    par = dict(dec.named_parameters())
-    for k, rg in ref_gs.items():
-        rel = float((par[k].grad.cpu() - rg).norm() / rg.norm())
-        assert rel <= 2e-2, "%s: relative L2 difference %.3e" % (k, rel)
-    rel = float((fet.grad.cpu() - rgf).norm() / rgf.norm())
-    assert rel <= 2e-2, "d/d(encoder features): relative L2 difference %.3e" % rel
-    named = dict(enc.named_parameters())
-    assert set(named) == set(ref_enc_gs)
-    num = den = 0.0
-    worst = (0.0, None)
-    for k, rg in ref_enc_gs.items():
-        dn, rn = float((named[k].grad.cpu() - rg).double().norm()), float(rg.double().norm())
-        num, den = num + dn * dn, den + rn * rn
-        worst = max(worst, (dn / rn, k))
-    assert worst[0] <= 4e-2, "%s: relative L2 difference %.3e" % (worst[1], worst[0])
-    assert (num / den) ** 0.5 <= 2.5e-2, "all encoder gradients: relative L2 difference %.3e (worst %s %.3e)" % ((num / den) ** 0.5, worst[1], worst[0])
+    import truth
+    outs, grads = truth.hip_run("cfg4", dev)
+    fx = _truth_check("cfg4", outs, grads)
+    e, _, sc = truth.output_error(fx, "feat", outs["feat"])
+    assert e <= 1e-3 * max(1.0, sc), "feat err %.3e" % e
+    assert abs(outs["loss"] - float(fx["loss64"])) <= 1e-4 * abs(float(fx["loss64"]))
 
 
 def test_cfg5_cut_batches_keep_their_companions(monkeypatch):
@@ -1213,19 +1082,20 @@ def test_d105_bottleneck_vs_reference(golden, storage, k, monkeypatch):
 
 
 def test_cfg5_geometry_vs_oracle(monkeypatch, libopt):
-    """BASELINE config 5's network at ITS geometry against the CPU oracle: drn_d_105 (Bottleneck blocks,
+    """BASELINE config 5's network at ITS geometry against the truth: drn_d_105 (Bottleneck blocks,
     models/drn.py:62-100, 344-348), 2 x 6 x 720 x 1280, train-mode BatchNorm, compact activation storage -- with the launch plan of the
-    stated N = 32 batch: MCDSEG_PP_CUS = 16 gives the 28800 pixels of the 90 x 160 maps the rounds of tiles 460800 pixels have on 256
+    stated N = 32 batch: the option PP_CUS = 16 gives the 28800 pixels of the 90 x 160 maps the rounds of tiles 460800 pixels have on 256
     CUs (whole rounds of 256 x 256 ping-pong tiles + the rest on 256 x 128 ones), and a 150 MB launch limit cuts the 2048-channel maps
-    along N with their companions, as the 2 GiB limit cuts them at N = 32.  Encoder features and logits against the oracle's fp32
-    forward (<= 1e-3, north_star), the cross-entropy gradient of EVERY parameter against the oracle's backward, kernel names asserted.
-    The gradient bounds are twice the distances tests/grad_truth_cfg2.py --cfg5 measured with an fp64 run of the oracle beside both
-    (profiles/r05_grad_truth_cfg5.txt)."""
+    along N with their companions, as the 2 GiB limit cuts them at N = 32.  Encoder features, logits and the cross-entropy gradient of
+    EVERY parameter against the CPU oracle's fp64 run (tests/golden/grad_truth_cfg5n2.npz; ``_truth_check``), kernel names asserted.
+    north_star's 1e-3 on logits is NOT what fp32 delivers on this network at this random initialisation, whoever computes it: through 105
+    train-mode BatchNorms the oracle's own fp32 logits are 2.1e-3 from its fp64 logits (features 1.2e-2 on a scale of 17), the HIP path's
+    2.2e-3 (1.1e-2); parameter gradients: oracle fp32 - fp64 5.8e-2 relative L2 over all 328 tensors, HIP - fp64 6.0e-2 (1.03x), the
+    worst tensor 1.34x [profiles/r06_truth_report.txt] -- the HIP path is as close to the truth as the reference's arithmetic is, and the
+    test holds it to that."""
     dev = _dev()
-    from loss import CrossEntropyLoss2d
+    import truth
     from mcdseg import ops
-    from models.model_util import get_models
-    from oracle import ref_loss, ref_models
     if ops.CONV_MATH != "f16x3":
         pytest.skip("the configuration's arithmetic is f16x3")
     n = 2
@@ -1234,25 +1104,6 @@ def test_cfg5_geometry_vs_oracle(monkeypatch, libopt):
     monkeypatch.setattr(ops, "MAX_CONV_BYTES", 150 << 20)
     assert len(ops._batch_pieces(ops.conv_desc((n, 2048, 90, 160), (512, 2048, 1, 1), 1, 0, 1))) == 2  # (the cut path is reached ...)
     assert len(ops._batch_pieces(ops.conv_desc((n, 1024, 90, 160), (256, 1024, 1, 1), 1, 0, 1))) == 1  # (... by the 2048-channel maps only)
-    g, f1, f2 = get_models("drn_d_105", 6, NC)
-    og, of1, of2 = ref_models.get_models("drn_d_105", 6, NC)
-    for m, o, seed in ((g, og, 71), (f1, of1, 72), (f2, of2, 73)):
-        fill_state_(m, seed), fill_state_(o, seed)
-        m.to(dev).train(), o.train()
-    src, lbl, _ = make_batch(78, n, 6, 720, 1280, NC)
-    cw = ref_loss.class_weights(NC)
-    threads = _all_threads()
-    try:
-        ref_feat = og(src)
-        ref_logits = of1(ref_feat)
-        rcrit = ref_loss.CrossEntropyLoss2d(cw)
-        (rcrit(ref_logits, lbl) + rcrit(of2(ref_feat), lbl)).backward()
-    finally:
-        torch.set_num_threads(threads)
-    ref_gs = {k: v.grad.clone() for k, v in og.named_parameters()}
-    ref_fgs = [m.up.weight.grad.clone() for m in (of1, of2)]
-    ref_feat, ref_logits = ref_feat.detach(), ref_logits.detach()[:, :, ::8, ::8].clone()
-    del og, of1, of2
     names = []
     timer_prev = ops.LAUNCH_TIMER
 
@@ -1262,10 +1113,7 @@ def test_cfg5_geometry_vs_oracle(monkeypatch, libopt):
             return False
     ops.LAUNCH_TIMER = _Names()
     try:
-        feat = g(src.to(dev))
-        logits = f1(feat)
-        crit = CrossEntropyLoss2d(cw.to(dev))
-        (crit(logits, lbl.to(dev)) + crit(f2(feat), lbl.to(dev))).backward()
+        outs, grads = truth.hip_run("cfg5n2", dev)
     finally:
         ops.LAUNCH_TIMER = timer_prev
     ran = set(names)
@@ -1283,37 +1131,27 @@ def test_cfg5_geometry_vs_oracle(monkeypatch, libopt):
                # 2 GiB one -- and a cut batch runs it on the f32 tap-packed kernel)
                "conv_wgrad_thin_kernel<8, true>"):
         assert wg in ran, "the backward pass did not run %s: %s" % (wg, sorted(ran))
-    err = float((feat.detach().cpu() - ref_feat).abs().max())
-    lerr = float((logits.detach()[:, :, ::8, ::8].cpu() - ref_logits).abs().max())
-    named = dict(g.named_parameters())
-    assert set(named) == set(ref_gs)
-    num = den = 0.0
-    worst = (0.0, None)
-    for k, rg in ref_gs.items():
-        got = named[k].grad.cpu()
-        dn, rn = float((got - rg).double().norm()), float(rg.double().norm())
-        num, den = num + dn * dn, den + rn * rn
-        worst = max(worst, (dn / rn, k))
-    overall = (num / den) ** 0.5
-    ups = [float((m.up.weight.grad.cpu() - rg).norm() / rg.norm()) for m, rg in zip((f1, f2), ref_fgs)]
-    print("cfg5 geometry N=%d: feat err %.3e, logit err %.3e, gradients overall %.3e, worst %s %.3e, up-sampling %.3e / %.3e"
-          % (n, err, lerr, overall, worst[1], worst[0], ups[0], ups[1]))
-    assert err <= CFG5_FEAT_ABS, "feat err %.3e" % err
-    assert lerr <= CFG5_LOGIT_ABS, "logit err %.3e" % lerr
-    assert worst[0] <= CFG5_GRAD_WORST, "%s: relative L2 difference %.3e" % (worst[1], worst[0])
-    assert overall <= CFG5_GRAD_OVERALL, "all generator gradients: relative L2 difference %.3e (worst tensor %s %.3e)" % (overall, worst[1], worst[0])
-    assert max(ups) <= CFG5_UP_REL, "up.weight: relative L2 difference %.3e / %.3e" % tuple(ups)
+    fx = _truth_check("cfg5n2", outs, grads)
+    dist = truth.distances(fx, grads)
+    for k in ("f1.up.weight", "f2.up.weight"):
+        assert dist[k][0] <= 2e-4 * dist[k][2], "%s: %.3e of its norm" % (k, dist[k][0] / dist[k][2])
 
 
-# Bounds of test_cfg5_geometry_vs_oracle = twice the HIP - oracle-fp32 distances of profiles/r05_grad_truth_cfg5.txt, the run of
-# tests/grad_truth_cfg2.py --cfg5 that has the oracle in fp64 beside both.  north_star's 1e-3 on logits is NOT what fp32 delivers on this
-# network at this random initialisation, whoever computes it: through 105 train-mode BatchNorms the oracle's own fp32 logits are 2.6e-3
-# from its fp64 logits (features 1.3e-2 on a scale of 22), the HIP path's 2.9e-3 (1.4e-2), the two fp32 results 3.8e-3 (1.9e-2) from each
-# other; parameter gradients: oracle fp32 - fp64 5.8e-2 relative L2 over all 328 tensors (worst tensor 7.8e-2), HIP - fp64 5.8e-2
-# (8.1e-2), HIP - oracle fp32 6.9e-2 (8.8e-2); up-sampling kernels 6.7e-5 / 6.8e-5 / 9.4e-5.  The HIP path is as close to the truth as
-# the reference's arithmetic is; the test holds it to twice its measured distance from the oracle's fp32.
-CFG5_FEAT_ABS, CFG5_LOGIT_ABS = 4e-2, 8e-3
-CFG5_GRAD_WORST, CFG5_GRAD_OVERALL, CFG5_UP_REL = 0.18, 0.14, 2e-4
+def test_cfg5_at_eight_pairs_vs_oracle(monkeypatch):
+    """... and the same network at N = 8 with NOTHING emulated: drn_d_105, 8 x 6 x 720 x 1280, compact storage,
+    the launch plans and batch cuts the library chooses by itself at this size (59 GB), against the CPU oracle's fp64 run of the same
+    pass (tests/golden/grad_truth_cfg5n8.npz: 135 s in fp32 + 279 s in fp64 on the GPU box's 128 cores when the fixture was made; 2 s
+    here).  Measured: all gradients 0.98x the fp32 oracle's own distance from the truth, worst tensor 1.25x; logits 2.4e-3 against 2.5e-3."""
+    dev = _dev()
+    import truth
+    from mcdseg import ops
+    if ops.CONV_MATH != "f16x3":
+        pytest.skip("the configuration's arithmetic is f16x3")
+    monkeypatch.setattr(ops, "ACT_STORAGE", "compact")
+    outs, grads = truth.hip_run("cfg5n8", dev)
+    _truth_check("cfg5n8", outs, grads)
+    del outs, grads
+    torch.cuda.empty_cache()
 
 
 def test_cfg5_stated_batch_equals_its_replicated_quarter(monkeypatch):
@@ -1667,3 +1505,41 @@ def test_fusion_classifiers_match_reference_vectors(variant):
             (gp,) = torch.autograd.grad(val, [p])
             assert abs(float(val) - float(g["probce_" + sfx])) <= 2e-6 * abs(float(g["probce_" + sfx]))
             close(gp, g["probce_grad_" + sfx], 2e-6, "probce grad " + sfx)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the full-size parity tests against the TRUTH.  tests/golden/grad_truth_*.npz hold, for each BASELINE
+# configuration at its stated size, the CPU oracle's fp64 results (every gradient tensor as its norm + a count-sketch or the tensor
+# itself, the forward outputs sub-sampled) together with the fp32 oracle's own distance from them -- written by
+# tests/golden/make_grad_truth.py, which runs the oracle twice on the GPU box's host.  The HIP path is held to a small multiple of the
+# fp32 ORACLE'S distance from the truth, per tensor and over all of them, instead of to twice its distance from the fp32 oracle (which
+# is wide enough for two independent fp32 errors and hides a systematic error of one layer behind them).  The multiples below are what the
+# measurements of profiles/r06_truth_report.txt leave room for: over all tensors the HIP path sits at 1.0-1.1x the oracle's own distance;
+# single small tensors (a BatchNorm bias of 16 elements) scatter, as two independent rounding errors of a few elements do.
+TRUTH_OVERALL = 1.3          # HIP - fp64 over all gradient tensors, in units of oracle32 - fp64            [measured 0.98 .. 1.14]
+TRUTH_P90 = 1.3              # ... and for 90 % of the single tensors                                       [measured 1.06 .. 1.23]
+TRUTH_PER_TENSOR = {"cfg2": 1.6, "cfg3": 1.9, "cfg4": 1.6, "cfg5n2": 1.6, "cfg5n8": 1.6}  # the worst tensor  [1.34, 1.60, 1.29, 1.34, 1.25]
+TRUTH_OUTPUT = 2.0           # max |HIP - fp64| of a forward output in units of the fp32 oracle's (+ 2e-6 of the scale)  [0.92 .. 1.43]
+
+
+def _truth_check(cfg, outs, grads):
+    import truth
+    fx = truth.load(cfg)
+    for name, t in outs.items():
+        if torch.is_tensor(t) and name + "/sub64" in fx.files:
+            e, e32, sc = truth.output_error(fx, name, t)
+            assert e <= TRUTH_OUTPUT * e32 + 2e-6 * sc, "%s %s: max |HIP - fp64| %.3e, the fp32 oracle's %.3e (scale %.3e)" % (cfg, name, e, e32, sc)
+    dist = truth.distances(fx, grads)
+    overall, worst, wname, dh, d32, noise = truth.summary(dist)
+    print("%s: HIP - fp64 %.3e, oracle32 - fp64 %.3e of the gradients' norm (%.2fx); worst tensor %.2fx (%s); %d noise-only tensors"
+          % (cfg, dh, d32, overall, worst, wname, len(noise)))
+    assert overall <= TRUTH_OVERALL, "%s: all gradients %.2fx the fp32 oracle's distance from the truth (worst %s %.2fx)" % (cfg, overall, wname, worst)
+    total0 = sum(n * n for _, _, n in dist.values()) ** 0.5
+    ratios = sorted(d / max(d32_, 2e-5 * n64) for d, d32_, n64 in dist.values() if n64 > 1e-9 * total0)
+    p90 = ratios[min(len(ratios) - 1, int(0.9 * len(ratios)))]
+    assert p90 <= TRUTH_P90, "%s: the 90th percentile of the per-tensor ratios is %.2fx" % (cfg, p90)
+    assert worst <= TRUTH_PER_TENSOR[cfg], "%s: %s is %.2fx the fp32 oracle's distance from the truth" % (cfg, wname, worst)
+    total = sum(n * n for _, _, n in dist.values()) ** 0.5
+    for name, d, d32_, n64 in noise:  # (zero up to rounding on both sides: a bias in front of a train-mode BatchNorm)
+        assert d <= 1e-6 * total, "%s: %s should vanish, has norm %.3e of %.3e" % (cfg, name, d, total)
+    return fx

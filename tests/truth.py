@@ -28,9 +28,9 @@ def distances(fx, grads):
     for name in names:
         g = grads[name].detach().double().cpu()
         if name + "/x64" in fx.files:
-            d = float((g - torch.from_numpy(fx[name + "/x64"]).reshape(g.shape)).norm())
+            d = float((g - torch.from_numpy(fx[name + "/x64"]).double().reshape(g.shape)).norm())
         else:
-            d = float((sketch(name, g) - torch.from_numpy(fx[name + "/s64"])).norm())
+            d = float((sketch(name, g) - torch.from_numpy(fx[name + "/s64"]).double()).norm())
         out[name] = (d, float(fx[name + "/d32"]), float(fx[name + "/n64"]))
     return out
 
@@ -58,7 +58,7 @@ def summary(dist, floor=2e-5):
 def output_error(fx, name, tensor):
     """(max |HIP - fp64| on the fixture's sub-sample, the fp32 oracle's own, the scale) of a forward output"""
     s = int(fx[name + "/stride"])
-    ref = torch.from_numpy(fx[name + "/sub64"])
+    ref = torch.from_numpy(fx[name + "/sub64"]).double()
     got = tensor.detach()[:, :, ::s, ::s].double().cpu()
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     return float((got - ref).abs().max()), float(fx[name + "/e32"]), float(fx[name + "/scale"])

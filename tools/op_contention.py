@@ -131,8 +131,98 @@ def worker(a):
     return 1 if bad else 0
 
 
+def simple_worker(a):
+    """``--op loss | up8_bwd | half``: one kernel family in a loop, every output bit for bit against iteration 0 -- the kernels whose waits
+    are hand-counted around LDS-DMAs the compiler does not see (csrc/common.h mcd_hidden_dma: the fused up-sampler + loss kernel, the
+    up-sampler's backward band kernel) at the benchmark's own size, and the 2-byte chain of round 6 (``half``); a missing wait shows as a
+    rare wrong value under load, which is what a second process on the same device provides (``--procs 2``)."""
+    import torch
+    from mcdseg import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    n, c, hi, wi = (int(v) for v in a.shape.split(","))
+    if a.op == "loss":
+        s1, s2 = (torch.randn(n, c, hi, wi, generator=g).to(dev) for _ in range(2))
+        w1, w2 = (torch.rand(c, 1, 16, 16, generator=g).to(dev) * 0.1 for _ in range(2))
+        lbl = torch.randint(0, c, (n, 8 * hi, 8 * wi), generator=g).to(dev)
+        cw = torch.ones(c)
+        cw[c - 1] = 0
+        cw = cw.to(dev)
+
+        def run():
+            out = {}
+            for tag, ce, df, lab in (("A", 1.0, 0.0, lbl), ("B", 1.0, -1.0, lbl), ("C", 0.0, 1.0, None)):  # the three forms of an MCD step
+                losses, g1, g2 = ops.up8_mcd_losses(s1, w1, s2, w2, lab, cw if lab is not None else None, ce_coef=ce, diff_coef=df)
+                out.update({tag + ".losses": losses, tag + ".g1": g1, tag + ".g2": g2})
+            return out
+    elif a.op == "up8_bwd":
+        gy = torch.randn(n, c, 8 * hi, 8 * wi, generator=g).to(dev)
+        s1 = torch.randn(n, c, hi, wi, generator=g).to(dev)
+        w1 = torch.rand(c, 1, 16, 16, generator=g).to(dev) * 0.1
+
+        def run():
+            out = {}
+            for tag, wx, ww in (("xw", True, True), ("x", True, False), ("w", False, True)):
+                dx, dw = ops.up8_backward(gy, s1, w1, wx, ww)
+                if dx is not None:
+                    out[tag + ".dx"] = dx
+                if dw is not None:
+                    out[tag + ".dw"] = dw
+            return out
+    else:  # half: a Bottleneck block of the 2-byte chain (one-term arithmetic, compact storage), forward + backward
+        import torch.nn as nn
+        from models.drn import Bottleneck, BatchNorm2d, Conv2d, ConvBNReLU
+        ops.CONV_MATH, ops.ACT_STORAGE = "f16x1", "compact"
+        torch.manual_seed(4)
+        net = nn.ModuleList([ConvBNReLU(Conv2d(32, c, kernel_size=3, padding=1, bias=False), BatchNorm2d(c), nn.ReLU(inplace=True)),
+                             Bottleneck(c, c // 4, dilation=(2, 2)), Bottleneck(c, c // 4, dilation=(2, 2)),
+                             ConvBNReLU(Conv2d(c, c, kernel_size=3, padding=1, bias=False), BatchNorm2d(c), nn.ReLU(inplace=True))]).to(dev).train()
+        x0 = torch.randn(n, 32, hi, wi, generator=g).to(dev)
+        gy = (torch.randn(n, c, hi, wi, generator=g) * 1e-5).to(dev)
+
+        def run():
+            for p in net.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_()
+            with ops.late_weight_grads(net):
+                with ops.trunk_internal():
+                    t = net[2](net[1](net[0](x)))
+                y = net[3](t)
+            y.backward(gy)
+            out = {"y": y.detach(), "dx": x.grad}
+            out.update({"grad." + k: p.grad for k, p in net.named_parameters()})
+            return out
+
+    def snap(d):
+        return {k: v.detach().clone() for k, v in d.items()}
+    ref = snap(run())
+    torch.cuda.synchronize()
+    bad = 0
+    for it in range(a.iters):
+        cur = run()
+        msgs = []
+        for k, v in ref.items():
+            u = cur[k]
+            same = torch.equal(v.view(torch.int32), u.view(torch.int32)) if v.dtype == torch.float32 else torch.equal(v, u)
+            if not same:
+                ne = v != u
+                msgs.append("%s: %d of %d elements differ, first at flat index %d: %r -> %r"
+                            % (k, int(ne.sum()), v.numel(), int(ne.flatten().nonzero()[0]), float(v.flatten()[ne.flatten()][0]), float(u.flatten()[ne.flatten()][0])))
+        if msgs:
+            bad += 1
+            print("[pid %d] %s iter %d differs:\n    %s" % (os.getpid(), a.op, it, "\n    ".join(msgs)), flush=True)
+            if bad >= 6:
+                break
+    print("[pid %d] %s %s done: %d of %d iterations differ (%d tensors compared bit for bit each)" % (os.getpid(), a.op, a.shape, bad, a.iters, len(ref)), flush=True)
+    return 1 if bad else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--op", choices=["conv", "loss", "up8_bwd", "half"], default="conv",
+                    help="conv (default): two fused conv+BN+ReLU groups with their BatchNorm-backward intermediates; loss / up8_bwd: the kernels "
+                         "with hand-counted waits around hidden LDS-DMAs, shape = N,C,Hi,Wi of the score maps (benchmark: 16,41,60,80); half: a "
+                         "Bottleneck block of the 2-byte chain, shape = N,C,H,W")
     ap.add_argument("--procs", type=int, default=1)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--shape", default="4,256,24,32")
@@ -141,8 +231,9 @@ def main():
     ap.add_argument("--side_lag", type=int, default=0, help="spin cycles in front of every kernel group launched on the side stream")
     a = ap.parse_args()
     if a.worker or a.procs == 1:
-        sys.exit(worker(a))
-    cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--iters", str(a.iters), "--shape", a.shape, "--dil", str(a.dil), "--side_lag", str(a.side_lag)]
+        sys.exit(worker(a) if a.op == "conv" else simple_worker(a))
+    cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--op", a.op, "--iters", str(a.iters), "--shape", a.shape, "--dil", str(a.dil),
+           "--side_lag", str(a.side_lag)]
     ps = [subprocess.Popen(cmd) for _ in range(a.procs)]
     rc = 0
     for p in ps:

@@ -14,6 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
+    if name.startswith("_ZN"):  # (a name rocprofv3 could not demangle: _Float16 / __bf16 vector types in the signature)
+        import re
+        m = re.search(r"\d+([a-z_0-9]+_kernel)(?:ILi(\d+)E)?", name)
+        if m:
+            return m.group(1) + ("<%s>" % m.group(2) if m.group(2) else "")
     return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
 
 
