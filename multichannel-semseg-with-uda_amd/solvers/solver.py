@@ -249,7 +249,8 @@ class MFNetMCDSolver(MCDSolver):
                          num_multiply_d_loss=1)  # adapt_mfnet_trainer.py:226-235 applies no multiplier
 
     def _features(self, x):
-        if not (MFNET_TWO_STREAMS and x.is_cuda):
+        timing = ops.LAUNCH_TIMER is not None and ops.LAUNCH_TIMER.wants("conv_wgrad")
+        if not (MFNET_TWO_STREAMS and x.is_cuda) or timing:  # (a step whose launches carry HIP-event pairs runs every kernel alone)
             return self.g_3ch(x[:, :3, :, :]), self.g_1ch(x[:, 3:, :, :])
         # the two encoders share nothing: the HHA one runs on a stream of its own (forward here; autograd runs a node's backward on its
         # forward's stream), so that each encoder's HBM-bound BatchNorm passes overlap the other's convolutions

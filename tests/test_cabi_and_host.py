@@ -186,7 +186,7 @@ def test_forward_and_data_gradient_plan_of_every_config2_layer():
             assert L.mcdseg_conv_split_stat_rows_for(ctypes.byref(desc), mid, 1) == 2 * ((16 * desc.Ho * desc.Wo + 319) // 320)
 
 
-def test_grad_box_protocol_and_kernel_names():
+def test_grad_box_protocol_and_kernel_names(tmp_path, monkeypatch):
     """Host logic of round 4 that needs no GPU: ``ops.GradBox`` (every producer of a shared gradient but the last leaves its tensor and
     reports None, the last returns what was left -- over several backward passes through one graph), the ping-pong kernel names the
     profilers key on, ``forward_fork`` off the GPU, and ``bench.is_forward_conv``'s reading of the template arguments."""
@@ -238,19 +238,31 @@ def test_grad_box_protocol_and_kernel_names():
     bwd = ["conv_gemm_split_pp_kernel<SplitF16x3, true, 4, 2, 1, 4>", "conv_gemm_split_kernel<SplitF16x3, 2, 2, 2, 2, true, false>",
            "conv_gemm_kernel<2, 2, 2, 2, 16, true>", "conv_stem_x6_kernel", "bn_apply_cb"]
     assert all(bench.is_forward_conv(n) for n in fwd) and not any(bench.is_forward_conv(n) for n in bwd)
-    # roofline.traffic is a lookup in the newest committed PMC table: refused unless the table was made from THIS set of kernels
+    # roofline.traffic is a lookup in a committed PMC table: refused unless the table was made from THIS build's kernel sources (their
+    # fingerprint is in the table) and from this set of kernels
     import glob
     import json
+    import shutil
+    from mcdseg import _lib
     tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    table = json.load(open(tables[-1]))["kernels"]
+    doc = json.load(open(tables[-1]))
+    table = doc["kernels"]
     name = next(n for n in table if n.startswith("conv_gemm_split_pp_kernel<SplitF16x3, false"))
     run = {n: dict(launches=v["launches_per_step"]) for n, v in table.items() if n.startswith("conv_") and "<" in n}
+    fake_root = str(tmp_path)
+    os.makedirs(os.path.join(fake_root, "profiles"))
+    monkeypatch.setattr(bench, "ROOT", fake_root)
+    json.dump(dict(doc, source_fingerprint="0" * 40), open(os.path.join(fake_root, "profiles", "r98_pmc_traffic.json"), "w"))
+    got, why = bench.pmc_traffic(name, run, 1)
+    assert got is None and "kernel sources changed" in why, why   # (a table of another build: the newest by name, and refused)
+    json.dump(dict(doc, source_fingerprint=_lib.source_fingerprint()), open(os.path.join(fake_root, "profiles", "r97_pmc_traffic.json"), "w"))
     got, source = bench.pmc_traffic(name, run, 1)
-    assert got == table[name]["hbm_bytes_per_launch"] and source.endswith(os.path.basename(tables[-1]))
+    assert got == table[name]["hbm_bytes_per_launch"] and source.endswith("r97_pmc_traffic.json")
     got, why = bench.pmc_traffic(name, dict(run, **{"conv_renamed_kernel<1, 2>": dict(launches=3)}), 1)
     assert got is None and "stale" in why and "conv_renamed_kernel<1, 2>" in why
     got, why = bench.pmc_traffic(name, dict(run, **{name: dict(launches=run[name]["launches"] + 6)}), 1)
     assert got is None and "times per step" in why
+    shutil.rmtree(os.path.join(fake_root, "profiles"))
     r = bench.kernel_roofline(name, dict(flops=3e12, bytes=1e9, ms=3.0, launches=10), "f16x3", None)
     assert abs(r["frac"] - 3 * r["frac_algorithmic"]) < 1e-3 and abs(r["frac_algorithmic"] - 1000.0 / 2500.0) < 1e-3
 

@@ -53,7 +53,10 @@ def main(tag):
             fk, wk = sum(v) / len(v), sum(write[k]) / len(write[k])
             table[k] = {"launches_per_step": len(v), "fetch_size_kb_mean": round(fk, 1), "write_size_kb_mean": round(wk, 1),
                         "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+        sys.path.insert(0, os.path.join(ROOT, "multichannel-semseg-with-uda_amd"))
+        from mcdseg import _lib
         json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (two passes) -- python3 bench.py --steps 1 --warmup 0",
+                   "source_fingerprint": _lib.source_fingerprint(),  # (of the kernel sources the counters were collected with: bench.py checks it)
                    "units": "FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes = (2*FETCH + WRITE) * 1024 (gfx950 FETCH_SIZE halving)",
                    "kernels": table}, open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     q = glob.glob(os.path.join(src, tag + "_sq", "*", "*counter_collection.csv"))
