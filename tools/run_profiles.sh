@@ -9,6 +9,8 @@ cd "${GRAFT_REPO_ROOT:-.}"
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# the fingerprint of the kernel sources these counters are collected with (bench.py quotes a PMC table only for the build it was made from)
+python3 -c "import sys; sys.path.insert(0, 'multichannel-semseg-with-uda_amd'); from mcdseg import _lib; print(_lib.source_fingerprint())" > "$OUT/${TAG}_fingerprint.txt"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -- python3 bench.py --steps 3 --warmup 1 --no_cpu_baseline --other_configs "" --literal_steps 0 --strict_steps 0 > "$OUT/${TAG}_bench_profiled.json" 2> "$OUT/${TAG}_stats.err"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_fetch" -- python3 bench.py --steps 1 --warmup 0 --no_cpu_baseline --literal_steps 0 --strict_steps 0 --other_configs "" > /dev/null 2> "$OUT/${TAG}_fetch.err"

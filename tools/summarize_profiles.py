@@ -56,7 +56,9 @@ def main(tag):
         sys.path.insert(0, os.path.join(ROOT, "multichannel-semseg-with-uda_amd"))
         from mcdseg import _lib
         json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (two passes) -- python3 bench.py --steps 1 --warmup 0",
-                   "source_fingerprint": _lib.source_fingerprint(),  # (of the kernel sources the counters were collected with: bench.py checks it)
+                   # (of the kernel sources the counters were collected with, written on the box by tools/run_profiles.sh: bench.py checks it)
+                   "source_fingerprint": (open(os.path.join(src, tag + "_fingerprint.txt")).read().strip()
+                                          if os.path.exists(os.path.join(src, tag + "_fingerprint.txt")) else _lib.source_fingerprint()),
                    "units": "FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes = (2*FETCH + WRITE) * 1024 (gfx950 FETCH_SIZE halving)",
                    "kernels": table}, open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     q = glob.glob(os.path.join(src, tag + "_sq", "*", "*counter_collection.csv"))
