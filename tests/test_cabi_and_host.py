@@ -486,3 +486,41 @@ def test_library_reads_no_environment_variable():
     assert (mcdseg.get_option("PP_CUS"), mcdseg.get_option("PINGPONG")) == (0, 3)
     with pytest.raises(RuntimeError, match="unknown option"):
         mcdseg.set_option("NO_SUCH_OPTION", 1)
+
+
+def test_two_byte_chain_host_rules():
+    """Round 6, no GPU: which convolutions of BASELINE config 5's network the 2-byte chain takes (``mcdseg_conv_split_half_ok``), which of
+    them run with two K-steps per barrier interval (``mcdseg_conv_split_pp_deep``), how their batches are cut, and how the stand-in
+    tensors announce themselves to autograd."""
+    import ctypes
+    from mcdseg import ops
+    L = ops.lib()
+
+    def d(n, cin, h, w, cout, k, s=1, dil=1):
+        return ops.conv_desc((n, cin, h, w), (cout, cin, k, k), s, dil * (k // 2), dil)
+    # the chain: both channel counts multiples of 8, at least 16 contraction channels, the one-term arithmetic only
+    for desc, fwd, bwd in ((d(32, 1024, 90, 160, 256, 1), 1, 1), (d(32, 256, 90, 160, 256, 3, dil=2), 1, 1), (d(32, 32, 360, 640, 256, 1, s=2), 1, 1),
+                           (d(32, 16, 720, 1280, 16, 3), 0, 0),          # the thin layers' window kernels: not the chain's
+                           (d(32, 16, 720, 1280, 32, 3, s=2), 1, 1),     # (the kernels could; ops keeps Cin <= 16 out: its weight gradient multiplies both pieces)
+                           (d(32, 6, 720, 1280, 16, 7), 0, 0),           # the stem
+                           (d(2, 512, 60, 80, 41, 1), 0, 0)):            # 41 channels: no unit layout
+        assert L.mcdseg_conv_split_half_ok(ctypes.byref(desc), 1, 0) == fwd and L.mcdseg_conv_split_half_ok(ctypes.byref(desc), 1, 1) == bwd, tuple(desc.__getattribute__(f) for f in ("Cin", "Cout", "KH"))
+        assert L.mcdseg_conv_split_half_ok(ctypes.byref(desc), 3, 0) == 0  # never in the fp32-grade arithmetic
+    # two K-steps per interval: an even number of K-steps, the one-term arithmetic
+    assert L.mcdseg_conv_split_pp_deep(ctypes.byref(d(32, 1024, 90, 160, 256, 1)), 1, 0) == 1
+    assert L.mcdseg_conv_split_pp_deep(ctypes.byref(d(4, 48, 128, 129, 256, 1)), 1, 0) == 0      # 3 K-steps
+    assert L.mcdseg_conv_split_pp_deep(ctypes.byref(d(32, 1024, 90, 160, 256, 1)), 3, 0) == 0
+    assert ops.pingpong_kernel_name(False, "f16x1", deep=True) == "conv_gemm_split_pp_kernel<SplitF16x1D, false, 4, 2, 1, 4>"
+    assert ops.pingpong_kernel_name(True, "f16x1", small=True, deep=True) == "conv_gemm_split_pp_kernel<SplitF16x1, true, 2, 2, 2, 2>"
+    assert ops.pingpong_kernel_name(False, "f16x3", deep=True) == "conv_gemm_split_pp_kernel<SplitF16x3, false, 4, 2, 1, 4>"
+    # batch cuts: config 5's 2048-channel maps at N = 32 are 3.8 GB in fp32 (two launches) and 1.9 GB as 16-bit units (one)
+    big = d(32, 2048, 90, 160, 512, 1)
+    assert len(ops._batch_pieces(big)) == 2 and ops._batch_pieces_half(big) == [(0, 32)]
+    assert ops._batch_pieces_half(d(64, 2048, 90, 160, 512, 1)) == [(0, 35), (35, 64)]
+    # the stand-in of a chain activation: a bfloat16 tensor of the logical shape with 2 bytes of storage
+    v = ops._virtual((2, 64, 8, 8), torch.device("cpu"), torch.bfloat16)
+    v._mcd_virtual = True
+    assert ops.is_half(v) and ops.is_virtual(v) and v.shape == (2, 64, 8, 8) and v.untyped_storage().nbytes() == 2
+    f = ops._virtual((2, 64, 8, 8), torch.device("cpu"))
+    f._mcd_virtual = True
+    assert not ops.is_half(f) and not ops.is_half(torch.zeros(2, dtype=torch.bfloat16))

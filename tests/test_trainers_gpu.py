@@ -354,7 +354,7 @@ def test_bench_with_one_rank_through_rccl(overlap):
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     args = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", "--height", "64", "--width", "96", "--no_cpu_baseline",
-            "--literal_steps", "0", "--batch_pool", "1"]
+            "--literal_steps", "1", "--batch_pool", "1"]
     r = _run_ranks(1, os.path.join(root, "bench.py"), args, extra_env={"MCDSEG_DIST_BACKEND": "nccl", "MCDSEG_DIST_FORCE": "1", "MCDSEG_DP_OVERLAP": overlap,
                                                                       "MCDSEG_DP_BUCKET_MB": "8"})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -377,3 +377,8 @@ def test_bench_with_one_rank_through_rccl(overlap):
     # ... and the bucketed exchange no longer pushes the weight gradients back onto the main stream: they stay on
     # the side stream and reach the buckets through FlatSGD's gradient sink
     assert line["wgrad_stream"]["deferred"] > 0, line["wgrad_stream"]
+    # round 6: the same invocation also measures the OTHER setting of MCDSEG_DP_OVERLAP after the timed region
+    other = line["dp_overlap_other_setting"]
+    assert other is not None and other["MCDSEG_DP_OVERLAP"] == ("0" if overlap == "1" else "1"), other
+    assert other["ms_per_step"] > 0 and other["collectives"]["collectives_per_step"] >= 7, other
+    assert ref["dp_overlap_other_setting"] is None
