@@ -58,8 +58,8 @@ MATH = {
 DTYPE_LABEL = {"f32": "f32",
                "bf16x6": "f32 (operands split 3-way into bf16, 6 cross terms on the bf16 MFMA pipe, fp32 accumulate)",
                "f16x3": "f32 (operands split 2-way into scaled fp16, 3 cross terms on the fp16 MFMA pipe, fp32 accumulate)",
-               "f16x1": "f16 (operands rounded to one scaled fp16 piece, fp32 accumulate, fp32 BatchNorm / loss / optimizer) -- REDUCED precision, "
-                        "not the judged configuration",
+               "f16x1": "f16 (operands rounded to one scaled fp16 piece, fp32 accumulate, fp32 BatchNorm / loss / optimizer arithmetic; with compact "
+                        "storage every trunk tensor is one 16-bit value per element) -- REDUCED precision, not the judged configuration",
                "mixed": "f32 (bf16x6 split for forward/dgrad, f32 MFMA for wgrad)"}
 TIMED_FAMILIES = {
     "all": ["conv_", "bn_", "up8_", "softmax_ce_l1", "sgd_", "loss_", "wgrad_", "split_", "pack_"],
@@ -218,7 +218,7 @@ def other_config(tag, dev, steps, n_class=41, want_roofline=False):
                 dom = max(kern, key=lambda n: kern[n]["ms"])
                 res["roofline"] = kernel_roofline(dom, kern[dom], ops.CONV_MATH, None)
                 res["timed_kernel_ms_per_step"] = round(total, 1)
-                res["kernel_ms"] = {n: round(v["ms"], 1) for n, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+                res["kernel_ms"] = {n: round(v["ms"], 1) for n, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:16]}
         del solver, src, lbl, tgt
         return res
     finally:
@@ -471,8 +471,10 @@ def _main():
     import torch
     from mcdseg import dist as mdist
     from mcdseg import ops
-    if args.dtype == "f16":
+    if args.dtype == "f16":  # (as the trainers' --dtype f16: the one-term arithmetic with 2-byte activation storage inside the trunk)
         ops.CONV_MATH = "f16x1"
+        if "MCDSEG_ACT_STORAGE" not in os.environ:
+            ops.ACT_STORAGE = "compact"
     rank, world, local = mdist.init_from_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))

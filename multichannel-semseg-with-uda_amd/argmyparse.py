@@ -44,7 +44,8 @@ def add_mi355x_flags(parser):
     g.add_argument("--no_tflog", action="store_true", help="do not require tensorboard_logger")
     g.add_argument("--dtype", choices=["f32", "f16"], default="f32",
                    help="arithmetic of the convolutions: f32 = fp32-grade (operands as two scaled fp16 pieces, three MFMA terms; the default, "
-                        "within 1e-3 of the reference), f16 = reduced precision (the leading fp16 piece only, one MFMA term; BASELINE config 5)")
+                        "within 1e-3 of the reference), f16 = reduced precision (BASELINE config 5's 'bf16': the leading fp16 piece only, one MFMA term, and "
+                        "2-byte activation storage inside the trunk)")
     return parser
 
 

@@ -18,9 +18,11 @@ class Run:
         torch.cuda.set_device(self.device)
         if getattr(args, "no_pretrained", False):
             os.environ["MCDSEG_PRETRAINED"] = "0"
-        if getattr(args, "dtype", "f32") == "f16":  # reduced-precision convolutions (mcdseg/ops.py CONV_MATH "f16x1")
-            from mcdseg import ops
-            ops.CONV_MATH = "f16x1"
+        if getattr(args, "dtype", "f32") == "f16":  # reduced precision (BASELINE config 5 "bf16"): one fp16 term per product and, inside the
+            from mcdseg import ops                   # trunk, ONE 16-bit value per activation / z / gradient element (ops.HALF_STORAGE) --
+            ops.CONV_MATH = "f16x1"                  # unless MCDSEG_ACT_STORAGE says how activations are to be kept
+            if "MCDSEG_ACT_STORAGE" not in os.environ:
+                ops.ACT_STORAGE = "compact"
         torch.manual_seed(getattr(args, "seed", 1234))
         self._log = None
         self._pipe = None

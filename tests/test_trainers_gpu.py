@@ -42,6 +42,34 @@ def test_adapt_trainer_checkpoint_and_resume(tmp_path, solver):
     assert ck2["epoch"] == 2 and int(ck2["g_state_dict"]["base.0.1.num_batches_tracked"]) == 28
 
 
+def test_adapt_trainer_in_the_two_byte_chain(tmp_path, monkeypatch):
+    """``adapt_trainer.py --dtype f16`` (BASELINE config 5's "bf16"): the one-term arithmetic with 2-byte activation storage inside the trunk,
+    end to end through the CLI -- the chain's kernels run, the checkpoint has the reference's layout and finite fp32 state, and a resumed
+    epoch continues from it."""
+    _need_gpu()
+    import adapt_trainer
+    import util
+    from mcdseg import ops
+    monkeypatch.delenv("MCDSEG_ACT_STORAGE", raising=False)
+    monkeypatch.setattr(ops, "CONV_MATH", ops.CONV_MATH)      # (the trainer sets both: restored when the test ends)
+    monkeypatch.setattr(ops, "ACT_STORAGE", ops.ACT_STORAGE)
+    names = []
+
+    class _Names:
+        def wants(self, name):
+            names.append(name)
+            return False
+    monkeypatch.setattr(ops, "LAUNCH_TIMER", _Names())
+    out = str(tmp_path / "out")
+    assert adapt_trainer.main(["suncg", "nyu", "--base_outdir", out, "--dtype", "f16"] + COMMON) == 0
+    assert (ops.CONV_MATH, ops.ACT_STORAGE) == ("f16x1", "compact")
+    assert {"bn_apply_half", "bn_bwd_reduce_half", "bn_bwd_apply_half"} <= set(names), sorted(set(names))
+    assert any("SplitF16x1" in nm for nm in names) and not any("SplitF16x3" in nm for nm in names), sorted(set(names))
+    ck = util.load_checkpoint(os.path.join(out, "suncg-train2nyu-train_6ch", "pth", "MCD-normal-drn_d_38-1.pth.tar"))
+    assert len(ck["g_state_dict"]) == 248 and all(v.dtype != torch.bfloat16 and torch.isfinite(v.float()).all() for v in ck["g_state_dict"].values())
+    assert int(ck["g_state_dict"]["base.0.1.num_batches_tracked"]) == 14
+
+
 def test_adapt_mfnet_trainer(tmp_path):
     _need_gpu()
     import adapt_mfnet_trainer
