@@ -592,6 +592,13 @@ def _batch_pieces_uncached(desc, wgrad_cb=None):
     # 32 x 720 x 1280 (1.89 GB per tensor) stay in one launch and keep their companions.  The WEIGHT gradient is slack-free only on
     # the plans that read both companions (mcdseg_conv_wgrad_fits states the library's own rule): the f32 plans of thin layers, the
     # split plan without companions and bf16x6's thin layers still gather fp32 values with the slack.
+    if wgrad_cb and CONV_MATH in MATH_ID and desc.Cin <= 16:
+        # the thin layers' window weight gradient (csrc/conv_wgrad_thin_tr.hip) reads both companions of the WHOLE batch through one
+        # descriptor each and nothing else: the library's own rule decides (round 6: the stem at BASELINE config 5's N = 32 -- a 1.9 GB dz,
+        # two 0.9 GB pieces of its companion -- was cut by the fp32 kernels' slack rule and fell back to the f32 tap-packed kernel: 37 ms)
+        m = MATH_ID[CONV_MATH]
+        if lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), m, 1) == 15 and lib().mcdseg_conv_wgrad_fits(ctypes.byref(desc), m, 1):
+            return [(0, desc.N)]
     split_only = CONV_MATH in MATH_ID and desc.Cin % 8 == 0 and desc.Cout % 8 == 0 and min(desc.Cin, desc.Cout) >= 16
     if wgrad_cb is not None:
         math = MATH_ID.get(CONV_MATH, 0)
@@ -1424,7 +1431,7 @@ class _ConvBNAct(torch.autograd.Function):
         # the stem: no input gradient and an input without a companion, but its weight gradient runs on split operands too
         # (conv_wgrad_thin_tr.hip) -- from the zero-padded companion of the network input and the companion of dz
         stem_tr = (ctx.needs_input_grad[1] and not ctx.needs_input_grad[0] and x_cb is None and desc.Cin % 8 != 0 and PRESPLIT
-                   and not ctx.x_virtual and len(_batch_pieces(desc)) == 1 and c % 8 == 0 and n * (c // 8) <= 65535
+                   and not ctx.x_virtual and len(_batch_pieces(desc, wgrad_cb=True)) == 1 and c % 8 == 0 and n * (c // 8) <= 65535
                    and _wgrad_thin_tr(desc))
         if stem_tr:
             x_cb, x_bound = split_companion_padded(x)
@@ -1447,7 +1454,9 @@ class _ConvBNAct(torch.autograd.Function):
         dz_cb = None
         # the fp32 dz is skipped when every consumer reads the split companion: dgrad (pre-split gather) and wgrad
         # (pre-split plans); a conv bias gradient or any fallback path still needs it
-        single = single_piece = len(_batch_pieces(desc)) == 1 or desc.Cin > 16  # (cut batches keep their companions, see forward)
+        # (cut batches keep their companions, see forward; the stem's window weight gradient takes the whole batch's companions whatever
+        # the forward pass was cut into)
+        single = single_piece = stem_tr or len(_batch_pieces(desc)) == 1 or desc.Cin > 16
         wgrad_cb = stem_tr or (x_cb is not None and use_cb and single_piece and _wgrad_split_plan(desc, True) and desc.Cin % 8 == 0
                                and desc.Cout % 8 == 0)
         skip_dz = (use_cb and single and not (ctx.has_bias and ctx.needs_input_grad[5])
