@@ -18,4 +18,9 @@ for mode in half full; do
     find "$d" -name "*kernel_trace.csv" -delete 2>/dev/null
   done
 done
+# SQ counters of the 2-byte chain's step (matrix-pipe busy fraction of the one-term kernels, wave-cycle breakdown of the BatchNorm kernels)
+export MCDSEG_HALF_STORAGE=1
+d="$OUT/${TAG}_cfg5_half_sq"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$d" -- python3 tools/bench_configs.py --cfg cfg5 --n5 8 --hw5 720 1280 --steps 0 > "$d.log" 2>&1
+find "$d" -name "*kernel_trace.csv" -delete 2>/dev/null
 ls -la "$OUT" | grep "${TAG}_cfg5" | head

@@ -65,6 +65,24 @@ def main(tag):
         out["batchnorm_hbm_gb_per_step"] = {"full": round(bn("full"), 1), "half": round(bn("half"), 1), "ratio": round(bn("half") / bn("full"), 3)}
         tot = lambda m: sum(v["hbm_gb_per_step"] for v in out[m]["families"].values())  # noqa: E731
         out["all_kernels_hbm_gb_per_step"] = {"full": round(tot("full"), 1), "half": round(tot("half"), 1), "ratio": round(tot("half") / tot("full"), 3)}
+    q = glob.glob(os.path.join(src, "%s_cfg5_half_sq" % tag, "*", "*counter_collection.csv"))
+    if q:
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(q[0])):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        sq = {}
+        for k, v in agg.items():
+            if not k.startswith(("conv_", "bn_")) or "GRBM_GUI_ACTIVE" not in v:
+                continue
+            tot = {c: sum(x) for c, x in v.items()}
+            cyc = tot["GRBM_GUI_ACTIVE"] / 8.0  # the counter sums the 8 XCDs
+            if cyc <= 0 or tot["SQ_WAVE_CYCLES"] <= 0:
+                continue
+            sq[k] = {"launches": len(v["SQ_WAVE_CYCLES"]), "kernel_cycles_per_launch": int(cyc / len(v["SQ_WAVE_CYCLES"])),
+                     "mfma_pipe_busy_frac": round(tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), 3),
+                     "wave_cycles_parked_frac": round(tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"], 3),
+                     "wave_cycles_issue_stalled_frac": round(tot["SQ_WAIT_INST_ANY"] / tot["SQ_WAVE_CYCLES"], 3)}
+        out["half_sq"] = {k: sq[k] for k in sorted(sq, key=lambda n: -sq[n]["kernel_cycles_per_launch"] * sq[n]["launches"])[:24]}
     out["command"] = "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 tools/bench_configs.py --cfg cfg5 --n5 8 --hw5 720 1280 --steps 0 " \
                      "with MCDSEG_CONV_MATH=f16x1 MCDSEG_ACT_STORAGE=compact and MCDSEG_HALF_STORAGE=0 (full) / 1 (half): one MCD step"
     path = os.path.join(ROOT, "profiles", tag + "_cfg5_bn_traffic.json")
