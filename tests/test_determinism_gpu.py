@@ -42,6 +42,20 @@ def test_fused_groups_are_bitwise_next_to_a_computing_neighbour(shape, dil, iter
     assert len(done) == 2 and all("done: 0 of" in ln for ln in done), r.stdout[-6000:]
 
 
+@pytest.mark.parametrize("op,shape,iters", [("half", "4,256,45,80", 100),     # round 6: a Bottleneck chain in 2-byte storage (16-bit epilogues, bf16 sums)
+                                            ("loss", "4,41,30,40", 200),      # the fused up-sampler + loss kernel (hidden LDS-DMA, counted vmcnt)
+                                            ("up8_bwd", "4,41,30,40", 200)])  # the up-sampler's backward band kernel (hidden LDS-DMA)
+def test_hand_waited_kernels_and_the_two_byte_chain_are_bitwise_under_load(op, shape, iters):
+    """``tools/op_contention.py --op``: the kernels whose waits are hand-counted around LDS-DMAs the compiler does not see, and round 6's
+    2-byte chain, each in a loop in TWO processes on the one device, every output of every iteration bit for bit that of iteration 0
+    (the long form at the benchmark's sizes: tools/run_soak.sh, profiles/r06_determinism_soak.log)"""
+    _need_gpu()
+    r = _tool("op_contention.py", ["--op", op, "--procs", "2", "--iters", str(iters), "--shape", shape])
+    assert r.returncode == 0, r.stdout[-6000:] + r.stderr[-3000:]
+    done = [ln for ln in r.stdout.splitlines() if "done:" in ln]
+    assert len(done) == 2 and all("done: 0 of" in ln for ln in done), r.stdout[-6000:]
+
+
 @pytest.mark.parametrize("mode,reps", [("grads", 3), ("step", 2)])  # (round 3 ran 5 / 3 repetitions: 90 s of the suite; the offending
 # instruction has since been banned from the library by a CPU disassembly test, so this is a regression guard, not a soak)
 def test_model_step_is_bitwise_with_two_ranks_and_a_copy_loop_on_the_device(mode, reps):
