@@ -80,10 +80,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
   // (sub == 2: the four classes have the same tile count and are interleaved -- tiles 4k .. 4k+3 are the four parities of ONE region,
   // neighbours on one XCD: they gather the same dY window through that L2 and their stride-2 stores meet there as whole lines)
   const bool ILV = SUB && p.sub == 2;
+  // (sub == 3: ROW classes -- a tile holds consecutive pixels of rows of one y-parity, BOTH x-parities: a wave's stores are as dense as
+  // a stride-1 layer's instead of 4 bytes in every 8.  The K loop walks every tap of the row class; a lane whose x-parity a tap does not
+  // reach gathers zeros for it (an out-of-range offset: no memory request) -- twice the matrix instructions of the four-class form for
+  // the same sums in the same order, in kernels that use a sixteenth of the pipe)
+  const bool ROW = SUB && p.sub == 3;
   if (SUB) cls = ILV ? (tile_n & 3) : (tile_n >= p.cls_tile0[1]) + (tile_n >= p.cls_tile0[2]) + (tile_n >= p.cls_tile0[3]);
-  const int ry = cls >> 1, rx = cls & 1;
+  const int ry = ROW ? cls : cls >> 1, rx = cls & 1;  // (ROW: the x-parity is the lane's own)
   const int Hc = SUB ? (p.Hd - ry + 1) >> 1 : p.Hd;
-  const int Wc = SUB ? (p.Wd - rx + 1) >> 1 : p.Wd;
+  const int Wc = SUB && !ROW ? (p.Wd - rx + 1) >> 1 : p.Wd;
   const int HWc = Hc * Wc;
   const int Pc = SUB ? p.N * HWc : p.P;
   const int ltile = SUB ? (ILV ? tile_n >> 2 : tile_n - p.cls_tile0[cls]) : tile_n;
@@ -96,14 +101,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
     yc = rem / Wc;
     xc = rem - yc * Wc;
     py = SUB ? 2 * yc + ry : yc;
-    px = SUB ? 2 * xc + rx : xc;
+    px = SUB && !ROW ? 2 * xc + rx : xc;
   }
   // taps of this class (all taps outside the class ordering)
   unsigned cls_taps = 0;
   if (SUB) {
     for (int q = 0; q < p.KH * p.KW; ++q) {
       const int qy = q / p.KW, qx = q - qy * p.KW;
-      if ((((ry + p.pad - qy * p.dil) | (rx + p.pad - qx * p.dil)) & 1) == 0) cls_taps |= 1u << q;
+      if ((((ry + p.pad - qy * p.dil) | (ROW ? 0 : rx + p.pad - qx * p.dil)) & 1) == 0) cls_taps |= 1u << q;
     }
   }
   constexpr unsigned OOB = 0x80000000u;
@@ -165,15 +170,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
     }
     l_ky = 0;
     l_kx = 0;
-    vbase = SUB ? pix_base + (unsigned)(yc * p.Ws + xc)
+    vbase = SUB ? pix_base + (unsigned)(yc * p.Ws + (ROW ? 0 : xc))
                 : (DGRAD ? pix_base + (unsigned)(py * p.Ws + px) : pix_base + (unsigned)(py * p.stride * p.Ws + px * p.stride));
   }
   auto fast_voff = [&]() {
     // wave-uniform; in a parity class the source pixel is (yc + (ry + pad - ky*dil)/2, ...), the numerators being even
-    const int rel = SUB ? ((ry + p.pad - l_ky * p.dil) >> 1) * p.Ws + ((rx + p.pad - l_kx * p.dil) >> 1)
+    const int rel = SUB ? ((ry + p.pad - l_ky * p.dil) >> 1) * p.Ws + (ROW ? 0 : (rx + p.pad - l_kx * p.dil) >> 1)
                         : (DGRAD ? (p.pad - l_ky * p.dil) * p.Ws + (p.pad - l_kx * p.dil)
                                  : (l_ky * p.dil - p.pad) * p.Ws + (l_kx * p.dil - p.pad));
-    l_voff = ((valid_mask >> l_tap) & 1u) ? (vbase + (unsigned)rel) * UNIT : OOB;
+    // (ROW: the source column is the lane's own -- (px + pad - kx dil) / 2, even wherever the mask bit is set)
+    const unsigned col = ROW ? (unsigned)((px + p.pad - l_kx * p.dil) >> 1) : 0u;
+    l_voff = ((valid_mask >> l_tap) & 1u) ? (vbase + (unsigned)rel + col) * UNIT : OOB;
   };
   if (SUB && cls_taps != 0) {  // start at the class's first tap
     l_tap = __builtin_ctz(cls_taps);
@@ -601,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvSplitParams
       rem = pp - n * HWc;
       if (SUB) {
         const int cy = rem / Wc;
-        rem = (2 * cy + ry) * p.Wd + 2 * (rem - cy * Wc) + rx;
+        rem = ROW ? (2 * cy + ry) * p.Wd + (rem - cy * Wc) : (2 * cy + ry) * p.Wd + 2 * (rem - cy * Wc) + rx;
       }
     }
     dbase[j] = (size_t)n * p.M * HWd + rem;
@@ -910,6 +917,21 @@ void launch_cfg(const ConvSplitParams& p, int64_t pix0, hipStream_t st) {
     const int c0 = q.cls_tile0[1];
     const bool interleave = mcd_opt(MCD_OPT_DGRAD_INTERLEAVE) != 0;
     if (interleave && q.cls_tile0[2] == 2 * c0 && q.cls_tile0[3] == 3 * c0 && t0 == 4 * c0) q.sub = 2;
+    // row classes (both x-parities in one tile: dense stores, twice the K-steps): measured alone at BASELINE config 2's shapes
+    // (tools/probes/dgrad_s2_ab.py, profiles/r06_dgrad_s2_forms.txt) they win where there is next to no K loop -- the 1 x 1 projections
+    // without an addend, 0.074 -> 0.050 ms at 32 -> 64 -- and lose on the 3 x 3 layers (0.253 -> 0.294 ms at 16 -> 32: those launches
+    // are bound by their short K loops' latency, not by the store pattern).  Option value 2 forces them everywhere (tests).
+    const bool row_auto = interleave && p.KH * p.KW == 1 && p.ep_res == nullptr && p.ep_res16 == nullptr;
+    if (mcd_opt(MCD_OPT_DGRAD_INTERLEAVE) == 2 || row_auto) {
+      q.sub = 3;
+      t0 = 0;
+      for (int c = 0; c < 2; ++c) {
+        q.cls_tile0[c] = t0;
+        t0 += ceil_div(p.N * ((p.Hd - c + 1) / 2) * p.Wd, BN);
+      }
+      q.cls_tile0[2] = q.cls_tile0[3] = q.cls_tile0[4] = t0;
+      n_tiles = t0;
+    }
   }
   dim3 grid(8 * ceil_div(n_tiles, 8) * (p.Mp / BM));
   if (p.src_cb != nullptr)

@@ -10,7 +10,7 @@
   X(BN_V4, 1)                 /* four-pixel forms of the companion-writing BatchNorm apply kernels */                        \
   X(BIGTILE_MIN_SLOTS, 1024)  /* tile slots from which the 4-wave 256 x 128 tile is preferred */                             \
   X(WIDETILE_MIN_SLOTS, 1024) /* ... and the 128 x 256 one */                                                                \
-  X(DGRAD_INTERLEAVE, 1)      /* stride-2 data gradient: the four parity classes of a region on neighbouring tiles */        \
+  X(DGRAD_INTERLEAVE, 1)      /* stride-2 data gradient: 0 classes in turn, 1 interleaved (+ row classes for 1x1), 2 row classes */ \
   X(DGRAD_ADD_LDS, 1)         /* data gradient + addend: the addend's tile staged through LDS (ping-pong kernel) */          \
   X(PACK_BLOCKS, 192)         /* workgroups per (convolution, image) of the table-driven weight pack */                      \
   X(PP_MIN_ROUNDS, 2)         /* fewest whole rounds of 256 x 256 tiles for which the ping-pong kernels take a convolution */ \

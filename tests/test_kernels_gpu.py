@@ -718,6 +718,39 @@ def test_folded_bn_inference_and_predict_tail():
     assert torch.equal(lab1.cpu(), z1.argmax(1).to(torch.uint8))
 
 
+@pytest.mark.parametrize("case", [(16, 32, 3, 21, 27, 2), (32, 64, 3, 20, 28, 2), (32, 64, 1, 20, 28, 2), (32, 64, 1, 21, 27, 2), (64, 128, 3, 13, 19, 3),
+                                  (64, 128, 1, 12, 20, 2), (128, 256, 3, 33, 40, 2), (32, 64, 3, 64, 96, 4)], ids=lambda c: "x".join(map(str, c)))
+def test_stride2_data_gradient_forms_are_bitwise(case, libopt):
+    """the three tilings of a stride-2 data gradient (library option DGRAD_INTERLEAVE: 0 = the four parity classes one after the other,
+    1 = interleaved on neighbouring tiles, 2 = ROW classes: both x-parities of a row in one tile, dense stores) sum the same products in
+    the same order: bit for bit one result -- from the fp32 operand, from the pre-split companion, and with the other gradient of the
+    same tensor added in the epilogue; and that result is the fp64 data gradient within the split arithmetic's error"""
+    dev = _dev()
+    from mcdseg import ops
+    cin, cout, k, h, w, n = case
+    x, wt, _, s, pad, d = _conv_inputs((cin, cout, k, 2, 1, h, w, n, False), 21)
+    desc = ops.conv_desc(x.shape, wt.shape, s, pad, d)
+    packed = ops.PackedWeights()
+    wf, wd, _ = packed.get(wt.to(dev), desc)
+    gy = torch.randn(n, cout, desc.Ho, desc.Wo, generator=torch.Generator().manual_seed(22)).to(dev)
+    other = torch.randn(x.shape, generator=torch.Generator().manual_seed(23)).to(dev)
+    gy_cb, gy_bound = ops.split_companion(gy)
+    got = {}
+    for form in (0, 1, 2):
+        libopt(DGRAD_INTERLEAVE=form)
+        got[form] = (ops._conv_dgrad(desc, gy, wd, w_bound=packed.w_bound),
+                     ops._conv_dgrad(desc, None, wd, dy_cb=gy_cb, dy_bound=gy_bound, w_bound=packed.w_bound) if gy_cb is not None else None,
+                     ops._conv_dgrad(desc, gy, wd, dy_cb=gy_cb, dy_bound=gy_bound, w_bound=packed.w_bound, addend=other))
+    for form in (1, 2):
+        for a, b, what in zip(got[0], got[form], ("fp32 operand", "companion", "with addend")):
+            if a is not None:
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), "form %d, %s" % (form, what)
+    x64 = x.double().requires_grad_()
+    ref = torch.autograd.grad(F.conv2d(x64, wt.double(), None, stride=2, padding=pad), x64, gy.double().cpu())[0]
+    _assert_close(got[2][0], ref, 2e-5, "dgrad")
+    _assert_close(got[2][2], ref + other.double().cpu(), 2e-5, "dgrad + addend")
+
+
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if min(c[0], c[1]) >= 16], ids=lambda c: "x".join(map(str, c[:5])))
 def test_conv_split_accuracy(case, monkeypatch):
     """split-precision paths (f16x3: two scaled fp16 pieces, three cross terms; bf16x6: three bf16 pieces, six terms): against

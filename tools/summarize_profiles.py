@@ -36,14 +36,19 @@ def counters(path, counter):
     return agg
 
 
+def newest(pattern):
+    """a tag collected twice leaves both runs' files in gpurun_out/ (gpurun merges, it does not replace): the latest run counts"""
+    return sorted(glob.glob(pattern), key=os.path.getmtime, reverse=True)
+
+
 def main(tag):
     out = os.path.join(ROOT, "profiles")
     src = os.path.join(ROOT, "gpurun_out")
-    stats = glob.glob(os.path.join(src, tag + "_stats", "*", "*kernel_stats.csv"))
+    stats = newest(os.path.join(src, tag + "_stats", "*", "*kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(out, tag + "_bench_kernel_stats.csv"))
-    f = glob.glob(os.path.join(src, tag + "_fetch", "*", "*counter_collection.csv"))
-    w = glob.glob(os.path.join(src, tag + "_write", "*", "*counter_collection.csv"))
+    f = newest(os.path.join(src, tag + "_fetch", "*", "*counter_collection.csv"))
+    w = newest(os.path.join(src, tag + "_write", "*", "*counter_collection.csv"))
     if f and w:
         fetch, write = counters(f[0], "FETCH_SIZE"), counters(w[0], "WRITE_SIZE")
         table = {}
@@ -61,7 +66,7 @@ def main(tag):
                                           if os.path.exists(os.path.join(src, tag + "_fingerprint.txt")) else _lib.source_fingerprint()),
                    "units": "FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes = (2*FETCH + WRITE) * 1024 (gfx950 FETCH_SIZE halving)",
                    "kernels": table}, open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
-    q = glob.glob(os.path.join(src, tag + "_sq", "*", "*counter_collection.csv"))
+    q = newest(os.path.join(src, tag + "_sq", "*", "*counter_collection.csv"))
     if q:
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(q[0])):
