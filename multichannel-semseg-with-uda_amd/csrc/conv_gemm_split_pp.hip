@@ -5,7 +5,7 @@
 // Why.  In conv_gemm_split_kernel a wave's K-step is a serial chain -- 12 fragment reads, 6 LDS-DMA issues with their scalar
 // bookkeeping, 24 matrix instructions, a counted wait, the workgroup barrier -- and the two waves that share a SIMD belong to
 // two independent workgroups, so nothing keeps one of them in its matrix phase while the other reads: measured matrix pipe
-// busy 0.61, 49 % of the wave cycles waiting to issue (profiles/r03zb_pmc_sq.json).  Here the SIMD partners are waves w and
+// busy 0.61, 49 % of the wave cycles waiting to issue (profiles/history/r03zb_pmc_sq.json).  Here the SIMD partners are waves w and
 // w + 4 of ONE workgroup and the workgroup's barriers alternate their roles (MI355X_MICROARCH.md "Two waves per SIMD";
 // cdna_hip_programming.md, the 8-phase GEMM template): between two barriers group 0 (waves 0-3, output rows 0-127) multiplies
 // -- nothing but 24 MFMAs -- while group 1 (waves 4-7, rows 128-255) reads its fragments of the same K-step, issues its share

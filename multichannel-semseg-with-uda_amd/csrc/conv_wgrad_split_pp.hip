@@ -609,7 +609,7 @@ int pp_compute_units() {
 // Two decompositions (MCDSEG_WGRAD_PP: 1 = stream-K, 2 or unset = the slab plan; 0 = this kernel off):
 //   stream-K   the flattened (tile, K-step) range in nwg equal pieces -- perfect balance, but the workgroups of an XCD sit at 32 different
 //              K positions, so every tile streams its operands through the fabric by itself: measured 2 x FETCH_SIZE = 2.9 GB per launch
-//              for 0.22 GB of algorithmic bytes (profiles/r04z_pmc_traffic.json), and the rate falls with the batch (430 TFLOP/s at
+//              for 0.22 GB of algorithmic bytes (profiles/history/r04z_pmc_traffic.json), and the rate falls with the batch (430 TFLOP/s at
 //              N = 8, 398 at 16, 382 at 32) as the operands outgrow the Infinity Cache;
 //   slab plan  the K range is cut into `slabs` = floor(rounds * CUs / tiles) slabs and item i = (slab i / tiles, tile i % tiles): the
 //              workgroups of one XCD hold consecutive items, i.e. the tiles (taps, channel blocks) of ONE slab, walk the same pixels

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn raw rocprofv3 output merged into gpurun_out/ into the small, committed summaries under profiles/.
 
-    python tools/summarize_profiles.py r01c      # reads gpurun_out/r01c_{stats,fetch,write}, writes profiles/r01c_*
+    python tools/summarize_profiles.py r01c      # reads gpurun_out/r01c_{stats,fetch,write}, writes profiles/history/r01c_*
 
 * <tag>_kernel_stats.csv : rocprofv3 --kernel-trace --stats summary of `bench.py --steps 2 --warmup 1` (verbatim)
 * <tag>_pmc_sq.json      : per kernel MFMA-pipe busy fraction and wave-cycle breakdown from gpurun_out/<tag>_sq (SQ counters)
