@@ -107,7 +107,7 @@ def main(argv=None):
         dec = model_dec.module if hasattr(model_dec, "module") else model_dec
         std_semseg, std_depth = dec.get_task_weights()
         if run.is_main:
-            print("std_semseg: %.4f, std_depth: %.4f" % (float(std_semseg), float(std_depth)))
+            print("std_semseg: %.4f, std_depth: %.4f" % (float(std_semseg.reshape(-1)[0]), float(std_depth.reshape(-1)[0])))  # (1-element arrays, as the reference returns them)
             print("Epoch [%d] DLoss: %.4f CLoss: %.4f" % (epoch, sums["d"], sums["c"]))
         for name, key in (("c_loss", "c"), ("d_loss", "d"), ("src_semseg_loss", "seg"), ("src_depth_loss", "sdep"),
                           ("tgt_depth_loss", "tdep")):
