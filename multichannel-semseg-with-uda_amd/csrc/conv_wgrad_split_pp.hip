@@ -62,6 +62,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams 
   constexpr int STAGE = 2 * NP * UNIT;  // [operand: dZ, X][piece]
   constexpr int NS = 3;
   static_assert(NS * STAGE <= 160 * 1024, "LDS");
+  // One-term arithmetic, policy SplitF16x1D (the second piece of neither operand is ever moved): the idle piece-1 slots of the three
+  // stages are three MORE stages -- logical stage c sits at (c % 3) * STAGE + (c / 3) * UNIT of both operands -- and a barrier interval
+  // takes TWO K-steps: 24 transposing reads and 16 matrix instructions per wave and phase instead of 12 and 8, the LDS-DMAs four to five
+  // K-steps ahead instead of two.  With one term a K-step is a third of the matrix work on half the bytes: the two barriers per step and
+  // the short prefetch held the kernel at 0.26-0.38 of the pipe on every layer of BASELINE config 5, 1 x 1 or 3 x 3
+  // (profiles/r06_wgrad_f16x1_shapes.txt).  The same stages in the same order: the same sums, bit for bit (SplitF16x1 keeps the
+  // one-step loop: option WGRAD_PP_DEEP = 0, tests).
+  constexpr bool DEEP = P::KDEEP == 2 && P::NPU == 1 && NP == 2;
+  constexpr int PRO = DEEP ? 4 : 2;  // K-steps the prologue puts in flight
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
 
   const int t = threadIdx.x;
@@ -176,6 +185,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams 
     int l_n = k0 / ntiles;
     int l_ty = (k0 - l_n * ntiles) / p.tiles_x;
     int l_tx = k0 - l_n * ntiles - l_ty * p.tiles_x;
+    auto stage_off = [](int c) { return DEEP ? (c < NS ? c * STAGE : (c - NS) * STAGE + UNIT) : c * STAGE; };
     auto issue = [&](int stage) {
 #if defined(__HIP_DEVICE_COMPILE__)
       if (dma_on) {
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams 
         const int soff = ((unsigned)iy < (unsigned)sH) ? (sbase + iy * sW + ux) * 16 + bias : 0x7FFFFFFF;
 #pragma unroll
         for (int d = 0; d < NDMA; ++d)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(unit_lds + stage * STAGE + d * DSTR), 16,
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(unit_lds + stage_off(stage) + d * DSTR), 16,
                                                    colok ? vconst[d] : OOB, soff, 0, 0);
       }
 #else
@@ -213,61 +223,125 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_pp_kernel(WgradPpParams 
 
     const int nsteps = k1 - k0;
     issue(0);
-    if (nsteps > 1) {
-      advance();
-      issue(1);
-    }
+#pragma unroll
+    for (int a = 1; a < PRO; ++a)
+      if (nsteps > a) {
+        advance();
+        issue(a);
+      }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (grp_id == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1 runs one barrier behind group 0 to the end of the K loop
 
-    frag fa[NP][WM], fb[NP][WN];
-    int cur = 0, nxt2 = 2;
-    for (int s = 0; s < nsteps; ++s) {
-      // ---- read phase (the partner group multiplies meanwhile)
-      const unsigned base_a = smem_lds + (unsigned)(cur * STAGE + a_lane), base_b = smem_lds + (unsigned)(cur * STAGE + b_lane);
-      // (compile-time offsets: operand, piece, 32-row block, second quad)
-#define MCD_A_FRAG(PC, I) \
-      if constexpr ((PC) < P::NPU) \
-        fa[PC][I] = frag_of(base_a, std::integral_constant<int, (PC) * UNIT + (I) * 256>{}, std::integral_constant<int, (PC) * UNIT + (I) * 256 + 64>{});
-#define MCD_B_FRAG(PC, J) \
-      if constexpr ((PC) < P::NPU) \
-        fb[PC][J] = frag_of(base_b, std::integral_constant<int, (NP + (PC)) * UNIT + (J) * 256>{}, std::integral_constant<int, (NP + (PC)) * UNIT + (J) * 256 + 64>{});
-      MCD_A_FRAG(0, 0) MCD_A_FRAG(0, 1) MCD_A_FRAG(0, 2) MCD_A_FRAG(0, 3) MCD_B_FRAG(0, 0) MCD_B_FRAG(0, 1)
-      MCD_A_FRAG(1, 0) MCD_A_FRAG(1, 1) MCD_A_FRAG(1, 2) MCD_A_FRAG(1, 3) MCD_B_FRAG(1, 0) MCD_B_FRAG(1, 1)
-#undef MCD_A_FRAG
-#undef MCD_B_FRAG
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 2 < nsteps) {
-        advance();
-        issue(nxt2);
-        // this wave's share of stage s+1 has landed (the share of stage s+2 stays in flight) and its fragment reads are back
-        if (dma_on)
-          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA) : "memory");
-        else
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      }
-      // (the reads above have completed: re-define their registers behind the wait)
+    if constexpr (DEEP) {
+      // ---- two K-steps per barrier interval: interval t = K-steps 2t, 2t + 1 = logical stages 2 dcur, 2 dcur + 1
+      const int nint = (nsteps + 1) >> 1;
+      frag fa2[2][WM], fb2[2][WN];
+      int dcur = 0, dnxt = 2;
+      for (int t = 0; t < nint; ++t) {
+        const bool has2 = 2 * t + 1 < nsteps;  // (uniform: an odd slab ends on a single K-step; the second stage's reads are then unused)
+        const unsigned off0 = (unsigned)stage_off(2 * dcur), off1 = (unsigned)stage_off(2 * dcur + 1);
+        const unsigned a0 = smem_lds + off0 + (unsigned)a_lane, b0 = smem_lds + off0 + (unsigned)b_lane;
+        const unsigned a1 = smem_lds + off1 + (unsigned)a_lane, b1 = smem_lds + off1 + (unsigned)b_lane;
+#define MCD_A2(U, BASE, I) fa2[U][I] = frag_of(BASE, std::integral_constant<int, (I) * 256>{}, std::integral_constant<int, (I) * 256 + 64>{});
+#define MCD_B2(U, BASE, J) \
+        fb2[U][J] = frag_of(BASE, std::integral_constant<int, NP * UNIT + (J) * 256>{}, std::integral_constant<int, NP * UNIT + (J) * 256 + 64>{});
+        MCD_A2(0, a0, 0) MCD_A2(0, a0, 1) MCD_A2(0, a0, 2) MCD_A2(0, a0, 3) MCD_B2(0, b0, 0) MCD_B2(0, b0, 1)
+        MCD_A2(1, a1, 0) MCD_A2(1, a1, 1) MCD_A2(1, a1, 2) MCD_A2(1, a1, 3) MCD_B2(1, b1, 0) MCD_B2(1, b1, 1)
+#undef MCD_A2
+#undef MCD_B2
+        __builtin_amdgcn_sched_barrier(0);
+        const int nx = 2 * (t + 2);  // first K-step of the interval after next: into the stages the previous interval read
+        if (nx + 1 < nsteps) {
+          advance();
+          issue(2 * dnxt);
+          advance();
+          issue(2 * dnxt + 1);
+          // this wave's shares of the next interval's two stages have landed (those just issued stay in flight); its reads are back
+          if (dma_on)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NDMA) : "memory");
+          else
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+          if (nx < nsteps) {
+            advance();
+            issue(2 * dnxt);
+          }
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
 #pragma unroll
-      for (int pc = 0; pc < P::NPU; ++pc) {
+        for (int u = 0; u < 2; ++u) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) asm volatile("" : "+v"(fa[pc][i]));
+          for (int i = 0; i < WM; ++i) asm volatile("" : "+v"(fa2[u][i]));
 #pragma unroll
-        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(fb[pc][j]));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- matrix phase (the partner group reads meanwhile): term-major, the sums and their order per tile of conv_wgrad_split_tr_kernel
-#pragma unroll
-      for (int tm = 0; tm < P::NTERMS; ++tm)
+          for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(fb2[u][j]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- matrix phase: K-step 2t into every tile, then K-step 2t + 1 -- per tile the order of the one-step loop
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-          for (int j = 0; j < WN; ++j) acc[i][j] = P::mfma(fa[P::TA[tm]][i], fb[P::TB[tm]][j], acc[i][j]);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_barrier" ::: "memory");
-      cur = cur == 2 ? 0 : cur + 1;
-      nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+          for (int j = 0; j < WN; ++j) acc[i][j] = P::mfma(fa2[0][i], fb2[0][j], acc[i][j]);
+        if (has2) {
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[i][j] = P::mfma(fa2[1][i], fb2[1][j], acc[i][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        dcur = dcur == 2 ? 0 : dcur + 1;
+        dnxt = dnxt == 2 ? 0 : dnxt + 1;
+      }
+    } else {
+      frag fa[NP][WM], fb[NP][WN];
+      int cur = 0, nxt2 = 2;
+      for (int s = 0; s < nsteps; ++s) {
+        // ---- read phase (the partner group multiplies meanwhile)
+        const unsigned base_a = smem_lds + (unsigned)(stage_off(cur) + a_lane), base_b = smem_lds + (unsigned)(stage_off(cur) + b_lane);
+        // (compile-time offsets: operand, piece, 32-row block, second quad)
+#define MCD_A_FRAG(PC, I) \
+        if constexpr ((PC) < P::NPU) \
+          fa[PC][I] = frag_of(base_a, std::integral_constant<int, (PC) * UNIT + (I) * 256>{}, std::integral_constant<int, (PC) * UNIT + (I) * 256 + 64>{});
+#define MCD_B_FRAG(PC, J) \
+        if constexpr ((PC) < P::NPU) \
+          fb[PC][J] = frag_of(base_b, std::integral_constant<int, (NP + (PC)) * UNIT + (J) * 256>{}, std::integral_constant<int, (NP + (PC)) * UNIT + (J) * 256 + 64>{});
+        MCD_A_FRAG(0, 0) MCD_A_FRAG(0, 1) MCD_A_FRAG(0, 2) MCD_A_FRAG(0, 3) MCD_B_FRAG(0, 0) MCD_B_FRAG(0, 1)
+        MCD_A_FRAG(1, 0) MCD_A_FRAG(1, 1) MCD_A_FRAG(1, 2) MCD_A_FRAG(1, 3) MCD_B_FRAG(1, 0) MCD_B_FRAG(1, 1)
+#undef MCD_A_FRAG
+#undef MCD_B_FRAG
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < nsteps) {
+          advance();
+          issue(nxt2);
+          // this wave's share of stage s+1 has landed (the share of stage s+2 stays in flight) and its fragment reads are back
+          if (dma_on)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA) : "memory");
+          else
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        // (the reads above have completed: re-define their registers behind the wait)
+#pragma unroll
+        for (int pc = 0; pc < P::NPU; ++pc) {
+#pragma unroll
+          for (int i = 0; i < WM; ++i) asm volatile("" : "+v"(fa[pc][i]));
+#pragma unroll
+          for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(fb[pc][j]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- matrix phase (the partner group reads meanwhile): term-major, the sums and their order per tile of conv_wgrad_split_tr_kernel
+#pragma unroll
+        for (int tm = 0; tm < P::NTERMS; ++tm)
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[i][j] = P::mfma(fa[P::TA[tm]][i], fb[P::TB[tm]][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+      }
     }
     if (grp_id == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's last matrix-phase barrier: the groups are level again
 
@@ -680,7 +754,9 @@ int mcdseg_internal_wgrad_pp_launch(const mcdseg_conv_desc* d, int math, const v
   p.x_piece_stride = math == MCDSEG_MATH_F16X1 ? 0 : (long long)(d->Ncb ? d->Ncb : d->N) * d->Cin * d->H * d->W * 2;  // (F16X1 reads piece 0 only)
   p.dy_piece_stride = math == MCDSEG_MATH_F16X1 ? 0 : (long long)(d->Ncb ? d->Ncb : d->N) * d->Cout * d->Ho * d->Wo * 2;
   const dim3 grid((unsigned)(8 * ceil_div(nwg, 8)));
-  if (math == MCDSEG_MATH_F16X1)
+  if (math == MCDSEG_MATH_F16X1 && mcd_opt(MCD_OPT_WGRAD_PP_DEEP) != 0)
+    hipLaunchKernelGGL(conv_wgrad_split_pp_kernel<SplitF16x1D>, grid, dim3(512), 0, st, p);  // six logical stages (see the kernel)
+  else if (math == MCDSEG_MATH_F16X1)
     hipLaunchKernelGGL(conv_wgrad_split_pp_kernel<SplitF16x1>, grid, dim3(512), 0, st, p);
   else
     hipLaunchKernelGGL(conv_wgrad_split_pp_kernel<SplitF16x3>, grid, dim3(512), 0, st, p);

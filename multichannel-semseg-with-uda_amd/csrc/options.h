@@ -29,6 +29,7 @@
   X(WGRAD_PP_CUS, 0)          /* weight gradient planned for this many CUs (0 = PP_CUS, else the device's) */                \
   X(WGRAD_PP, 2)              /* ping-pong weight gradient: 0 off, 1 stream-K, 2 the slab plan */                            \
   X(WGRAD_PP3, 1)             /* row-of-taps ping-pong weight gradient */                                                    \
+  X(WGRAD_PP_DEEP, 1)         /* one-term arithmetic: six logical LDS stages in the ping-pong weight gradient (SplitF16x1D) */ \
   X(UP8_LOSS_DMA, 1)          /* fused up-sampler + loss: the LDS-DMA kernel (0 = register-staged) */                        \
   X(UP8_BAND_ROWS, -1)        /* up-sampler backward: 0 = two separate kernels, n = rows per band, -1 = the plan's own */
 

@@ -808,7 +808,10 @@ def wgrad_split_kernel_name(d, have_cb):
     if v == 15:  # csrc/conv_wgrad_thin_tr.hip: <channel groups of the input, row tiles, column tiles, tile rows> (no policy argument)
         cfg = lib().mcdseg_conv_wgrad_thin_tr_config(ctypes.byref(d))  # (the library's own choice, not a restatement of it)
         return "conv_wgrad_thin_tr_kernel<%d, %d, %d, %d>" % (cfg // 1000000, cfg // 10000 % 100, cfg // 100 % 100, cfg % 100)
-    return _WGRAD_NAMES.get(v, "conv_wgrad<%s>") % POLICY[CONV_MATH]
+    policy = POLICY[CONV_MATH]
+    if v == 17 and CONV_MATH == "f16x1" and get_option("WGRAD_PP_DEEP"):
+        policy = "SplitF16x1D"  # six logical stages (csrc/conv_wgrad_split_pp.hip)
+    return _WGRAD_NAMES.get(v, "conv_wgrad<%s>") % policy
 
 
 def _wgrad_thin_tr(desc):

@@ -56,7 +56,7 @@ def device():
 
 LIB_OPTIONS = ("BN_STATS_ONE", "BN_REVERSE", "BN_V4", "BIGTILE_MIN_SLOTS", "WIDETILE_MIN_SLOTS", "DGRAD_INTERLEAVE", "DGRAD_ADD_LDS", "PACK_BLOCKS",
                "PP_MIN_ROUNDS", "PP_CUS", "PINGPONG", "PP_WIDE_FILL", "PP_WIDE128", "PP_DEEP", "THIN_WINDOW", "WGRAD_WGS", "WGRAD_THIN_TR", "WGRAD_TR64",
-               "WGRAD_TR", "WGRAD_BIG", "WGRAD_TWOTAP", "WGRAD_PP_CUS", "WGRAD_PP", "WGRAD_PP3", "UP8_LOSS_DMA", "UP8_BAND_ROWS")
+               "WGRAD_TR", "WGRAD_BIG", "WGRAD_TWOTAP", "WGRAD_PP_CUS", "WGRAD_PP", "WGRAD_PP3", "WGRAD_PP_DEEP", "UP8_LOSS_DMA", "UP8_BAND_ROWS")
 
 
 @pytest.fixture

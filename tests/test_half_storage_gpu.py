@@ -323,3 +323,38 @@ def test_mfnet_and_multitask_models_run_in_the_two_byte_chain():
     for model in ("MFNet-ScoreAddFusion", "multitask"):
         assert got[(model, "chain")][0] <= 1.25 * got[(model, "two")][0], got
         assert got[(model, "chain")][1] <= 3e-2, got
+
+
+@pytest.mark.parametrize("case", [(256, 256, 3, 1, 2, 60, 80, 16), (1024, 256, 1, 1, 1, 90, 160, 4), (512, 512, 3, 1, 4, 24, 32, 6), (392, 504, 3, 1, 4, 29, 37, 8),
+                                  (256, 400, 3, 2, 1, 63, 81, 6), (256, 256, 1, 1, 1, 8, 40, 2)], ids=lambda c: "x".join(map(str, c)))
+def test_six_stage_weight_gradient_is_bitwise_the_three_stage_kernel(case, monkeypatch, libopt):
+    """the one-term ping-pong weight gradient with the idle piece-1 LDS slots used as three more stages (``conv_wgrad_split_pp_kernel<SplitF16x1D>``:
+    the DMAs five K-steps ahead instead of two) against the three-stage kernel (option WGRAD_PP_DEEP = 0): the same stages in the same
+    order, the same sums bit for bit -- also where a slab holds fewer K-steps than the pipeline is deep (the last case); and both are the
+    fp64 weight gradient within the one-term arithmetic's error"""
+    dev = _dev()
+    import ctypes
+    from mcdseg import ops
+    monkeypatch.setattr(ops, "CONV_MATH", "f16x1")
+    cin, cout, k, s, d, h, w, n = case
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(n, cin, h, w, generator=g).to(dev)
+    desc = ops.conv_desc(x.shape, (cout, cin, k, k), s, d * (k // 2), d)
+    gy = torch.randn(n, cout, desc.Ho, desc.Wo, generator=g).to(dev)
+    x_cb, x_bound = ops.split_companion(x)
+    gy_cb, gy_bound = ops.split_companion(gy)
+    if ops.lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), ops.MATH_ID["f16x1"], 1) != 17:
+        pytest.skip("not a ping-pong weight-gradient geometry")
+    got = {}
+    for deep in (1, 0):
+        libopt(WGRAD_PP_DEEP=deep)
+        assert ("SplitF16x1D" in ops.wgrad_split_kernel_name(desc, True)) == bool(deep)
+        got[deep] = ops._conv_wgrad(desc, x, gy, x_cb, gy_cb, x_bound, gy_bound)
+        again = ops._conv_wgrad(desc, x, gy, x_cb, gy_cb, x_bound, gy_bound)
+        assert torch.equal(got[deep].view(torch.int32), again.view(torch.int32))
+    assert torch.equal(got[1].view(torch.int32), got[0].view(torch.int32))
+    x64 = x.double().cpu()
+    w64 = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    ref = torch.autograd.grad(torch.nn.functional.conv2d(x64, w64, None, stride=s, padding=d * (k // 2), dilation=d), w64, gy.double().cpu())[0]
+    err = float((got[1].double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-3, err  # (operands rounded to 11 bits)
