@@ -326,12 +326,12 @@ def test_mfnet_and_multitask_models_run_in_the_two_byte_chain():
 
 
 @pytest.mark.parametrize("case", [(256, 256, 3, 1, 2, 60, 80, 16), (1024, 256, 1, 1, 1, 90, 160, 4), (512, 512, 3, 1, 4, 24, 32, 6), (392, 504, 3, 1, 4, 29, 37, 8),
-                                  (256, 400, 3, 2, 1, 63, 81, 6), (256, 256, 1, 1, 1, 8, 40, 2)], ids=lambda c: "x".join(map(str, c)))
+                                  (256, 400, 3, 2, 1, 63, 81, 6), (256, 256, 1, 1, 1, 33, 1000, 4)], ids=lambda c: "x".join(map(str, c)))
 def test_six_stage_weight_gradient_is_bitwise_the_three_stage_kernel(case, monkeypatch, libopt):
     """the one-term ping-pong weight gradient with the idle piece-1 LDS slots used as three more stages (``conv_wgrad_split_pp_kernel<SplitF16x1D>``:
     the DMAs five K-steps ahead instead of two) against the three-stage kernel (option WGRAD_PP_DEEP = 0): the same stages in the same
-    order, the same sums bit for bit -- also where a slab holds fewer K-steps than the pipeline is deep (the last case); and both are the
-    fp64 weight gradient within the one-term arithmetic's error"""
+    order, the same sums bit for bit -- slabs of an odd number of K-steps (the second case: 57; the last: 33) end on a single-step interval;
+    and both are the fp64 weight gradient within the one-term arithmetic's error"""
     dev = _dev()
     import ctypes
     from mcdseg import ops
@@ -344,7 +344,7 @@ def test_six_stage_weight_gradient_is_bitwise_the_three_stage_kernel(case, monke
     x_cb, x_bound = ops.split_companion(x)
     gy_cb, gy_bound = ops.split_companion(gy)
     if ops.lib().mcdseg_conv_wgrad_variant(ctypes.byref(desc), ops.MATH_ID["f16x1"], 1) != 17:
-        pytest.skip("not a ping-pong weight-gradient geometry")
+        pytest.fail("not a ping-pong weight-gradient geometry")
     got = {}
     for deep in (1, 0):
         libopt(WGRAD_PP_DEEP=deep)
