@@ -398,6 +398,9 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
                   mcd_f16x4 o;
 #pragma unroll
                   for (int k = 0; k < 4; ++k) o[k] = (_Float16)(v[k] * inv_zs);
+#if defined(MCD_ABLATE) && (MCD_ABLATE & 256)  // timing only (never shipped): the 16-bit results of one pixel column in 32 only
+                  if (l31 == 0)
+#endif
                   *reinterpret_cast<mcd_f16x4*>(dst) = o;
                 }
               }
@@ -475,7 +478,11 @@ __global__ __launch_bounds__(512, (WM * WN <= 4 ? 4 : 2)) void conv_gemm_split_p
       }
     }
   }
+#if defined(MCD_ABLATE) && (MCD_ABLATE & 512)  // timing only (never shipped): no BatchNorm partial rows
+  if (false) {
+#else
   if (!DGRAD && p.stats != nullptr) {
+#endif
     int cntw = p.P - p_wave;
     cntw = cntw < 0 ? 0 : (cntw > 32 * WN ? 32 * WN : cntw);
     const float inv = cntw > 0 ? 1.f / (float)cntw : 0.f;
