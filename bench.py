@@ -535,6 +535,8 @@ def _main():
                 "note": "HIP events on the compute stream around every all-reduce (or around the wait for a bucketed one): the time that "
                         "stream stands still for the exchange, rank 0"}
     coll = coll_summary(collectives, args.steps)
+    # (the name the JSON line gives the exchange: RCCL is torch.distributed's "nccl" backend on ROCm; tests on one GPU use gloo)
+    backend_name = {"nccl": "rccl"}.get(torch.distributed.get_backend(), torch.distributed.get_backend()) if mdist.is_distributed() else "none"
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if mdist.is_distributed():
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
@@ -717,8 +719,8 @@ def _main():
                                    % (args.net, args.input_ch, args.batch, args.height, args.width),
                        "pairs_per_gpu": args.batch, "global_pairs": args.batch * world, "parallelism": "dp%d" % world,
                        "collectives": ("none (single process)" if not mdist.is_distributed() else
-                                       ("rccl (forced, 1 rank)" if world == 1 else "rccl all-reduce of the flat gradient buffer over %d ranks, one rank "
-                                        "per GPU%s" % (world, ", bucketed during backward (MCDSEG_DP_OVERLAP=1)" if os.environ.get("MCDSEG_DP_OVERLAP") == "1" else ""))),
+                                       ("%s (forced, 1 rank)" % backend_name if world == 1 else "%s all-reduce of the flat gradient buffer over %d ranks, one rank "
+                                        "per GPU%s" % (backend_name, world, ", bucketed during backward (MCDSEG_DP_OVERLAP=1)" if os.environ.get("MCDSEG_DP_OVERLAP") == "1" else ""))),
                        "streams": {"0": "one stream", "1": "weight gradients on a side stream beside their data gradient",
                                    "2": "weight gradients of the trunk on a side stream, joined when each backward pass ends (MCDSEG_OVERLAP_WGRAD=2); "
                                         "the timer_steps run them on the main stream, so every HIP-event pair brackets a kernel running alone"}[ops.OVERLAP_WGRAD],
