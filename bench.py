@@ -537,6 +537,8 @@ def _main():
     coll = coll_summary(collectives, args.steps)
     # (the name the JSON line gives the exchange: RCCL is torch.distributed's "nccl" backend on ROCm; tests on one GPU use gloo)
     backend_name = {"nccl": "rccl"}.get(torch.distributed.get_backend(), torch.distributed.get_backend()) if mdist.is_distributed() else "none"
+    if mdist.is_distributed() and mdist.native_comm() is not None:
+        backend_name = "rccl through the C ABI (mcdseg_allreduce)"  # MCDSEG_NATIVE_RCCL=1
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if mdist.is_distributed():
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)

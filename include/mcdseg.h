@@ -32,6 +32,19 @@ extern "C" {
 int mcdseg_version(void);
 const char* mcdseg_last_error(void);
 
+/* Data parallelism (mcdseg_allreduce(buf, count, comm, stream) over RCCL): what the reference gets from
+ * torch.nn.DataParallel's gradient reduction (/root/reference/models/model_util.py:283-284).  A communicator of the library's own:
+ * rank 0 draws an id (mcdseg_comm_unique_id: MCDSEG_COMM_ID_BYTES bytes) and hands it to the other ranks by any means (the host side:
+ * a broadcast over the process group it already has), every rank calls mcdseg_comm_init (collective); mcdseg_allreduce sums `count`
+ * fp32 values in place over the ranks, enqueued on `stream` -- asynchronous, no host synchronisation, like every other entry point.
+ * RCCL is bound at run time (the librccl the process has loaded already -- PyTorch's -- else librccl.so.1 on the loader's path):
+ * the library does not link it, and returns -38 (ENOSYS) where there is none.  csrc/comm.hip. */
+#define MCDSEG_COMM_ID_BYTES 128
+int mcdseg_comm_unique_id(void* id128);
+int mcdseg_comm_init(void** comm, int32_t nranks, const void* id128, int32_t rank);
+int mcdseg_comm_destroy(void* comm);
+int mcdseg_allreduce(float* buf, int64_t count, void* comm, void* stream);
+
 /* Plan / development options (tile choices, launch plans, kernel forms: csrc/options.h lists them with their defaults).  The library
  * never reads the process environment: whoever wants another plan says so through this call.  The table is process-wide (a backward
  * pass runs on other threads than the forward pass that built its graph) and read at every launch; a name may carry the "MCDSEG_"

@@ -31,6 +31,10 @@ _SIGNATURES = {
     "mcdseg_option_name": (ctypes.c_char_p, [c_i32]),
     "mcdseg_set_option": (c_int, [ctypes.c_char_p, c_i64]),
     "mcdseg_get_option": (c_int, [ctypes.c_char_p, _P(c_i64), _P(c_i64)]),
+    "mcdseg_comm_unique_id": (c_int, [c_void_p]),
+    "mcdseg_comm_init": (c_int, [_P(c_void_p), c_i32, c_void_p, c_i32]),
+    "mcdseg_comm_destroy": (c_int, [c_void_p]),
+    "mcdseg_allreduce": (c_int, [c_void_p, c_i64, c_void_p, c_void_p]),
     "mcdseg_conv_packed_dims": (c_int, [_P(ConvDesc), _P(c_i32), _P(c_i32), _P(c_i32), _P(c_i32)]),
     "mcdseg_conv_pack_weights": (c_int, [_P(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcdseg_conv_stat_rows": (c_i64, [_P(ConvDesc)]),

@@ -72,11 +72,54 @@ class _timed_collective:
             COLLECTIVE_EVENTS.append((self.nbytes, self.t0, self.t1))
 
 
+# MCDSEG_NATIVE_RCCL=1: the gradient exchange through the library's own communicator (include/mcdseg.h: mcdseg_comm_init /
+# mcdseg_allreduce, csrc/comm.hip) instead of torch.distributed's -- RCCL called from the C ABI on the stream the caller names, no
+# ProcessGroup stream in between.  The process group stays for what it is good at: the rendezvous (the communicator's id travels over
+# it), barriers, the scalar exchanges.  Off by default: a one-GPU box can prove the path with one rank only
+# (tests/test_trainers_gpu.py::test_native_rccl_allreduce_one_rank), RCCL refusing two ranks on one device.
+NATIVE_RCCL = os.environ.get("MCDSEG_NATIVE_RCCL", "0") == "1"
+_NATIVE = {"comm": None, "stream": None}
+
+
+def native_comm():
+    """the library's communicator over all ranks of the process group (created on first use: collective), or None"""
+    if not (NATIVE_RCCL and is_distributed() and torch.cuda.is_available()):
+        return None
+    if _NATIVE["comm"] is None:
+        import ctypes
+        from ._lib import check, lib
+        L = lib()
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank() == 0:
+            buf = (ctypes.c_ubyte * 128)()
+            check(L.mcdseg_comm_unique_id(buf), "comm_unique_id")
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if dist.get_world_size() > 1:  # the id travels over the process group the ranks already share
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = ident.to(dev)
+            dist.broadcast(t, src=0)
+            ident = t.cpu()
+        raw = (ctypes.c_ubyte * 128)(*ident.tolist())
+        comm = ctypes.c_void_p()
+        check(L.mcdseg_comm_init(ctypes.byref(comm), dist.get_world_size(), raw, dist.get_rank()), "comm_init")
+        _NATIVE["comm"] = comm
+    return _NATIVE["comm"]
+
+
+def _native_all_reduce(flat, stream):
+    from ._lib import check, lib
+    assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+    check(lib().mcdseg_allreduce(flat.data_ptr(), flat.numel(), native_comm(), stream.cuda_stream), "allreduce")
+
+
 def all_reduce_sum_(flat):
     """In-place sum of a flat buffer over all ranks (no-op when not distributed)."""
     if is_distributed():
         with _timed_collective(flat):
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            if flat.is_cuda and flat.dtype == torch.float32 and native_comm() is not None:
+                _native_all_reduce(flat, torch.cuda.current_stream(flat.device))  # stream-ordered on the caller's stream
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 
@@ -85,15 +128,36 @@ class _AsyncSum:
 
     def __init__(self, flat):
         self.flat = flat
-        self.work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
         self.waited = False
+        self.done = None
+        if flat.is_cuda and flat.dtype == torch.float32 and native_comm() is not None:
+            # the library's communicator: the exchange runs on a stream of its own behind the caller's work so far; ``wait`` orders the
+            # caller's stream behind it (an event, no host synchronisation)
+            cur = torch.cuda.current_stream(flat.device)
+            if _NATIVE["stream"] is None:
+                _NATIVE["stream"] = torch.cuda.Stream(flat.device)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            _NATIVE["stream"].wait_event(ready)
+            _native_all_reduce(flat, _NATIVE["stream"])
+            self.done = torch.cuda.Event()
+            self.done.record(_NATIVE["stream"])
+            self.work = None
+        else:
+            self.work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def _order(self):
+        if self.work is not None:
+            self.work.wait()
+        else:
+            torch.cuda.current_stream(self.flat.device).wait_event(self.done)
 
     def wait(self):
         if self.waited:  # (FlatSGD waits again when it resets its buckets: that orders the stream it is called on, but it is the same
-            self.work.wait()  # exchange -- counted once in bench.py's ``collectives``)
+            self._order()  # exchange -- counted once in bench.py's ``collectives``)
             return
         with _timed_collective(self.flat):
-            self.work.wait()
+            self._order()
         self.waited = True
 
 

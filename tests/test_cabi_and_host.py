@@ -524,3 +524,20 @@ def test_two_byte_chain_host_rules():
     f = ops._virtual((2, 64, 8, 8), torch.device("cpu"))
     f._mcd_virtual = True
     assert not ops.is_half(f) and not ops.is_half(torch.zeros(2, dtype=torch.bfloat16))
+
+
+def test_comm_entry_points_validate_their_arguments():
+    """include/mcdseg.h "Data parallelism": the argument checks of the communicator entry points happen before RCCL is looked up (no GPU
+    here): a null communicator, a null buffer, a rank outside the job are -EINVAL with a message; destroying nothing is a no-op"""
+    import ctypes
+    from mcdseg._lib import lib
+    L = lib()
+    buf = (ctypes.c_float * 4)()
+    assert L.mcdseg_allreduce(buf, 4, None, None) == -22 and b"null communicator" in L.mcdseg_last_error()
+    comm = ctypes.c_void_p()
+    ident = (ctypes.c_ubyte * 128)()
+    assert L.mcdseg_comm_init(None, 1, ident, 0) == -22
+    assert L.mcdseg_comm_init(ctypes.byref(comm), 2, ident, 2) == -22 and b"rank 2 of 2" in L.mcdseg_last_error()
+    assert L.mcdseg_comm_init(ctypes.byref(comm), 0, ident, 0) == -22
+    assert L.mcdseg_comm_unique_id(None) == -22
+    assert L.mcdseg_comm_destroy(None) == 0

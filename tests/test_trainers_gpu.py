@@ -410,3 +410,46 @@ def test_bench_with_one_rank_through_rccl(overlap):
     assert other is not None and other["MCDSEG_DP_OVERLAP"] == ("0" if overlap == "1" else "1"), other
     assert other["ms_per_step"] > 0 and other["collectives"]["collectives_per_step"] >= 7, other
     assert ref["dp_overlap_other_setting"] is None
+
+
+def test_native_rccl_allreduce_one_rank():
+    """``mcdseg_comm_unique_id`` / ``mcdseg_comm_init`` / ``mcdseg_allreduce`` / ``mcdseg_comm_destroy`` (include/mcdseg.h "Data
+    parallelism", csrc/comm.hip): RCCL called from the C ABI on the caller's stream.  What one GPU can show: a communicator of one rank,
+    the sum over one rank leaves the buffer as it is (bit for bit, stream-ordered behind the kernel that wrote it), errors are reported
+    -- and ``bench.py`` with ``MCDSEG_NATIVE_RCCL=1`` runs the step's gradient exchange through it (both MCDSEG_DP_OVERLAP settings in
+    the one invocation) with the losses of the plain single-process run."""
+    _need_gpu()
+    import ctypes
+    import json
+    import torch
+    from mcdseg._lib import check, lib
+    L = lib()
+    dev = torch.device("cuda:0")
+    ident = (ctypes.c_ubyte * 128)()
+    check(L.mcdseg_comm_unique_id(ident), "comm_unique_id")
+    assert any(ident)
+    comm = ctypes.c_void_p()
+    check(L.mcdseg_comm_init(ctypes.byref(comm), 1, ident, 0), "comm_init")
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        x = torch.randn(3 * 1000 * 1000 + 7, device=dev)
+        ref = x.clone()
+        check(L.mcdseg_allreduce(x.data_ptr(), x.numel(), comm, s.cuda_stream), "allreduce")
+        check(L.mcdseg_allreduce(x.data_ptr(), 0, comm, s.cuda_stream), "allreduce of nothing")
+    s.synchronize()
+    assert torch.equal(x, ref)
+    check(L.mcdseg_comm_destroy(comm), "comm_destroy")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", "--height", "64", "--width", "96", "--no_cpu_baseline",
+            "--literal_steps", "1", "--batch_pool", "1", "--other_configs", "", "--strict_steps", "0"]
+    lines = {}
+    for native in ("1", "0"):
+        r = _run_ranks(1, os.path.join(root, "bench.py"), args, extra_env={"MCDSEG_DIST_BACKEND": "nccl", "MCDSEG_DIST_FORCE": "1",
+                                                                          "MCDSEG_NATIVE_RCCL": native, "MCDSEG_DP_BUCKET_MB": "8"})
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines[native] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    a, b = lines["1"], lines["0"]
+    assert a["config"]["collectives"].startswith("rccl through the C ABI (mcdseg_allreduce)") and b["config"]["collectives"] == "rccl (forced, 1 rank)"
+    assert a["config"]["c_loss"] == b["config"]["c_loss"] and a["config"]["d_loss"] == b["config"]["d_loss"]
+    assert a["collectives"]["bytes_per_step"] == b["collectives"]["bytes_per_step"] > 5 * 4 * 26_000_000
+    assert a["dp_overlap_other_setting"]["collectives"]["bytes_per_step"] == a["collectives"]["bytes_per_step"]
